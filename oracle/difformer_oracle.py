@@ -1,0 +1,243 @@
+"""CPU oracle for the DIFFormer propagation layer -- TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy restatement of the reference algorithm
+(`/root/reference/node classification/difformer.py`).  It exists to *check*
+the HIP path; it is never the thing shipped or measured.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
+it.  Nothing under `difformer_amd/` imports it.
+
+Parity pinning: the reference ships no golden vectors / KATs for this path
+(SURVEY.md section 8c).  The oracle is therefore pinned against outputs of the
+reference *itself*, generated in the build container by importing the
+reference source verbatim (`tests/golden/make_golden.py`, fixtures under
+`tests/golden/*.npz`).  `tests/test_oracle_golden.py` checks every function
+here against those fixtures.
+
+Every function cites the reference lines it restates.  All arithmetic runs in
+the dtype of the inputs (float32 mirrors the reference CPU path, float64 is
+the high-precision ground truth the parity metric of SURVEY.md section 8d is
+taken against).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CLIB = None
+
+
+def _load_clib():
+    """Optional C restatement of gcn_conv (oracle/gcn_conv_ref.c) for large graphs."""
+    global _CLIB
+    if _CLIB is None:
+        path = os.path.join(_HERE, "_build", "liboracle_gcn.so")
+        if os.path.exists(path):
+            lib = ctypes.CDLL(path)
+            for name in ("oracle_gcn_conv_f32", "oracle_gcn_conv_f64"):
+                fn = getattr(lib, name)
+                fn.restype = ctypes.c_int
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                               ctypes.c_void_p, ctypes.c_int]
+            _CLIB = lib
+        else:
+            _CLIB = False
+    return _CLIB
+
+
+# --------------------------------------------------------------------------
+# a1: full_attention_conv, kernel == 'simple'   (difformer.py:18-39)
+# --------------------------------------------------------------------------
+def simple_attention(qs, ks, vs):
+    """qs [N,H,M], ks [L,H,M], vs [L,H,D] -> [N,H,D].
+
+    difformer.py:20-21  global Frobenius normalisation of the WHOLE q / k tensors
+    difformer.py:25-26  numerator  q . (K^T V)
+    difformer.py:27-29  + sum_l v_l, broadcast over queries (needs N == L)
+    difformer.py:32-34  normaliser q . (sum_l k_l)
+    difformer.py:37-39  + N, divide
+    """
+    dt = qs.dtype
+    if qs.shape[0] != vs.shape[0]:
+        # difformer.py:29 adds a [L,H,D] tensor to a [N,H,D] one
+        raise ValueError("simple kernel requires N == L (difformer.py:29)")
+    qn = qs / np.sqrt(np.sum(qs * qs, dtype=dt)).astype(dt)
+    kn = ks / np.sqrt(np.sum(ks * ks, dtype=dt)).astype(dt)
+    n_query = dt.type(qs.shape[0])
+    ktv = np.einsum("lhm,lhd->hmd", kn, vs)              # :25
+    num = np.einsum("nhm,hmd->nhd", qn, ktv)             # :26
+    num = num + vs.sum(axis=0, dtype=dt)[None]           # :27-29
+    ksum = kn.sum(axis=0, dtype=dt)                      # :32-33
+    den = np.einsum("nhm,hm->nh", qn, ksum)[..., None]   # :34,:37
+    den = den + n_query                                  # :38
+    return (num / den).astype(dt)                        # :39
+
+
+def simple_attention_weights(qs, ks):
+    """output_attn branch, difformer.py:42-43 (shape-valid only for H == 1)."""
+    dt = qs.dtype
+    qn = qs / np.sqrt(np.sum(qs * qs, dtype=dt)).astype(dt)
+    kn = ks / np.sqrt(np.sum(ks * ks, dtype=dt)).astype(dt)
+    den = np.einsum("nhm,hm->nh", qn, kn.sum(axis=0, dtype=dt))[..., None] + dt.type(qs.shape[0])
+    return (np.einsum("nhm,lhm->nlh", qn, kn) / den).astype(dt)
+
+
+# --------------------------------------------------------------------------
+# a2: full_attention_conv, kernel == 'sigmoid'  (difformer.py:45-56)
+# --------------------------------------------------------------------------
+def sigmoid_attention(qs, ks, vs, return_weights=False):
+    """qs [N,H,M], ks [L,H,M], vs [L,H,D] -> [N,H,D]; N may differ from L.
+
+    difformer.py:47     S = sigmoid(q . k)           [N,L,H]
+    difformer.py:50-52  row sums over l
+    difformer.py:55-56  (S / rowsum) . V
+    """
+    dt = qs.dtype
+    s = np.einsum("nhm,lhm->nlh", qs, ks)
+    s = (1.0 / (1.0 + np.exp(-s))).astype(dt)
+    den = s.sum(axis=1, dtype=dt)[:, None, :]
+    att = (s / den).astype(dt)
+    out = np.einsum("nlh,lhd->nhd", att, vs).astype(dt)
+    return (out, att) if return_weights else out
+
+
+def full_attention_conv(qs, ks, vs, kernel, output_attn=False):
+    """Dispatch mirroring difformer.py:10-61."""
+    if kernel == "simple":
+        out = simple_attention(qs, ks, vs)
+        return (out, simple_attention_weights(qs, ks)) if output_attn else out
+    if kernel == "sigmoid":
+        return sigmoid_attention(qs, ks, vs, return_weights=output_attn)
+    raise ValueError(f"unknown kernel {kernel!r}")
+
+
+# --------------------------------------------------------------------------
+# a3: gcn_conv  (difformer.py:63-79; torch_sparse 0.6.10 SparseTensor+matmul and
+#     torch_geometric.utils.degree are un-vendored dependencies: their published
+#     semantics are restated here -- degree = bincount, matmul(adj, x) = sum-SpMM)
+# --------------------------------------------------------------------------
+def gcn_edge_values(edge_index, num_nodes, edge_weight=None, dtype=np.float32):
+    """Per-edge value of the normalised adjacency, difformer.py:65-74.
+
+    d = in-degree counted over `col` only (:66); value_e = w_e * d[col]^-1/2 *
+    d[row]^-1/2 (:67-73); non-finite -> 0 (:74; a zero-degree source gives inf).
+    The degree vector and both d^-1/2 factors are float32 in the reference
+    (`.float()`, :66) whatever the feature dtype, and so they are here.
+    """
+    row = np.asarray(edge_index[0], dtype=np.int64)
+    col = np.asarray(edge_index[1], dtype=np.int64)
+    f32 = np.float32
+    deg = np.bincount(col, minlength=num_nodes).astype(f32)       # `.float()`, :66
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        dn_in = np.sqrt(f32(1.0) / deg[col])                       # float32 whatever x is
+        dn_out = np.sqrt(f32(1.0) / deg[row])
+        if edge_weight is None:
+            val = (np.ones(row.shape[0], dtype=f32) * dn_in * dn_out).astype(dtype)   # :71
+        else:
+            val = np.asarray(edge_weight).astype(dtype) * dn_in.astype(dtype) * dn_out.astype(dtype)  # :73
+    val = np.where(np.isfinite(val), val, dtype(0.0)).astype(dtype)
+    return row, col, val
+
+
+def gcn_conv(x, edge_index, edge_weight=None):
+    """x [N,H,D] -> [N,H,D]:  out[col_e] += value_e * x[row_e]  for every edge.
+
+    difformer.py:75 builds SparseTensor(row=col, col=row, value) i.e. the edge
+    (row -> col) lands on output row `col`; :76-78 apply the same adjacency to
+    every head.  Duplicate edges accumulate.
+    """
+    dt = x.dtype
+    n, h, d = x.shape
+    e = int(np.asarray(edge_index).shape[1])
+    lib = _load_clib()
+    if lib and e >= 100000 and dt in (np.float32, np.float64):
+        ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+        xc = np.ascontiguousarray(x).reshape(n, h * d)
+        out = np.zeros_like(xc)
+        w = None if edge_weight is None else np.ascontiguousarray(edge_weight, dtype=dt)
+        fn = lib.oracle_gcn_conv_f32 if dt == np.float32 else lib.oracle_gcn_conv_f64
+        rc = fn(xc.ctypes.data, ei.ctypes.data, None if w is None else w.ctypes.data,
+                n, e, h * d, out.ctypes.data, int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 1)))
+        if rc != 0:
+            raise RuntimeError(f"oracle_gcn_conv failed rc={rc}")
+        return out.reshape(n, h, d)
+    row, col, val = gcn_edge_values(edge_index, n, edge_weight, dtype=dt.type)
+    out = np.zeros((n, h * d), dtype=dt)
+    np.add.at(out, col, val[:, None] * x.reshape(n, h * d)[row])
+    return out.reshape(n, h, d)
+
+
+# --------------------------------------------------------------------------
+# a4: DIFFormerConv.forward  (difformer.py:113-145)
+# --------------------------------------------------------------------------
+def linear(x, weight, bias):
+    """nn.Linear: x @ W^T + b."""
+    return (x @ weight.T + bias).astype(x.dtype)
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm over the last dim (biased variance, eps inside the sqrt)."""
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    return ((x - mu) / np.sqrt(var + x.dtype.type(eps)) * weight + bias).astype(x.dtype)
+
+
+def difformer_conv(p, prefix, query_input, source_input, edge_index, edge_weight, x_0, cfg):
+    """One propagation layer.  `p` maps state_dict keys -> numpy arrays.
+
+    difformer.py:115-120 projections (use_weight=False: value = source reshaped [N,1,D])
+    difformer.py:126     attention
+    difformer.py:129-136 + gcn_conv, or convex mix when graph_weight > 0
+    difformer.py:137     mean over heads
+    difformer.py:139-140 += x_0 when use_source
+    """
+    h, d = cfg["num_heads"], cfg["hidden_channels"]
+    q = linear(query_input, p[prefix + "Wq.weight"], p[prefix + "Wq.bias"]).reshape(-1, h, d)
+    k = linear(source_input, p[prefix + "Wk.weight"], p[prefix + "Wk.bias"]).reshape(-1, h, d)
+    if cfg.get("use_weight", True):
+        v = linear(source_input, p[prefix + "Wv.weight"], p[prefix + "Wv.bias"]).reshape(-1, h, d)
+    else:
+        v = source_input.reshape(-1, 1, d)
+    att = full_attention_conv(q, k, v, cfg.get("kernel", "simple"))
+    if cfg.get("use_graph", True):
+        g = gcn_conv(v, edge_index, edge_weight)
+        gw = cfg.get("graph_weight", -1)
+        dt = att.dtype.type
+        out = (dt(1 - gw) * att + dt(gw) * g) if gw > 0 else (att + g)
+    else:
+        out = att
+    out = out.mean(axis=1).astype(query_input.dtype)
+    if cfg.get("use_source", False):
+        out = out + x_0
+    return out
+
+
+# --------------------------------------------------------------------------
+# a5: DIFFormer.forward (eval mode: dropout is identity)  (difformer.py:184-209)
+# --------------------------------------------------------------------------
+def difformer_forward(p, x, edge_index, edge_weight, cfg, return_layers=False):
+    """cfg keys: hidden_channels, num_layers, num_heads, kernel, alpha, use_bn,
+    use_residual, use_weight, use_graph, graph_weight, use_source."""
+    dt = x.dtype.type
+    alpha = dt(cfg.get("alpha", 0.5))
+    h = linear(x, p["fcs.0.weight"], p["fcs.0.bias"])                  # :188
+    if cfg.get("use_bn", True):
+        h = layer_norm(h, p["bns.0.weight"], p["bns.0.bias"])          # :189-190
+    h = np.maximum(h, dt(0))                                           # :191
+    layers = [h]                                                       # :195
+    for i in range(cfg["num_layers"]):
+        h = difformer_conv(p, f"convs.{i}.", h, h, edge_index, edge_weight, layers[0], cfg)  # :199
+        if cfg.get("use_residual", True):
+            h = alpha * h + (dt(1) - alpha) * layers[i]                # :200-201
+        if cfg.get("use_bn", True):
+            h = layer_norm(h, p[f"bns.{i + 1}.weight"], p[f"bns.{i + 1}.bias"])  # :202-203
+        layers.append(h)                                               # :205
+    out = linear(h, p["fcs.1.weight"], p["fcs.1.bias"])                # :208
+    return (out, layers) if return_layers else out
+
+
+def cast_params(p, dtype):
+    return {k: np.asarray(v).astype(dtype) for k, v in p.items()}

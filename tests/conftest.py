@@ -1,0 +1,52 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(family):
+    """-> {case_name: {key: ndarray}} from tests/golden/golden_<family>.npz."""
+    z = np.load(os.path.join(GOLDEN_DIR, f"golden_{family}.npz"), allow_pickle=False)
+    cases = {}
+    for k in z.files:
+        case, key = k.split("::", 1)
+        cases.setdefault(case, {})[key] = z[k]
+    return cases
+
+
+def split_model_case(c):
+    """-> (cfg dict, state_dict of ndarrays) from a golden 'model' case."""
+    cfg, sd = {}, {}
+    for k, v in c.items():
+        if k.startswith("cfg/"):
+            x = v.item() if v.shape == () else v
+            cfg[k[4:]] = x
+        elif k.startswith("sd/"):
+            sd[k[3:]] = v
+    return cfg, sd
+
+
+def rel_err(y, ref):
+    """Norm-wise parity metric of SURVEY.md section 8d: max|y - ref| / max|ref|."""
+    y = np.asarray(y, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    denom = np.max(np.abs(ref)) if ref.size else 1.0
+    if denom == 0:
+        denom = 1.0
+    return float(np.max(np.abs(y - ref)) / denom) if ref.size else 0.0
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return {fam: load_golden(fam) for fam in ("attn", "attnw", "gcn", "model")}

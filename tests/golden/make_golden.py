@@ -1,0 +1,205 @@
+"""Generate golden input/output vectors by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes (tests/golden/*.npz) are committed and travel to the GPU box.
+
+    python tests/golden/make_golden.py
+
+The reference file `node classification/difformer.py` is imported verbatim.
+Its two un-vendored dependencies are absent from this image, so three symbols
+are shimmed with their published semantics:
+  torch_sparse.SparseTensor(row, col, value, sparse_sizes)  -> plain COO record
+  torch_sparse.matmul(adj, x)    -> sum-SpMM: out[adj.row] += value * x[adj.col]
+  torch_geometric.utils.degree(index, N) -> bincount as float
+Everything else (full_attention_conv, DIFFormerConv, DIFFormer) executes the
+reference source unchanged.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/node classification/difformer.py"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_reference():
+    ts = types.ModuleType("torch_sparse")
+
+    class SparseTensor:  # record only; layout/ordering is irrelevant to a sum-SpMM
+        def __init__(self, row, col, value, sparse_sizes):
+            self.row, self.col, self.value, self.sizes = row, col, value, sparse_sizes
+
+    def matmul(adj, x):
+        out = torch.zeros((adj.sizes[0],) + tuple(x.shape[1:]), dtype=x.dtype)
+        out.index_add_(0, adj.row, x[adj.col] * adj.value.to(x.dtype)[:, None])
+        return out
+
+    ts.SparseTensor, ts.matmul = SparseTensor, matmul
+    tg = types.ModuleType("torch_geometric")
+    tgu = types.ModuleType("torch_geometric.utils")
+
+    def degree(index, num_nodes):
+        return torch.zeros(num_nodes).scatter_add_(0, index, torch.ones(index.shape[0]))
+
+    tgu.degree = degree
+    tg.utils = tgu
+    sys.modules.update({"torch_sparse": ts, "torch_geometric": tg, "torch_geometric.utils": tgu})
+    spec = importlib.util.spec_from_file_location("ref_difformer", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def rand_graph(g, n, e, isolated=0):
+    """Random multigraph with duplicates; the last `isolated` nodes never appear as a
+    destination (zero in-degree) but do appear as sources -> inf -> 0 values."""
+    row = torch.randint(0, n, (e,), generator=g)
+    col = torch.randint(0, n - isolated, (e,), generator=g)
+    # force duplicates
+    row[: e // 10] = row[e // 10: 2 * (e // 10)]
+    col[: e // 10] = col[e // 10: 2 * (e // 10)]
+    return torch.stack([row, col]).long()
+
+
+def both(fn):
+    """Run fn under float32 default dtype and under float64 default dtype
+    (the reference hard-codes default-dtype torch.ones, difformer.py:27,32,50)."""
+    res = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dt)
+        res[name] = fn(dt)
+    torch.set_default_dtype(torch.float32)
+    return res
+
+
+def main():
+    ref = load_reference()
+    g = torch.Generator().manual_seed(20240925)
+    cases = {}
+
+    # ---- a1 / a2: full_attention_conv ------------------------------------
+    attn_shapes = [  # (tag, kernel, N, L, H, M)
+        ("simple_n64_h1_d64", "simple", 64, 64, 1, 64),
+        ("simple_n37_h2_d16", "simple", 37, 37, 2, 16),
+        ("simple_n50_h3_d10", "simple", 50, 50, 3, 10),
+        ("simple_n130_h1_d32", "simple", 130, 130, 1, 32),
+        ("sigmoid_n48_h1_d64", "sigmoid", 48, 48, 1, 64),
+        ("sigmoid_n30_l45_h2_d16", "sigmoid", 30, 45, 2, 16),
+        ("sigmoid_n33_h1_d10", "sigmoid", 33, 33, 1, 10),
+    ]
+    for tag, kern, n, l, h, m in attn_shapes:
+        q = torch.randn(n, h, m, generator=g)
+        k = torch.randn(l, h, m, generator=g)
+        v = torch.randn(l, h, m, generator=g)
+        r = both(lambda dt: ref.full_attention_conv(q.to(dt), k.to(dt), v.to(dt), kern).numpy())
+        cases["attn/" + tag] = dict(q=q.numpy(), k=k.numpy(), v=v.numpy(), out_f32=r["f32"], out_f64=r["f64"],
+                                    kernel=np.array(kern))
+    # attention weights (output_attn) for H == 1
+    q = torch.randn(20, 1, 8, generator=g); k = torch.randn(20, 1, 8, generator=g); v = torch.randn(20, 1, 8, generator=g)
+    for kern in ("simple", "sigmoid"):
+        r = both(lambda dt: [t.numpy() for t in ref.full_attention_conv(q.to(dt), k.to(dt), v.to(dt), kern, True)])
+        cases[f"attnw/{kern}_n20"] = dict(q=q.numpy(), k=k.numpy(), v=v.numpy(), out_f32=r["f32"][0], attn_f32=r["f32"][1],
+                                          out_f64=r["f64"][0], attn_f64=r["f64"][1], kernel=np.array(kern))
+
+    # ---- a3: gcn_conv ------------------------------------------------------
+    gcn_shapes = [  # (tag, N, E, H, D, weighted, isolated)
+        ("n60_e300_h1_d64", 60, 300, 1, 64, False, 0),
+        ("n60_e300_h1_d64_w", 60, 300, 1, 64, True, 0),
+        ("n45_e200_h2_d16_iso", 45, 200, 2, 16, False, 5),
+        ("n45_e200_h2_d16_iso_w", 45, 200, 2, 16, True, 5),
+        ("n200_e5000_h1_d10", 200, 5000, 1, 10, True, 3),
+        ("n16_e0_h1_d8", 16, 0, 1, 8, False, 0),
+    ]
+    for tag, n, e, h, d, weighted, iso in gcn_shapes:
+        x = torch.randn(n, h, d, generator=g)
+        ei = rand_graph(g, n, e, iso) if e else torch.zeros(2, 0, dtype=torch.long)
+        w = None
+        if weighted:
+            w = torch.rand(e, generator=g) + 0.1
+            w[::7] = 0.0  # zero weight on a zero-degree source gives 0*inf = NaN -> 0
+        r = both(lambda dt: ref.gcn_conv(x.to(dt), ei, None if w is None else w.to(dt)).numpy())
+        c = dict(x=x.numpy(), edge_index=ei.numpy(), out_f32=r["f32"], out_f64=r["f64"])
+        if w is not None:
+            c["edge_weight"] = w.numpy()
+        cases["gcn/" + tag] = c
+
+    # ---- a4 / a5: DIFFormerConv + DIFFormer.forward ------------------------
+    model_cfgs = [
+        dict(tag="s_default", n=96, f_in=24, hidden=64, c=7, num_layers=2, num_heads=1, kernel="simple"),
+        dict(tag="s_cli_flags", n=80, f_in=64, hidden=64, c=5, num_layers=3, num_heads=1, kernel="simple",
+             use_bn=False, use_residual=False, use_weight=False, use_graph=True),
+        dict(tag="s_h2_src_gw", n=70, f_in=12, hidden=16, c=4, num_layers=2, num_heads=2, kernel="simple",
+             graph_weight=0.3, use_source=True, alpha=0.3),
+        dict(tag="s_nograph_l4", n=128, f_in=20, hidden=64, c=10, num_layers=4, num_heads=1, kernel="simple",
+             use_graph=False),
+        dict(tag="a_default", n=72, f_in=24, hidden=64, c=7, num_layers=2, num_heads=1, kernel="sigmoid"),
+        dict(tag="a_h2_weighted", n=50, f_in=10, hidden=16, c=3, num_layers=2, num_heads=2, kernel="sigmoid",
+             weighted=True),
+        dict(tag="s_d10_weighted", n=40, f_in=6, hidden=10, c=2, num_layers=2, num_heads=1, kernel="simple",
+             weighted=True, use_source=True),
+    ]
+    for mc in model_cfgs:
+        mc = dict(mc)
+        tag, n, f_in, hidden, c = (mc.pop(k) for k in ("tag", "n", "f_in", "hidden", "c"))
+        weighted = mc.pop("weighted", False)
+        x = torch.randn(n, f_in, generator=g)
+        ei = rand_graph(g, n, 6 * n, isolated=2)
+        loops = torch.arange(n - 2).repeat(2, 1)          # self loops as main.py:76 would add
+        ei = torch.cat([ei, loops], dim=1)
+        w = (torch.rand(ei.shape[1], generator=g) + 0.05) if weighted else None
+        use_graph = mc.get("use_graph", True)
+
+        def run(dt):
+            # identical (float32-valued) parameters in both runs: draw them under float32
+            torch.set_default_dtype(torch.float32)
+            torch.manual_seed(123)
+            model = ref.DIFFormer(f_in, hidden, c, **mc)
+            model.reset_parameters()
+            with torch.no_grad():
+                # perturb LayerNorm affine params so they are exercised
+                for bn in model.bns:
+                    bn.weight.add_(0.1 * torch.randn(bn.weight.shape, generator=torch.Generator().manual_seed(7)))
+                    bn.bias.add_(0.1 * torch.randn(bn.bias.shape, generator=torch.Generator().manual_seed(8)))
+            torch.set_default_dtype(dt)
+            model = model.to(dt).eval()
+            with torch.no_grad():
+                out = model(x.to(dt), ei if use_graph else None, None if w is None else w.to(dt))
+                # first propagation layer on its own (a4)
+                h0 = torch.relu(model.bns[0](model.fcs[0](x.to(dt)))) if model.use_bn else torch.relu(model.fcs[0](x.to(dt)))
+                conv0 = model.convs[0](h0, h0, ei if use_graph else None, None if w is None else w.to(dt), h0)
+            sd = {k: v.float().numpy() for k, v in model.state_dict().items()}
+            return out.numpy(), conv0.numpy(), sd
+
+        r = both(run)
+        case = dict(x=x.numpy(), edge_index=ei.numpy(), out_f32=r["f32"][0], conv0_f32=r["f32"][1],
+                    out_f64=r["f64"][0], conv0_f64=r["f64"][1])
+        if w is not None:
+            case["edge_weight"] = w.numpy()
+        for k, v in r["f32"][2].items():
+            case["sd/" + k] = v
+        cfg = dict(hidden_channels=hidden, out_channels=c, in_channels=f_in, num_layers=2, num_heads=1,
+                   kernel="simple", alpha=0.5, use_bn=True, use_residual=True, use_weight=True, use_graph=True,
+                   graph_weight=-1, use_source=False)
+        cfg.update(mc)
+        for k, v in cfg.items():
+            case["cfg/" + k] = np.array(v)
+        cases["model/" + tag] = case
+
+    # one file per family keeps the fixtures small and diff-able
+    for fam in ("attn", "attnw", "gcn", "model"):
+        flat = {}
+        for name, c in cases.items():
+            if name.split("/")[0] != fam:
+                continue
+            for k, v in c.items():
+                flat[name.split("/", 1)[1] + "::" + k] = v
+        np.savez_compressed(os.path.join(OUT, f"golden_{fam}.npz"), **flat)
+        print(fam, len(flat), "arrays")
+
+
+if __name__ == "__main__":
+    main()
