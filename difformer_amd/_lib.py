@@ -1,0 +1,86 @@
+"""ctypes binding of libdifformer_hip.so (C ABI: include/difformer_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or does not
+export the expected ABI the import of any operator fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdifformer_hip.so")
+ABI_VERSION = 1
+
+c_i64, c_int, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/difformer_hip.h one to one
+SIGNATURES = {
+    "dif_version": (c_int, []),
+    "dif_last_error": (ctypes.c_char_p, []),
+    "dif_simple_reduced_len": (c_sz, [c_int, c_int, c_int]),
+    "dif_simple_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int]),
+    "dif_simple_reduce_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int,
+                                      c_vp, c_vp, c_sz, c_vp]),
+    "dif_simple_apply_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp]),
+    "dif_sigmoid_workspace_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
+    "dif_sigmoid_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int,
+                                     c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "dif_csr_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "dif_csr_build": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dif_gcn_spmm_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int,
+                                 c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_vp]),
+    "dif_layer_tail_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,
+                                   c_vp, c_vp, c_f32, c_vp, c_i64, c_vp]),
+}
+
+_lib = None
+
+
+class DifformerHipError(RuntimeError):
+    """A C-ABI call returned non-zero (argument rejected or HIP runtime failure)."""
+
+
+def _single_hip_runtime():
+    """Two HIP runtimes in one process (torch's bundled one + a system one) do not share
+    streams or allocations; refuse to run in that state."""
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise ImportError(f"difformer_amd: more than one HIP runtime mapped: {sorted(paths)}; "
+                          "import torch before difformer_amd so that both share torch's libamdhip64")
+
+
+def load():
+    """Load the shared library once; raise ImportError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"difformer_amd: HIP extension not built ({LIB_PATH} missing). Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C difformer_amd/csrc`. "
+            "There is no CPU / eager fallback.")
+    import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so the SONAME is shared)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"difformer_amd: {LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    ver = lib.dif_version()
+    if ver != ABI_VERSION:
+        raise ImportError(f"difformer_amd: ABI version mismatch (library {ver}, host {ABI_VERSION}); rebuild")
+    _single_hip_runtime()
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dif_last_error()
+        raise DifformerHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

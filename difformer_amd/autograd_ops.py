@@ -1,0 +1,149 @@
+"""Autograd glue so the reference's unchanged training scripts (`main.py:130` loss.backward())
+keep working: the FORWARD of every operator is the HIP kernel; the BACKWARD re-derives the
+gradient on the device with differentiable tensor ops (hand-written backward kernels are the
+"next" row of SURVEY.md section 8f).  Under torch.no_grad() / eval these wrappers are
+pass-throughs to ops.py.  Nothing here touches the CPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _no_sharded_training(shard):
+    if shard is not None and shard.world > 1:
+        raise NotImplementedError("difformer_amd: row-sharded execution is forward-only; train with one GPU per "
+                                  "replica (batches are independent, main-batch.py:126-142)")
+
+
+def _grad_by_recompute(fn, inputs, grad_out):
+    """d(fn)/d(inputs) . grad_out with fn expressed in differentiable device-side tensor ops."""
+    leaves = [None if t is None else t.detach().requires_grad_(True) for t in inputs]
+    with torch.enable_grad():
+        out = fn(*leaves)
+    live = [t for t in leaves if t is not None]
+    grads = torch.autograd.grad(out, live, grad_out, allow_unused=True)
+    it = iter(grads)
+    return tuple(None if t is None else next(it) for t in leaves)
+
+
+# ---- differentiable restatements used ONLY inside backward() --------------------------------------
+def _simple_expr(q, k, v):
+    s = 1.0 / (torch.linalg.vector_norm(q) * torch.linalg.vector_norm(k))
+    ktv = torch.einsum("lhm,lhd->hmd", k, v)
+    num = s * torch.einsum("nhm,hmd->nhd", q, ktv) + v.sum(dim=0)
+    den = s * torch.einsum("nhm,hm->nh", q, k.sum(dim=0)) + q.shape[0]
+    return num / den.unsqueeze(-1)
+
+
+def _sigmoid_expr(q, k, v):
+    s = torch.sigmoid(torch.einsum("nhm,lhm->nlh", q, k))
+    return torch.einsum("nlh,lhd->nhd", s / s.sum(dim=1, keepdim=True), v)
+
+
+def _tail_expr(alpha, eps, has_ln):
+    def fn(conv, x0, prev, w, b):
+        z = conv.mean(dim=1)
+        if x0 is not None:
+            z = z + x0
+        if prev is not None:
+            z = alpha * z + (1.0 - alpha) * prev
+        if has_ln:
+            z = torch.nn.functional.layer_norm(z, (z.shape[-1],), w, b, eps)
+        return z
+    return fn
+
+
+class _SimpleAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v):
+        ctx.save_for_backward(q, k, v)
+        return ops.simple_attention(q, k, v)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _grad_by_recompute(_simple_expr, ctx.saved_tensors, g.contiguous())
+
+
+class _SigmoidAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v):
+        ctx.save_for_backward(q, k, v)
+        return ops.sigmoid_attention(q, k, v)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _grad_by_recompute(_sigmoid_expr, ctx.saved_tensors, g.contiguous())
+
+
+class _GcnAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, csr, x, attn, attn_scale, gcn_scale):
+        ctx.csr, ctx.attn_scale, ctx.gcn_scale, ctx.has_attn = csr, attn_scale, gcn_scale, attn is not None
+        return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        csr = ctx.csr
+        n, H, D = g.shape
+        g2 = g.reshape(n, H * D)
+        # transposed product: grad_x[src_e] += val_e * g[dst_e]
+        counts = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
+        dst = torch.repeat_interleave(torch.arange(n, device=g.device), counts)
+        gx = torch.zeros_like(g2)
+        src = csr.src[: csr.nnz].long()
+        val = csr.val[: csr.nnz]
+        step = max(1, (1 << 26) // max(H * D, 1))  # bound the [chunk, F] temporary
+        for s in range(0, csr.nnz, step):
+            e = slice(s, min(s + step, csr.nnz))
+            gx.index_add_(0, src[e], g2[dst[e]] * val[e].unsqueeze(1))
+        gx = (ctx.gcn_scale * gx).reshape(n, H, D)
+        return None, gx, (ctx.attn_scale * g if ctx.has_attn else None), None, None
+
+
+class _LayerTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, conv, x0, prev, alpha, w, b, eps):
+        ctx.save_for_backward(conv, x0, prev, w, b)
+        ctx.alpha, ctx.eps = alpha, eps
+        return ops.layer_tail(conv, x0, prev, alpha, w, b, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        conv, x0, prev, w, b = ctx.saved_tensors
+        grads = _grad_by_recompute(_tail_expr(ctx.alpha, ctx.eps, w is not None), (conv, x0, prev, w, b),
+                                   g.contiguous())
+        return grads[0], grads[1], grads[2], None, grads[3], grads[4], None
+
+
+# ---- public wrappers -----------------------------------------------------------------------------
+def simple_attention(q, k, v, shard=None):
+    if _needs_grad(q, k, v):
+        _no_sharded_training(shard)
+        return _SimpleAttention.apply(q, k, v)
+    return ops.simple_attention(q, k, v, shard)
+
+
+def sigmoid_attention(q, k, v, shard=None):
+    if _needs_grad(q, k, v):
+        _no_sharded_training(shard)
+        return _SigmoidAttention.apply(q, k, v)
+    return ops.sigmoid_attention(q, k, v, shard)
+
+
+def gcn_aggregate(csr, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard=None):
+    if _needs_grad(x, attn):
+        _no_sharded_training(shard)
+        return _GcnAggregate.apply(csr, x, attn, attn_scale, gcn_scale)
+    return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard)
+
+
+def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5):
+    if _needs_grad(conv, x0, prev, ln_weight, ln_bias):
+        return _LayerTail.apply(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
+    return ops.layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps)

@@ -1,0 +1,172 @@
+"""Tensor-level wrapper of the C ABI: allocation (torch caching allocator), stream plumbing
+(torch's current HIP stream) and layout checks.  No arithmetic happens here.
+
+Every method requires float32 tensors resident on a ROCm device and raises otherwise --
+the package has no CPU or eager path.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _require_device(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "difformer_amd: operands must live on the MI355X (got a CPU tensor); this package has no "
+                "CPU fallback -- move the model and inputs to the GPU with .to('cuda')")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"difformer_amd: operands on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f"difformer_amd: {name} must be float32 (got {t.dtype}); the reference path is fp32 "
+                        "(difformer.py:27)")
+    return t
+
+
+def _row_major(t, width):
+    """Return (tensor, leading dimension in elements) with the trailing dims dense so that
+    row r starts at data_ptr + r*ld*4 and holds `width` contiguous floats.  Strided row views
+    (e.g. column slices of a fused projection) are passed through without a copy."""
+    ok = t.stride(-1) == 1 or t.shape[-1] == 1
+    if ok and t.dim() == 3:
+        ok = t.stride(1) == t.shape[2] or t.shape[1] == 1
+    if ok and t.shape[0] > 1:
+        ok = t.stride(0) >= width
+    if not ok:
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else width
+    return t, int(ld)
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # ---- a1 --------------------------------------------------------------------------------
+    def simple_reduce(self, q, k, v):
+        dev = _require_device(q, k, v)
+        n, H, M = q.shape
+        D = v.shape[2]
+        q, ldq = _row_major(_f32(q, "q"), H * M)
+        k, ldk = _row_major(_f32(k, "k"), H * M)
+        v, ldv = _row_major(_f32(v, "v"), H * D)
+        reduced = torch.empty(self.lib.dif_simple_reduced_len(H, M, D), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.dif_simple_workspace_bytes(n, H, M, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.dif_simple_reduce_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, n, H, M, D,
+                                                _ptr(reduced), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_simple_reduce_f32")
+        return reduced
+
+    def simple_apply(self, q, reduced, n_global, D):
+        dev = _require_device(q, reduced)
+        n, H, M = q.shape
+        q, ldq = _row_major(_f32(q, "q"), H * M)
+        out = torch.empty((n, H, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.dif_simple_apply_f32(_ptr(q), ldq, _ptr(reduced), n, int(n_global), H, M, D,
+                                               _ptr(out), H * D, _stream(dev))
+        _lib.check(rc, "dif_simple_apply_f32")
+        return out
+
+    # ---- a2 --------------------------------------------------------------------------------
+    def sigmoid_attention(self, q, k, v):
+        dev = _require_device(q, k, v)
+        N, H, M = q.shape
+        L, D = k.shape[0], v.shape[2]
+        q, ldq = _row_major(_f32(q, "q"), H * M)
+        k, ldk = _row_major(_f32(k, "k"), H * M)
+        v, ldv = _row_major(_f32(v, "v"), H * D)
+        out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.dif_sigmoid_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, N, L, H, M, D,
+                                               _ptr(out), H * D, None, 0, _stream(dev))
+        _lib.check(rc, "dif_sigmoid_attn_f32")
+        return out
+
+    # ---- a3 --------------------------------------------------------------------------------
+    def csr_build(self, edge_index, edge_weight, num_nodes):
+        dev = _require_device(edge_index, edge_weight)
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise TypeError("difformer_amd: edge_index must be an int64 tensor of shape [2, E]")
+        ei = edge_index.contiguous()
+        E = int(ei.shape[1])
+        ew = None
+        if edge_weight is not None:
+            ew = _f32(edge_weight, "edge_weight").contiguous()
+            if ew.numel() != E:
+                raise ValueError("difformer_amd: edge_weight must have one entry per edge")
+        rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+        src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        val = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        ws_bytes = self.lib.dif_csr_workspace_bytes(E, num_nodes)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), _ptr(rowptr), _ptr(src), _ptr(val),
+                                        _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_csr_build")
+        if int(status.item()) != 0:  # one sync per (cold) build
+            raise IndexError(f"difformer_amd: edge_index holds node ids outside [0, {num_nodes})")
+        return rowptr, src, val
+
+    def spmm(self, rowptr, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0, gcn_scale=1.0):
+        dev = _require_device(rowptr, src, val, x, attn)
+        F = x.shape[1]
+        x, ldx = _row_major(_f32(x, "x"), F)
+        if x.shape[0] != n_nodes:
+            raise ValueError(f"difformer_amd: spmm needs all {n_nodes} source rows, got {x.shape[0]}")
+        lda = 0
+        if attn is not None:
+            attn, lda = _row_major(_f32(attn, "attn"), F)
+        out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.dif_gcn_spmm_f32(_ptr(rowptr), _ptr(src), _ptr(val), n_nodes, nnz, _ptr(x), ldx,
+                                           row_begin, n_rows, F, _ptr(attn), lda, float(attn_scale),
+                                           float(gcn_scale), _ptr(out), F, _stream(dev))
+        _lib.check(rc, "dif_gcn_spmm_f32")
+        return out
+
+    # ---- a4 / a5 tail ----------------------------------------------------------------------
+    def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps):
+        dev = _require_device(conv, x0, prev, ln_weight, ln_bias)
+        n, H, D = conv.shape
+        conv, ldc = _row_major(_f32(conv, "conv"), H * D)
+        ldx0 = ldp = 0
+        if x0 is not None:
+            x0, ldx0 = _row_major(_f32(x0, "x0"), D)
+        if prev is not None:
+            prev, ldp = _row_major(_f32(prev, "prev"), D)
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.dif_layer_tail_f32(_ptr(conv), ldc, n, H, D, _ptr(x0), ldx0, _ptr(prev), ldp,
+                                             float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
+                                             _ptr(out), D, _stream(dev))
+        _lib.check(rc, "dif_layer_tail_f32")
+        return out

@@ -1,0 +1,339 @@
+// a3 (cold half): COO edge_index -> normalised CSR over destination rows.
+// Replaces, for node classification/difformer.py:63-75,
+//   torch_geometric.utils.degree(col, N)           (:66)   -> csr_count_kernel (int atomics)
+//   d_norm_in/out, value, nan_to_num               (:67-74) -> csr_fill_kernel
+//   torch_sparse.SparseTensor(row=col, col=row,..) (:75)   -> stable LSD radix sort by destination
+// The reference redoes all of this in every layer of every forward; here it runs once per
+// (edge_index, edge_weight) and the host caches the result.
+//
+// Everything is integer / index work except the per-entry value, which is computed with the
+// same float32 operations as the reference (correctly rounded 1/d, sqrt, two multiplies), so
+// rowptr/src are exact and val is bit-identical to the CPU path.
+// The sort is stable (entries of a row keep edge order) => the SpMM sums in a fixed order.
+#include "dif_common.h"
+
+namespace {
+
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanBlock * kScanItems;  // 1024 values per block
+
+constexpr int kSortWaves = 4;       // independent waves per block
+constexpr int kSortRounds = 64;     // 64 lanes x 64 rounds = 4096 keys per wave chunk
+constexpr int kSortChunk = 64 * kSortRounds;
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct Plan {
+    int64_t E, N;
+    int64_t n_chunks;      // sort chunks (waves)
+    int64_t table_len;     // kRadix * n_chunks
+    int passes;            // radix passes over the destination id
+    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_deg, off_dinv, off_table, off_bsum, total;
+};
+
+Plan make_plan(int64_t E, int64_t N) {
+    Plan p;
+    p.E = E; p.N = N;
+    p.n_chunks = (E + kSortChunk - 1) / kSortChunk;
+    if (p.n_chunks < 1) p.n_chunks = 1;
+    p.table_len = p.n_chunks * kRadix;
+    int bits = 1;
+    while ((int64_t(1) << bits) < N) ++bits;
+    p.passes = (bits + kRadixBits - 1) / kRadixBits;
+    const size_t e = static_cast<size_t>(E > 0 ? E : 1);
+    const int64_t scan_n = (p.table_len > N + 1) ? p.table_len : (N + 1);
+    size_t o = 0;
+    p.off_keys_a = o; o += align256(e * 4);
+    p.off_keys_b = o; o += align256(e * 4);
+    p.off_vals_a = o; o += align256(e * 4);
+    p.off_vals_b = o; o += align256(e * 4);
+    p.off_deg = o;    o += align256(static_cast<size_t>(N + 1) * 4);
+    p.off_dinv = o;   o += align256(static_cast<size_t>(N + 1) * 4);
+    p.off_table = o;  o += align256(static_cast<size_t>(p.table_len) * 4);
+    p.off_bsum = o;   o += align256(static_cast<size_t>((scan_n + kScanTile - 1) / kScanTile + 1) * 4);
+    p.total = o;
+    return p;
+}
+
+// ---- degree count + sort keys (destination) / values (edge id) ------------------------------
+__global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ edge_index, int64_t E,
+                                                        int64_t N, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals, int32_t* __restrict__ deg,
+                                                        int32_t* __restrict__ status) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < E; e += stride) {
+        const int64_t r = edge_index[e];       // source       (row, difformer.py:65)
+        int64_t c = edge_index[E + e];         // destination  (col)
+        if (r < 0 || r >= N || c < 0 || c >= N) {
+            atomicOr(status, 1);
+            c = 0;  // keep the build memory-safe; the host rejects the result
+        }
+        keys[e] = static_cast<uint32_t>(c);
+        vals[e] = static_cast<uint32_t>(e);
+        atomicAdd(&deg[c], 1);                 // in-degree over `col` only (:66)
+    }
+}
+
+// ---- device-wide exclusive scan of int32 (3 phases) -----------------------------------------
+__global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(const int32_t* __restrict__ in, int64_t n,
+                                                                     int32_t* __restrict__ bsum) {
+    __shared__ int32_t sm[kScanBlock / 64];
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile;
+    int32_t a = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        const int64_t idx = base + i * kScanBlock + threadIdx.x;
+        if (idx < n) a += in[idx];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// single block: exclusive scan of the block sums in place; bsum[nb] = grand total
+__global__ __launch_bounds__(1024) void scan_of_sums_kernel(int32_t* __restrict__ bsum, int64_t nb) {
+    __shared__ int32_t sm[1024];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t idx = base + threadIdx.x;
+        const int32_t x = (idx < nb) ? bsum[idx] : 0;
+        sm[threadIdx.x] = x;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+            const int32_t t = (static_cast<int>(threadIdx.x) >= off) ? sm[threadIdx.x - off] : 0;
+            __syncthreads();
+            sm[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int32_t c = carry;
+        if (idx < nb) bsum[idx] = c + sm[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + sm[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[nb] = carry;
+}
+
+// out[i] = exclusive prefix of in; out may alias in.  If out_total != nullptr, *out_total = sum.
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const int32_t* in, int64_t n,
+                                                                const int32_t* __restrict__ bsum, int64_t nb,
+                                                                int32_t* out, int32_t* out_total) {
+    __shared__ int32_t sm_w[kScanBlock / 64];
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // blocked arrangement: thread t owns items [t*4, t*4+4) of the tile
+    int32_t x[kScanItems];
+    int32_t tsum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        const int64_t idx = base + static_cast<int64_t>(threadIdx.x) * kScanItems + i;
+        x[i] = (idx < n) ? in[idx] : 0;
+        tsum += x[i];
+    }
+    int32_t incl = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) sm_w[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += sm_w[w];
+    int32_t run = bsum[blockIdx.x] + woff + incl - tsum;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        const int64_t idx = base + static_cast<int64_t>(threadIdx.x) * kScanItems + i;
+        if (idx < n) out[idx] = run;
+        run += x[i];
+    }
+    if (out_total && blockIdx.x == 0 && threadIdx.x == 0) *out_total = bsum[nb];
+}
+
+int exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* out_total, int32_t* bsum,
+                   hipStream_t st) {
+    const int64_t nb = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(static_cast<unsigned>(nb)), dim3(kScanBlock), 0, st, in, n, bsum);
+    hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(static_cast<unsigned>(nb)), dim3(kScanBlock), 0, st, in, n, bsum, nb,
+                       out, out_total);
+    return dif::launch_status("exclusive_scan");
+}
+
+// dinv[n] = sqrt(1/deg[n])  (float32, correctly rounded: difformer.py:67-68); deg 0 -> inf
+__global__ __launch_bounds__(256) void csr_dinv_kernel(const int32_t* __restrict__ deg, int64_t N,
+                                                       float* __restrict__ dinv) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < N) dinv[i] = sqrtf(1.0f / static_cast<float>(deg[i]));
+}
+
+// ---- stable LSD radix sort, 8 bits per pass; each WAVE owns a 4096-key chunk -------------------
+__global__ __launch_bounds__(64 * kSortWaves) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
+                                                                    int shift, int64_t n_chunks,
+                                                                    int32_t* __restrict__ table) {
+    __shared__ int32_t hist[kSortWaves][kRadix];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t chunk = static_cast<int64_t>(blockIdx.x) * kSortWaves + wave;
+#pragma unroll
+    for (int i = 0; i < kRadix / 64; ++i) hist[wave][lane + 64 * i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (chunk < n_chunks) {
+        const int64_t base = chunk * kSortChunk;
+#pragma unroll 8
+        for (int i = 0; i < kSortRounds; ++i) {
+            const int64_t idx = base + i * 64 + lane;
+            if (idx < n) atomicAdd(&hist[wave][(keys[idx] >> shift) & (kRadix - 1)], 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < kRadix / 64; ++i) {
+            const int d = lane + 64 * i;
+            table[static_cast<int64_t>(d) * n_chunks + chunk] = hist[wave][d];  // digit-major
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * kSortWaves) void radix_scatter_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n, int shift,
+    int64_t n_chunks, const int32_t* __restrict__ table, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out) {
+    __shared__ int32_t base_s[kSortWaves][kRadix];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t chunk = static_cast<int64_t>(blockIdx.x) * kSortWaves + wave;
+    if (chunk >= n_chunks) return;
+    volatile int32_t* base = base_s[wave];
+#pragma unroll
+    for (int i = 0; i < kRadix / 64; ++i) {
+        const int d = lane + 64 * i;
+        base[d] = table[static_cast<int64_t>(d) * n_chunks + chunk];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t cbase = chunk * kSortChunk;
+    for (int i = 0; i < kSortRounds; ++i) {
+        const int64_t idx = cbase + i * 64 + lane;
+        const bool valid = idx < n;
+        if (!__any(valid)) break;
+        const uint32_t key = valid ? keys_in[idx] : 0u;
+        const uint32_t val = valid ? vals_in[idx] : 0u;
+        const uint32_t digit = (key >> shift) & (kRadix - 1);
+        // lanes holding the same digit (wave64 "match any" from 8 ballots)
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        if (valid) {
+            const int rank = __popcll(m & lt_mask);
+            const int32_t dst = base[digit] + rank;
+            keys_out[dst] = key;
+            vals_out[dst] = val;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (m & lt_mask) == 0) base[digit] += __popcll(m);  // lowest lane of each group
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- per-entry source id and normalised value ---------------------------------------------------
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
+                                                       const float* __restrict__ edge_weight,
+                                                       const uint32_t* __restrict__ dst_sorted,
+                                                       const uint32_t* __restrict__ eid_sorted,
+                                                       const float* __restrict__ dinv, int32_t* __restrict__ src,
+                                                       float* __restrict__ val) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < E; k += stride) {
+        const uint32_t e = eid_sorted[k];
+        int64_t r = edge_index[e];
+        if (r < 0 || r >= N) r = 0;            // flagged in status by csr_count_kernel
+        const uint32_t c = dst_sorted[k];
+        const float dn_in = dinv[c];
+        const float dn_out = dinv[r];
+        // :71 / :73 -- (w * d_norm_in) * d_norm_out, float32, no contraction
+        float v = edge_weight ? __fmul_rn(__fmul_rn(edge_weight[e], dn_in), dn_out) : __fmul_rn(dn_in, dn_out);
+        if (!isfinite(v)) v = 0.f;             // :74 nan_to_num(nan=0, posinf=0, neginf=0)
+        src[k] = static_cast<int32_t>(r);
+        val[k] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dif_csr_workspace_bytes(int64_t E, int64_t N) {
+    if (E < 0 || N <= 0) return 0;
+    return make_plan(E, N).total;
+}
+
+extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, const float* edge_weight,
+                             int32_t* rowptr, int32_t* src, float* val, int32_t* status, void* workspace,
+                             size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && E >= 0, DIF_E_BADARG, "dif_csr_build: need N > 0 and E >= 0");
+    DIF_REQUIRE(E < (int64_t(1) << 31) - 4096 && N < (int64_t(1) << 31) - 1, DIF_E_RANGE,
+                "dif_csr_build: E and N must fit int32 (E=%lld, N=%lld)", static_cast<long long>(E),
+                static_cast<long long>(N));
+    DIF_REQUIRE(rowptr && status && workspace && (E == 0 || (edge_index && src && val)), DIF_E_BADARG,
+                "dif_csr_build: null pointer");
+    const Plan p = make_plan(E, N);
+    DIF_REQUIRE(workspace_bytes >= p.total, DIF_E_WORKSPACE, "dif_csr_build: workspace too small (%zu < %zu)",
+                workspace_bytes, p.total);
+    DIF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DIF_E_BADARG,
+                "dif_csr_build: workspace must be 256-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    uint32_t* keys_a = reinterpret_cast<uint32_t*>(ws + p.off_keys_a);
+    uint32_t* keys_b = reinterpret_cast<uint32_t*>(ws + p.off_keys_b);
+    uint32_t* vals_a = reinterpret_cast<uint32_t*>(ws + p.off_vals_a);
+    uint32_t* vals_b = reinterpret_cast<uint32_t*>(ws + p.off_vals_b);
+    int32_t* deg = reinterpret_cast<int32_t*>(ws + p.off_deg);
+    float* dinv = reinterpret_cast<float*>(ws + p.off_dinv);
+    int32_t* table = reinterpret_cast<int32_t*>(ws + p.off_table);
+    int32_t* bsum = reinterpret_cast<int32_t*>(ws + p.off_bsum);
+
+    hipError_t he = hipMemsetAsync(deg, 0, static_cast<size_t>(N + 1) * 4, st);
+    if (he == hipSuccess) he = hipMemsetAsync(status, 0, 4, st);
+    if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_csr_build: memset: %s", hipGetErrorString(he));
+
+    const int64_t cap = 8 * dif::kCUs;
+    if (E > 0) {
+        int64_t g = (E + 255) / 256;
+        if (g > cap) g = cap;
+        hipLaunchKernelGGL(csr_count_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N,
+                           keys_a, vals_a, deg, status);
+        if (int rc = dif::launch_status("csr_count_kernel")) return rc;
+    }
+    hipLaunchKernelGGL(csr_dinv_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, st, deg, N, dinv);
+    if (int rc = dif::launch_status("csr_dinv_kernel")) return rc;
+    // rowptr[0..N] = exclusive scan of deg[0..N] (deg[N] == 0, so rowptr[N] = E)
+    if (int rc = exclusive_scan(deg, N + 1, rowptr, nullptr, bsum, st)) return rc;
+    if (E == 0) return 0;
+
+    uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
+    const unsigned sort_grid = static_cast<unsigned>((p.n_chunks + kSortWaves - 1) / kSortWaves);
+    for (int pass = 0; pass < p.passes; ++pass) {
+        const int shift = pass * kRadixBits;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, E, shift,
+                           p.n_chunks, table);
+        if (int rc = dif::launch_status("radix_hist_kernel")) return rc;
+        if (int rc = exclusive_scan(table, p.table_len, table, nullptr, bsum, st)) return rc;
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, vin, E, shift,
+                           p.n_chunks, table, kout, vout);
+        if (int rc = dif::launch_status("radix_scatter_kernel")) return rc;
+        uint32_t* t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    int64_t g = (E + 255) / 256;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N,
+                       edge_weight, kin, vin, dinv, src, val);
+    return dif::launch_status("csr_fill_kernel");
+}

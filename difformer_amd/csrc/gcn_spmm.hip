@@ -1,0 +1,220 @@
+// a3 (hot half): normalised-adjacency SpMM  -- node classification/difformer.py:75-78
+//   out[r,:] = gcn_scale * sum_{e in CSR row r} val_e * x[src_e,:]   (+ attn_scale * attn[r,:])
+// One launch covers all H*D feature columns (the reference loops H torch_sparse.matmul calls
+// and stacks), and the `attention + gcn` / convex mix of difformer.py:130-134 rides in the
+// epilogue so the layer does not re-read both operands.
+//
+// Gather-bound: per entry one 4*F-byte source row is fetched through L1/L2 (x stays resident in
+// L2 / Infinity Cache), against 8 bytes of streamed CSR.  Layout choices:
+//   - G = F/4 lanes (rounded to a power of two) each own one float4 of the feature row, so a
+//     wave issues 64/G independent 16-byte gathers per instruction, every one a full 16*G-byte
+//     contiguous segment of a source row;
+//   - CSR src/val are read 64 entries at a time with one coalesced dword load each and handed
+//     to the gathering lanes by ds_bpermute (no per-entry index loads);
+//   - accumulation stays in registers; the 64/G partial rows are folded with xor-shuffles in a
+//     fixed order -> deterministic, no atomics.
+// High-degree rows (ogbn-proteins, ~600 entries) use a whole wave per row; low-degree graphs
+// (Cora ~5, Pokec batches ~3) use one G-lane group per row.
+#include "dif_common.h"
+
+namespace {
+
+using dif::f32x4;
+
+template <int W> struct Vec;
+template <> struct Vec<4> { using T = f32x4; };
+template <> struct Vec<1> { using T = float; };
+
+template <int W>
+__device__ __forceinline__ typename Vec<W>::T vzero() {
+    if constexpr (W == 4) return f32x4{0.f, 0.f, 0.f, 0.f};
+    else return 0.f;
+}
+
+template <int W>
+__device__ __forceinline__ typename Vec<W>::T vload(const float* p) {
+    if constexpr (W == 4) return *reinterpret_cast<const f32x4*>(p);
+    else return *p;
+}
+
+template <int W>
+__device__ __forceinline__ void vstore(float* p, typename Vec<W>::T v) {
+    if constexpr (W == 4) *reinterpret_cast<f32x4*>(p) = v;
+    else *p = v;
+}
+
+template <int W>
+__device__ __forceinline__ typename Vec<W>::T vshfl_xor(typename Vec<W>::T v, int m) {
+    if constexpr (W == 4) {
+        f32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = __shfl_xor(v[i], m, 64);
+        return r;
+    } else {
+        return __shfl_xor(v, m, 64);
+    }
+}
+
+constexpr int kGatherUnroll = 8;
+
+// ---- whole wave per destination row ---------------------------------------------------------
+// grid (row blocks, column chunks of G*W floats); 256 threads = 4 rows in flight per block.
+template <int G, int W>
+__global__ __launch_bounds__(256) void spmm_wave_row_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const float* __restrict__ val,
+    const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+    const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, float* __restrict__ out,
+    int64_t ldo) {
+    using V = typename Vec<W>::T;
+    constexpr int EPW = 64 / G;  // entries gathered per wave instruction
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / G;    // which of the EPW concurrent entries
+    const int li = lane % G;
+    const int col = blockIdx.y * (G * W) + li * W;
+    const bool active = col < F;
+    const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int64_t nw = static_cast<int64_t>(gridDim.x) * 4;
+    const float* xcol = x + col;
+
+    for (int64_t row = gw; row < n_rows; row += nw) {
+        const int64_t r = row_begin + row;
+        const int32_t e0 = rowptr[r], e1 = rowptr[r + 1];
+        V acc = vzero<W>();
+        for (int32_t base = e0; base < e1; base += 64) {
+            const int32_t idx = base + lane;
+            const int32_t my_src = (idx < e1) ? src[idx] : 0;
+            const float my_val = (idx < e1) ? val[idx] : 0.f;
+            const int cnt = (e1 - base < 64) ? (e1 - base) : 64;
+            const int steps = (cnt + EPW - 1) / EPW;
+            for (int j0 = 0; j0 < steps; j0 += kGatherUnroll) {
+                V xv[kGatherUnroll];
+                float w[kGatherUnroll];
+#pragma unroll
+                for (int u = 0; u < kGatherUnroll; ++u) {
+                    const int ent = ((j0 + u) * EPW + sub) & 63;
+                    const int32_t s = __shfl(my_src, ent, 64);
+                    w[u] = (j0 + u < steps) ? __shfl(my_val, ent, 64) : 0.f;
+                    xv[u] = (active && j0 + u < steps) ? vload<W>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
+                }
+#pragma unroll
+                for (int u = 0; u < kGatherUnroll; ++u) acc += w[u] * xv[u];
+            }
+        }
+        // fold the EPW partial rows (fixed tree)
+#pragma unroll
+        for (int m = G; m < 64; m <<= 1) acc += vshfl_xor<W>(acc, m);
+        if (sub == 0 && active) {
+            V o = gcn_scale * acc;
+            if (attn) o += attn_scale * vload<W>(attn + row * lda + col);
+            vstore<W>(out + row * ldo + col, o);
+        }
+    }
+}
+
+// ---- one G-lane group per destination row (low-degree graphs) ---------------------------------
+template <int G, int W>
+__global__ __launch_bounds__(256) void spmm_group_row_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const float* __restrict__ val,
+    const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+    const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, float* __restrict__ out,
+    int64_t ldo) {
+    using V = typename Vec<W>::T;
+    constexpr int RPB = 256 / G;  // rows per block
+    const int li = threadIdx.x % G;
+    const int col = blockIdx.y * (G * W) + li * W;
+    const bool active = col < F;
+    const float* xcol = x + col;
+    const int64_t nrb = (n_rows + RPB - 1) / RPB;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int64_t row = rb * RPB + threadIdx.x / G;
+        if (row >= n_rows) continue;
+        const int64_t r = row_begin + row;
+        const int32_t e0 = rowptr[r], e1 = rowptr[r + 1];
+        V acc = vzero<W>();
+        for (int32_t e = e0; e < e1; e += 4) {
+            V xv[4];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = e + u < e1;
+                const int32_t s = ok ? src[e + u] : 0;
+                w[u] = ok ? val[e + u] : 0.f;
+                xv[u] = (ok && active) ? vload<W>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += w[u] * xv[u];
+        }
+        if (active) {
+            V o = gcn_scale * acc;
+            if (attn) o += attn_scale * vload<W>(attn + row * lda + col);
+            vstore<W>(out + row * ldo + col, o);
+        }
+    }
+}
+
+template <int G, int W>
+int launch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t* src, const float* val,
+           const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
+           float attn_scale, float gcn_scale, float* out, int64_t ldo) {
+    const int gy = (F + G * W - 1) / (G * W);
+    const int64_t cap = 8 * dif::kCUs;
+    if (wave_mode) {
+        int64_t gx = (n_rows + 3) / 4;
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL((spmm_wave_row_kernel<G, W>), dim3(static_cast<unsigned>(gx), gy), dim3(256), 0, st, rowptr,
+                           src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, out, ldo);
+    } else {
+        constexpr int RPB = 256 / G;
+        int64_t gx = (n_rows + RPB - 1) / RPB;
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL((spmm_group_row_kernel<G, W>), dim3(static_cast<unsigned>(gx), gy), dim3(256), 0, st,
+                           rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, out, ldo);
+    }
+    return dif::launch_status("spmm kernel");
+}
+
+}  // namespace
+
+static int spmm_dispatch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t* src,
+                         const float* val, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                         const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo,
+                         bool vec) {
+#define DIF_SPMM(G, W) \
+    return launch<G, W>(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, out, ldo)
+    if (vec) {
+        const int q = F / 4;
+        if (q <= 1) DIF_SPMM(1, 4);
+        if (q <= 2) DIF_SPMM(2, 4);
+        if (q <= 4) DIF_SPMM(4, 4);
+        if (q <= 8) DIF_SPMM(8, 4);
+        if (q <= 16) DIF_SPMM(16, 4);
+        if (q <= 32) DIF_SPMM(32, 4);
+        DIF_SPMM(64, 4);
+    } else {
+        if (F <= 4) DIF_SPMM(4, 1);
+        if (F <= 8) DIF_SPMM(8, 1);
+        if (F <= 16) DIF_SPMM(16, 1);
+        if (F <= 32) DIF_SPMM(32, 1);
+        DIF_SPMM(64, 1);
+    }
+#undef DIF_SPMM
+}
+
+extern "C" int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* src, const float* val, int64_t n_nodes,
+                                int64_t nnz, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                                const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out,
+                                int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && F > 0 && row_begin >= 0 && n_nodes > 0 && nnz >= 0, DIF_E_BADARG,
+                "dif_gcn_spmm_f32: need n_rows > 0, F > 0, row_begin >= 0, n_nodes > 0, nnz >= 0");
+    DIF_REQUIRE(row_begin + n_rows <= n_nodes, DIF_E_BADARG, "dif_gcn_spmm_f32: row range exceeds n_nodes");
+    DIF_REQUIRE(rowptr && x && out && (nnz == 0 || (src && val)), DIF_E_BADARG, "dif_gcn_spmm_f32: null pointer");
+    DIF_REQUIRE(ldx >= F && ldo >= F && (!attn || lda >= F), DIF_E_BADARG,
+                "dif_gcn_spmm_f32: leading dimension smaller than a row");
+    DIF_REQUIRE((F + 255) / 256 <= 65535, DIF_E_RANGE, "dif_gcn_spmm_f32: F too large");
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && (!attn || lda % 4 == 0) &&
+                     dif::aligned16(x) && dif::aligned16(out) && (!attn || dif::aligned16(attn));
+    // row mapping: a whole wave per row pays off once a row keeps the wave's gather slots busy
+    const bool wave_mode = nnz / n_nodes >= 16;
+    return spmm_dispatch(wave_mode, static_cast<hipStream_t>(stream), rowptr, src, val, x, ldx, row_begin, n_rows, F,
+                         attn, lda, attn_scale, gcn_scale, out, ldo, vec);
+}

@@ -1,0 +1,134 @@
+// a4/a5 tail: everything between the propagation operators and the next layer, in one pass.
+//   node classification/difformer.py:137      final_output.mean(dim=1)         (heads)
+//   node classification/difformer.py:139-140  final_output += x_0               (use_source)
+//   node classification/difformer.py:200-201  x = alpha*x + (1-alpha)*layer_[i] (use_residual)
+//   node classification/difformer.py:202-203  x = LayerNorm(x)                  (use_bn; eps 1e-5, affine)
+// (dropout, :204, is the identity in eval mode.)  HBM-bound: reads conv [n,H,D] (+x0, prev),
+// writes [n,D]; the reference does each line as its own full pass.
+#include "dif_common.h"
+
+namespace {
+
+using dif::f32x4;
+
+// G lanes x float4 hold one row (D <= 4G, D % 4 == 0); 256/G rows per block.
+template <int G>
+__global__ __launch_bounds__(256) void layer_tail_vec_kernel(const float* __restrict__ conv, int64_t ldc,
+                                                             int64_t n_rows, int H, int D,
+                                                             const float* __restrict__ x0, int64_t ldx0,
+                                                             const float* __restrict__ prev, int64_t ldp, float alpha,
+                                                             const float* __restrict__ ln_w,
+                                                             const float* __restrict__ ln_b, float eps,
+                                                             float* __restrict__ out, int64_t ldo) {
+    constexpr int RPB = 256 / G;
+    const int li = threadIdx.x % G;
+    const int col = 4 * li;
+    const bool active = col < D;
+    const float inv_h = 1.0f / static_cast<float>(H);
+    const float inv_d = 1.0f / static_cast<float>(D);
+    f32x4 w4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+    if (ln_w && active) { w4 = *reinterpret_cast<const f32x4*>(ln_w + col); b4 = *reinterpret_cast<const f32x4*>(ln_b + col); }
+    const int64_t nrb = (n_rows + RPB - 1) / RPB;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int64_t row = rb * RPB + threadIdx.x / G;
+        const bool ok = active && row < n_rows;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const float* c = conv + row * ldc + col;
+            for (int h = 0; h < H; ++h) z += *reinterpret_cast<const f32x4*>(c + static_cast<int64_t>(h) * D);
+            if (H > 1) z *= inv_h;                                                  // :137
+            if (x0) z += *reinterpret_cast<const f32x4*>(x0 + row * ldx0 + col);    // :139-140
+            if (prev) z = alpha * z + (1.0f - alpha) * *reinterpret_cast<const f32x4*>(prev + row * ldp + col);  // :201
+        }
+        if (ln_w) {                                                                 // :202-203
+            float s = z[0] + z[1] + z[2] + z[3];
+#pragma unroll
+            for (int m = 1; m < G; m <<= 1) s += __shfl_xor(s, m, 64);
+            const float mu = s * inv_d;
+            f32x4 dz = ok ? (z - mu) : f32x4{0.f, 0.f, 0.f, 0.f};
+            float v = dz[0] * dz[0] + dz[1] * dz[1] + dz[2] * dz[2] + dz[3] * dz[3];
+#pragma unroll
+            for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+            const float rstd = 1.0f / sqrtf(v * inv_d + eps);
+            z = dz * rstd * w4 + b4;
+        }
+        if (ok) *reinterpret_cast<f32x4*>(out + row * ldo + col) = z;
+    }
+}
+
+// generic shapes: one wave per row, two passes (z parked in `out`)
+__global__ __launch_bounds__(256) void layer_tail_generic_kernel(const float* __restrict__ conv, int64_t ldc,
+                                                                 int64_t n_rows, int H, int D,
+                                                                 const float* __restrict__ x0, int64_t ldx0,
+                                                                 const float* __restrict__ prev, int64_t ldp,
+                                                                 float alpha, const float* __restrict__ ln_w,
+                                                                 const float* __restrict__ ln_b, float eps,
+                                                                 float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int64_t nw = static_cast<int64_t>(gridDim.x) * 4;
+    const float inv_h = 1.0f / static_cast<float>(H);
+    const float inv_d = 1.0f / static_cast<float>(D);
+    for (int64_t row = gw; row < n_rows; row += nw) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            float z = 0.f;
+            for (int h = 0; h < H; ++h) z += conv[row * ldc + static_cast<int64_t>(h) * D + d];
+            if (H > 1) z *= inv_h;
+            if (x0) z += x0[row * ldx0 + d];
+            if (prev) z = alpha * z + (1.0f - alpha) * prev[row * ldp + d];
+            out[row * ldo + d] = z;
+            s += z;
+        }
+        if (!ln_w) continue;
+        const float mu = dif::wave_sum(s) * inv_d;
+        float v = 0.f;
+        for (int d = lane; d < D; d += 64) { const float dz = out[row * ldo + d] - mu; v += dz * dz; }
+        const float rstd = 1.0f / sqrtf(dif::wave_sum(v) * inv_d + eps);
+        for (int d = lane; d < D; d += 64) out[row * ldo + d] = (out[row * ldo + d] - mu) * rstd * ln_w[d] + ln_b[d];
+    }
+}
+
+}  // namespace
+
+extern "C" int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, int D, const float* x0,
+                                  int64_t ldx0, const float* prev, int64_t ldp, float alpha, const float* ln_weight,
+                                  const float* ln_bias, float ln_eps, float* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && H > 0 && D > 0, DIF_E_BADARG, "dif_layer_tail_f32: n_rows, H, D must be positive");
+    DIF_REQUIRE(conv && out, DIF_E_BADARG, "dif_layer_tail_f32: null pointer");
+    DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
+                "dif_layer_tail_f32: ln_weight and ln_bias must be given together");
+    DIF_REQUIRE(ldc >= static_cast<int64_t>(H) * D && ldo >= D && (!x0 || ldx0 >= D) && (!prev || ldp >= D), DIF_E_BADARG,
+                "dif_layer_tail_f32: leading dimension smaller than a row");
+    DIF_REQUIRE(out != conv || H == 1, DIF_E_BADARG, "dif_layer_tail_f32: in-place only for H == 1");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = (D % 4 == 0) && D <= 256 && (ldc % 4 == 0) && (ldo % 4 == 0) && (!x0 || ldx0 % 4 == 0) &&
+                     (!prev || ldp % 4 == 0) && dif::aligned16(conv) && dif::aligned16(out) &&
+                     (!x0 || dif::aligned16(x0)) && (!prev || dif::aligned16(prev)) &&
+                     (!ln_weight || (dif::aligned16(ln_weight) && dif::aligned16(ln_bias)));
+    const int64_t cap = 8 * dif::kCUs;
+    if (vec) {
+        const int q = D / 4;
+#define DIF_TAIL(G)                                                                                         \
+    do {                                                                                                    \
+        int64_t gx = (n_rows + (256 / G) - 1) / (256 / G);                                                  \
+        if (gx > cap) gx = cap;                                                                             \
+        hipLaunchKernelGGL((layer_tail_vec_kernel<G>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, \
+                           ldc, n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, out, ldo); \
+    } while (0)
+        if (q <= 1) DIF_TAIL(1);
+        else if (q <= 2) DIF_TAIL(2);
+        else if (q <= 4) DIF_TAIL(4);
+        else if (q <= 8) DIF_TAIL(8);
+        else if (q <= 16) DIF_TAIL(16);
+        else if (q <= 32) DIF_TAIL(32);
+        else DIF_TAIL(64);
+#undef DIF_TAIL
+    } else {
+        int64_t gx = (n_rows + 3) / 4;
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL(layer_tail_generic_kernel, dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, ldc,
+                           n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, out, ldo);
+    }
+    return dif::launch_status("layer_tail kernel");
+}

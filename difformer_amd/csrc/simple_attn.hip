@@ -1,0 +1,404 @@
+// a1: full_attention_conv(..., kernel='simple')  -- node classification/difformer.py:18-39
+//
+// The reference spends ~17 ATen launches on
+//     out = ((q/|Q|) (k/|K|)^T v + sum_l v) / ((q/|Q|) . sum_l (k/|K|) + N)
+// Re-associated (difformer.py:25-26 already does the K^T V first) this is two streaming passes:
+//   reduce : KtV[h] = K_h^T V_h (MxD), ksum[h], vsum[h], sum q*q, sum k*k      (reads Q,K,V once)
+//   apply  : out = (s q KtV + vsum) / (s q.ksum + N),  s = 1/(|Q||K|)          (reads Q, writes out)
+// Both contractions run on the exact-f32 matrix core op v_mfma_f32_16x16x4_f32: the 4-row
+// contraction step of that shape matches a wave reading 4 whole 256-B rows with one
+// global_load_dwordx4 (16 lanes x 16 B per row), so the HBM stream stays fully coalesced and
+// no LDS transpose is needed.  HBM-bound: 4*N*H*D*4 bytes per layer.
+#include "dif_common.h"
+
+namespace {
+
+using dif::f32x4;
+
+constexpr int kTile = 64;       // m / d extent one workgroup accumulates (16 MFMA tiles of 16x16)
+constexpr int kRedWaves = 4;    // waves per reduce workgroup
+constexpr int kRedUnroll = 4;   // 4-row steps in flight per wave iteration (16 rows, 4 KB per stream)
+constexpr int kMaxChunks = 512; // row chunks = partial records = workgroups along x
+
+struct Shape {
+    int H, M, D, MT, DT;
+    int t_main;  // H*M*D + H*M + H*D
+    int tiles;   // H*MT*DT
+};
+
+__host__ __device__ inline Shape make_shape(int H, int M, int D) {
+    Shape s;
+    s.H = H; s.M = M; s.D = D;
+    s.MT = (M + kTile - 1) / kTile;
+    s.DT = (D + kTile - 1) / kTile;
+    s.t_main = H * M * D + H * M + H * D;
+    s.tiles = H * s.MT * s.DT;
+    return s;
+}
+
+// 4 consecutive floats of row r starting at column c (c % 4 == 0); zero outside [0,n) x [0,width).
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_row4(const float* __restrict__ base, int64_t ld, int64_t r,
+                                           int64_t n, int col0, int c, int width) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (r >= n) return z;
+    const float* p = base + r * ld + col0 + c;
+    if (VEC) {
+        if (c < width) z = *reinterpret_cast<const f32x4*>(p);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (c + i < width) z[i] = p[i];
+    }
+    return z;
+}
+
+// ------------------------------------------------------------------------------------------
+// reduce: grid (P row chunks, H*MT*DT tiles), 256 threads.  Per 4-row step a lane holds
+//   kx = K[r0 + lane/16][m0 + 4*(lane%16) .. +3],  vx = V[same row][d0 + 4*(lane%16) .. +3]
+// and MFMA (t,u) accumulates  D[i][j] += sum_k A[i][k] B[k][j]  with A[i=lane%16][k=lane/16] =
+// kx[t], B[k][j=lane%16] = vx[u], i.e. KtV[m0 + 4i + t][d0 + 4j + u].
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void simple_reduce_kernel(
+    const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
+    const float* __restrict__ v, int64_t ldv, int64_t n_rows, Shape sh, float* __restrict__ ws,
+    int64_t ws_stride) {
+    __shared__ __attribute__((aligned(16))) float sm_tile[kTile * kTile];
+    __shared__ float sm_k[kRedWaves][kTile];
+    __shared__ float sm_v[kRedWaves][kTile];
+    __shared__ float sm_s[kRedWaves][2];
+
+    const int y = blockIdx.y;
+    const int dt = y % sh.DT;
+    const int mt = (y / sh.DT) % sh.MT;
+    const int h = y / (sh.DT * sh.MT);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int mc = mt * kTile + 4 * l15;  // this lane's first m column inside head h
+    const int dc = dt * kTile + 4 * l15;
+    const bool do_k = (dt == 0);
+    const bool do_v = (mt == 0);
+    const bool do_q = do_k && do_v;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ks = {0.f, 0.f, 0.f, 0.f}, vs = {0.f, 0.f, 0.f, 0.f};
+    float ksq = 0.f, qsq = 0.f;
+
+    const int64_t n_steps = (n_rows + 3) / 4;
+    const int64_t n_iters = (n_steps + kRedUnroll - 1) / kRedUnroll;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kRedWaves + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kRedWaves;
+
+    for (int64_t it = first; it < n_iters; it += stride) {
+        f32x4 kx[kRedUnroll], vx[kRedUnroll], qx[kRedUnroll];
+#pragma unroll
+        for (int s = 0; s < kRedUnroll; ++s) {
+            const int64_t r = (it * kRedUnroll + s) * 4 + lg;
+            kx[s] = load_row4<VEC>(k, ldk, r, n_rows, h * sh.M, mc, sh.M);
+            vx[s] = load_row4<VEC>(v, ldv, r, n_rows, h * sh.D, dc, sh.D);
+            if (do_q) qx[s] = load_row4<VEC>(q, ldq, r, n_rows, h * sh.M, mc, sh.M);
+        }
+#pragma unroll
+        for (int s = 0; s < kRedUnroll; ++s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[s][t], vx[s][u], acc[t][u], 0, 0, 0);
+            if (do_k) {
+                ks += kx[s];
+                ksq += kx[s][0] * kx[s][0] + kx[s][1] * kx[s][1] + kx[s][2] * kx[s][2] + kx[s][3] * kx[s][3];
+            }
+            if (do_v) vs += vx[s];
+            if (do_q) qsq += qx[s][0] * qx[s][0] + qx[s][1] * qx[s][1] + qx[s][2] * qx[s][2] + qx[s][3] * qx[s][3];
+        }
+    }
+
+    // ---- fold the 4 waves (fixed order: deterministic) ---------------------------------
+    // lane owns KtV_local[16*lg + 4*reg + t][4*l15 + u]: for fixed (t,reg) the 4 u's are one float4
+#pragma unroll
+    for (int w = 0; w < kRedWaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    f32x4 val = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+                    f32x4* dst = reinterpret_cast<f32x4*>(&sm_tile[(16 * lg + 4 * reg + t) * kTile + 4 * l15]);
+                    if (w == 0) *dst = val; else *dst += val;
+                }
+        }
+        __syncthreads();
+    }
+    // column sums: fold the four 16-lane row groups, then the waves
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a = ks[i], b = vs[i];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        if (lg == 0) { sm_k[wave][4 * l15 + i] = a; sm_v[wave][4 * l15 + i] = b; }
+    }
+    qsq = dif::wave_sum(qsq);
+    ksq = dif::wave_sum(ksq);
+    if (lane == 0) { sm_s[wave][0] = qsq; sm_s[wave][1] = ksq; }
+    __syncthreads();
+
+    float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
+    float* rec_ktv = rec + static_cast<int64_t>(h) * sh.M * sh.D;
+    for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
+        const int m = mt * kTile + e / kTile, d = dt * kTile + e % kTile;
+        if (m < sh.M && d < sh.D) rec_ktv[static_cast<int64_t>(m) * sh.D + d] = sm_tile[e];
+    }
+    if (threadIdx.x < kTile) {
+        const int c = threadIdx.x;
+        if (do_k && mt * kTile + c < sh.M)
+            rec[sh.H * sh.M * sh.D + h * sh.M + mt * kTile + c] =
+                ((sm_k[0][c] + sm_k[1][c]) + sm_k[2][c]) + sm_k[3][c];
+        if (do_v && dt * kTile + c < sh.D)
+            rec[sh.H * sh.M * sh.D + sh.H * sh.M + h * sh.D + dt * kTile + c] =
+                ((sm_v[0][c] + sm_v[1][c]) + sm_v[2][c]) + sm_v[3][c];
+    }
+    if (threadIdx.x == 0) {
+        rec[sh.t_main + 2 * y + 0] = do_q ? ((sm_s[0][0] + sm_s[1][0]) + sm_s[2][0]) + sm_s[3][0] : 0.f;
+        rec[sh.t_main + 2 * y + 1] = do_k ? ((sm_s[0][1] + sm_s[1][1]) + sm_s[2][1]) + sm_s[3][1] : 0.f;
+    }
+}
+
+// Column-sum of the P partial records -> `reduced`.  Blocks 0..nb-2: 64 columns x 16 record
+// slices each; last block: the two Frobenius scalars (P x tiles entries each).
+constexpr int kFinSlices = 16;
+__global__ __launch_bounds__(1024) void simple_finalize_kernel(const float* __restrict__ ws, int P,
+                                                               int64_t ws_stride, Shape sh,
+                                                               float* __restrict__ reduced) {
+    __shared__ float sm[kFinSlices][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    if (blockIdx.x + 1 < gridDim.x) {
+        const int col = blockIdx.x * 64 + c;
+        float a = 0.f;
+        if (col < sh.t_main)
+            for (int p = sl; p < P; p += kFinSlices) a += ws[p * ws_stride + col];
+        sm[sl][c] = a;
+        __syncthreads();
+        if (sl == 0 && col < sh.t_main) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < kFinSlices; ++i) t += sm[i][c];
+            reduced[col] = t;
+        }
+    } else {
+        // scalars: thread tid strides over (p, tile) pairs; which = 0 (q) / 1 (k)
+        float a0 = 0.f, a1 = 0.f;
+        const int total = P * sh.tiles;
+        for (int i = threadIdx.x; i < total; i += 1024) {
+            const int p = i / sh.tiles, yy = i % sh.tiles;
+            a0 += ws[p * ws_stride + sh.t_main + 2 * yy];
+            a1 += ws[p * ws_stride + sh.t_main + 2 * yy + 1];
+        }
+        a0 = dif::wave_sum(a0);
+        a1 = dif::wave_sum(a1);
+        if (c == 0) { sm[sl][0] = a0; sm[sl][1] = a1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < kFinSlices; ++i) { t0 += sm[i][0]; t1 += sm[i][1]; }
+            reduced[sh.t_main] = t0;
+            reduced[sh.t_main + 1] = t1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// apply: out^T tile = (s KtV)^T . Q^T on the MFMA:  D[i][j] = sum_k A[i][k] B[k][j] with
+//   i <-> d, j <-> row, k <-> m.  Per 16-row step lane holds qv[c] = Q[r0 + lane%16][16c +
+//   4*(lane/16) .. +3]; k-step (c,t) contracts m = 16c + 4k + t, so B = qv[c][t] and
+//   A = s*KtV[16c + 4*(lane/16) + t][16*dtl + lane%16] (register-resident when M,D <= 64).
+//   The lane ends up with out[r0 + lane%16][16*dtl + 4*(lane/16) .. +3]: one float4 store.
+// ------------------------------------------------------------------------------------------
+template <bool VEC, bool SINGLE>
+__global__ __launch_bounds__(256) void simple_apply_kernel(const float* __restrict__ q, int64_t ldq,
+                                                           const float* __restrict__ reduced,
+                                                           int64_t n_rows, float n_global, Shape sh,
+                                                           float* __restrict__ out, int64_t ldo) {
+    const int h = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const float* ktv = reduced + static_cast<int64_t>(h) * sh.M * sh.D;
+    const float* ksum = reduced + sh.H * sh.M * sh.D + h * sh.M;
+    const float* vsum = reduced + sh.H * sh.M * sh.D + sh.H * sh.M + h * sh.D;
+    // difformer.py:20-21: qs / ||qs||, ks / ||ks|| with the norm over the WHOLE tensor
+    const float s = 1.0f / (sqrtf(reduced[sh.t_main]) * sqrtf(reduced[sh.t_main + 1]));
+
+    float afrag[4][4][4];  // [dtl][c][t]
+    float kfrag[4][4];     // [c][t] = s * ksum[16c + 4lg + t]
+    auto load_frags = [&](int mt, int dt) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = mt * kTile + 16 * c + 4 * lg + t;
+                kfrag[c][t] = (m < sh.M) ? s * ksum[m] : 0.f;
+#pragma unroll
+                for (int dtl = 0; dtl < 4; ++dtl) {
+                    const int d = dt * kTile + 16 * dtl + l15;
+                    afrag[dtl][c][t] = (m < sh.M && d < sh.D) ? s * ktv[static_cast<int64_t>(m) * sh.D + d] : 0.f;
+                }
+            }
+    };
+    if (SINGLE) load_frags(0, 0);
+
+    const int64_t n_steps = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
+    for (int64_t st = first; st < n_steps; st += stride) {
+        const int64_t r = st * 16 + l15;
+        float den = 0.f;
+        for (int dt = 0; dt < sh.DT; ++dt) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int dtl = 0; dtl < 4; ++dtl) acc[dtl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float dpart = 0.f;
+            for (int mt = 0; mt < sh.MT; ++mt) {
+                if (!SINGLE) load_frags(mt, dt);
+                f32x4 qv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    qv[c] = load_row4<VEC>(q, ldq, r, n_rows, h * sh.M, mt * kTile + 16 * c + 4 * lg, sh.M);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int dtl = 0; dtl < 4; ++dtl)
+                            acc[dtl] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[dtl][c][t], qv[c][t], acc[dtl], 0, 0, 0);
+                        dpart += qv[c][t] * kfrag[c][t];
+                    }
+            }
+            if (dt == 0) {
+                // q . (s ksum): fold the 4 lane groups that share this row
+                dpart += __shfl_xor(dpart, 16, 64);
+                dpart += __shfl_xor(dpart, 32, 64);
+                den = dpart + n_global;  // difformer.py:37-38
+            }
+            if (r < n_rows) {
+#pragma unroll
+                for (int dtl = 0; dtl < 4; ++dtl) {
+                    const int d0 = dt * kTile + 16 * dtl + 4 * lg;
+                    float* o = out + r * ldo + h * sh.D + d0;
+                    if (VEC) {
+                        if (d0 < sh.D) {
+                            const f32x4 vs4 = *reinterpret_cast<const f32x4*>(vsum + d0);
+                            *reinterpret_cast<f32x4*>(o) = (acc[dtl] + vs4) / den;  // :29, :39
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (d0 + i < sh.D) o[i] = (acc[dtl][i] + vsum[d0 + i]) / den;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int reduce_chunks(int64_t n_rows) {
+    const int64_t n_iters = ((n_rows + 3) / 4 + kRedUnroll - 1) / kRedUnroll;
+    int64_t p = (n_iters + kRedWaves - 1) / kRedWaves;
+    if (p < 1) p = 1;
+    if (p > kMaxChunks) p = kMaxChunks;
+    return static_cast<int>(p);
+}
+
+int check_shape(int64_t n_rows, int H, int M, int D) {
+    DIF_REQUIRE(n_rows > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG,
+                "simple attention: n_rows, H, M, D must be positive (got %lld, %d, %d, %d)",
+                static_cast<long long>(n_rows), H, M, D);
+    DIF_REQUIRE(static_cast<int64_t>(H) * M * D + static_cast<int64_t>(H) * (M + D) + 2 < (1ll << 30),
+                DIF_E_RANGE, "simple attention: H*M*D too large");
+    DIF_REQUIRE(static_cast<int64_t>(H) * ((M + kTile - 1) / kTile) * ((D + kTile - 1) / kTile) <= 65535,
+                DIF_E_RANGE, "simple attention: too many head tiles");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t dif_simple_reduced_len(int H, int M, int D) {
+    if (H <= 0 || M <= 0 || D <= 0) return 0;
+    return static_cast<size_t>(make_shape(H, M, D).t_main) + 2;
+}
+
+extern "C" size_t dif_simple_workspace_bytes(int64_t n_rows, int H, int M, int D) {
+    if (n_rows <= 0 || H <= 0 || M <= 0 || D <= 0) return 0;
+    const Shape sh = make_shape(H, M, D);
+    const size_t rec = (static_cast<size_t>(sh.t_main) + 2 * static_cast<size_t>(sh.tiles) + 3) & ~size_t(3);
+    return rec * sizeof(float) * static_cast<size_t>(reduce_chunks(n_rows));
+}
+
+extern "C" int dif_simple_reduce_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                                     const float* v, int64_t ldv, int64_t n_rows, int H, int M, int D,
+                                     float* reduced, void* workspace, size_t workspace_bytes,
+                                     dif_stream_t stream) {
+    if (int rc = check_shape(n_rows, H, M, D)) return rc;
+    DIF_REQUIRE(q && k && v && reduced && workspace, DIF_E_BADARG, "dif_simple_reduce_f32: null pointer");
+    DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D, DIF_E_BADARG,
+                "dif_simple_reduce_f32: leading dimension smaller than a row");
+    DIF_REQUIRE(workspace_bytes >= dif_simple_workspace_bytes(n_rows, H, M, D), DIF_E_WORKSPACE,
+                "dif_simple_reduce_f32: workspace too small (%zu < %zu)", workspace_bytes,
+                dif_simple_workspace_bytes(n_rows, H, M, D));
+    DIF_REQUIRE(dif::aligned16(workspace), DIF_E_BADARG, "dif_simple_reduce_f32: workspace not 16-byte aligned");
+    const Shape sh = make_shape(H, M, D);
+    const int P = reduce_chunks(n_rows);
+    const int64_t rec = (static_cast<int64_t>(sh.t_main) + 2 * sh.tiles + 3) & ~int64_t(3);
+    const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) &&
+                     dif::aligned16(q) && dif::aligned16(k) && dif::aligned16(v);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* ws = static_cast<float*>(workspace);
+    dim3 grid(P, sh.tiles), block(256);
+    if (vec)
+        hipLaunchKernelGGL(simple_reduce_kernel<true>, grid, block, 0, st, q, ldq, k, ldk, v, ldv, n_rows, sh, ws, rec);
+    else
+        hipLaunchKernelGGL(simple_reduce_kernel<false>, grid, block, 0, st, q, ldq, k, ldk, v, ldv, n_rows, sh, ws, rec);
+    if (int rc = dif::launch_status("simple_reduce_kernel")) return rc;
+    const int nb = (sh.t_main + 63) / 64 + 1;
+    hipLaunchKernelGGL(simple_finalize_kernel, dim3(nb), dim3(1024), 0, st, ws, P, rec, sh, reduced);
+    return dif::launch_status("simple_finalize_kernel");
+}
+
+extern "C" int dif_simple_apply_f32(const float* q, int64_t ldq, const float* reduced, int64_t n_rows,
+                                    int64_t n_global, int H, int M, int D, float* out, int64_t ldo,
+                                    dif_stream_t stream) {
+    if (int rc = check_shape(n_rows, H, M, D)) return rc;
+    DIF_REQUIRE(q && reduced && out, DIF_E_BADARG, "dif_simple_apply_f32: null pointer");
+    DIF_REQUIRE(ldq >= H * M && ldo >= H * D, DIF_E_BADARG, "dif_simple_apply_f32: leading dimension smaller than a row");
+    DIF_REQUIRE(n_global >= n_rows, DIF_E_BADARG, "dif_simple_apply_f32: n_global < n_rows");
+    DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_simple_apply_f32: too many heads");
+    const Shape sh = make_shape(H, M, D);
+    const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldo % 4 == 0) && dif::aligned16(q) &&
+                     dif::aligned16(out) && dif::aligned16(reduced) && ((H * M * D + H * M) % 4 == 0);
+    const bool single = (sh.MT == 1 && sh.DT == 1);
+    const int64_t n_steps = (n_rows + 15) / 16;
+    int64_t gx = (n_steps + 3) / 4;
+    const int64_t cap = 8 * dif::kCUs;  // <= 8 resident 256-thread workgroups per CU
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(static_cast<unsigned>(gx), H), block(256);
+    const float nf = static_cast<float>(n_global);
+#define DIF_LAUNCH_APPLY(V, S) \
+    hipLaunchKernelGGL((simple_apply_kernel<V, S>), grid, block, 0, st, q, ldq, reduced, n_rows, nf, sh, out, ldo)
+    if (vec && single) DIF_LAUNCH_APPLY(true, true);
+    else if (vec) DIF_LAUNCH_APPLY(true, false);
+    else if (single) DIF_LAUNCH_APPLY(false, true);
+    else DIF_LAUNCH_APPLY(false, false);
+#undef DIF_LAUNCH_APPLY
+    return dif::launch_status("simple_apply_kernel");
+}

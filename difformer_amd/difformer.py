@@ -1,0 +1,217 @@
+"""Drop-in replacement for the reference module `difformer` on MI355X.
+
+Same public names, constructor arguments, defaults, `forward` signatures and `state_dict` keys
+as `node classification/difformer.py` (the superset of the three task-folder copies), so
+`from difformer import *` in the reference's parse.py (`node classification/parse.py:2`) keeps
+working once `difformer.py` in a task folder is replaced by `dropin/difformer.py`.
+
+What differs is where the arithmetic runs: every propagation operator is a hand-written gfx950
+kernel behind the C ABI of include/difformer_hip.h (see ops.py); this file only sequences them.
+There is no CPU path: tensors must be float32 on the GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from . import autograd_ops as ag
+
+__all__ = ["full_attention_conv", "gcn_conv", "DIFFormerConv", "DIFFormer"]
+
+
+def _dense_attention(qs, ks, kernel):
+    """Dense [N,L,H] attention weights for visualisation (`output_attn`, difformer.py:42-43 /
+    :47-55).  O(N*L) by definition and outside the timed path: plain device-side tensor ops."""
+    if kernel == "simple":
+        qn = qs / torch.linalg.vector_norm(qs)
+        kn = ks / torch.linalg.vector_norm(ks)
+        den = torch.einsum("nhm,hm->nh", qn, kn.sum(dim=0)).unsqueeze(-1) + qs.shape[0]
+        return torch.einsum("nhm,lhm->nlh", qn, kn) / den
+    s = torch.sigmoid(torch.einsum("nhm,lhm->nlh", qs, ks))
+    return s / s.sum(dim=1, keepdim=True)
+
+
+def full_attention_conv(qs, ks, vs, kernel, output_attn=False):
+    """qs [N,H,M], ks [L,H,M], vs [L,H,D] -> [N,H,D]  (reference: difformer.py:10-61)."""
+    if kernel == "simple":
+        out = ag.simple_attention(qs, ks, vs)
+    elif kernel == "sigmoid":
+        out = ag.sigmoid_attention(qs, ks, vs)
+    else:
+        raise ValueError(f"unknown attention kernel {kernel!r} (expected 'simple' or 'sigmoid')")
+    if output_attn:
+        return out, _dense_attention(qs, ks, kernel)
+    return out
+
+
+def gcn_conv(x, edge_index, edge_weight):
+    """x [N,H,D], edge_index [2,E] int64, edge_weight [E] or None -> [N,H,D]
+    (reference: difformer.py:63-79).  The normalised CSR is built on first use and cached."""
+    csr = ops.csr_cache.get(edge_index, edge_weight, x.shape[0])
+    return ag.gcn_aggregate(csr, x)
+
+
+class DIFFormerConv(nn.Module):
+    """One DIFFormer propagation layer (reference: difformer.py:81-145)."""
+
+    def __init__(self, in_channels, out_channels, num_heads, kernel='simple', use_graph=True, use_weight=True,
+                 graph_weight=-1, use_source=False):
+        super().__init__()
+        # creation order Wk, Wq, Wv as in the reference so seeded initialisation matches
+        self.Wk = nn.Linear(in_channels, out_channels * num_heads)
+        self.Wq = nn.Linear(in_channels, out_channels * num_heads)
+        if use_weight:
+            self.Wv = nn.Linear(in_channels, out_channels * num_heads)
+        self.out_channels = out_channels
+        self.num_heads = num_heads
+        self.kernel = kernel
+        self.use_graph = use_graph
+        self.use_weight = use_weight
+        self.graph_weight = graph_weight
+        self.use_source = use_source
+        self.row_shard = None  # set through DIFFormer.set_row_shard for multi-GPU runs
+
+    def reset_parameters(self):
+        self.Wk.reset_parameters()
+        self.Wq.reset_parameters()
+        if self.use_weight:
+            self.Wv.reset_parameters()
+
+    # -- projections: one fused GEMM when query and source are the same tensor -----------------
+    def _project(self, query_input, source_input):
+        H, D = self.num_heads, self.out_channels
+        if query_input is source_input:
+            mods = [self.Wq, self.Wk] + ([self.Wv] if self.use_weight else [])
+            w = torch.cat([m.weight for m in mods], dim=0)
+            b = torch.cat([m.bias for m in mods], dim=0)
+            qkv = F.linear(source_input, w, b)               # [n, (2|3)*H*D]; q/k/v are column slices
+            q = qkv[:, : H * D].reshape(-1, H, D)
+            k = qkv[:, H * D: 2 * H * D].reshape(-1, H, D)
+            v = qkv[:, 2 * H * D:].reshape(-1, H, D) if self.use_weight else None
+        else:
+            q = self.Wq(query_input).reshape(-1, H, D)
+            k = self.Wk(source_input).reshape(-1, H, D)
+            v = self.Wv(source_input).reshape(-1, H, D) if self.use_weight else None
+        if v is None:
+            v = source_input.reshape(-1, 1, D)                # difformer.py:120
+        return q, k, v
+
+    def _propagate(self, query_input, source_input, edge_index, edge_weight):
+        """-> (conv [n,H,D] before the head mean, q, k)."""
+        H = self.num_heads
+        shard = self.row_shard
+        q, k, v = self._project(query_input, source_input)
+        v_att = v if v.shape[1] == H else v.expand(-1, H, -1).contiguous()
+        if self.kernel == 'simple':
+            attn = ag.simple_attention(q, k, v_att, shard)
+        elif self.kernel == 'sigmoid':
+            attn = ag.sigmoid_attention(q, k, v_att, shard)
+        else:
+            raise ValueError(f"unknown attention kernel {self.kernel!r}")
+        if not self.use_graph:
+            return attn, q, k
+        if edge_index is None:
+            raise ValueError("use_graph=True needs an edge_index")
+        n_global = shard.n_global if shard is not None else v.shape[0]
+        csr = ops.csr_cache.get(edge_index, edge_weight, n_global)
+        if self.graph_weight > 0:                              # difformer.py:130-132
+            a_s, g_s = 1.0 - self.graph_weight, float(self.graph_weight)
+        else:                                                  # difformer.py:134
+            a_s, g_s = 1.0, 1.0
+        if v.shape[1] == H:
+            conv = ag.gcn_aggregate(csr, v, attn, a_s, g_s, shard)
+        else:  # use_weight=False with several heads: the [n,1,D] aggregate broadcasts over heads
+            conv = a_s * attn + g_s * ag.gcn_aggregate(csr, v, None, 1.0, 1.0, shard)
+        return conv, q, k
+
+    def forward(self, query_input, source_input, edge_index=None, edge_weight=None, x_0=None, output_attn=False):
+        conv, q, k = self._propagate(query_input, source_input, edge_index, edge_weight)
+        out = ag.layer_tail(conv, x_0 if self.use_source else None)   # head mean (+ x_0), :137-140
+        if output_attn:
+            return out, _dense_attention(q, k, self.kernel)
+        return out
+
+
+class DIFFormer(nn.Module):
+    """DIFFormer model (reference: difformer.py:147-226).
+    x: node features [N, in_channels]; edge_index [2, E] int64 (or None when use_graph=False);
+    returns logits [N, out_channels]."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers=2, num_heads=1, kernel='simple',
+                 alpha=0.5, dropout=0.5, use_bn=True, use_residual=True, use_weight=True, use_graph=True,
+                 graph_weight=-1, use_source=False):
+        super().__init__()
+        self.convs = nn.ModuleList()
+        self.fcs = nn.ModuleList()
+        self.fcs.append(nn.Linear(in_channels, hidden_channels))
+        self.bns = nn.ModuleList()
+        self.bns.append(nn.LayerNorm(hidden_channels))
+        for _ in range(num_layers):
+            self.convs.append(DIFFormerConv(hidden_channels, hidden_channels, num_heads=num_heads, kernel=kernel,
+                                            use_graph=use_graph, use_weight=use_weight, graph_weight=graph_weight,
+                                            use_source=use_source))
+            self.bns.append(nn.LayerNorm(hidden_channels))
+        self.fcs.append(nn.Linear(hidden_channels, out_channels))
+        self.dropout = dropout
+        self.activation = F.relu
+        self.use_bn = use_bn
+        self.residual = use_residual
+        self.alpha = alpha
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+        for fc in self.fcs:
+            fc.reset_parameters()
+
+    def set_row_shard(self, shard):
+        """Multi-GPU: `shard` (dist.RowShard) says which contiguous block of node rows this rank
+        holds; forward() then takes the LOCAL rows of x and the GLOBAL edge_index."""
+        for conv in self.convs:
+            conv.row_shard = shard
+        return self
+
+    def _input_layer(self, x, training):
+        x = self.fcs[0](x)
+        if self.use_bn:
+            x = self.bns[0](x)
+        x = self.activation(x)
+        return F.dropout(x, p=self.dropout, training=training)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        layer_ = []
+        x = self._input_layer(x, self.training)                # difformer.py:188-192
+        layer_.append(x)
+        for i, conv in enumerate(self.convs):
+            c, _, _ = conv._propagate(x, x, edge_index, edge_weight)
+            bn = self.bns[i + 1] if self.use_bn else None
+            # head mean, + layer_[0] (use_source), alpha-residual, LayerNorm: one kernel (:137-140, :200-203)
+            x = ag.layer_tail(c, layer_[0] if conv.use_source else None,
+                              layer_[i] if self.residual else None, self.alpha,
+                              bn.weight if bn is not None else None, bn.bias if bn is not None else None,
+                              bn.eps if bn is not None else 1e-5)
+            x = F.dropout(x, p=self.dropout, training=self.training)
+            layer_.append(x)
+        return self.fcs[-1](x)                                 # :208
+
+    def get_attentions(self, x):
+        """Dense per-layer attention [layers, N, N, H] (difformer.py:211-226; no graph term,
+        as in the reference, which passes no edge_index here)."""
+        layer_, attentions = [], []
+        x = self._input_layer(x, False)
+        layer_.append(x)
+        for i, conv in enumerate(self.convs):
+            q, k, v = conv._project(x, x)
+            attentions.append(_dense_attention(q, k, conv.kernel))
+            v_att = v if v.shape[1] == conv.num_heads else v.expand(-1, conv.num_heads, -1).contiguous()
+            c = full_attention_conv(q, k, v_att, conv.kernel)
+            bn = self.bns[i + 1] if self.use_bn else None
+            x = ag.layer_tail(c, None, layer_[i] if self.residual else None, self.alpha,
+                              bn.weight if bn is not None else None, bn.bias if bn is not None else None,
+                              bn.eps if bn is not None else 1e-5)
+            layer_.append(x)
+        return torch.stack(attentions, dim=0)

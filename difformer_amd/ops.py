@@ -1,0 +1,137 @@
+"""Operators of the DIFFormer propagation layer on MI355X (shard-aware, no arithmetic of their own).
+
+    simple_attention / sigmoid_attention  <- full_attention_conv   (difformer.py:10-61)
+    GraphCSR + gcn_aggregate              <- gcn_conv              (difformer.py:63-79)
+    layer_tail                            <- difformer.py:137-140, :200-203
+
+Each function drives the HIP kernels through `backend_hip.HipBackend`; with a `RowShard` it
+adds the single exchange step the operator needs (dist.py).
+"""
+from __future__ import annotations
+
+import weakref
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from .dist import RowShard
+
+_BACKEND = None
+
+
+def get_backend():
+    """The HIP backend (created on first use; import fails loudly if the .so is missing)."""
+    global _BACKEND
+    if _BACKEND is None:
+        from .backend_hip import HipBackend
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+# ------------------------------------------------------------------------------------------
+# a1 / a2
+# ------------------------------------------------------------------------------------------
+def simple_attention(qs, ks, vs, shard: Optional[RowShard] = None):
+    """qs, ks [n,H,M], vs [n,H,D] (this rank's rows) -> [n,H,D].  difformer.py:18-39."""
+    if qs.shape[0] != vs.shape[0] or ks.shape[0] != vs.shape[0]:
+        # difformer.py:29 adds a [L,H,D] tensor to a [N,H,D] one: the reference raises too
+        raise RuntimeError(f"simple kernel needs as many queries as sources (N={qs.shape[0]}, L={vs.shape[0]}; "
+                           "difformer.py:29)")
+    be = get_backend()
+    reduced = be.simple_reduce(qs, ks, vs)
+    n_global = qs.shape[0]
+    if shard is not None and shard.world > 1:
+        shard.all_reduce_sum(reduced)          # the one exchange step: H*(M*D+M+D)+2 floats
+        n_global = shard.n_global
+    return be.simple_apply(qs, reduced, n_global, vs.shape[2])
+
+
+def sigmoid_attention(qs, ks, vs, shard: Optional[RowShard] = None):
+    """qs [n,H,M] local queries; ks, vs local sources -> [n,H,D].  difformer.py:45-56."""
+    if shard is not None and shard.world > 1:
+        ks = shard.all_gather_rows(ks)
+        vs = shard.all_gather_rows(vs)
+    return get_backend().sigmoid_attention(qs, ks, vs)
+
+
+# ------------------------------------------------------------------------------------------
+# a3
+# ------------------------------------------------------------------------------------------
+class GraphCSR:
+    """Normalised adjacency in CSR over destination rows (built once per graph, on device)."""
+
+    def __init__(self, rowptr, src, val, num_nodes, nnz):
+        self.rowptr, self.src, self.val = rowptr, src, val
+        self.num_nodes, self.nnz = int(num_nodes), int(nnz)
+
+    @classmethod
+    def build(cls, edge_index, edge_weight, num_nodes):
+        rowptr, src, val = get_backend().csr_build(edge_index, edge_weight, int(num_nodes))
+        return cls(rowptr, src, val, num_nodes, edge_index.shape[1])
+
+
+class _CSRCache:
+    """The reference rebuilds degree / values / SparseTensor in every layer of every forward
+    (difformer.py:66-75).  We key the built CSR on the identity *and* version of the tensors the
+    caller passes, so `forward(x, edge_index)` keeps its signature and in-place edits or new
+    tensors still trigger a rebuild."""
+
+    def __init__(self, capacity=8):
+        self.capacity = capacity
+        self.entries = OrderedDict()
+
+    @staticmethod
+    def _key(edge_index, edge_weight, num_nodes):
+        k = (id(edge_index), edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes),
+             str(edge_index.device))
+        if edge_weight is not None:
+            k += (id(edge_weight), edge_weight.data_ptr(), edge_weight._version)
+        return k
+
+    def get(self, edge_index, edge_weight, num_nodes):
+        key = self._key(edge_index, edge_weight, num_nodes)
+        hit = self.entries.get(key)
+        if hit is not None:
+            ei_ref, ew_ref, csr = hit
+            if ei_ref() is edge_index and (edge_weight is None or ew_ref() is edge_weight):
+                self.entries.move_to_end(key)
+                return csr
+            del self.entries[key]
+        csr = GraphCSR.build(edge_index, edge_weight, num_nodes)
+        self.entries[key] = (weakref.ref(edge_index), weakref.ref(edge_weight) if edge_weight is not None else None,
+                             csr)
+        while len(self.entries) > self.capacity:
+            self.entries.popitem(last=False)
+        return csr
+
+    def clear(self):
+        self.entries.clear()
+
+
+csr_cache = _CSRCache()
+
+
+def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard: Optional[RowShard] = None):
+    """x [n,H,D] (this rank's rows of the value tensor) -> gcn_scale * A_hat x (+ attn_scale * attn).
+
+    difformer.py:75-78 plus the combine of :130-134.  Sharded: all-gather x, SpMM over the local
+    destination rows."""
+    n, H, D = x.shape
+    x2 = x.reshape(n, H * D)
+    row_begin, n_rows = 0, n
+    if shard is not None and shard.world > 1:
+        x2 = shard.all_gather_rows(x2)         # the one exchange step: N*H*D floats
+        row_begin, n_rows = shard.row_begin, shard.n_local
+    a2 = None if attn is None else attn.reshape(n, H * D)
+    out = get_backend().spmm(csr.rowptr, csr.src, csr.val, csr.num_nodes, csr.nnz, x2, row_begin, n_rows, a2,
+                             attn_scale, gcn_scale)
+    return out.reshape(n_rows, H, D)
+
+
+# ------------------------------------------------------------------------------------------
+# a4 / a5 tail
+# ------------------------------------------------------------------------------------------
+def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5):
+    """conv [n,H,D] -> [n,D]: head mean (+x0) -> alpha-residual with prev -> LayerNorm."""
+    return get_backend().layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps)

@@ -1,0 +1,123 @@
+/*
+ * difformer_hip.h -- C ABI of libdifformer_hip.so, the MI355X (gfx950) hot path of the
+ * DIFFormer propagation layer.
+ *
+ * The reference (qitianwu/DIFFormer) has no FFI of its own: its boundary for this path is
+ * the Python module `difformer` (`node classification/parse.py:2,6-7`).  The Python host in
+ * `difformer_amd/difformer.py` keeps that module's names and signatures and binds the entry
+ * points below through `ctypes`; each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (row-major, 16-byte aligned, leading dimensions given in ELEMENTS), including all
+ *     workspaces -- the library never allocates, frees or synchronises;
+ *   - work is enqueued on the `stream` argument only (a hipStream_t passed as void*; NULL =
+ *     the null stream), so every call is stream-ordered and graph-capturable;
+ *   - return 0 on success, a negative DIF_E_* code for a rejected argument, or a positive
+ *     hipError_t for a runtime failure; `dif_last_error()` returns a thread-local message.
+ *     No C++ exception crosses this boundary;
+ *   - functions are stateless and re-entrant; one process per GPU for multi-GPU.
+ */
+#ifndef DIFFORMER_HIP_H
+#define DIFFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIF_ABI_VERSION 1
+
+#define DIF_E_BADARG   (-1)  /* null pointer, non-positive size, misaligned pointer */
+#define DIF_E_SHAPE    (-2)  /* shape the kernels do not cover */
+#define DIF_E_WORKSPACE (-3) /* workspace smaller than dif_*_workspace_bytes() */
+#define DIF_E_RANGE    (-4)  /* size exceeds an internal 32-bit index */
+
+typedef void* dif_stream_t; /* hipStream_t */
+
+int dif_version(void);
+const char* dif_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * a1  full_attention_conv(qs, ks, vs, 'simple')     node classification/difformer.py:18-39
+ *
+ * Stage 1 (`reduce`): one pass over K, V (and Q for its norm) producing the per-head global
+ * sums the closed form needs.  `reduced` layout (float32, dif_simple_reduced_len() values):
+ *     [ KtV  H*M*D ][ ksum  H*M ][ vsum  H*D ][ sum(q*q) ][ sum(k*k) ]
+ * all UN-normalised (the Frobenius scale 1/(|Q||K|) of difformer.py:20-21 is applied in
+ * stage 2).  In a row-sharded run every rank reduces its own rows and the host all-reduces
+ * (sum) this buffer across ranks before stage 2.
+ * Stage 2 (`apply`):  out[n,h,:] = (s*q[n,h,:]*KtV[h] + vsum[h]) / (s*q[n,h,:]*ksum[h] + n_global)
+ * with s = 1/(sqrt(sum q*q)*sqrt(sum k*k)); n_global is N of difformer.py:22,38.
+ * q,k are [n_rows,H,M], v and out [n_rows,H,D]; ld* = elements between consecutive rows.
+ * ------------------------------------------------------------------------------------- */
+size_t dif_simple_reduced_len(int H, int M, int D);
+size_t dif_simple_workspace_bytes(int64_t n_rows, int H, int M, int D);
+int dif_simple_reduce_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                          const float* v, int64_t ldv, int64_t n_rows, int H, int M, int D,
+                          float* reduced, void* workspace, size_t workspace_bytes,
+                          dif_stream_t stream);
+int dif_simple_apply_f32(const float* q, int64_t ldq, const float* reduced, int64_t n_rows,
+                         int64_t n_global, int H, int M, int D, float* out, int64_t ldo,
+                         dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a2  full_attention_conv(qs, ks, vs, 'sigmoid')    node classification/difformer.py:45-56
+ *     out[n,h,:] = sum_l sigmoid(q[n,h,:].k[l,h,:]) v[l,h,:] / sum_l sigmoid(q[n,h,:].k[l,h,:])
+ * q [N,H,M], k [L,H,M], v [L,H,D], out [N,H,D]; N may differ from L.  The [N,L,H] score
+ * tensor is never materialised.
+ * ------------------------------------------------------------------------------------- */
+size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M, int D);
+int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                         const float* v, int64_t ldv, int64_t N, int64_t L, int H, int M, int D,
+                         float* out, int64_t ldo, void* workspace, size_t workspace_bytes,
+                         dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a3  gcn_conv(x, edge_index, edge_weight)          node classification/difformer.py:63-79
+ *     (replaces torch_geometric.utils.degree :66, torch_sparse.SparseTensor :75 and
+ *      torch_sparse.matmul :77)
+ *
+ * dif_csr_build: COO edge_index [2,E] int64 (row = source, col = destination) -> CSR over
+ * DESTINATION rows: rowptr [N+1] int32, src [E] int32 (source node of each entry) and
+ * val [E] float32 = w_e * deg[col_e]^-1/2 * deg[row_e]^-1/2 with non-finite -> 0
+ * (:66-74; deg = in-degree over `col`).  Entries of a row are ordered by (source, edge id):
+ * stable, so the SpMM result is run-to-run deterministic.  status[0] (device int32) is set
+ * non-zero if any index is outside [0,N).
+ * dif_gcn_spmm_f32: out[r, :] = gcn_scale * sum_{e in row r} val_e * x[src_e, :]
+ *                                (+ attn_scale * attn[r, :] when attn != NULL)
+ * for r in [row_begin, row_begin + n_rows): the adjacency product of :75-78 over all H*D
+ * feature columns at once, with the `attention + gcn` / convex mix of :130-134 folded in.
+ * `x` holds ALL n_nodes source rows (the full graph); out/attn hold only the n_rows local
+ * rows.  n_nodes / nnz are the CSR extents (rowptr has n_nodes+1 entries, rowptr[n_nodes] = nnz);
+ * they pick the row->wave mapping (wave per row for dense rows, lane group per row otherwise).
+ * ------------------------------------------------------------------------------------- */
+size_t dif_csr_workspace_bytes(int64_t E, int64_t N);
+int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, const float* edge_weight,
+                  int32_t* rowptr, int32_t* src, float* val, int32_t* status, void* workspace,
+                  size_t workspace_bytes, dif_stream_t stream);
+int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* src, const float* val,
+                     int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
+                     int64_t row_begin, int64_t n_rows, int F,
+                     const float* attn, int64_t lda, float attn_scale, float gcn_scale,
+                     float* out, int64_t ldo, dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a4/a5  tail of DIFFormerConv.forward + the per-layer tail of DIFFormer.forward
+ *        node classification/difformer.py:137 (mean over heads), :139-140 (+= x_0),
+ *        :200-201 (alpha residual), :202-203 (LayerNorm, eps 1e-5, affine)
+ *   y = mean_h conv[n,h,:] (+ x0[n,:]) ; z = residual ? alpha*y + (1-alpha)*prev[n,:] : y ;
+ *   out = ln_weight ? LayerNorm(z) * ln_weight + ln_bias : z
+ * conv [n_rows,H,D]; x0, prev, out [n_rows,D]; x0 / prev / ln_weight may be NULL.
+ * ------------------------------------------------------------------------------------- */
+int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, int D,
+                       const float* x0, int64_t ldx0, const float* prev, int64_t ldp,
+                       float alpha, const float* ln_weight, const float* ln_bias, float ln_eps,
+                       float* out, int64_t ldo, dif_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFORMER_HIP_H */

@@ -1,0 +1,293 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed golden vectors.
+
+Tolerance (BASELINE.json north_star: 1e-4 rel fp32; metric of SURVEY.md section 8d):
+    max|y - y64| / max|y64| <= 1e-4   against the float64 oracle / float64 reference run.
+Integer / index work (CSR rowptr, source ids) and the per-entry values are checked BIT-EXACT.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, split_model_case
+from oracle import difformer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+ATTN = load_golden("attn")
+GCN = load_golden("gcn")
+MODEL = load_golden("model")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------ a1 / a2 golden
+@pytest.mark.parametrize("name", sorted(ATTN))
+def test_full_attention_conv_golden(name, dev):
+    from difformer_amd import full_attention_conv
+    c = ATTN[name]
+    out = full_attention_conv(t(c["q"], dev), t(c["k"], dev), t(c["v"], dev), str(c["kernel"]))
+    assert out.shape == c["out_f64"].shape and out.dtype == torch.float32
+    assert rel_err(out.cpu().numpy(), c["out_f64"]) < TOL
+
+
+# ------------------------------------------------------------------ a1 seeded sizes + properties
+@pytest.mark.parametrize("n,h,d", [(1, 1, 64), (15, 1, 64), (17, 2, 32), (2708, 1, 64), (50000, 1, 64),
+                                   (4099, 1, 128), (1000, 1, 300), (777, 3, 20), (333, 1, 7), (132534, 1, 64)])
+def test_simple_attention_vs_oracle(n, h, d, dev):
+    from difformer_amd import full_attention_conv
+    g = torch.Generator().manual_seed(n * 7 + d)
+    q, k, v = (torch.randn(n, h, d, generator=g) for _ in range(3))
+    out = full_attention_conv(q.to(dev), k.to(dev), v.to(dev), "simple").cpu().numpy()
+    ref = orc.simple_attention(q.double().numpy(), k.double().numpy(), v.double().numpy())
+    assert rel_err(out, ref) < TOL
+
+
+def test_simple_attention_strided_views(dev):
+    """q/k/v as column slices of one fused projection (leading dimension 3*H*D), no copies."""
+    from difformer_amd import full_attention_conv
+    g = torch.Generator().manual_seed(5)
+    n, h, d = 1234, 1, 64
+    qkv = torch.randn(n, 3 * h * d, generator=g).to(dev)
+    q, k, v = (qkv[:, i * h * d:(i + 1) * h * d].reshape(n, h, d) for i in range(3))
+    out = full_attention_conv(q, k, v, "simple").cpu().numpy()
+    ref = orc.simple_attention(*(x.cpu().double().numpy() for x in (q, k, v)))
+    assert rel_err(out, ref) < TOL
+
+
+def test_simple_attention_is_invariant_to_row_permutation_of_sources(dev):
+    """Size-independent property at full ogbn-proteins size: permuting (k_l, v_l) pairs leaves the
+    output unchanged up to summation order."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n = 132534
+    q, k, v = (torch.randn(n, 1, 64, generator=g).to(dev) for _ in range(3))
+    perm = torch.randperm(n, generator=g).to(dev)
+    be = ops.get_backend()
+    r1 = be.simple_reduce(q, k, v)
+    r2 = be.simple_reduce(q, k[perm].contiguous(), v[perm].contiguous())
+    assert rel_err(r2.cpu().numpy(), r1.cpu().numpy()) < 1e-5
+    o1 = be.simple_apply(q, r1, n, 64)
+    o2 = be.simple_apply(q, r2, n, 64)
+    assert rel_err(o2.cpu().numpy(), o1.cpu().numpy()) < 1e-5
+
+
+def test_simple_requires_equal_lengths(dev):
+    from difformer_amd import full_attention_conv
+    q = torch.randn(8, 1, 16, device=dev); k = torch.randn(9, 1, 16, device=dev)
+    with pytest.raises(RuntimeError):
+        full_attention_conv(q, k, k, "simple")
+
+
+# ------------------------------------------------------------------ a2 seeded sizes
+@pytest.mark.parametrize("n,l,h,d", [(1, 1, 1, 64), (16, 16, 1, 64), (100, 257, 2, 32), (2708, 2708, 1, 64),
+                                     (300, 300, 1, 128), (123, 77, 1, 300), (200, 200, 3, 20), (65, 65, 1, 7)])
+def test_sigmoid_attention_vs_oracle(n, l, h, d, dev):
+    from difformer_amd import full_attention_conv
+    g = torch.Generator().manual_seed(n + l + d)
+    q = torch.randn(n, h, d, generator=g) * 0.5
+    k = torch.randn(l, h, d, generator=g) * 0.5
+    v = torch.randn(l, h, d, generator=g)
+    out = full_attention_conv(q.to(dev), k.to(dev), v.to(dev), "sigmoid").cpu().numpy()
+    ref = orc.sigmoid_attention(q.double().numpy(), k.double().numpy(), v.double().numpy())
+    assert rel_err(out, ref) < TOL
+
+
+def test_sigmoid_attention_saturated_scores(dev):
+    """Large |q.k| drives sigma to 0 / 1; no overflow, rows still normalise."""
+    from difformer_amd import full_attention_conv
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(64, 1, 64, generator=g) * 4
+    k = torch.randn(80, 1, 64, generator=g) * 4
+    v = torch.randn(80, 1, 64, generator=g)
+    out = full_attention_conv(q.to(dev), k.to(dev), v.to(dev), "sigmoid").cpu().numpy()
+    ref = orc.sigmoid_attention(q.double().numpy(), k.double().numpy(), v.double().numpy())
+    assert np.isfinite(out).all() and rel_err(out, ref) < TOL
+
+
+# ------------------------------------------------------------------ a3
+def _csr_reference(edge_index, n, edge_weight):
+    row, col, val = orc.gcn_edge_values(edge_index, n, edge_weight, dtype=np.float32)
+    order = np.argsort(col, kind="stable")
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=n))]).astype(np.int32)
+    return rowptr, row[order].astype(np.int32), val[order]
+
+
+@pytest.mark.parametrize("name", sorted(GCN))
+def test_gcn_conv_golden(name, dev):
+    from difformer_amd import gcn_conv, ops
+    c = GCN[name]
+    w = c.get("edge_weight")
+    ei = t(c["edge_index"], dev)
+    wt = None if w is None else t(w, dev)
+    n = c["x"].shape[0]
+    if ei.shape[1]:
+        csr = ops.GraphCSR.build(ei, wt, n)
+        rp, src, val = _csr_reference(c["edge_index"], n, w)
+        assert np.array_equal(csr.rowptr.cpu().numpy(), rp)                       # integer work: exact
+        assert np.array_equal(csr.src.cpu().numpy()[: csr.nnz], src)
+        assert np.array_equal(csr.val.cpu().numpy()[: csr.nnz].view(np.uint32), val.view(np.uint32))  # bit-exact
+    out = gcn_conv(t(c["x"], dev), ei, wt)
+    assert rel_err(out.cpu().numpy(), c["out_f64"]) < 1e-5
+
+
+@pytest.mark.parametrize("n,e,h,d,weighted", [(2708, 13264, 1, 64, False), (5000, 400000, 1, 64, True),
+                                              (3000, 50000, 2, 32, False), (1000, 20000, 1, 300, True),
+                                              (4000, 30000, 1, 10, False), (100000, 330000, 1, 64, False),
+                                              (20000, 3000000, 1, 64, False)])
+def test_gcn_conv_vs_oracle(n, e, h, d, weighted, dev):
+    from difformer_amd import gcn_conv, ops
+    g = torch.Generator().manual_seed(e + n)
+    x = torch.randn(n, h, d, generator=g)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[1, : e // 3] = torch.randint(0, max(n // 50, 1), (e // 3,), generator=g)   # skewed in-degree
+    w = (torch.rand(e, generator=g) + 0.1) if weighted else None
+    eid, wd = ei.to(dev), None if w is None else w.to(dev)
+    csr = ops.GraphCSR.build(eid, wd, n)
+    rp, src, val = _csr_reference(ei.numpy(), n, None if w is None else w.numpy())
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rp)
+    assert np.array_equal(csr.src.cpu().numpy()[: csr.nnz], src)
+    assert np.array_equal(csr.val.cpu().numpy()[: csr.nnz].view(np.uint32), val.view(np.uint32))
+    out = gcn_conv(x.to(dev), eid, wd).cpu().numpy()
+    ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), None if w is None else w.double().numpy())
+    assert rel_err(out, ref) < 1e-5
+
+
+def test_gcn_conv_linearity_and_determinism(dev):
+    """Size-independent properties: A(ax + by) = a Ax + b Ay, and bitwise run-to-run reproducibility."""
+    from difformer_amd import gcn_conv
+    g = torch.Generator().manual_seed(21)
+    n, e = 30000, 2000000
+    ei = torch.randint(0, n, (2, e), generator=g).to(dev)
+    x, y = torch.randn(n, 1, 64, generator=g).to(dev), torch.randn(n, 1, 64, generator=g).to(dev)
+    ax, ay, axy = gcn_conv(x, ei, None), gcn_conv(y, ei, None), gcn_conv(2.0 * x - 0.5 * y, ei, None)
+    assert rel_err(axy.cpu().numpy(), (2.0 * ax - 0.5 * ay).cpu().numpy()) < 1e-5
+    assert torch.equal(gcn_conv(x, ei, None), ax)
+
+
+def test_gcn_conv_rejects_bad_indices(dev):
+    from difformer_amd import gcn_conv
+    x = torch.randn(10, 1, 8, device=dev)
+    ei = torch.tensor([[0, 1, 11], [1, 2, 3]], device=dev)
+    with pytest.raises(IndexError):
+        gcn_conv(x, ei, None)
+
+
+def test_csr_cache_tracks_identity_and_version(dev):
+    from difformer_amd import ops
+    ops.csr_cache.clear()
+    ei = torch.randint(0, 50, (2, 300), device=dev)
+    a = ops.csr_cache.get(ei, None, 50)
+    assert ops.csr_cache.get(ei, None, 50) is a
+    ei[0, 0] = (ei[0, 0] + 1) % 50            # in-place edit bumps _version -> rebuild
+    assert ops.csr_cache.get(ei, None, 50) is not a
+    assert ops.csr_cache.get(ei.clone(), None, 50) is not ops.csr_cache.get(ei, None, 50)
+
+
+# ------------------------------------------------------------------ a4 / a5
+def test_layer_tail_vs_oracle(dev):
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for n, h, d in [(1000, 1, 64), (333, 2, 32), (200, 1, 300), (129, 3, 10), (50, 1, 256)]:
+        conv = torch.randn(n, h, d, generator=g)
+        x0, prev = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+        w, b = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g)
+        for use_x0, use_prev, use_ln in [(True, True, True), (False, True, True), (False, False, False), (True, False, True)]:
+            out = ops.layer_tail(conv.to(dev), x0.to(dev) if use_x0 else None, prev.to(dev) if use_prev else None,
+                                 0.3, w.to(dev) if use_ln else None, b.to(dev) if use_ln else None, 1e-5).cpu().numpy()
+            z = conv.double().numpy().mean(axis=1)
+            if use_x0:
+                z = z + x0.double().numpy()
+            if use_prev:
+                z = 0.3 * z + 0.7 * prev.double().numpy()
+            if use_ln:
+                z = orc.layer_norm(z, w.double().numpy(), b.double().numpy())
+            assert rel_err(out, z) < 1e-5, (n, h, d, use_x0, use_prev, use_ln)
+
+
+@pytest.mark.parametrize("name", sorted(MODEL))
+def test_model_forward_golden(name, dev):
+    """DIFFormer.forward and DIFFormerConv.forward with the reference's own state_dict."""
+    from difformer_amd import DIFFormer
+    c = MODEL[name]
+    cfg, sd = split_model_case(c)
+    kw = {k: cfg[k] for k in ("num_layers", "num_heads", "kernel", "alpha", "use_bn", "use_residual", "use_weight",
+                              "use_graph", "graph_weight", "use_source")}
+    kw["kernel"] = str(kw["kernel"])
+    model = DIFFormer(int(cfg["in_channels"]), int(cfg["hidden_channels"]), int(cfg["out_channels"]), **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).eval()
+    ei = t(c["edge_index"], dev) if cfg["use_graph"] else None
+    w = c.get("edge_weight")
+    wt = None if w is None else t(w, dev)
+    with torch.no_grad():
+        out = model(t(c["x"], dev), ei, wt)
+        h0 = model._input_layer(t(c["x"], dev), False)
+        conv0 = model.convs[0](h0, h0, ei, wt, h0)
+    assert rel_err(out.cpu().numpy(), c["out_f64"]) < TOL
+    assert rel_err(conv0.cpu().numpy(), c["conv0_f64"]) < TOL
+
+
+@pytest.mark.parametrize("kernel,n,f_in,layers,use_graph", [("simple", 2708, 1433, 2, True),     # C1
+                                                            ("sigmoid", 2708, 1433, 2, True),    # C2
+                                                            ("simple", 50000, 512, 4, False)])   # C3
+def test_model_forward_baseline_configs(kernel, n, f_in, layers, use_graph, dev):
+    from difformer_amd import DIFFormer
+    torch.manual_seed(123)
+    model = DIFFormer(f_in, 64, 7, num_layers=layers, kernel=kernel, use_graph=use_graph).eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(n, f_in, generator=g)
+    x = x / x.sum(dim=1, keepdim=True) if use_graph else torch.randn(n, f_in, generator=g)
+    ei = None
+    if use_graph:
+        pairs = torch.randint(0, n, (2, 5278), generator=g)
+        ei = torch.cat([pairs, pairs.flip(0), torch.arange(n).repeat(2, 1)], dim=1)
+    cfg = dict(hidden_channels=64, num_layers=layers, num_heads=1, kernel=kernel, alpha=0.5, use_bn=True,
+               use_residual=True, use_weight=True, use_graph=use_graph, graph_weight=-1, use_source=False)
+    p = {k: v.double().numpy() for k, v in model.state_dict().items()}
+    ref = orc.difformer_forward(p, x.double().numpy(), None if ei is None else ei.numpy(), None, cfg)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(x.to(dev), None if ei is None else ei.to(dev))
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    """No CPU fallback: a CPU operand raises instead of silently computing somewhere else."""
+    from difformer_amd import full_attention_conv
+    q = torch.randn(8, 1, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        full_attention_conv(q, q, q, "simple")
+
+
+def test_training_step_gradients_match_autograd_of_closed_form(dev):
+    """loss.backward() through the HIP forward (reference main.py:119-131)."""
+    from difformer_amd import DIFFormer
+    torch.manual_seed(1)
+    n = 300
+    model = DIFFormer(16, 32, 4, num_layers=2, kernel="simple").to(dev).train()
+    model.dropout = 0.0
+    x = torch.randn(n, 16, device=dev)
+    ei = torch.randint(0, n, (2, 2000), device=dev)
+    out = model(x, ei)
+    out.square().mean().backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    # finite-difference check on one weight entry
+    p = model.convs[0].Wq.weight
+    eps = 1e-2
+    with torch.no_grad():
+        base = p[0, 0].item()
+        p[0, 0] = base + eps; lp = model(x, ei).square().mean().item()
+        p[0, 0] = base - eps; lm = model(x, ei).square().mean().item()
+        p[0, 0] = base
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - grads["convs.0.Wq.weight"][0, 0].item()) < 0.1 * abs(fd) + 1e-4
