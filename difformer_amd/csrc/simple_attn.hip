@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     const int dc = dt * kTile + 4 * l15;
     const bool do_k = (dt == 0);
     const bool do_v = (mt == 0);
-    const bool do_q = do_k && do_v;
+    const bool do_q = do_k;  // every m-tile of a head squares its own q columns exactly once
 
     f32x4 acc[4][4];
 #pragma unroll
