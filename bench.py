@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- DIFFormer-layer forward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]           (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+
+Workload (BASELINE.json configs[3], the config the north_star target is quoted on; it fits one GPU):
+  ogbn-proteins-shaped synthetic graph: N=132,534 nodes, 39,561,252 undirected pairs stored in both
+  directions (as OGB stores them) + N self-loops (main.py:73-76) = 79,255,038 CSR entries; F_in=8,
+  C=112; DIFFormer-s: hidden 64, H=1, 4 layers, kernel='simple', use_graph, use_weight, use_bn,
+  use_residual; fp32; random-init weights (seed 123), x ~ N(0,1); eval mode, no_grad.
+A "step" is one DIFFormer.forward over the whole graph with the CSR already cached (warm); the cold
+CSR build is timed separately and reported in `cold_csr_build_ms`.  With N>1 GPUs the node rows are
+sharded (strong scaling: total work fixed): one all-reduce of the 4,226-float reduce record and one
+all-gather of the value rows per layer over RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the gcn_conv SpMM): algorithmic
+bytes per launch = 8*nnz + 4*(N+1) + 2*n_rows*H*D*4 over its mean duration from
+HIP events recorded on the launching stream inside the timed region.  `cpu_baseline` times the oracle
+port (numpy + OpenMP C) of the same forward on the host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (N, undirected pairs, F_in, classes, hidden, layers, kernel, use_graph)
+    "ogbn-proteins-s": (132534, 39561252, 8, 112, 64, 4, "simple", True),
+    "cora-s": (2708, 5278, 1433, 7, 64, 2, "simple", True),
+    "cora-a": (2708, 5278, 1433, 7, 64, 2, "sigmoid", True),
+    "cifar50k-s": (50000, 0, 512, 10, 64, 4, "simple", False),
+}
+
+
+def make_graph(n, pairs, dev):
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = torch.randint(0, n, (pairs,), generator=g, device=dev)
+    b = torch.randint(0, n, (pairs,), generator=g, device=dev)
+    loops = torch.arange(n, device=dev)
+    return torch.stack([torch.cat([a, b, loops]), torch.cat([b, a, loops])]).contiguous()
+
+
+def cpu_baseline(model, x, edge_index, cfg, n_layers):
+    """Oracle port timed on the host: input MLP + ONE propagation layer + output MLP on the full graph;
+    the propagation-layer time is multiplied by the layer count (every layer does identical work)."""
+    from oracle import difformer_oracle as orc
+    p = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    xh = x.cpu().numpy()
+    ei = None if edge_index is None else edge_index.cpu().numpy()
+    cores = os.cpu_count() or 1
+    os.environ["ORACLE_THREADS"] = str(cores)
+    t0 = time.perf_counter()
+    h = orc.linear(xh, p["fcs.0.weight"], p["fcs.0.bias"])
+    h = np.maximum(orc.layer_norm(h, p["bns.0.weight"], p["bns.0.bias"]), np.float32(0))
+    t1 = time.perf_counter()
+    c = orc.difformer_conv(p, "convs.0.", h, h, ei, None, h, cfg)
+    c = np.float32(0.5) * c + np.float32(0.5) * h
+    c = orc.layer_norm(c, p["bns.1.weight"], p["bns.1.bias"])
+    t2 = time.perf_counter()
+    orc.linear(c, p["fcs.1.weight"], p["fcs.1.bias"])
+    t3 = time.perf_counter()
+    total = (t1 - t0) + n_layers * (t2 - t1) + (t3 - t2)
+    return {"value": x.shape[0] / total, "unit": "nodes/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (numpy + OpenMP C gcn_conv) on the full graph: input MLP + 1 of {n_layers} propagation "
+                      f"layers ({t2 - t1:.2f} s, x{n_layers}) + output MLP; forward = {total:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ogbn-proteins-s", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-kernel", action="store_true", help="also print mean ms per C-ABI entry point (stderr)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from difformer_amd import DIFFormer, RowShard, ops
+
+    n, pairs, f_in, classes, hidden, layers, kernel, use_graph = WORKLOADS[args.workload]
+    torch.manual_seed(123)
+    model = DIFFormer(f_in, hidden, classes, num_layers=layers, num_heads=1, kernel=kernel, use_graph=use_graph)
+    model.reset_parameters()
+    model = model.to(dev).eval()
+    gx = torch.Generator(device=dev).manual_seed(1)
+    x_full = torch.randn(n, f_in, generator=gx, device=dev)
+    edge_index = make_graph(n, pairs, dev) if use_graph else None
+    nnz = 0 if edge_index is None else int(edge_index.shape[1])
+
+    shard = RowShard.from_process_group(n) if world > 1 else None
+    x = x_full if shard is None else shard.local_rows(x_full).contiguous()
+    if shard is not None:
+        model.set_row_shard(shard)
+    n_local = x.shape[0]
+
+    be = ops.get_backend()
+    cold_ms = None
+    with torch.no_grad():
+        if use_graph:  # cold: CSR build (degree, values, stable sort), once per graph
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ops.csr_cache.get(edge_index, None, n)
+            torch.cuda.synchronize()
+            cold_ms = (time.perf_counter() - t0) * 1e3
+        for _ in range(args.warmup):
+            model(x, edge_index)
+        be.kernel_events = {}
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(x, edge_index)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    ktimes = be.kernel_times_ms()
+    be.kernel_events = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n * args.steps / elapsed
+
+    # roofline of the dominant kernel on this rank
+    if use_graph:
+        dom, alg_bytes = "dif_gcn_spmm_f32", 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * 4
+        dom_name = "spmm_wave_row_kernel (gcn_conv)"
+    elif kernel == "simple":
+        dom, alg_bytes = "dif_simple_reduce_f32", 3.0 * n_local * hidden * 4
+        dom_name = "simple_reduce_kernel"
+    else:
+        dom, alg_bytes = "dif_sigmoid_attn_f32", 4.0 * n_local * hidden * 4
+        dom_name = "sigmoid_attn_kernel"
+    dom_ms = float(np.mean(ktimes[dom])) if ktimes.get(dom) else None
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms}
+
+    if args.per_kernel and rank == 0:
+        for k, v in sorted(ktimes.items()):
+            print(f"[per-kernel] {k}: calls={len(v)} mean={np.mean(v) * 1e3:.1f} us min={np.min(v) * 1e3:.1f} us",
+                  file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cfg = dict(hidden_channels=hidden, num_layers=layers, num_heads=1, kernel=kernel, alpha=0.5, use_bn=True,
+                   use_residual=True, use_weight=True, use_graph=use_graph, graph_weight=-1, use_source=False)
+        cpu = cpu_baseline(model, x_full, edge_index, cfg, layers)
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "DIFFormer-layer forward nodes/sec", "value": value, "unit": "nodes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "nodes": n, "csr_entries": nnz, "in_channels": f_in,
+                       "hidden": hidden, "heads": 1, "layers": layers, "kernel": kernel, "use_graph": use_graph,
+                       "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+                       "csr": "warm (cached); cold build reported in cold_csr_build_ms"},
+            "cold_csr_build_ms": cold_ms, "roofline": roofline, "cpu_baseline": cpu,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

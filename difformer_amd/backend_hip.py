@@ -59,11 +59,41 @@ def _row_major(t, width):
     return t, int(ld)
 
 
+class _Timed:
+    """Optional HIP-event bracket around one C-ABI call (events on the launching stream)."""
+
+    def __init__(self, backend, name, dev):
+        self.rec = backend.kernel_events
+        self.name, self.dev = name, dev
+
+    def __enter__(self):
+        self.ctx = torch.cuda.device(self.dev)
+        self.ctx.__enter__()
+        if self.rec is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream(self.dev))
+            self.rec.setdefault(self.name, []).append((self.start, end))
+        return self.ctx.__exit__(*exc)
+
+
 class HipBackend:
     name = "hip"
 
     def __init__(self):
         self.lib = _lib.load()
+        # bench.py sets this to a dict to collect (start, end) HIP events per entry point
+        self.kernel_events = None
+
+    def kernel_times_ms(self):
+        """{entry point: [ms per call]} from the collected events (synchronises)."""
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.kernel_events or {}).items()}
 
     # ---- a1 --------------------------------------------------------------------------------
     def simple_reduce(self, q, k, v):
@@ -76,7 +106,7 @@ class HipBackend:
         reduced = torch.empty(self.lib.dif_simple_reduced_len(H, M, D), dtype=torch.float32, device=dev)
         ws_bytes = self.lib.dif_simple_workspace_bytes(n, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _Timed(self, "dif_simple_reduce_f32", dev):
             rc = self.lib.dif_simple_reduce_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, n, H, M, D,
                                                 _ptr(reduced), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_simple_reduce_f32")
@@ -87,7 +117,7 @@ class HipBackend:
         n, H, M = q.shape
         q, ldq = _row_major(_f32(q, "q"), H * M)
         out = torch.empty((n, H, D), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _Timed(self, "dif_simple_apply_f32", dev):
             rc = self.lib.dif_simple_apply_f32(_ptr(q), ldq, _ptr(reduced), n, int(n_global), H, M, D,
                                                _ptr(out), H * D, _stream(dev))
         _lib.check(rc, "dif_simple_apply_f32")
@@ -102,7 +132,7 @@ class HipBackend:
         k, ldk = _row_major(_f32(k, "k"), H * M)
         v, ldv = _row_major(_f32(v, "v"), H * D)
         out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _Timed(self, "dif_sigmoid_attn_f32", dev):
             rc = self.lib.dif_sigmoid_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, N, L, H, M, D,
                                                _ptr(out), H * D, None, 0, _stream(dev))
         _lib.check(rc, "dif_sigmoid_attn_f32")
@@ -126,7 +156,7 @@ class HipBackend:
         status = torch.empty(1, dtype=torch.int32, device=dev)
         ws_bytes = self.lib.dif_csr_workspace_bytes(E, num_nodes)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _Timed(self, "dif_csr_build", dev):
             rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), _ptr(rowptr), _ptr(src), _ptr(val),
                                         _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_csr_build")
@@ -144,7 +174,7 @@ class HipBackend:
         if attn is not None:
             attn, lda = _row_major(_f32(attn, "attn"), F)
         out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _Timed(self, "dif_gcn_spmm_f32", dev):
             rc = self.lib.dif_gcn_spmm_f32(_ptr(rowptr), _ptr(src), _ptr(val), n_nodes, nnz, _ptr(x), ldx,
                                            row_begin, n_rows, F, _ptr(attn), lda, float(attn_scale),
                                            float(gcn_scale), _ptr(out), F, _stream(dev))
@@ -164,7 +194,7 @@ class HipBackend:
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _Timed(self, "dif_layer_tail_f32", dev):
             rc = self.lib.dif_layer_tail_f32(_ptr(conv), ldc, n, H, D, _ptr(x0), ldx0, _ptr(prev), ldp,
                                              float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
                                              _ptr(out), D, _stream(dev))
