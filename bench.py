@@ -121,7 +121,7 @@ def main():
         if use_graph:  # cold: CSR build (degree, values, stable sort), once per graph
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ops.csr_cache.get(edge_index, None, n)
+            ops.csr_cache.get(edge_index, None, n, hidden * 4)
             torch.cuda.synchronize()
             cold_ms = (time.perf_counter() - t0) * 1e3
         for _ in range(args.warmup):

@@ -139,7 +139,7 @@ class HipBackend:
         return out
 
     # ---- a3 --------------------------------------------------------------------------------
-    def csr_build(self, edge_index, edge_weight, num_nodes):
+    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1):
         dev = _require_device(edge_index, edge_weight)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise TypeError("difformer_amd: edge_index must be an int64 tensor of shape [2, E]")
@@ -154,18 +154,22 @@ class HipBackend:
         src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         val = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
         status = torch.empty(1, dtype=torch.int32, device=dev)
-        ws_bytes = self.lib.dif_csr_workspace_bytes(E, num_nodes)
+        blkptr = None
+        if n_blocks > 1:
+            blkptr = torch.empty((n_blocks + 1) * num_nodes, dtype=torch.int32, device=dev)
+        ws_bytes = self.lib.dif_csr_workspace_bytes(E, num_nodes, n_blocks)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _Timed(self, "dif_csr_build", dev):
-            rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), _ptr(rowptr), _ptr(src), _ptr(val),
-                                        _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
+            rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), n_blocks, _ptr(rowptr), _ptr(blkptr),
+                                        _ptr(src), _ptr(val), _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_csr_build")
         if int(status.item()) != 0:  # one sync per (cold) build
             raise IndexError(f"difformer_amd: edge_index holds node ids outside [0, {num_nodes})")
-        return rowptr, src, val
+        return rowptr, blkptr, src, val
 
-    def spmm(self, rowptr, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0, gcn_scale=1.0):
-        dev = _require_device(rowptr, src, val, x, attn)
+    def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
+             gcn_scale=1.0):
+        dev = _require_device(rowptr, blkptr, src, val, x, attn)
         F = x.shape[1]
         x, ldx = _row_major(_f32(x, "x"), F)
         if x.shape[0] != n_nodes:
@@ -175,7 +179,8 @@ class HipBackend:
             attn, lda = _row_major(_f32(attn, "attn"), F)
         out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
         with _Timed(self, "dif_gcn_spmm_f32", dev):
-            rc = self.lib.dif_gcn_spmm_f32(_ptr(rowptr), _ptr(src), _ptr(val), n_nodes, nnz, _ptr(x), ldx,
+            rc = self.lib.dif_gcn_spmm_f32(_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes, nnz,
+                                           _ptr(x), ldx,
                                            row_begin, n_rows, F, _ptr(attn), lda, float(attn_scale),
                                            float(gcn_scale), _ptr(out), F, _stream(dev))
         _lib.check(rc, "dif_gcn_spmm_f32")

@@ -152,6 +152,127 @@ __global__ __launch_bounds__(256) void spmm_group_row_kernel(
     }
 }
 
+// ---- source-blocked sweep (large dense graphs: x does not fit the 4 MiB L2 of an XCD) -------------
+// CSR rows are grouped by source block (gcn_csr.hip).  One persistent 16-wave workgroup per CU;
+// every wave owns a panel of `rpw` consecutive destination rows whose accumulators live in its
+// slice of LDS, and sweeps the source blocks 0..NB-1 in order.  All CUs therefore gather from the
+// same ~2.5 MiB slice of x at about the same time and the slice is served by L2 instead of the
+// Infinity Cache (measured on MI355X: 17.7 TB/s of gathers when the touched span is <= 4 MiB
+// against 8.0 TB/s over the whole 32 MiB -- scripts/exp_spmm_locality.py).
+// Inside a block visit the wave's S = 64/G lane groups each walk one row's group of entries:
+// G entries are fetched per lane group with one coalesced (non-temporal) load of src/val, then
+// handed out by ds_bpermute, so there is no per-entry index load and no cross-lane reduction.
+constexpr int kBlkWaves = 16;
+constexpr int kBlkLdsFloats = 36864;  // 144 KiB of the CU's 160 KiB
+
+template <int G, int W>
+__global__ __launch_bounds__(64 * kBlkWaves) void spmm_blocked_kernel(
+    const int32_t* __restrict__ blkptr, int64_t n_nodes, int n_blocks, const int32_t* __restrict__ src,
+    const float* __restrict__ val, const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows,
+    int F, const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale,
+    float* __restrict__ out, int64_t ldo, int rpw) {
+    using V = typename Vec<W>::T;
+    constexpr int S = 64 / G;       // rows walked concurrently by one wave
+    constexpr int RW = G * W;       // floats of LDS per accumulator row
+    __shared__ __attribute__((aligned(16))) float acc_lds[kBlkLdsFloats];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int slot = lane / G;
+    const int li = lane % G;
+    const int col = li * W;
+    const bool active = col < F;
+    const float* xcol = x + col;
+    float* my = acc_lds + wave * rpw * RW;
+
+    const int64_t n_panels = (n_rows + rpw - 1) / rpw;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlkWaves + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlkWaves;
+    for (int64_t panel = first; panel < n_panels; panel += stride) {
+        const int64_t row0 = panel * rpw;
+        const int nrw = (n_rows - row0 < rpw) ? static_cast<int>(n_rows - row0) : rpw;
+        const int nq = (nrw + S - 1) / S;
+        for (int i = lane; i < rpw * RW; i += 64) my[i] = 0.f;
+
+        for (int b = 0; b < n_blocks; ++b) {
+            const int32_t* p0 = blkptr + static_cast<int64_t>(b) * n_nodes + row_begin + row0;
+            const int32_t e0v = (lane < nrw) ? p0[lane] : 0;
+            const int32_t e1v = (lane < nrw) ? p0[n_nodes + lane] : 0;
+            for (int q = 0; q < nq; ++q) {
+                const int rl = q * S + slot;
+                const int32_t e0 = __shfl(e0v, rl, 64);
+                const int32_t e1 = __shfl(e1v, rl, 64);
+                const int len = e1 - e0;
+                int maxlen = len;
+#pragma unroll
+                for (int m = G; m < 64; m <<= 1) {
+                    const int o = __shfl_xor(maxlen, m, 64);
+                    maxlen = o > maxlen ? o : maxlen;
+                }
+                if (maxlen <= 0) continue;
+                V acc = vzero<W>();
+                for (int c = 0; c < maxlen; c += G) {
+                    const int32_t idx = e0 + c + li;
+                    const bool ok = idx < e1;
+                    const int32_t s_v = ok ? __builtin_nontemporal_load(src + idx) : 0;
+                    const float w_v = ok ? __builtin_nontemporal_load(val + idx) : 0.f;
+                    const int cnt = len - c;                       // this row's entries left (may be <= 0)
+                    const int mcnt = (maxlen - c < G) ? (maxlen - c) : G;
+                    for (int j0 = 0; j0 < mcnt; j0 += kGatherUnroll) {
+                        V xv[kGatherUnroll];
+                        float w[kGatherUnroll];
+#pragma unroll
+                        for (int u = 0; u < kGatherUnroll; ++u) {
+                            const int j = j0 + u;
+                            const int from = slot * G + (j & (G - 1));
+                            const int32_t s = __shfl(s_v, from, 64);
+                            w[u] = __shfl(w_v, from, 64);
+                            const bool take = active && j < cnt && j < G;
+                            if (!take) w[u] = 0.f;
+                            xv[u] = take ? vload<W>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
+                        }
+#pragma unroll
+                        for (int u = 0; u < kGatherUnroll; ++u) acc += w[u] * xv[u];
+                    }
+                }
+                if (len > 0 && active) {
+                    float* a = my + rl * RW + col;
+                    vstore<W>(a, vload<W>(a) + acc);
+                }
+            }
+        }
+        // panel epilogue: S rows per step, each a full contiguous row segment
+        for (int q = 0; q < nq; ++q) {
+            const int rl = q * S + slot;
+            if (rl < nrw && active) {
+                const int64_t row = row0 + rl;
+                V o = gcn_scale * vload<W>(my + rl * RW + col);
+                if (attn) o += attn_scale * vload<W>(attn + row * lda + col);
+                vstore<W>(out + row * ldo + col, o);
+            }
+        }
+    }
+}
+
+template <int G, int W>
+int launch_blocked(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
+                   const float* val, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                   const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo) {
+    constexpr int S = 64 / G;
+    constexpr int RW = G * W;
+    const int rpw_max = (kBlkLdsFloats / kBlkWaves / RW < 64) ? kBlkLdsFloats / kBlkWaves / RW : 64;
+    int64_t rpw = (n_rows + static_cast<int64_t>(dif::kCUs) * kBlkWaves - 1) / (static_cast<int64_t>(dif::kCUs) * kBlkWaves);
+    if (rpw < S) rpw = S;
+    if (rpw > rpw_max) rpw = rpw_max / S * S;
+    const int64_t n_panels = (n_rows + rpw - 1) / rpw;
+    int64_t grid = (n_panels + kBlkWaves - 1) / kBlkWaves;
+    if (grid > dif::kCUs) grid = dif::kCUs;
+    hipLaunchKernelGGL((spmm_blocked_kernel<G, W>), dim3(static_cast<unsigned>(grid)), dim3(64 * kBlkWaves), 0, st,
+                       blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale,
+                       gcn_scale, out, ldo, static_cast<int>(rpw));
+    return dif::launch_status("spmm_blocked_kernel");
+}
+
 template <int G, int W>
 int launch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t* src, const float* val,
            const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
@@ -200,21 +321,32 @@ static int spmm_dispatch(bool wave_mode, hipStream_t st, const int32_t* rowptr, 
 #undef DIF_SPMM
 }
 
-extern "C" int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* src, const float* val, int64_t n_nodes,
-                                int64_t nnz, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-                                const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out,
-                                int64_t ldo, dif_stream_t stream) {
-    DIF_REQUIRE(n_rows > 0 && F > 0 && row_begin >= 0 && n_nodes > 0 && nnz >= 0, DIF_E_BADARG,
-                "dif_gcn_spmm_f32: need n_rows > 0, F > 0, row_begin >= 0, n_nodes > 0, nnz >= 0");
+extern "C" int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
+                                const float* val, int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
+                                int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
+                                float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && F > 0 && row_begin >= 0 && n_nodes > 0 && nnz >= 0 && n_blocks >= 1, DIF_E_BADARG,
+                "dif_gcn_spmm_f32: need n_rows > 0, F > 0, row_begin >= 0, n_nodes > 0, nnz >= 0, n_blocks >= 1");
     DIF_REQUIRE(row_begin + n_rows <= n_nodes, DIF_E_BADARG, "dif_gcn_spmm_f32: row range exceeds n_nodes");
     DIF_REQUIRE(rowptr && x && out && (nnz == 0 || (src && val)), DIF_E_BADARG, "dif_gcn_spmm_f32: null pointer");
+    DIF_REQUIRE(n_blocks == 1 || blkptr, DIF_E_BADARG, "dif_gcn_spmm_f32: n_blocks > 1 needs blkptr");
     DIF_REQUIRE(ldx >= F && ldo >= F && (!attn || lda >= F), DIF_E_BADARG,
                 "dif_gcn_spmm_f32: leading dimension smaller than a row");
     DIF_REQUIRE((F + 255) / 256 <= 65535, DIF_E_RANGE, "dif_gcn_spmm_f32: F too large");
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && (!attn || lda % 4 == 0) &&
                      dif::aligned16(x) && dif::aligned16(out) && (!attn || dif::aligned16(attn));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_blocks > 1 && vec && F <= 256 && nnz > 0) {
+#define DIF_BLK(G) \
+    return launch_blocked<G, 4>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, \
+                                attn_scale, gcn_scale, out, ldo)
+        if (F <= 64) DIF_BLK(16);
+        if (F <= 128) DIF_BLK(32);
+        DIF_BLK(64);
+#undef DIF_BLK
+    }
     // row mapping: a whole wave per row pays off once a row keeps the wave's gather slots busy
     const bool wave_mode = nnz / n_nodes >= 16;
-    return spmm_dispatch(wave_mode, static_cast<hipStream_t>(stream), rowptr, src, val, x, ldx, row_begin, n_rows, F,
-                         attn, lda, attn_scale, gcn_scale, out, ldo, vec);
+    return spmm_dispatch(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale,
+                         gcn_scale, out, ldo, vec);
 }

@@ -58,17 +58,34 @@ def sigmoid_attention(qs, ks, vs, shard: Optional[RowShard] = None):
 # ------------------------------------------------------------------------------------------
 # a3
 # ------------------------------------------------------------------------------------------
+L2_SLICE_BYTES = 2.5 * 2 ** 20   # target size of the x slice one source block covers (L2 is 4 MiB / XCD)
+
+
+def choose_source_blocks(num_nodes, row_bytes, nnz):
+    """Source blocks for the blocked SpMM: 1 (plain CSR) when x fits L2 or rows are too sparse for
+    the per-(row, block) groups to amortise; otherwise ~2.5 MiB of x per block, at most 64."""
+    total = float(num_nodes) * float(row_bytes)
+    if total <= 4 * 2 ** 20 or nnz < 64 * num_nodes:
+        return 1
+    nb = int(round(total / L2_SLICE_BYTES))
+    nb = max(2, min(nb, 64))
+    # keep >= ~24 entries per (row, block) group on average
+    while nb > 2 and nnz / (num_nodes * nb) < 24:
+        nb -= 1
+    return nb
+
+
 class GraphCSR:
     """Normalised adjacency in CSR over destination rows (built once per graph, on device)."""
 
-    def __init__(self, rowptr, src, val, num_nodes, nnz):
-        self.rowptr, self.src, self.val = rowptr, src, val
+    def __init__(self, rowptr, blkptr, n_blocks, src, val, num_nodes, nnz):
+        self.rowptr, self.blkptr, self.n_blocks, self.src, self.val = rowptr, blkptr, int(n_blocks), src, val
         self.num_nodes, self.nnz = int(num_nodes), int(nnz)
 
     @classmethod
-    def build(cls, edge_index, edge_weight, num_nodes):
-        rowptr, src, val = get_backend().csr_build(edge_index, edge_weight, int(num_nodes))
-        return cls(rowptr, src, val, num_nodes, edge_index.shape[1])
+    def build(cls, edge_index, edge_weight, num_nodes, n_blocks=1):
+        rowptr, blkptr, src, val = get_backend().csr_build(edge_index, edge_weight, int(num_nodes), int(n_blocks))
+        return cls(rowptr, blkptr, n_blocks, src, val, num_nodes, edge_index.shape[1])
 
 
 class _CSRCache:
@@ -82,15 +99,17 @@ class _CSRCache:
         self.entries = OrderedDict()
 
     @staticmethod
-    def _key(edge_index, edge_weight, num_nodes):
+    def _key(edge_index, edge_weight, num_nodes, n_blocks):
         k = (id(edge_index), edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes),
-             str(edge_index.device))
+             int(n_blocks), str(edge_index.device))
         if edge_weight is not None:
             k += (id(edge_weight), edge_weight.data_ptr(), edge_weight._version)
         return k
 
-    def get(self, edge_index, edge_weight, num_nodes):
-        key = self._key(edge_index, edge_weight, num_nodes)
+    def get(self, edge_index, edge_weight, num_nodes, row_bytes=256):
+        """`row_bytes` = bytes of one feature row the SpMM will gather (H*D*4); picks the blocking."""
+        n_blocks = choose_source_blocks(num_nodes, row_bytes, edge_index.shape[1])
+        key = self._key(edge_index, edge_weight, num_nodes, n_blocks)
         hit = self.entries.get(key)
         if hit is not None:
             ei_ref, ew_ref, csr = hit
@@ -98,7 +117,7 @@ class _CSRCache:
                 self.entries.move_to_end(key)
                 return csr
             del self.entries[key]
-        csr = GraphCSR.build(edge_index, edge_weight, num_nodes)
+        csr = GraphCSR.build(edge_index, edge_weight, num_nodes, n_blocks)
         self.entries[key] = (weakref.ref(edge_index), weakref.ref(edge_weight) if edge_weight is not None else None,
                              csr)
         while len(self.entries) > self.capacity:
@@ -124,8 +143,8 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
         x2 = shard.all_gather_rows(x2)         # the one exchange step: N*H*D floats
         row_begin, n_rows = shard.row_begin, shard.n_local
     a2 = None if attn is None else attn.reshape(n, H * D)
-    out = get_backend().spmm(csr.rowptr, csr.src, csr.val, csr.num_nodes, csr.nnz, x2, row_begin, n_rows, a2,
-                             attn_scale, gcn_scale)
+    out = get_backend().spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x2,
+                             row_begin, n_rows, a2, attn_scale, gcn_scale)
     return out.reshape(n_rows, H, D)
 
 

@@ -83,9 +83,13 @@ int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ld
  * dif_csr_build: COO edge_index [2,E] int64 (row = source, col = destination) -> CSR over
  * DESTINATION rows: rowptr [N+1] int32, src [E] int32 (source node of each entry) and
  * val [E] float32 = w_e * deg[col_e]^-1/2 * deg[row_e]^-1/2 with non-finite -> 0
- * (:66-74; deg = in-degree over `col`).  Entries of a row are ordered by (source, edge id):
- * stable, so the SpMM result is run-to-run deterministic.  status[0] (device int32) is set
- * non-zero if any index is outside [0,N).
+ * (:66-74; deg = in-degree over `col`).  Entries of a row are ordered by (source block, edge
+ * id) -- a stable sort, so the SpMM result is run-to-run deterministic.  n_blocks >= 1 cuts the
+ * sources into contiguous blocks of ceil(N/n_blocks) nodes; with n_blocks > 1, blkptr
+ * [(n_blocks+1) x N] int32 (block-major) receives the start of every (row, block) group and the
+ * SpMM sweeps the blocks in order so the gathered slice of x stays L2-resident (choose
+ * n_blocks ~ N*F*4 / 2.5 MiB; 1 = plain CSR).  status[0] (device int32) is set non-zero if any
+ * index is outside [0,N).
  * dif_gcn_spmm_f32: out[r, :] = gcn_scale * sum_{e in row r} val_e * x[src_e, :]
  *                                (+ attn_scale * attn[r, :] when attn != NULL)
  * for r in [row_begin, row_begin + n_rows): the adjacency product of :75-78 over all H*D
@@ -94,13 +98,13 @@ int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ld
  * rows.  n_nodes / nnz are the CSR extents (rowptr has n_nodes+1 entries, rowptr[n_nodes] = nnz);
  * they pick the row->wave mapping (wave per row for dense rows, lane group per row otherwise).
  * ------------------------------------------------------------------------------------- */
-size_t dif_csr_workspace_bytes(int64_t E, int64_t N);
+size_t dif_csr_workspace_bytes(int64_t E, int64_t N, int n_blocks);
 int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, const float* edge_weight,
-                  int32_t* rowptr, int32_t* src, float* val, int32_t* status, void* workspace,
-                  size_t workspace_bytes, dif_stream_t stream);
-int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* src, const float* val,
-                     int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
-                     int64_t row_begin, int64_t n_rows, int F,
+                  int n_blocks, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
+                  int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream);
+int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
+                     const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
+                     const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                      const float* attn, int64_t lda, float attn_scale, float gcn_scale,
                      float* out, int64_t ldo, dif_stream_t stream);
 

@@ -14,10 +14,10 @@ for span in (2048, 8192, 16384, 32768, 65536, n):
     ei = torch.stack([src, dst])
     csr = ops.GraphCSR.build(ei, None, n)
     for _ in range(2):
-        be.spmm(csr.rowptr, csr.src, csr.val, n, e, x, 0, n)
+        be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, n, e, x, 0, n)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5):
-        be.spmm(csr.rowptr, csr.src, csr.val, n, e, x, 0, n)
+        be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, n, e, x, 0, n)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     print(f"span {span:7d} rows ({span*256/2**20:6.1f} MiB): {dt*1e3:.3f} ms  gather {e*256/dt/1e12:.2f} TB/s", flush=True)
     del csr, ei, src

@@ -165,11 +165,25 @@ def test_sigmoid_attention_saturated_scores(dev):
 
 
 # ------------------------------------------------------------------ a3
-def _csr_reference(edge_index, n, edge_weight):
+def _csr_reference(edge_index, n, edge_weight, n_blocks=1):
+    """numpy statement of the CSR layout: entries sorted (stably) by destination, then source block."""
     row, col, val = orc.gcn_edge_values(edge_index, n, edge_weight, dtype=np.float32)
-    order = np.argsort(col, kind="stable")
-    rowptr = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=n))]).astype(np.int32)
-    return rowptr, row[order].astype(np.int32), val[order]
+    block_rows = -(-n // n_blocks)
+    key = col * n_blocks + row // block_rows
+    order = np.argsort(key, kind="stable")
+    kptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=n * n_blocks))]).astype(np.int32)
+    rowptr = kptr[::n_blocks].copy()
+    blkptr = np.concatenate([kptr[:-1].reshape(n, n_blocks).T, kptr[n_blocks::n_blocks][None]], axis=0)
+    return rowptr, row[order].astype(np.int32), val[order], blkptr.astype(np.int32)
+
+
+def _check_csr(csr, edge_index, n, w, n_blocks):
+    rp, src, val, blk = _csr_reference(edge_index, n, w, n_blocks)
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rp)                                   # integer work: exact
+    assert np.array_equal(csr.src.cpu().numpy()[: csr.nnz], src)
+    assert np.array_equal(csr.val.cpu().numpy()[: csr.nnz].view(np.uint32), val.view(np.uint32))  # bit-exact
+    if n_blocks > 1:
+        assert np.array_equal(csr.blkptr.cpu().numpy().reshape(n_blocks + 1, n), blk)
 
 
 @pytest.mark.parametrize("name", sorted(GCN))
@@ -180,13 +194,14 @@ def test_gcn_conv_golden(name, dev):
     ei = t(c["edge_index"], dev)
     wt = None if w is None else t(w, dev)
     n = c["x"].shape[0]
-    if ei.shape[1]:
-        csr = ops.GraphCSR.build(ei, wt, n)
-        rp, src, val = _csr_reference(c["edge_index"], n, w)
-        assert np.array_equal(csr.rowptr.cpu().numpy(), rp)                       # integer work: exact
-        assert np.array_equal(csr.src.cpu().numpy()[: csr.nnz], src)
-        assert np.array_equal(csr.val.cpu().numpy()[: csr.nnz].view(np.uint32), val.view(np.uint32))  # bit-exact
-    out = gcn_conv(t(c["x"], dev), ei, wt)
+    x = t(c["x"], dev)
+    for n_blocks in (1, 3):
+        if ei.shape[1]:
+            csr = ops.GraphCSR.build(ei, wt, n, n_blocks)
+            _check_csr(csr, c["edge_index"], n, w, n_blocks)
+            out = ops.gcn_aggregate(csr, x)                  # n_blocks > 1 exercises the blocked sweep
+            assert rel_err(out.cpu().numpy(), c["out_f64"]) < 1e-5
+    out = gcn_conv(x, ei, wt)
     assert rel_err(out.cpu().numpy(), c["out_f64"]) < 1e-5
 
 
@@ -202,13 +217,13 @@ def test_gcn_conv_vs_oracle(n, e, h, d, weighted, dev):
     ei[1, : e // 3] = torch.randint(0, max(n // 50, 1), (e // 3,), generator=g)   # skewed in-degree
     w = (torch.rand(e, generator=g) + 0.1) if weighted else None
     eid, wd = ei.to(dev), None if w is None else w.to(dev)
-    csr = ops.GraphCSR.build(eid, wd, n)
-    rp, src, val = _csr_reference(ei.numpy(), n, None if w is None else w.numpy())
-    assert np.array_equal(csr.rowptr.cpu().numpy(), rp)
-    assert np.array_equal(csr.src.cpu().numpy()[: csr.nnz], src)
-    assert np.array_equal(csr.val.cpu().numpy()[: csr.nnz].view(np.uint32), val.view(np.uint32))
-    out = gcn_conv(x.to(dev), eid, wd).cpu().numpy()
     ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), None if w is None else w.double().numpy())
+    for n_blocks in (1, 5):
+        csr = ops.GraphCSR.build(eid, wd, n, n_blocks)
+        _check_csr(csr, ei.numpy(), n, None if w is None else w.numpy(), n_blocks)
+        out = ops.gcn_aggregate(csr, x.to(dev)).cpu().numpy()
+        assert rel_err(out, ref) < 1e-5, n_blocks
+    out = gcn_conv(x.to(dev), eid, wd).cpu().numpy()
     assert rel_err(out, ref) < 1e-5
 
 
