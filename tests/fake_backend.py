@@ -1,0 +1,77 @@
+"""TEST-ONLY stand-in for difformer_amd.backend_hip.HipBackend, built on the oracle.
+
+It lets the host logic (row sharding, collectives, CSR caching, module plumbing) run on CPU tensors
+in the `-m "not gpu"` suite.  It mirrors the HipBackend method contract (same arguments, same
+`reduced` record layout, same CSR layout); the product never imports it.
+"""
+import numpy as np
+import torch
+
+from oracle import difformer_oracle as orc
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+class OracleBackend:
+    name = "oracle-fake"
+    kernel_events = None
+
+    def simple_reduce(self, q, k, v):
+        q, k, v = (_np(t).astype(np.float64) for t in (q, k, v))
+        rec = np.concatenate([np.einsum("lhm,lhd->hmd", k, v).ravel(), k.sum(0).ravel(), v.sum(0).ravel(),
+                              [(q * q).sum(), (k * k).sum()]])
+        return torch.from_numpy(rec.astype(np.float32))
+
+    def simple_apply(self, q, reduced, n_global, D):
+        q = _np(q).astype(np.float64)
+        n, H, M = q.shape
+        r = _np(reduced).astype(np.float64)
+        ktv = r[: H * M * D].reshape(H, M, D)
+        ksum = r[H * M * D: H * M * D + H * M].reshape(H, M)
+        vsum = r[H * M * D + H * M: H * M * D + H * M + H * D].reshape(H, D)
+        s = 1.0 / (np.sqrt(r[-2]) * np.sqrt(r[-1]))
+        num = s * np.einsum("nhm,hmd->nhd", q, ktv) + vsum[None]
+        den = s * np.einsum("nhm,hm->nh", q, ksum)[..., None] + n_global
+        return torch.from_numpy((num / den).astype(np.float32))
+
+    def sigmoid_attention(self, q, k, v):
+        return torch.from_numpy(orc.sigmoid_attention(*(_np(t).astype(np.float64) for t in (q, k, v))).astype(np.float32))
+
+    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1):
+        ei = _np(edge_index)
+        row, col, val = orc.gcn_edge_values(ei, num_nodes, _np(edge_weight), dtype=np.float32)
+        block_rows = -(-num_nodes // n_blocks)
+        key = col * n_blocks + row // block_rows
+        order = np.argsort(key, kind="stable")
+        kptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=num_nodes * n_blocks))]).astype(np.int32)
+        rowptr = kptr[::n_blocks].copy()
+        blk = None
+        if n_blocks > 1:
+            blk = np.concatenate([kptr[:-1].reshape(num_nodes, n_blocks).T, kptr[n_blocks::n_blocks][None]], axis=0)
+            blk = torch.from_numpy(blk.astype(np.int32).ravel())
+        return (torch.from_numpy(rowptr), blk, torch.from_numpy(row[order].astype(np.int32)),
+                torch.from_numpy(val[order]))
+
+    def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
+             gcn_scale=1.0):
+        rp, s, w, xx = _np(rowptr), _np(src)[:nnz], _np(val)[:nnz].astype(np.float64), _np(x).astype(np.float64)
+        assert xx.shape[0] == n_nodes
+        dst = np.repeat(np.arange(n_nodes), np.diff(rp))
+        full = np.zeros((n_nodes, xx.shape[1]))
+        np.add.at(full, dst, w[:, None] * xx[s])
+        out = gcn_scale * full[row_begin:row_begin + n_rows]
+        if attn is not None:
+            out = out + attn_scale * _np(attn).astype(np.float64)
+        return torch.from_numpy(out.astype(np.float32))
+
+    def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps):
+        z = _np(conv).astype(np.float64).mean(axis=1)
+        if x0 is not None:
+            z = z + _np(x0)
+        if prev is not None:
+            z = alpha * z + (1.0 - alpha) * _np(prev)
+        if ln_weight is not None:
+            z = orc.layer_norm(z, _np(ln_weight).astype(np.float64), _np(ln_bias).astype(np.float64), eps)
+        return torch.from_numpy(z.astype(np.float32))

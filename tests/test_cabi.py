@@ -1,0 +1,76 @@
+"""The C-ABI shared library loads and exports exactly what include/difformer_hip.h declares.
+No compute call is made (there is no GPU here): only loading, host-side size arithmetic and the
+argument checks that run before any HIP call."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "difformer_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dif_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from difformer_amd import _lib
+    return _lib.load()
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_functions()
+    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and len(names) == 12
+
+
+def test_library_exports_every_declared_symbol(lib):
+    raw = ctypes.CDLL(lib._name)
+    for name in declared_functions():
+        assert hasattr(raw, name), f"{name} declared in difformer_hip.h but not exported"
+
+
+def test_python_binding_covers_the_header_exactly():
+    from difformer_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+
+
+def test_version_and_size_helpers(lib):
+    assert lib.dif_version() == 1
+    assert lib.dif_simple_reduced_len(1, 64, 64) == 64 * 64 + 64 + 64 + 2          # 4,226 floats
+    assert lib.dif_simple_reduced_len(2, 16, 16) == 2 * (256 + 32) + 2
+    assert lib.dif_simple_workspace_bytes(132534, 1, 64, 64) >= 4226 * 4
+    assert lib.dif_simple_workspace_bytes(0, 1, 64, 64) == 0
+    small, big = lib.dif_csr_workspace_bytes(1000, 100, 1), lib.dif_csr_workspace_bytes(79255038, 132534, 13)
+    assert 0 < small < big and big > 4 * 4 * 79255038
+    assert lib.dif_sigmoid_workspace_bytes(10, 10, 1, 8, 8) == 0
+
+
+def test_argument_checks_reject_before_touching_the_device(lib):
+    """Bad arguments return a negative DIF_E_* code and set dif_last_error; nothing is launched."""
+    rc = lib.dif_simple_reduce_f32(None, 64, None, 64, None, 64, 10, 1, 64, 64, None, None, 0, None)
+    assert rc == -1 and b"null pointer" in lib.dif_last_error()
+    rc = lib.dif_simple_reduce_f32(None, 64, None, 64, None, 64, 0, 1, 64, 64, None, None, 0, None)
+    assert rc == -1 and b"positive" in lib.dif_last_error()
+    rc = lib.dif_sigmoid_attn_f32(None, 8, None, 8, None, 8, 4, 4, 1, 8, 8, None, 8, None, 0, None)
+    assert rc == -1
+    rc = lib.dif_csr_build(None, 10, 0, None, 1, None, None, None, None, None, None, 0, None)
+    assert rc == -1
+    rc = lib.dif_csr_build(None, 2 ** 31, 10, None, 1, None, None, None, None, None, None, 0, None)
+    assert rc == -4                                                                    # DIF_E_RANGE
+    rc = lib.dif_gcn_spmm_f32(None, None, 1, None, None, 10, 5, None, 8, 0, 20, 8, None, 0, 1.0, 1.0, None, 8, None)
+    assert rc == -1 and b"row range" in lib.dif_last_error()
+    rc = lib.dif_layer_tail_f32(None, 8, 4, 1, 8, None, 0, None, 0, 0.5, None, None, 1e-5, None, 8, None)
+    assert rc == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from difformer_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU / eager fallback"):
+        _lib.load()
