@@ -23,6 +23,9 @@ SIGNATURES = {
     "dif_simple_reduce_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int,
                                       c_vp, c_vp, c_sz, c_vp]),
     "dif_simple_apply_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp]),
+    "dif_project_reduce_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
+    "dif_project_reduce_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                                       c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "dif_sigmoid_workspace_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
     "dif_sigmoid_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int,
                                      c_vp, c_i64, c_vp, c_sz, c_vp]),
@@ -31,7 +34,10 @@ SIGNATURES = {
     "dif_gcn_spmm_f32": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int,
                                  c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "dif_layer_tail_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,
-                                   c_vp, c_vp, c_f32, c_vp, c_i64, c_vp]),
+                                   c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
+    "dif_gcn_spmm_tail_f32": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int,
+                                      c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp, c_f32,
+                                      c_vp, c_i64, c_vp]),
 }
 
 _lib = None
@@ -39,6 +45,10 @@ _lib = None
 
 class DifformerHipError(RuntimeError):
     """A C-ABI call returned non-zero (argument rejected or HIP runtime failure)."""
+
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
 
 
 def _single_hip_runtime():
@@ -83,4 +93,4 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().dif_last_error()
-        raise DifformerHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+        raise DifformerHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}", rc)

@@ -143,7 +143,27 @@ def gcn_aggregate(csr, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard=None):
     return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard)
 
 
+def gcn_aggregate_tail(csr, x, attn, attn_scale, gcn_scale, shard, x0, prev, alpha, ln_weight, ln_bias, eps):
+    """SpMM + combine + layer tail -> [n, D].  One fused kernel when nothing needs a gradient and the
+    layer has a single head; otherwise the two operators run back to back."""
+    d = x.shape[2]
+    fused = (x.shape[1] == 1 and (d <= 64 or (d % 4 == 0 and d <= 256)) and
+             not _needs_grad(x, attn, x0, prev, ln_weight, ln_bias))
+    if fused:
+        tail = dict(x0=x0, prev=prev, alpha=alpha, ln_weight=ln_weight, ln_bias=ln_bias, eps=eps)
+        return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard, tail)[:, 0, :]
+    conv = gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard)
+    return layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
+
+
 def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5):
     if _needs_grad(conv, x0, prev, ln_weight, ln_bias):
         return _LayerTail.apply(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
     return ops.layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
+
+
+def norm_relu(x, ln_weight, ln_bias, eps):
+    """LayerNorm -> ReLU of the input layer (difformer.py:189-191) in one kernel when no gradient is needed."""
+    if _needs_grad(x, ln_weight, ln_bias):
+        return torch.relu(torch.nn.functional.layer_norm(x, (x.shape[-1],), ln_weight, ln_bias, eps))
+    return ops.layer_tail(x.unsqueeze(1), None, None, 0.5, ln_weight, ln_bias, eps, relu=True)

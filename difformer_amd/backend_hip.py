@@ -112,6 +112,23 @@ class HipBackend:
         _lib.check(rc, "dif_simple_reduce_f32")
         return reduced
 
+    def project_reduce(self, x, Wq, bq, Wk, bk, Wv, bv, H, D):
+        """x [n,C] -> (q [n,H,D], v [n,H,D], reduced): projections fused with stage 1 of the simple kernel."""
+        dev = _require_device(x, Wq, bq, Wk, bk, Wv, bv)
+        n, C = x.shape
+        x, ldx = _row_major(_f32(x, "x"), C)
+        ws_ = [_f32(t, "projection parameter").contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
+        q = torch.empty((n, H, D), dtype=torch.float32, device=dev)
+        v = torch.empty((n, H, D), dtype=torch.float32, device=dev)
+        reduced = torch.empty(self.lib.dif_simple_reduced_len(H, D, D), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.dif_project_reduce_workspace_bytes(n, H, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_project_reduce_f32", dev):
+            rc = self.lib.dif_project_reduce_f32(_ptr(x), ldx, n, C, *[_ptr(t) for t in ws_], H, D, _ptr(q), H * D,
+                                                 _ptr(v), H * D, _ptr(reduced), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_project_reduce_f32")
+        return q, v, reduced
+
     def simple_apply(self, q, reduced, n_global, D):
         dev = _require_device(q, reduced)
         n, H, M = q.shape
@@ -168,7 +185,8 @@ class HipBackend:
         return rowptr, blkptr, src, val
 
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
-             gcn_scale=1.0):
+             gcn_scale=1.0, tail=None):
+        """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps): fuse the layer tail (H == 1)."""
         dev = _require_device(rowptr, blkptr, src, val, x, attn)
         F = x.shape[1]
         x, ldx = _row_major(_f32(x, "x"), F)
@@ -178,16 +196,33 @@ class HipBackend:
         if attn is not None:
             attn, lda = _row_major(_f32(attn, "attn"), F)
         out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
+        if tail is None:
+            with _Timed(self, "dif_gcn_spmm_f32", dev):
+                rc = self.lib.dif_gcn_spmm_f32(_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes, nnz,
+                                               _ptr(x), ldx, row_begin, n_rows, F, _ptr(attn), lda, float(attn_scale),
+                                               float(gcn_scale), _ptr(out), F, _stream(dev))
+            _lib.check(rc, "dif_gcn_spmm_f32")
+            return out
+        x0, prev, lw, lb = tail.get("x0"), tail.get("prev"), tail.get("ln_weight"), tail.get("ln_bias")
+        _require_device(x0, prev, lw, lb)
+        ldx0 = ldp = 0
+        if x0 is not None:
+            x0, ldx0 = _row_major(_f32(x0, "x0"), F)
+        if prev is not None:
+            prev, ldp = _row_major(_f32(prev, "prev"), F)
+        if lw is not None:
+            lw, lb = lw.contiguous(), lb.contiguous()
         with _Timed(self, "dif_gcn_spmm_f32", dev):
-            rc = self.lib.dif_gcn_spmm_f32(_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes, nnz,
-                                           _ptr(x), ldx,
-                                           row_begin, n_rows, F, _ptr(attn), lda, float(attn_scale),
-                                           float(gcn_scale), _ptr(out), F, _stream(dev))
-        _lib.check(rc, "dif_gcn_spmm_f32")
+            rc = self.lib.dif_gcn_spmm_tail_f32(_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes,
+                                                nnz, _ptr(x), ldx, row_begin, n_rows, F, _ptr(attn), lda,
+                                                float(attn_scale), float(gcn_scale), _ptr(x0), ldx0, _ptr(prev), ldp,
+                                                float(tail.get("alpha", 0.5)), _ptr(lw), _ptr(lb),
+                                                float(tail.get("eps", 1e-5)), _ptr(out), F, _stream(dev))
+        _lib.check(rc, "dif_gcn_spmm_tail_f32")
         return out
 
     # ---- a4 / a5 tail ----------------------------------------------------------------------
-    def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps):
+    def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         dev = _require_device(conv, x0, prev, ln_weight, ln_bias)
         n, H, D = conv.shape
         conv, ldc = _row_major(_f32(conv, "conv"), H * D)
@@ -202,6 +237,6 @@ class HipBackend:
         with _Timed(self, "dif_layer_tail_f32", dev):
             rc = self.lib.dif_layer_tail_f32(_ptr(conv), ldc, n, H, D, _ptr(x0), ldx0, _ptr(prev), ldp,
                                              float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
-                                             _ptr(out), D, _stream(dev))
+                                             int(bool(relu)), _ptr(out), D, _stream(dev))
         _lib.check(rc, "dif_layer_tail_f32")
         return out

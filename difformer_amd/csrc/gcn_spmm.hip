@@ -55,6 +55,45 @@ __device__ __forceinline__ typename Vec<W>::T vshfl_xor(typename Vec<W>::T v, in
     }
 }
 
+// Optional fused layer tail (H == 1 only; difformer.py:139-140, :200-203): applied to the finished
+// row `o` held by a G-lane group (W floats per lane, lanes with col >= F inactive).
+struct Tail {
+    const float* x0;   int64_t ldx0;   // += x_0            (use_source)
+    const float* prev; int64_t ldp;    // alpha-residual    (use_residual)
+    float alpha;
+    const float* ln_w; const float* ln_b; float eps;   // LayerNorm (use_bn)
+    int enabled;
+};
+
+template <int G, int W>
+__device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, const Tail& t, int64_t row, int col,
+                                                         bool ok, int F) {
+    using V = typename Vec<W>::T;
+    if (ok) {
+        if (t.x0) o += vload<W>(t.x0 + row * t.ldx0 + col);
+        if (t.prev) o = t.alpha * o + (1.0f - t.alpha) * vload<W>(t.prev + row * t.ldp + col);
+    }
+    if (t.ln_w) {   // wave-uniform
+        const float inv_d = 1.0f / static_cast<float>(F);
+        float s = 0.f;
+        if (ok) { if constexpr (W == 4) s = o[0] + o[1] + o[2] + o[3]; else s = o; }
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) s += __shfl_xor(s, m, 64);
+        const float mu = s * inv_d;
+        V dz = vzero<W>();
+        float v = 0.f;
+        if (ok) {
+            dz = o - mu;
+            if constexpr (W == 4) v = dz[0] * dz[0] + dz[1] * dz[1] + dz[2] * dz[2] + dz[3] * dz[3]; else v = dz * dz;
+        }
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+        const float rstd = 1.0f / sqrtf(v * inv_d + t.eps);
+        if (ok) o = dz * rstd * vload<W>(t.ln_w + col) + vload<W>(t.ln_b + col);
+    }
+    return o;
+}
+
 constexpr int kGatherUnroll = 8;
 
 // ---- whole wave per destination row ---------------------------------------------------------
@@ -63,8 +102,8 @@ template <int G, int W>
 __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const float* __restrict__ val,
     const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-    const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, float* __restrict__ out,
-    int64_t ldo) {
+    const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail tail,
+    float* __restrict__ out, int64_t ldo) {
     using V = typename Vec<W>::T;
     constexpr int EPW = 64 / G;  // entries gathered per wave instruction
     const int lane = threadIdx.x & 63;
@@ -103,11 +142,11 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
         // fold the EPW partial rows (fixed tree)
 #pragma unroll
         for (int m = G; m < 64; m <<= 1) acc += vshfl_xor<W>(acc, m);
-        if (sub == 0 && active) {
-            V o = gcn_scale * acc;
-            if (attn) o += attn_scale * vload<W>(attn + row * lda + col);
-            vstore<W>(out + row * ldo + col, o);
-        }
+        const bool ok = (sub == 0 && active);
+        V o = gcn_scale * acc;
+        if (ok && attn) o += attn_scale * vload<W>(attn + row * lda + col);
+        if (tail.enabled) o = apply_tail<G, W>(o, tail, row, col, ok, F);
+        if (ok) vstore<W>(out + row * ldo + col, o);
     }
 }
 
@@ -116,8 +155,8 @@ template <int G, int W>
 __global__ __launch_bounds__(256) void spmm_group_row_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const float* __restrict__ val,
     const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-    const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, float* __restrict__ out,
-    int64_t ldo) {
+    const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail tail,
+    float* __restrict__ out, int64_t ldo) {
     using V = typename Vec<W>::T;
     constexpr int RPB = 256 / G;  // rows per block
     const int li = threadIdx.x % G;
@@ -127,9 +166,9 @@ __global__ __launch_bounds__(256) void spmm_group_row_kernel(
     const int64_t nrb = (n_rows + RPB - 1) / RPB;
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         const int64_t row = rb * RPB + threadIdx.x / G;
-        if (row >= n_rows) continue;
-        const int64_t r = row_begin + row;
-        const int32_t e0 = rowptr[r], e1 = rowptr[r + 1];
+        const bool rok = row < n_rows;
+        const int64_t r = row_begin + (rok ? row : 0);
+        const int32_t e0 = rok ? rowptr[r] : 0, e1 = rok ? rowptr[r + 1] : 0;
         V acc = vzero<W>();
         for (int32_t e = e0; e < e1; e += 4) {
             V xv[4];
@@ -144,11 +183,11 @@ __global__ __launch_bounds__(256) void spmm_group_row_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc += w[u] * xv[u];
         }
-        if (active) {
-            V o = gcn_scale * acc;
-            if (attn) o += attn_scale * vload<W>(attn + row * lda + col);
-            vstore<W>(out + row * ldo + col, o);
-        }
+        const bool ok = active && rok;
+        V o = gcn_scale * acc;
+        if (ok && attn) o += attn_scale * vload<W>(attn + row * lda + col);
+        if (tail.enabled) o = apply_tail<G, W>(o, tail, row, col, ok, F);
+        if (ok) vstore<W>(out + row * ldo + col, o);
     }
 }
 
@@ -162,19 +201,22 @@ __global__ __launch_bounds__(256) void spmm_group_row_kernel(
 // Inside a block visit the wave's S = 64/G lane groups each walk one row's group of entries:
 // G entries are fetched per lane group with one coalesced (non-temporal) load of src/val, then
 // handed out by ds_bpermute, so there is no per-entry index load and no cross-lane reduction.
-constexpr int kBlkWaves = 16;
-constexpr int kBlkLdsFloats = 36864;  // 144 KiB of the CU's 160 KiB
+constexpr int kBlkWaves = 16;          // waves per workgroup
+constexpr int kBlkLdsBytesPerCU = 147456;  // 144 KiB of the CU's 160 KiB for accumulators
+constexpr int kBlkPre = 4;             // G-entry chunks of a (row, block) group fetched in one batch
 
-template <int G, int W>
-__global__ __launch_bounds__(64 * kBlkWaves) void spmm_blocked_kernel(
+// WPC = workgroups per CU (1: 16 waves/CU, 128-VGPR budget; 2: 32 waves/CU, 64-VGPR budget)
+template <int G, int W, int WPC, int UNROLL>
+__global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_blocked_kernel(
     const int32_t* __restrict__ blkptr, int64_t n_nodes, int n_blocks, const int32_t* __restrict__ src,
     const float* __restrict__ val, const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows,
-    int F, const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale,
+    int F, const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail tail,
     float* __restrict__ out, int64_t ldo, int rpw) {
     using V = typename Vec<W>::T;
     constexpr int S = 64 / G;       // rows walked concurrently by one wave
     constexpr int RW = G * W;       // floats of LDS per accumulator row
-    __shared__ __attribute__((aligned(16))) float acc_lds[kBlkLdsFloats];
+    constexpr int kLdsFloats = kBlkLdsBytesPerCU / 4 / WPC;
+    __shared__ __attribute__((aligned(16))) float acc_lds[kLdsFloats];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -198,10 +240,36 @@ __global__ __launch_bounds__(64 * kBlkWaves) void spmm_blocked_kernel(
             const int32_t* p0 = blkptr + static_cast<int64_t>(b) * n_nodes + row_begin + row0;
             const int32_t e0v = (lane < nrw) ? p0[lane] : 0;
             const int32_t e1v = (lane < nrw) ? p0[n_nodes + lane] : 0;
+
+            // entries of the NEXT quad are fetched while the current one gathers
+            int32_t e0n = __shfl(e0v, slot, 64), e1n = __shfl(e1v, slot, 64);
+            int32_t sn[kBlkPre];
+            float wn[kBlkPre];
+#pragma unroll
+            for (int c = 0; c < kBlkPre; ++c) {
+                const int32_t idx = e0n + c * G + li;
+                const bool ok = idx < e1n;
+                sn[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
+                wn[c] = ok ? __builtin_nontemporal_load(val + idx) : 0.f;
+            }
             for (int q = 0; q < nq; ++q) {
                 const int rl = q * S + slot;
-                const int32_t e0 = __shfl(e0v, rl, 64);
-                const int32_t e1 = __shfl(e1v, rl, 64);
+                const int32_t e0 = e0n, e1 = e1n;
+                int32_t sv[kBlkPre];
+                float wv[kBlkPre];
+#pragma unroll
+                for (int c = 0; c < kBlkPre; ++c) { sv[c] = sn[c]; wv[c] = wn[c]; }
+                if (q + 1 < nq) {
+                    e0n = __shfl(e0v, rl + S, 64);
+                    e1n = __shfl(e1v, rl + S, 64);
+#pragma unroll
+                    for (int c = 0; c < kBlkPre; ++c) {
+                        const int32_t idx = e0n + c * G + li;
+                        const bool ok = idx < e1n;
+                        sn[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
+                        wn[c] = ok ? __builtin_nontemporal_load(val + idx) : 0.f;
+                    }
+                }
                 const int len = e1 - e0;
                 int maxlen = len;
 #pragma unroll
@@ -211,28 +279,36 @@ __global__ __launch_bounds__(64 * kBlkWaves) void spmm_blocked_kernel(
                 }
                 if (maxlen <= 0) continue;
                 V acc = vzero<W>();
-                for (int c = 0; c < maxlen; c += G) {
-                    const int32_t idx = e0 + c + li;
-                    const bool ok = idx < e1;
-                    const int32_t s_v = ok ? __builtin_nontemporal_load(src + idx) : 0;
-                    const float w_v = ok ? __builtin_nontemporal_load(val + idx) : 0.f;
-                    const int cnt = len - c;                       // this row's entries left (may be <= 0)
-                    const int mcnt = (maxlen - c < G) ? (maxlen - c) : G;
-                    for (int j0 = 0; j0 < mcnt; j0 += kGatherUnroll) {
-                        V xv[kGatherUnroll];
-                        float w[kGatherUnroll];
+                for (int c0 = 0; c0 < maxlen; c0 += kBlkPre * G) {
+                    if (c0 > 0) {  // rare: a group longer than kBlkPre*G entries
 #pragma unroll
-                        for (int u = 0; u < kGatherUnroll; ++u) {
-                            const int j = j0 + u;
-                            const int from = slot * G + (j & (G - 1));
-                            const int32_t s = __shfl(s_v, from, 64);
-                            w[u] = __shfl(w_v, from, 64);
-                            const bool take = active && j < cnt && j < G;
-                            if (!take) w[u] = 0.f;
-                            xv[u] = take ? vload<W>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
+                        for (int c = 0; c < kBlkPre; ++c) {
+                            const int32_t idx = e0 + c0 + c * G + li;
+                            const bool ok = idx < e1;
+                            sv[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
+                            wv[c] = ok ? __builtin_nontemporal_load(val + idx) : 0.f;
                         }
+                    }
 #pragma unroll
-                        for (int u = 0; u < kGatherUnroll; ++u) acc += w[u] * xv[u];
+                    for (int c = 0; c < kBlkPre; ++c) {
+#pragma unroll
+                        for (int j0 = 0; j0 < G; j0 += UNROLL) {
+                            if (c0 + c * G + j0 < maxlen) {        // wave-uniform
+                                V xv[UNROLL];
+                                float w[UNROLL];
+#pragma unroll
+                                for (int u = 0; u < UNROLL; ++u) {
+                                    const int from = slot * G + j0 + u;
+                                    const int32_t sidx = __shfl(sv[c], from, 64);
+                                    w[u] = __shfl(wv[c], from, 64);
+                                    const bool take = active && (c0 + c * G + j0 + u < len);
+                                    if (!take) w[u] = 0.f;
+                                    xv[u] = take ? vload<W>(xcol + static_cast<int64_t>(sidx) * ldx) : vzero<W>();
+                                }
+#pragma unroll
+                                for (int u = 0; u < UNROLL; ++u) acc += w[u] * xv[u];
+                            }
+                        }
                     }
                 }
                 if (len > 0 && active) {
@@ -244,52 +320,69 @@ __global__ __launch_bounds__(64 * kBlkWaves) void spmm_blocked_kernel(
         // panel epilogue: S rows per step, each a full contiguous row segment
         for (int q = 0; q < nq; ++q) {
             const int rl = q * S + slot;
-            if (rl < nrw && active) {
-                const int64_t row = row0 + rl;
-                V o = gcn_scale * vload<W>(my + rl * RW + col);
+            const bool ok = rl < nrw && active;
+            const int64_t row = row0 + rl;
+            V o = vzero<W>();
+            if (ok) {
+                o = gcn_scale * vload<W>(my + rl * RW + col);
                 if (attn) o += attn_scale * vload<W>(attn + row * lda + col);
-                vstore<W>(out + row * ldo + col, o);
             }
+            if (tail.enabled) o = apply_tail<G, W>(o, tail, row, col, ok, F);
+            if (ok) vstore<W>(out + row * ldo + col, o);
         }
     }
+}
+
+template <int G, int W, int WPC, int UNROLL>
+int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
+                     const float* val, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                     const float* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail& tail, float* out,
+        int64_t ldo) {
+    constexpr int S = 64 / G;
+    constexpr int RW = G * W;
+    constexpr int kLdsFloats = kBlkLdsBytesPerCU / 4 / WPC;
+    const int64_t slots = static_cast<int64_t>(dif::kCUs) * WPC * kBlkWaves;   // waves resident on the chip
+    const int rpw_max = (kLdsFloats / kBlkWaves / RW < 64) ? kLdsFloats / kBlkWaves / RW : 64;
+    int64_t rpw = (n_rows + slots - 1) / slots;
+    if (rpw < S) rpw = S;
+    if (rpw > rpw_max) rpw = rpw_max / S * S;
+    const int64_t n_panels = (n_rows + rpw - 1) / rpw;
+    int64_t grid = (n_panels + kBlkWaves - 1) / kBlkWaves;
+    if (grid > dif::kCUs * WPC) grid = dif::kCUs * WPC;
+    hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL>), dim3(static_cast<unsigned>(grid)),
+                       dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F,
+                       attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
+    return dif::launch_status("spmm_blocked_kernel");
 }
 
 template <int G, int W>
 int launch_blocked(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
                    const float* val, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-                   const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo) {
-    constexpr int S = 64 / G;
-    constexpr int RW = G * W;
-    const int rpw_max = (kBlkLdsFloats / kBlkWaves / RW < 64) ? kBlkLdsFloats / kBlkWaves / RW : 64;
-    int64_t rpw = (n_rows + static_cast<int64_t>(dif::kCUs) * kBlkWaves - 1) / (static_cast<int64_t>(dif::kCUs) * kBlkWaves);
-    if (rpw < S) rpw = S;
-    if (rpw > rpw_max) rpw = rpw_max / S * S;
-    const int64_t n_panels = (n_rows + rpw - 1) / rpw;
-    int64_t grid = (n_panels + kBlkWaves - 1) / kBlkWaves;
-    if (grid > dif::kCUs) grid = dif::kCUs;
-    hipLaunchKernelGGL((spmm_blocked_kernel<G, W>), dim3(static_cast<unsigned>(grid)), dim3(64 * kBlkWaves), 0, st,
-                       blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale,
-                       gcn_scale, out, ldo, static_cast<int>(rpw));
-    return dif::launch_status("spmm_blocked_kernel");
+                   const float* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail& tail, float* out,
+        int64_t ldo) {
+    // 1 workgroup (16 waves) per CU, 8 gathers in flight per wave: best of the measured variants
+    // (2 workgroups per CU need a 64-VGPR budget and spill)
+    return launch_blocked_v<G, W, 1, 8>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn,
+                                        lda, attn_scale, gcn_scale, tail, out, ldo);
 }
 
 template <int G, int W>
 int launch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t* src, const float* val,
            const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
-           float attn_scale, float gcn_scale, float* out, int64_t ldo) {
+           float attn_scale, float gcn_scale, const Tail& tail, float* out, int64_t ldo) {
     const int gy = (F + G * W - 1) / (G * W);
     const int64_t cap = 8 * dif::kCUs;
     if (wave_mode) {
         int64_t gx = (n_rows + 3) / 4;
         if (gx > cap) gx = cap;
         hipLaunchKernelGGL((spmm_wave_row_kernel<G, W>), dim3(static_cast<unsigned>(gx), gy), dim3(256), 0, st, rowptr,
-                           src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, out, ldo);
+                           src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, tail, out, ldo);
     } else {
         constexpr int RPB = 256 / G;
         int64_t gx = (n_rows + RPB - 1) / RPB;
         if (gx > cap) gx = cap;
         hipLaunchKernelGGL((spmm_group_row_kernel<G, W>), dim3(static_cast<unsigned>(gx), gy), dim3(256), 0, st,
-                           rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, out, ldo);
+                           rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, tail, out, ldo);
     }
     return dif::launch_status("spmm kernel");
 }
@@ -298,10 +391,10 @@ int launch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t*
 
 static int spmm_dispatch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t* src,
                          const float* val, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-                         const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo,
-                         bool vec) {
+                         const float* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail& tail,
+                         float* out, int64_t ldo, bool vec) {
 #define DIF_SPMM(G, W) \
-    return launch<G, W>(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, out, ldo)
+    return launch<G, W>(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, tail, out, ldo)
     if (vec) {
         const int q = F / 4;
         if (q <= 1) DIF_SPMM(1, 4);
@@ -321,25 +414,37 @@ static int spmm_dispatch(bool wave_mode, hipStream_t st, const int32_t* rowptr, 
 #undef DIF_SPMM
 }
 
-extern "C" int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
-                                const float* val, int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
-                                int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
-                                float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream) {
+static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src, const float* val,
+                      int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows,
+                      int F, const float* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail& tail,
+                      float* out, int64_t ldo, dif_stream_t stream) {
     DIF_REQUIRE(n_rows > 0 && F > 0 && row_begin >= 0 && n_nodes > 0 && nnz >= 0 && n_blocks >= 1, DIF_E_BADARG,
-                "dif_gcn_spmm_f32: need n_rows > 0, F > 0, row_begin >= 0, n_nodes > 0, nnz >= 0, n_blocks >= 1");
-    DIF_REQUIRE(row_begin + n_rows <= n_nodes, DIF_E_BADARG, "dif_gcn_spmm_f32: row range exceeds n_nodes");
-    DIF_REQUIRE(rowptr && x && out && (nnz == 0 || (src && val)), DIF_E_BADARG, "dif_gcn_spmm_f32: null pointer");
-    DIF_REQUIRE(n_blocks == 1 || blkptr, DIF_E_BADARG, "dif_gcn_spmm_f32: n_blocks > 1 needs blkptr");
+                "dif_gcn_spmm: need n_rows > 0, F > 0, row_begin >= 0, n_nodes > 0, nnz >= 0, n_blocks >= 1");
+    DIF_REQUIRE(row_begin + n_rows <= n_nodes, DIF_E_BADARG, "dif_gcn_spmm: row range exceeds n_nodes");
+    DIF_REQUIRE(rowptr && x && out && (nnz == 0 || (src && val)), DIF_E_BADARG, "dif_gcn_spmm: null pointer");
+    DIF_REQUIRE(n_blocks == 1 || blkptr, DIF_E_BADARG, "dif_gcn_spmm: n_blocks > 1 needs blkptr");
     DIF_REQUIRE(ldx >= F && ldo >= F && (!attn || lda >= F), DIF_E_BADARG,
-                "dif_gcn_spmm_f32: leading dimension smaller than a row");
-    DIF_REQUIRE((F + 255) / 256 <= 65535, DIF_E_RANGE, "dif_gcn_spmm_f32: F too large");
-    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && (!attn || lda % 4 == 0) &&
-                     dif::aligned16(x) && dif::aligned16(out) && (!attn || dif::aligned16(attn));
+                "dif_gcn_spmm: leading dimension smaller than a row");
+    DIF_REQUIRE((F + 255) / 256 <= 65535, DIF_E_RANGE, "dif_gcn_spmm: F too large");
+    bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && (!attn || lda % 4 == 0) &&
+               dif::aligned16(x) && dif::aligned16(out) && (!attn || dif::aligned16(attn));
+    if (tail.enabled) {
+        DIF_REQUIRE((tail.ln_w == nullptr) == (tail.ln_b == nullptr), DIF_E_BADARG,
+                    "dif_gcn_spmm_tail_f32: ln_weight and ln_bias must be given together");
+        DIF_REQUIRE((!tail.x0 || tail.ldx0 >= F) && (!tail.prev || tail.ldp >= F), DIF_E_BADARG,
+                    "dif_gcn_spmm_tail_f32: leading dimension smaller than a row");
+        vec = vec && (!tail.x0 || (tail.ldx0 % 4 == 0 && dif::aligned16(tail.x0))) &&
+              (!tail.prev || (tail.ldp % 4 == 0 && dif::aligned16(tail.prev))) &&
+              (!tail.ln_w || (dif::aligned16(tail.ln_w) && dif::aligned16(tail.ln_b)));
+        // the LayerNorm statistics are folded inside one lane group: the whole row must fit it
+        DIF_REQUIRE(F <= (vec ? 256 : 64), DIF_E_SHAPE, "dif_gcn_spmm_tail_f32: fused tail needs F <= %d here",
+                    vec ? 256 : 64);
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n_blocks > 1 && vec && F <= 256 && nnz > 0) {
 #define DIF_BLK(G) \
     return launch_blocked<G, 4>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, \
-                                attn_scale, gcn_scale, out, ldo)
+                                attn_scale, gcn_scale, tail, out, ldo)
         if (F <= 64) DIF_BLK(16);
         if (F <= 128) DIF_BLK(32);
         DIF_BLK(64);
@@ -348,5 +453,26 @@ extern "C" int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, in
     // row mapping: a whole wave per row pays off once a row keeps the wave's gather slots busy
     const bool wave_mode = nnz / n_nodes >= 16;
     return spmm_dispatch(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale,
-                         gcn_scale, out, ldo, vec);
+                         gcn_scale, tail, out, ldo, vec);
+}
+
+extern "C" int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
+                                const float* val, int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
+                                int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
+                                float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream) {
+    Tail tail = {};
+    return spmm_entry(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
+                      attn_scale, gcn_scale, tail, out, ldo, stream);
+}
+
+extern "C" int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
+                                     const float* val, int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
+                                     int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
+                                     float attn_scale, float gcn_scale, const float* x0, int64_t ldx0,
+                                     const float* prev, int64_t ldp, float alpha, const float* ln_weight,
+                                     const float* ln_bias, float ln_eps, float* out, int64_t ldo,
+                                     dif_stream_t stream) {
+    Tail tail = {x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, 1};
+    return spmm_entry(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
+                      attn_scale, gcn_scale, tail, out, ldo, stream);
 }

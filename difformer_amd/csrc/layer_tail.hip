@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void layer_tail_vec_kernel(const float* __rest
                                                              const float* __restrict__ x0, int64_t ldx0,
                                                              const float* __restrict__ prev, int64_t ldp, float alpha,
                                                              const float* __restrict__ ln_w,
-                                                             const float* __restrict__ ln_b, float eps,
+                                                             const float* __restrict__ ln_b, float eps, int relu,
                                                              float* __restrict__ out, int64_t ldo) {
     constexpr int RPB = 256 / G;
     const int li = threadIdx.x % G;
@@ -52,6 +52,10 @@ __global__ __launch_bounds__(256) void layer_tail_vec_kernel(const float* __rest
             const float rstd = 1.0f / sqrtf(v * inv_d + eps);
             z = dz * rstd * w4 + b4;
         }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = fmaxf(z[i], 0.f);
+        }
         if (ok) *reinterpret_cast<f32x4*>(out + row * ldo + col) = z;
     }
 }
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void layer_tail_generic_kernel(const float* __
                                                                  const float* __restrict__ x0, int64_t ldx0,
                                                                  const float* __restrict__ prev, int64_t ldp,
                                                                  float alpha, const float* __restrict__ ln_w,
-                                                                 const float* __restrict__ ln_b, float eps,
+                                                                 const float* __restrict__ ln_b, float eps, int relu,
                                                                  float* __restrict__ out, int64_t ldo) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void layer_tail_generic_kernel(const float* __
             if (H > 1) z *= inv_h;
             if (x0) z += x0[row * ldx0 + d];
             if (prev) z = alpha * z + (1.0f - alpha) * prev[row * ldp + d];
-            out[row * ldo + d] = z;
+            out[row * ldo + d] = (relu && !ln_w) ? fmaxf(z, 0.f) : z;
             s += z;
         }
         if (!ln_w) continue;
@@ -85,7 +89,10 @@ __global__ __launch_bounds__(256) void layer_tail_generic_kernel(const float* __
         float v = 0.f;
         for (int d = lane; d < D; d += 64) { const float dz = out[row * ldo + d] - mu; v += dz * dz; }
         const float rstd = 1.0f / sqrtf(dif::wave_sum(v) * inv_d + eps);
-        for (int d = lane; d < D; d += 64) out[row * ldo + d] = (out[row * ldo + d] - mu) * rstd * ln_w[d] + ln_b[d];
+        for (int d = lane; d < D; d += 64) {
+            const float y = (out[row * ldo + d] - mu) * rstd * ln_w[d] + ln_b[d];
+            out[row * ldo + d] = relu ? fmaxf(y, 0.f) : y;
+        }
     }
 }
 
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(256) void layer_tail_generic_kernel(const float* __
 
 extern "C" int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, int D, const float* x0,
                                   int64_t ldx0, const float* prev, int64_t ldp, float alpha, const float* ln_weight,
-                                  const float* ln_bias, float ln_eps, float* out, int64_t ldo, dif_stream_t stream) {
+                                  const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo,
+                                  dif_stream_t stream) {
     DIF_REQUIRE(n_rows > 0 && H > 0 && D > 0, DIF_E_BADARG, "dif_layer_tail_f32: n_rows, H, D must be positive");
     DIF_REQUIRE(conv && out, DIF_E_BADARG, "dif_layer_tail_f32: null pointer");
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
@@ -114,7 +122,7 @@ extern "C" int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows
         int64_t gx = (n_rows + (256 / G) - 1) / (256 / G);                                                  \
         if (gx > cap) gx = cap;                                                                             \
         hipLaunchKernelGGL((layer_tail_vec_kernel<G>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, \
-                           ldc, n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, out, ldo); \
+                           ldc, n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, relu, out, ldo); \
     } while (0)
         if (q <= 1) DIF_TAIL(1);
         else if (q <= 2) DIF_TAIL(2);
@@ -128,7 +136,7 @@ extern "C" int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows
         int64_t gx = (n_rows + 3) / 4;
         if (gx > cap) gx = cap;
         hipLaunchKernelGGL(layer_tail_generic_kernel, dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, ldc,
-                           n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, out, ldo);
+                           n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, relu, out, ldo);
     }
     return dif::launch_status("layer_tail kernel");
 }

@@ -254,7 +254,27 @@ __global__ __launch_bounds__(256) void simple_apply_kernel(const float* __restri
                 }
             }
     };
-    if (SINGLE) load_frags(0, 0);
+    if (SINGLE) {
+        // the 64x64 record tile is fetched once per workgroup (coalesced) and handed to the lanes'
+        // fragment registers through LDS; each wave then streams many 16-row steps with it
+        __shared__ float sm_ktv[kTile * (kTile + 4)];
+        __shared__ float sm_ks[kTile];
+        for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
+            const int m = e / kTile, d = e % kTile;
+            sm_ktv[m * (kTile + 4) + d] = (m < sh.M && d < sh.D) ? s * ktv[static_cast<int64_t>(m) * sh.D + d] : 0.f;
+        }
+        if (threadIdx.x < kTile) sm_ks[threadIdx.x] = (threadIdx.x < sh.M) ? s * ksum[threadIdx.x] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = 16 * c + 4 * lg + t;
+                kfrag[c][t] = sm_ks[m];
+#pragma unroll
+                for (int dtl = 0; dtl < 4; ++dtl) afrag[dtl][c][t] = sm_ktv[m * (kTile + 4) + 16 * dtl + l15];
+            }
+    }
 
     const int64_t n_steps = (n_rows + 15) / 16;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
@@ -387,7 +407,7 @@ extern "C" int dif_simple_apply_f32(const float* q, int64_t ldq, const float* re
     const bool single = (sh.MT == 1 && sh.DT == 1);
     const int64_t n_steps = (n_rows + 15) / 16;
     int64_t gx = (n_steps + 3) / 4;
-    const int64_t cap = 8 * dif::kCUs;  // <= 8 resident 256-thread workgroups per CU
+    const int64_t cap = 2 * dif::kCUs;  // persistent: the per-wave fragment prologue is paid once per ~4+ steps
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -98,8 +98,9 @@ class DIFFormerConv(nn.Module):
             v = source_input.reshape(-1, 1, D)                # difformer.py:120
         return q, k, v
 
-    def _propagate(self, query_input, source_input, edge_index, edge_weight):
-        """-> (conv [n,H,D] before the head mean, q, k)."""
+    def _layer(self, query_input, source_input, edge_index, edge_weight, x0=None, prev=None, alpha=0.5,
+               ln_weight=None, ln_bias=None, eps=1e-5):
+        """Propagation (:115-136) followed by the tail (:137-140 and, when given, :200-203) -> ([n,D], q, k)."""
         H = self.num_heads
         shard = self.row_shard
         q, k, v = self._project(query_input, source_input)
@@ -111,7 +112,7 @@ class DIFFormerConv(nn.Module):
         else:
             raise ValueError(f"unknown attention kernel {self.kernel!r}")
         if not self.use_graph:
-            return attn, q, k
+            return ag.layer_tail(attn, x0, prev, alpha, ln_weight, ln_bias, eps), q, k
         if edge_index is None:
             raise ValueError("use_graph=True needs an edge_index")
         n_global = shard.n_global if shard is not None else v.shape[0]
@@ -121,14 +122,15 @@ class DIFFormerConv(nn.Module):
         else:                                                  # difformer.py:134
             a_s, g_s = 1.0, 1.0
         if v.shape[1] == H:
-            conv = ag.gcn_aggregate(csr, v, attn, a_s, g_s, shard)
+            out = ag.gcn_aggregate_tail(csr, v, attn, a_s, g_s, shard, x0, prev, alpha, ln_weight, ln_bias, eps)
         else:  # use_weight=False with several heads: the [n,1,D] aggregate broadcasts over heads
             conv = a_s * attn + g_s * ag.gcn_aggregate(csr, v, None, 1.0, 1.0, shard)
-        return conv, q, k
+            out = ag.layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
+        return out, q, k
 
     def forward(self, query_input, source_input, edge_index=None, edge_weight=None, x_0=None, output_attn=False):
-        conv, q, k = self._propagate(query_input, source_input, edge_index, edge_weight)
-        out = ag.layer_tail(conv, x_0 if self.use_source else None)   # head mean (+ x_0), :137-140
+        out, q, k = self._layer(query_input, source_input, edge_index, edge_weight,
+                                x_0 if self.use_source else None)          # head mean (+ x_0), :137-140
         if output_attn:
             return out, _dense_attention(q, k, self.kernel)
         return out
@@ -178,8 +180,9 @@ class DIFFormer(nn.Module):
     def _input_layer(self, x, training):
         x = self.fcs[0](x)
         if self.use_bn:
-            x = self.bns[0](x)
-        x = self.activation(x)
+            x = ag.norm_relu(x, self.bns[0].weight, self.bns[0].bias, self.bns[0].eps)   # :189-191
+        else:
+            x = self.activation(x)
         return F.dropout(x, p=self.dropout, training=training)
 
     def forward(self, x, edge_index, edge_weight=None):
@@ -187,13 +190,13 @@ class DIFFormer(nn.Module):
         x = self._input_layer(x, self.training)                # difformer.py:188-192
         layer_.append(x)
         for i, conv in enumerate(self.convs):
-            c, _, _ = conv._propagate(x, x, edge_index, edge_weight)
             bn = self.bns[i + 1] if self.use_bn else None
-            # head mean, + layer_[0] (use_source), alpha-residual, LayerNorm: one kernel (:137-140, :200-203)
-            x = ag.layer_tail(c, layer_[0] if conv.use_source else None,
-                              layer_[i] if self.residual else None, self.alpha,
-                              bn.weight if bn is not None else None, bn.bias if bn is not None else None,
-                              bn.eps if bn is not None else 1e-5)
+            # head mean, + layer_[0] (use_source), alpha-residual, LayerNorm ride in the last kernel of the
+            # layer (:137-140, :200-203)
+            x, _, _ = conv._layer(x, x, edge_index, edge_weight, layer_[0] if conv.use_source else None,
+                                  layer_[i] if self.residual else None, self.alpha,
+                                  bn.weight if bn is not None else None, bn.bias if bn is not None else None,
+                                  bn.eps if bn is not None else 1e-5)
             x = F.dropout(x, p=self.dropout, training=self.training)
             layer_.append(x)
         return self.fcs[-1](x)                                 # :208

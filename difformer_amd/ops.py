@@ -131,11 +131,13 @@ class _CSRCache:
 csr_cache = _CSRCache()
 
 
-def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard: Optional[RowShard] = None):
+def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard: Optional[RowShard] = None,
+                  tail=None):
     """x [n,H,D] (this rank's rows of the value tensor) -> gcn_scale * A_hat x (+ attn_scale * attn).
 
     difformer.py:75-78 plus the combine of :130-134.  Sharded: all-gather x, SpMM over the local
-    destination rows."""
+    destination rows.  `tail` (H == 1 only) = dict(x0, prev, alpha, ln_weight, ln_bias, eps) fuses the
+    layer tail of :139-140 / :200-203 into the SpMM epilogue; the result is then [n, 1, D]."""
     n, H, D = x.shape
     x2 = x.reshape(n, H * D)
     row_begin, n_rows = 0, n
@@ -144,13 +146,13 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
         row_begin, n_rows = shard.row_begin, shard.n_local
     a2 = None if attn is None else attn.reshape(n, H * D)
     out = get_backend().spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x2,
-                             row_begin, n_rows, a2, attn_scale, gcn_scale)
+                             row_begin, n_rows, a2, attn_scale, gcn_scale, tail)
     return out.reshape(n_rows, H, D)
 
 
 # ------------------------------------------------------------------------------------------
 # a4 / a5 tail
 # ------------------------------------------------------------------------------------------
-def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5):
-    """conv [n,H,D] -> [n,D]: head mean (+x0) -> alpha-residual with prev -> LayerNorm."""
-    return get_backend().layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
+def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
+    """conv [n,H,D] -> [n,D]: head mean (+x0) -> alpha-residual with prev -> LayerNorm (-> ReLU)."""
+    return get_backend().layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu)

@@ -64,6 +64,21 @@ int dif_simple_apply_f32(const float* q, int64_t ldq, const float* reduced, int6
                          dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a4+a1 fused  DIFFormerConv.forward :115-118 (Wq/Wk/Wv Linear) + stage 1 of the simple kernel
+ * (:20-34) in one pass over x [n_rows, C_in]:  q = x Wq^T + bq and v = x Wv^T + bv are written
+ * ([n_rows, H*D]), k = x Wk^T + bk stays in registers, and `reduced` receives the same record as
+ * dif_simple_reduce_f32 (M = D).  W* are the nn.Linear weights [H*D, C_in] row-major, b* [H*D].
+ * Covers C_in <= 64 and D <= 64 (DIF_E_SHAPE otherwise: run the Linear layers + dif_simple_reduce_f32).
+ * ------------------------------------------------------------------------------------- */
+size_t dif_project_reduce_workspace_bytes(int64_t n_rows, int H, int D);
+int dif_project_reduce_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in,
+                           const float* Wq, const float* bq, const float* Wk, const float* bk,
+                           const float* Wv, const float* bv, int H, int D,
+                           float* q_out, int64_t ldq, float* v_out, int64_t ldv,
+                           float* reduced, void* workspace, size_t workspace_bytes,
+                           dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a2  full_attention_conv(qs, ks, vs, 'sigmoid')    node classification/difformer.py:45-56
  *     out[n,h,:] = sum_l sigmoid(q[n,h,:].k[l,h,:]) v[l,h,:] / sum_l sigmoid(q[n,h,:].k[l,h,:])
  * q [N,H,M], k [L,H,M], v [L,H,D], out [N,H,D]; N may differ from L.  The [N,L,H] score
@@ -113,13 +128,25 @@ int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
  *        node classification/difformer.py:137 (mean over heads), :139-140 (+= x_0),
  *        :200-201 (alpha residual), :202-203 (LayerNorm, eps 1e-5, affine)
  *   y = mean_h conv[n,h,:] (+ x0[n,:]) ; z = residual ? alpha*y + (1-alpha)*prev[n,:] : y ;
- *   out = ln_weight ? LayerNorm(z) * ln_weight + ln_bias : z
+ *   out = ln_weight ? LayerNorm(z) * ln_weight + ln_bias : z ;  out = relu ? max(out, 0) : out
+ *   (relu = 1 serves the input layer, difformer.py:188-191: Linear -> LayerNorm -> ReLU)
  * conv [n_rows,H,D]; x0, prev, out [n_rows,D]; x0 / prev / ln_weight may be NULL.
  * ------------------------------------------------------------------------------------- */
 int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, int D,
                        const float* x0, int64_t ldx0, const float* prev, int64_t ldp,
                        float alpha, const float* ln_weight, const float* ln_bias, float ln_eps,
-                       float* out, int64_t ldo, dif_stream_t stream);
+                       int relu, float* out, int64_t ldo, dif_stream_t stream);
+
+/* dif_gcn_spmm_f32 with the tail above fused into its epilogue (H == 1 layers: conv row = feature
+ * row, F = D <= 256): out = tail(gcn_scale * A_hat x (+ attn_scale * attn)).  Saves the [n,D] round
+ * trip between the two kernels.  Returns DIF_E_SHAPE when the row does not fit one lane group. */
+int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
+                          const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
+                          const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                          const float* attn, int64_t lda, float attn_scale, float gcn_scale,
+                          const float* x0, int64_t ldx0, const float* prev, int64_t ldp, float alpha,
+                          const float* ln_weight, const float* ln_bias, float ln_eps,
+                          float* out, int64_t ldo, dif_stream_t stream);
 
 #ifdef __cplusplus
 }

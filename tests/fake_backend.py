@@ -55,7 +55,7 @@ class OracleBackend:
                 torch.from_numpy(val[order]))
 
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
-             gcn_scale=1.0):
+             gcn_scale=1.0, tail=None):
         rp, s, w, xx = _np(rowptr), _np(src)[:nnz], _np(val)[:nnz].astype(np.float64), _np(x).astype(np.float64)
         assert xx.shape[0] == n_nodes
         dst = np.repeat(np.arange(n_nodes), np.diff(rp))
@@ -64,9 +64,13 @@ class OracleBackend:
         out = gcn_scale * full[row_begin:row_begin + n_rows]
         if attn is not None:
             out = out + attn_scale * _np(attn).astype(np.float64)
-        return torch.from_numpy(out.astype(np.float32))
+        out = torch.from_numpy(out.astype(np.float32))
+        if tail is not None:
+            out = self.layer_tail(out[:, None, :], tail.get("x0"), tail.get("prev"), tail.get("alpha", 0.5),
+                                  tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5))
+        return out
 
-    def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps):
+    def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         z = _np(conv).astype(np.float64).mean(axis=1)
         if x0 is not None:
             z = z + _np(x0)
@@ -74,4 +78,6 @@ class OracleBackend:
             z = alpha * z + (1.0 - alpha) * _np(prev)
         if ln_weight is not None:
             z = orc.layer_norm(z, _np(ln_weight).astype(np.float64), _np(ln_bias).astype(np.float64), eps)
+        if relu:
+            z = np.maximum(z, 0.0)
         return torch.from_numpy(z.astype(np.float32))

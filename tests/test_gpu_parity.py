@@ -279,6 +279,49 @@ def test_layer_tail_vs_oracle(dev):
             assert rel_err(out, z) < 1e-5, (n, h, d, use_x0, use_prev, use_ln)
 
 
+@pytest.mark.parametrize("n,e,d,n_blocks", [(3000, 30000, 64, 1),      # lane-group-per-row kernel
+                                            (3000, 300000, 64, 1),     # wave-per-row kernel
+                                            (20000, 3000000, 64, 4),   # blocked sweep
+                                            (2000, 100000, 128, 3), (1500, 60000, 10, 1), (900, 40000, 256, 2)])
+def test_spmm_with_fused_tail_matches_unfused(n, e, d, n_blocks, dev):
+    """dif_gcn_spmm_tail_f32 == dif_gcn_spmm_f32 followed by dif_layer_tail_f32, and both match the oracle."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    x = torch.randn(n, 1, d, generator=g).to(dev)
+    attn = torch.randn(n, 1, d, generator=g).to(dev)
+    x0, prev = torch.randn(n, d, generator=g).to(dev), torch.randn(n, d, generator=g).to(dev)
+    w, b = (torch.rand(d, generator=g) + 0.5).to(dev), torch.randn(d, generator=g).to(dev)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    csr = ops.GraphCSR.build(ei.to(dev), None, n, n_blocks)
+    ref_conv = 0.7 * orc.gcn_conv(x.cpu().double().numpy(), ei.numpy(), None) + 0.3 * attn.cpu().double().numpy()
+    for use_x0, use_prev, use_ln in [(True, True, True), (False, True, True), (False, False, False), (True, False, True)]:
+        tail = dict(x0=x0 if use_x0 else None, prev=prev if use_prev else None, alpha=0.3,
+                    ln_weight=w if use_ln else None, ln_bias=b if use_ln else None, eps=1e-5)
+        fused = ops.gcn_aggregate(csr, x, attn, 0.3, 0.7, None, tail)[:, 0, :]
+        conv = ops.gcn_aggregate(csr, x, attn, 0.3, 0.7)
+        unfused = ops.layer_tail(conv, tail["x0"], tail["prev"], 0.3, tail["ln_weight"], tail["ln_bias"], 1e-5)
+        z = ref_conv[:, 0, :]
+        if use_x0:
+            z = z + x0.cpu().double().numpy()
+        if use_prev:
+            z = 0.3 * z + 0.7 * prev.cpu().double().numpy()
+        if use_ln:
+            z = orc.layer_norm(z, w.cpu().double().numpy(), b.cpu().double().numpy())
+        assert rel_err(fused.cpu().numpy(), z) < 2e-5
+        assert rel_err(unfused.cpu().numpy(), z) < 2e-5
+
+
+def test_layer_tail_relu(dev):
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for d in (64, 10, 300):
+        x = torch.randn(500, 1, d, generator=g)
+        w, b = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g)
+        out = ops.layer_tail(x.to(dev), None, None, 0.5, w.to(dev), b.to(dev), 1e-5, relu=True).cpu().numpy()
+        ref = np.maximum(orc.layer_norm(x[:, 0].double().numpy(), w.double().numpy(), b.double().numpy()), 0)
+        assert rel_err(out, ref) < 1e-5 and (out >= 0).all()
+
+
 @pytest.mark.parametrize("name", sorted(MODEL))
 def test_model_forward_golden(name, dev):
     """DIFFormer.forward and DIFFormerConv.forward with the reference's own state_dict."""
