@@ -150,7 +150,7 @@ def main():
     # roofline of the dominant kernel on this rank
     if use_graph:
         dom, alg_bytes = "dif_gcn_spmm_f32", 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * 4
-        dom_name = "spmm_wave_row_kernel (gcn_conv)"
+        dom_name = "spmm_blocked_kernel (gcn_conv)"
     elif kernel == "simple":
         dom, alg_bytes = "dif_simple_reduce_f32", 3.0 * n_local * hidden * 4
         dom_name = "simple_reduce_kernel"
@@ -159,8 +159,18 @@ def main():
         dom_name = "sigmoid_attn_kernel"
     dom_ms = float(np.mean(ktimes[dom])) if ktimes.get(dom) else None
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+    # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    # correction + WRITE_SIZE, calibrated; scripts/pmc_traffic.sh) stored under profiles/ -- a counter run cannot
+    # share a process with this timed run.  Only valid for the single-GPU workload it was collected on.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_c4.json")
+    if world == 1 and use_graph and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("workload") == args.workload:
+            traffic = tj["kernels"].get("spmm_blocked_kernel", {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic_c4.json (rocprofv3 PMC, separate passes)" if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms}
 
     if args.per_kernel and rank == 0:

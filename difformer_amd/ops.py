@@ -47,6 +47,18 @@ def simple_attention(qs, ks, vs, shard: Optional[RowShard] = None):
     return be.simple_apply(qs, reduced, n_global, vs.shape[2])
 
 
+def project_simple_attention(x, Wq, bq, Wk, bk, Wv, bv, H, D, shard: Optional[RowShard] = None):
+    """x [n,C] (local rows) -> (attn [n,H,D], v [n,H,D]).  Projections (difformer.py:115-118) fused with
+    stage 1 of the simple kernel; k never reaches HBM.  Needs C <= 64 and D <= 64."""
+    be = get_backend()
+    q, v, reduced = be.project_reduce(x, Wq, bq, Wk, bk, Wv, bv, H, D)
+    n_global = x.shape[0]
+    if shard is not None and shard.world > 1:
+        shard.all_reduce_sum(reduced)
+        n_global = shard.n_global
+    return be.simple_apply(q, reduced, n_global, D), v
+
+
 def sigmoid_attention(qs, ks, vs, shard: Optional[RowShard] = None):
     """qs [n,H,M] local queries; ks, vs local sources -> [n,H,D].  difformer.py:45-56."""
     if shard is not None and shard.world > 1:

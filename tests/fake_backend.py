@@ -24,6 +24,11 @@ class OracleBackend:
                               [(q * q).sum(), (k * k).sum()]])
         return torch.from_numpy(rec.astype(np.float32))
 
+    def project_reduce(self, x, Wq, bq, Wk, bk, Wv, bv, H, D):
+        lin = torch.nn.functional.linear
+        q, k, v = (lin(x, w, b).reshape(-1, H, D) for w, b in ((Wq, bq), (Wk, bk), (Wv, bv)))
+        return q, v, self.simple_reduce(q, k, v)
+
     def simple_apply(self, q, reduced, n_global, D):
         q = _np(q).astype(np.float64)
         n, H, M = q.shape

@@ -102,6 +102,30 @@ def test_simple_apply_with_synthetic_record(n, h, d, dev):
     assert rel_err(np.where(ok, out, 0), np.where(ok, num / den_signed, 0)) < 1e-5
 
 
+@pytest.mark.parametrize("n,c,h,d", [(1, 64, 1, 64), (16, 64, 1, 64), (1000, 64, 1, 64), (132534, 64, 1, 64),
+                                     (777, 32, 2, 32), (513, 20, 3, 10), (300, 7, 1, 64), (4099, 64, 2, 64)])
+def test_project_reduce_vs_numpy(n, c, h, d, dev):
+    """Fused projection + reduce: q, v equal x W^T + b, and the record equals the one computed from them."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + c + d)
+    x = torch.randn(n, c, generator=g)
+    W = [torch.randn(h * d, c, generator=g) / np.sqrt(c) for _ in range(3)]
+    b = [torch.randn(h * d, generator=g) * 0.3 for _ in range(3)]
+    q, v, rec = ops.get_backend().project_reduce(x.to(dev), W[0].to(dev), b[0].to(dev), W[1].to(dev), b[1].to(dev),
+                                                 W[2].to(dev), b[2].to(dev), h, d)
+    x64 = x.double().numpy()
+    q64, k64, v64 = ((x64 @ W[i].double().numpy().T + b[i].double().numpy()).reshape(n, h, d) for i in range(3))
+    assert rel_err(q.cpu().numpy(), q64) < 1e-5 and rel_err(v.cpu().numpy(), v64) < 1e-5
+    rec = rec.cpu().numpy().astype(np.float64)
+    o = 0
+    for name, ref in (("ktv", np.einsum("lhm,lhd->hmd", k64, v64)), ("ksum", k64.sum(0)), ("vsum", v64.sum(0))):
+        got = rec[o:o + ref.size].reshape(ref.shape)
+        o += ref.size
+        assert rel_err(got, ref) < 1e-5, name
+    assert abs(rec[o] - (q64 ** 2).sum()) < 1e-5 * (q64 ** 2).sum()
+    assert abs(rec[o + 1] - (k64 ** 2).sum()) < 1e-5 * (k64 ** 2).sum()
+
+
 def test_simple_attention_strided_views(dev):
     """q/k/v as column slices of one fused projection (leading dimension 3*H*D), no copies."""
     from difformer_amd import full_attention_conv
