@@ -35,6 +35,7 @@ SIGNATURES = {
                                  c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "dif_layer_tail_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,
                                    c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
+    "dif_linear_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
     "dif_gcn_spmm_tail_f32": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int,
                                       c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp, c_f32,
                                       c_vp, c_i64, c_vp]),

@@ -167,3 +167,19 @@ def norm_relu(x, ln_weight, ln_bias, eps):
     if _needs_grad(x, ln_weight, ln_bias):
         return torch.relu(torch.nn.functional.layer_norm(x, (x.shape[-1],), ln_weight, ln_bias, eps))
     return ops.layer_tail(x.unsqueeze(1), None, None, 0.5, ln_weight, ln_bias, eps, relu=True)
+
+
+def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
+    """nn.Linear (-> LayerNorm) (-> ReLU).  Narrow inputs (C_in <= 64) run the fused HIP kernel when no gradient is
+    needed; wide ones use the vendor GEMM (rocBLAS via F.linear) followed by the fused LayerNorm/ReLU kernel."""
+    fn = torch.nn.functional
+    grad = _needs_grad(x, weight, bias, ln_weight, ln_bias)
+    if not grad and x.dim() == 2 and x.shape[1] <= 64 and (ln_weight is None or weight.shape[0] <= 64):
+        return ops.linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
+    y = fn.linear(x, weight, bias)
+    if ln_weight is not None:
+        if grad:
+            y = fn.layer_norm(y, (y.shape[-1],), ln_weight, ln_bias, eps)
+            return torch.relu(y) if relu else y
+        return ops.layer_tail(y.unsqueeze(1), None, None, 0.5, ln_weight, ln_bias, eps, relu=relu)
+    return torch.relu(y) if relu else y

@@ -221,6 +221,22 @@ class HipBackend:
         _lib.check(rc, "dif_gcn_spmm_tail_f32")
         return out
 
+    # ---- a5 ends: narrow Linear (+ LayerNorm + ReLU) -------------------------------------------
+    def linear(self, x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
+        dev = _require_device(x, weight, bias, ln_weight, ln_bias)
+        n, C = x.shape
+        Co = weight.shape[0]
+        x, ldx = _row_major(_f32(x, "x"), C)
+        weight, bias = _f32(weight, "weight").contiguous(), _f32(bias, "bias").contiguous()
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        out = torch.empty((n, Co), dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_linear_f32", dev):
+            rc = self.lib.dif_linear_f32(_ptr(x), ldx, n, C, _ptr(weight), _ptr(bias), Co, _ptr(ln_weight), _ptr(ln_bias),
+                                         float(eps), int(bool(relu)), _ptr(out), Co, _stream(dev))
+        _lib.check(rc, "dif_linear_f32")
+        return out
+
     # ---- a4 / a5 tail ----------------------------------------------------------------------
     def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         dev = _require_device(conv, x0, prev, ln_weight, ln_bias)

@@ -1,0 +1,154 @@
+// a5 ends: the input MLP (node classification/difformer.py:188-191  Linear -> LayerNorm -> ReLU) and the
+// output Linear (:208) for the narrow shapes DIFFormer uses (C_in <= 64: ogbn-proteins 8->64, hidden->classes
+// 64->112).  One pass: x read once, y written once, LayerNorm/ReLU applied in registers.  Vendor GEMMs are
+// tuned for large K and spend ~100 us on these (K = 8: 4 MB in, 34 MB out).
+//
+// MFMA plan (v_mfma_f32_16x16x4_f32, exact fp32), per wave and 16-row tile, 64 output features per
+// workgroup column (grid.y):  D[i <-> row][j <-> feature] = sum_c X[row][c] W[feature][c]
+//   A[i=lane%16][k=lane/16] = X[r0 + lane%16][16cq + 4*(lane/16) + t]   (dwordx4 loads)
+//   B[k=lane/16][j=lane%16] = W[f0 + 16ft + lane%16][16cq + 4*(lane/16) + t]   (registers; <= 64 per wave)
+// HBM-bound: (C_in + C_out) * 4 bytes per row.
+#include "dif_common.h"
+
+namespace {
+
+using dif::f32x4;
+
+constexpr int kLinStride = 68;
+
+// grid (row chunks, ceil(C_out/64)); 256 threads.  KQ = number of 16-channel groups of C_in actually used (1..4).
+template <int KQ>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows,
+                                                            int C_in, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, int C_out,
+                                                            const float* __restrict__ ln_w,
+                                                            const float* __restrict__ ln_b, float eps, int relu,
+                                                            float* __restrict__ out, int64_t ldo, int vec) {
+    __shared__ __attribute__((aligned(16))) float sm_w[64 * kLinStride];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int f0 = blockIdx.y * 64;
+
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int f = e >> 6, c = e & 63;
+        sm_w[f * kLinStride + c] = (f0 + f < C_out && c < C_in) ? W[static_cast<int64_t>(f0 + f) * C_in + c] : 0.f;
+    }
+    __syncthreads();
+    // weight fragments stay in registers for the whole row sweep
+    f32x4 wf[4][KQ];
+    float bfr[4], lw[4], lb[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        const int f = f0 + 16 * ft + l15;
+        bfr[ft] = (f < C_out) ? bias[f] : 0.f;
+        lw[ft] = (ln_w && f < C_out) ? ln_w[f] : 0.f;
+        lb[ft] = (ln_w && f < C_out) ? ln_b[f] : 0.f;
+#pragma unroll
+        for (int cq = 0; cq < KQ; ++cq)
+            wf[ft][cq] = *reinterpret_cast<const f32x4*>(&sm_w[(16 * ft + l15) * kLinStride + 16 * cq + 4 * lg]);
+    }
+    const float inv_c = 1.0f / static_cast<float>(C_out);
+
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
+    for (int64_t tile = first; tile < n_tiles; tile += stride) {
+        const int64_t r0 = tile * 16;
+        const int64_t r = r0 + l15;
+        f32x4 xa[KQ];
+#pragma unroll
+        for (int cq = 0; cq < KQ; ++cq) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const int c = 16 * cq + 4 * lg;
+            if (r < n_rows) {
+                const float* p = x + r * ldx + c;
+                if (vec && c + 3 < C_in) {
+                    z = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (c + i < C_in) z[i] = p[i];
+                }
+            }
+            xa[cq] = z;
+        }
+        f32x4 y[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] = f32x4{bfr[ft], bfr[ft], bfr[ft], bfr[ft]};
+#pragma unroll
+        for (int cq = 0; cq < KQ; ++cq)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cq][t], wf[ft][cq][t], y[ft], 0, 0, 0);
+
+        if (ln_w) {   // LayerNorm over the C_out <= 64 features of each row (row = 4*lg + reg)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float s = 0.f;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    if (16 * ft + l15 < C_out) s += y[ft][reg];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+                const float mu = s * inv_c;
+                float v = 0.f;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    if (16 * ft + l15 < C_out) { const float dz = y[ft][reg] - mu; v += dz * dz; }
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+                const float rstd = 1.0f / sqrtf(v * inv_c + eps);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) y[ft][reg] = (y[ft][reg] - mu) * rstd * lw[ft] + lb[ft];
+            }
+        }
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f = f0 + 16 * ft + l15;
+            if (f < C_out) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t rr = r0 + 4 * lg + reg;
+                    if (rr < n_rows) out[rr * ldo + f] = relu ? fmaxf(y[ft][reg], 0.f) : y[ft][reg];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const float* W, const float* bias,
+                              int C_out, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                              float* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && C_in > 0 && C_out > 0, DIF_E_BADARG, "dif_linear_f32: n_rows, C_in, C_out must be positive");
+    DIF_REQUIRE(x && W && bias && out, DIF_E_BADARG, "dif_linear_f32: null pointer");
+    DIF_REQUIRE(C_in <= 64, DIF_E_SHAPE, "dif_linear_f32: covers C_in <= 64 (got %d); use the vendor GEMM", C_in);
+    DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
+                "dif_linear_f32: ln_weight and ln_bias must be given together");
+    DIF_REQUIRE(!ln_weight || C_out <= 64, DIF_E_SHAPE, "dif_linear_f32: fused LayerNorm needs C_out <= 64");
+    DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear_f32: leading dimension smaller than a row");
+    const int gy = (C_out + 63) / 64;
+    DIF_REQUIRE(gy <= 65535, DIF_E_RANGE, "dif_linear_f32: C_out too large");
+    const int vec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned16(x);
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    int64_t gx = (n_tiles + 3) / 4;
+    const int64_t cap = 4 * dif::kCUs;
+    if (gx > cap) gx = cap;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(static_cast<unsigned>(gx), gy), block(256);
+    const int kq = (C_in + 15) / 16;
+#define DIF_LIN(KQ) \
+    hipLaunchKernelGGL((skinny_linear_kernel<KQ>), grid, block, 0, st, x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, \
+                       ln_bias, ln_eps, relu, out, ldo, vec)
+    if (kq == 1) DIF_LIN(1);
+    else if (kq == 2) DIF_LIN(2);
+    else if (kq == 3) DIF_LIN(3);
+    else DIF_LIN(4);
+#undef DIF_LIN
+    return dif::launch_status("skinny_linear_kernel");
+}

@@ -195,11 +195,9 @@ class DIFFormer(nn.Module):
         return self
 
     def _input_layer(self, x, training):
-        x = self.fcs[0](x)
-        if self.use_bn:
-            x = ag.norm_relu(x, self.bns[0].weight, self.bns[0].bias, self.bns[0].eps)   # :189-191
-        else:
-            x = self.activation(x)
+        bn = self.bns[0] if self.use_bn else None                     # :188-191 in one kernel
+        x = ag.linear(x, self.fcs[0].weight, self.fcs[0].bias, bn.weight if bn is not None else None,
+                      bn.bias if bn is not None else None, bn.eps if bn is not None else 1e-5, relu=True)
         return F.dropout(x, p=self.dropout, training=training)
 
     def forward(self, x, edge_index, edge_weight=None):
@@ -216,7 +214,7 @@ class DIFFormer(nn.Module):
                                   bn.eps if bn is not None else 1e-5)
             x = F.dropout(x, p=self.dropout, training=self.training)
             layer_.append(x)
-        return self.fcs[-1](x)                                 # :208
+        return ag.linear(x, self.fcs[-1].weight, self.fcs[-1].bias)   # :208
 
     def get_attentions(self, x):
         """Dense per-layer attention [layers, N, N, H] (difformer.py:211-226; no graph term,

@@ -168,3 +168,8 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
 def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
     """conv [n,H,D] -> [n,D]: head mean (+x0) -> alpha-residual with prev -> LayerNorm (-> ReLU)."""
     return get_backend().layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu)
+
+
+def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
+    """x W^T + b (-> LayerNorm) (-> ReLU) for C_in <= 64 (difformer.py:188-191, :208)."""
+    return get_backend().linear(x, weight, bias, ln_weight, ln_bias, eps, relu)

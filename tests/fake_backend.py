@@ -75,6 +75,10 @@ class OracleBackend:
                                   tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5))
         return out
 
+    def linear(self, x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
+        y = torch.nn.functional.linear(x, weight, bias)
+        return self.layer_tail(y.unsqueeze(1), None, None, 0.5, ln_weight, ln_bias, eps, relu)
+
     def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         z = _np(conv).astype(np.float64).mean(axis=1)
         if x0 is not None:

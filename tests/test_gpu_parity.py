@@ -335,6 +335,25 @@ def test_spmm_with_fused_tail_matches_unfused(n, e, d, n_blocks, dev):
         assert rel_err(unfused.cpu().numpy(), z) < 2e-5
 
 
+@pytest.mark.parametrize("n,ci,co,ln,relu", [(132534, 8, 64, True, True), (5000, 64, 112, False, False),
+                                              (777, 33, 7, False, False), (1000, 64, 64, True, False),
+                                              (100, 10, 10, True, True), (17, 1, 200, False, True)])
+def test_skinny_linear_vs_numpy(n, ci, co, ln, relu, dev):
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(ci * 100 + co)
+    x = torch.randn(n, ci, generator=g)
+    W, b = torch.randn(co, ci, generator=g) / np.sqrt(ci), torch.randn(co, generator=g)
+    lw, lb = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
+    out = ops.linear(x.to(dev), W.to(dev), b.to(dev), lw.to(dev) if ln else None, lb.to(dev) if ln else None, 1e-5,
+                     relu).cpu().numpy()
+    ref = x.double().numpy() @ W.double().numpy().T + b.double().numpy()
+    if ln:
+        ref = orc.layer_norm(ref, lw.double().numpy(), lb.double().numpy())
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert rel_err(out, ref) < 1e-5
+
+
 def test_layer_tail_relu(dev):
     from difformer_amd import ops
     g = torch.Generator().manual_seed(2)
