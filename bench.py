@@ -152,8 +152,8 @@ def main():
         dom, alg_bytes = "dif_gcn_spmm_f32", 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * 4
         dom_name = "spmm_blocked_kernel (gcn_conv)"
     elif kernel == "simple":
-        dom, alg_bytes = "dif_simple_reduce_f32", 3.0 * n_local * hidden * 4
-        dom_name = "simple_reduce_kernel"
+        dom, alg_bytes = "dif_project_reduce_f32", 3.0 * n_local * hidden * 4
+        dom_name = "project_reduce_kernel (+finalize)"
     else:
         dom, alg_bytes = "dif_sigmoid_attn_f32", 4.0 * n_local * hidden * 4
         dom_name = "sigmoid_attn_kernel"
@@ -168,6 +168,8 @@ def main():
         tj = json.load(open(tpath))
         if tj.get("workload") == args.workload:
             traffic = tj["kernels"].get("spmm_blocked_kernel", {}).get("hbm_bytes_per_launch")
+    if dom == "dif_sigmoid_attn_f32" and False:
+        pass
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": "profiles/r01_pmc_traffic_c4.json (rocprofv3 PMC, separate passes)" if traffic else None,

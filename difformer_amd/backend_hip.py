@@ -149,9 +149,11 @@ class HipBackend:
         k, ldk = _row_major(_f32(k, "k"), H * M)
         v, ldv = _row_major(_f32(v, "v"), H * D)
         out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.dif_sigmoid_workspace_bytes(N, L, H, M, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         with _Timed(self, "dif_sigmoid_attn_f32", dev):
             rc = self.lib.dif_sigmoid_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, N, L, H, M, D,
-                                               _ptr(out), H * D, None, 0, _stream(dev))
+                                               _ptr(out), H * D, _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_sigmoid_attn_f32")
         return out
 

@@ -17,150 +17,259 @@ namespace {
 
 using dif::f32x4;
 
-constexpr int kWaves = 8;     // waves per workgroup; each takes every 8th 16-key tile
-constexpr int kQTile = 16;    // queries per workgroup
-constexpr int kDTile = 64;    // output columns per workgroup (grid.z covers D > 64)
+constexpr int kWaves = 8;     // waves per workgroup; each takes every 8th 16-key tile of the workgroup's key range
+constexpr int kQT = 2;        // 16-query tiles per wave: every K / V fragment fetched from L2 feeds 2x the MFMAs
+constexpr int kQGroup = 16 * kQT;   // queries per workgroup
+constexpr int kDTile = 64;    // output columns per workgroup (grid.y covers heads x ceil(D/64))
 
+// Branch-free fragment load: out-of-range rows / columns are read from a clamped (valid) address and
+// zeroed afterwards, so the compiler can issue all of a tile's loads back to back (a guarded load is
+// its own exec-masked branch region and serialises).
 template <bool VEC>
 __device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld, int64_t r, int64_t n,
                                      int col0, int c, int width) {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if (r >= n) return z;
-    const float* p = base + r * ld + col0 + c;
+    const bool rok = r < n;
+    const int64_t rc = rok ? r : n - 1;
+    f32x4 z;
     if (VEC) {
-        if (c < width) z = *reinterpret_cast<const f32x4*>(p);
+        const bool cok = c < width;                       // width % 4 == 0 here
+        z = *reinterpret_cast<const f32x4*>(base + rc * ld + col0 + (cok ? c : 0));
+        if (!(rok && cok)) z = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (c + i < width) z[i] = p[i];
+        for (int i = 0; i < 4; ++i) {
+            const bool cok = c + i < width;
+            const float t = base[rc * ld + col0 + (cok ? c + i : 0)];
+            z[i] = (rok && cok) ? t : 0.f;
+        }
     }
     return z;
 }
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigma(x) with the hardware exp2 / rcp (each ~1 ulp): far inside the 1e-4 parity budget, and ~5x
+// fewer VALU instructions than expf + IEEE division next to the MFMAs.
+__device__ __forceinline__ float sigmoidf(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
-// grid: (ceil(N/16), H, ceil(D/64)); block 512.
+// grid: (ceil(N/32), H * ceil(D/64), S key splits); block 512.
+// S == 1: writes the normalised output.  S > 1 (small N: not enough query groups to fill 256 CUs): writes
+// un-normalised partial sums and row sums to `part` [S][N][H*D] / `pden` [S][N][H*DT]; sigmoid_combine_kernel
+// finishes.
 template <bool VEC, bool QREG>
 __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restrict__ q, int64_t ldq,
                                                            const float* __restrict__ k, int64_t ldk,
                                                            const float* __restrict__ v, int64_t ldv,
-                                                           int64_t N, int64_t L, int M, int D,
-                                                           float* __restrict__ out, int64_t ldo) {
-    __shared__ __attribute__((aligned(16))) float sm_o[kWaves][kQTile * kDTile];
-    __shared__ float sm_den[kWaves][kQTile];
+                                                           int64_t N, int64_t L, int H, int M, int D,
+                                                           float* __restrict__ out, int64_t ldo,
+                                                           float* __restrict__ part, float* __restrict__ pden) {
+    __shared__ __attribute__((aligned(16))) float sm_o[kWaves][kQGroup * kDTile];   // 64 KiB
+    __shared__ float sm_den[kWaves][kQGroup];
 
-    const int h = blockIdx.y;
-    const int dt = blockIdx.z;
+    const int DT = (D + kDTile - 1) / kDTile;
+    const int h = blockIdx.y / DT;
+    const int dt = blockIdx.y % DT;
+    const int S = gridDim.z;
+    const int split = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l15 = lane & 15;
     const int lg = lane >> 4;
-    const int64_t qrow = static_cast<int64_t>(blockIdx.x) * kQTile + l15;
+    const int64_t q0 = static_cast<int64_t>(blockIdx.x) * kQGroup;
     const int m_chunks = (M + 63) / 64;
 
     // Q fragments for the (only) m-chunk stay in registers when M <= 64
-    f32x4 qv[4];
+    f32x4 qv[kQT][4];
     if (QREG) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qv[c] = ld4<VEC>(q, ldq, qrow, N, h * M, 16 * c + 4 * lg, M);
+        for (int t = 0; t < kQT; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qv[t][c] = ld4<VEC>(q, ldq, q0 + 16 * t + l15, N, h * M, 16 * c + 4 * lg, M);
     }
 
-    f32x4 acc_o[4];
+    f32x4 acc_o[kQT][4];
+    float den[kQT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc_o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float den = 0.f;
+    for (int t = 0; t < kQT; ++t) {
+        den[t] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc_o[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
+    // this workgroup's key tiles: [kt0, kt1)
     const int64_t n_ktiles = (L + 15) / 16;
-    for (int64_t kt = wave; kt < n_ktiles; kt += kWaves) {
+    const int64_t per = (n_ktiles + S - 1) / S;
+    const int64_t kt0 = split * per;
+    const int64_t kt1 = (kt0 + per < n_ktiles) ? kt0 + per : n_ktiles;
+    for (int64_t kt = kt0 + wave; kt < kt1; kt += kWaves) {
         const int64_t kbase = kt * 16;
-        // ---- S^T tile -------------------------------------------------------------------
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        // ---- S^T tiles (one per query tile) ------------------------------------------------
+        f32x4 s[kQT];
+#pragma unroll
+        for (int t = 0; t < kQT; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int mc = 0; mc < m_chunks; ++mc) {
             f32x4 kx[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) kx[c] = ld4<VEC>(k, ldk, kbase + l15, L, h * M, mc * 64 + 16 * c + 4 * lg, M);
             if (!QREG) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) qv[c] = ld4<VEC>(q, ldq, qrow, N, h * M, mc * 64 + 16 * c + 4 * lg, M);
+                for (int t = 0; t < kQT; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        qv[t][c] = ld4<VEC>(q, ldq, q0 + 16 * t + l15, N, h * M, mc * 64 + 16 * c + 4 * lg, M);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[c][t], qv[c][t], s, 0, 0, 0);
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < kQT; ++t)      // independent accumulator chains back to back
+                        s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[c][u], qv[t][c][u], s[t], 0, 0, 0);
         }
         // ---- V fragments: A[i=l15 <-> d][k=lg] = V[kbase + 4*lg + reg][d0 + 16*dtl + l15] ----
         float vf[4][4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t key = kbase + 4 * lg + reg;
+            const bool kok = key < L;
+            const float* vrow = v + (kok ? key : L - 1) * ldv + h * D;
 #pragma unroll
             for (int dtl = 0; dtl < 4; ++dtl) {
                 const int d = dt * kDTile + 16 * dtl + l15;
-                vf[dtl][reg] = (key < L && d < D) ? v[key * ldv + h * D + d] : 0.f;
+                const bool dok = d < D;
+                const float t = vrow[dok ? d : 0];
+                vf[dtl][reg] = (kok && dok) ? t : 0.f;
             }
         }
         // ---- P = sigma(S), masked beyond L (difformer.py:47) -----------------------------
-        f32x4 p;
+        f32x4 p[kQT];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            p[reg] = (kbase + 4 * lg + reg < L) ? sigmoidf(s[reg]) : 0.f;
-            den += p[reg];                                            // :50-51 row sum
-        }
+        for (int t = 0; t < kQT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                p[t][reg] = (kbase + 4 * lg + reg < L) ? sigmoidf(s[t][reg]) : 0.f;
+                den[t] += p[t][reg];                                      // :50-51 row sum
+            }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
             for (int dtl = 0; dtl < 4; ++dtl)
-                acc_o[dtl] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dtl][reg], p[reg], acc_o[dtl], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < kQT; ++t)
+                    acc_o[t][dtl] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dtl][reg], p[t][reg], acc_o[t][dtl], 0, 0, 0);
     }
 
     // rows (queries) are shared by the 4 lane groups: fold, then fold the 8 waves through LDS
-    den += __shfl_xor(den, 16, 64);
-    den += __shfl_xor(den, 32, 64);
-    if (lg == 0) sm_den[wave][l15] = den;
-    // lane holds O^T[d = 16*dtl + 4*lg + reg][query = l15] -> store as [query][d]
 #pragma unroll
-    for (int dtl = 0; dtl < 4; ++dtl)
-        *reinterpret_cast<f32x4*>(&sm_o[wave][l15 * kDTile + 16 * dtl + 4 * lg]) = acc_o[dtl];
+    for (int t = 0; t < kQT; ++t) {
+        float dsum = den[t];
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
+        if (lg == 0) sm_den[wave][16 * t + l15] = dsum;
+        // lane holds O^T[d = 16*dtl + 4*lg + reg][query = 16t + l15] -> store as [query][d]
+#pragma unroll
+        for (int dtl = 0; dtl < 4; ++dtl)
+            *reinterpret_cast<f32x4*>(&sm_o[wave][(16 * t + l15) * kDTile + 16 * dtl + 4 * lg]) = acc_o[t][dtl];
+    }
     __syncthreads();
 
-    for (int e = threadIdx.x; e < kQTile * kDTile; e += 512) {
+    for (int e = threadIdx.x; e < kQGroup * kDTile; e += 512) {
         const int qi = e / kDTile, dl = e % kDTile;
         float o = 0.f, dn = 0.f;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) { o += sm_o[w][e]; dn += sm_den[w][qi]; }
-        const int64_t row = static_cast<int64_t>(blockIdx.x) * kQTile + qi;
+        const int64_t row = q0 + qi;
         const int d = dt * kDTile + dl;
-        if (row < N && d < D) out[row * ldo + h * D + d] = o / dn;   // :55-56
+        if (row < N && d < D) {
+            if (S == 1) {
+                out[row * ldo + h * D + d] = o / dn;                       // :55-56
+            } else {
+                part[(static_cast<int64_t>(split) * N + row) * (H * D) + h * D + d] = o;
+                if (dl == 0) pden[(static_cast<int64_t>(split) * N + row) * (H * DT) + h * DT + dt] = dn;
+            }
+        }
     }
+}
+
+// S > 1: out = (sum_s part[s]) / (sum_s pden[s])
+__global__ __launch_bounds__(256) void sigmoid_combine_kernel(const float* __restrict__ part,
+                                                              const float* __restrict__ pden, int64_t N, int H,
+                                                              int D, int S, float* __restrict__ out, int64_t ldo) {
+    const int DT = (D + kDTile - 1) / kDTile;
+    const int64_t total = N * H * D;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * 256) {
+        const int64_t row = e / (H * D);
+        const int c = static_cast<int>(e % (H * D));
+        const int h = c / D, d = c % D;
+        float o = 0.f, dn = 0.f;
+        for (int s = 0; s < S; ++s) {
+            o += part[(static_cast<int64_t>(s) * N + row) * (H * D) + c];
+            dn += pden[(static_cast<int64_t>(s) * N + row) * (H * DT) + h * DT + d / kDTile];
+        }
+        out[row * ldo + c] = o / dn;
+    }
+}
+
+int key_splits(int64_t N, int64_t L, int H, int D) {
+    const int64_t groups = ((N + kQGroup - 1) / kQGroup) * H * ((D + kDTile - 1) / kDTile);
+    const int64_t n_ktiles = (L + 15) / 16;
+    int64_t s = (dif::kCUs + groups - 1) / groups;              // aim at one 8-wave workgroup per CU
+    const int64_t smax = (n_ktiles + kWaves - 1) / kWaves;        // keep >= one key tile per wave
+    if (s > smax) s = smax;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+    return static_cast<int>(s);
 }
 
 }  // namespace
 
-extern "C" size_t dif_sigmoid_workspace_bytes(int64_t, int64_t, int, int, int) { return 0; }
+extern "C" size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M, int D) {
+    (void)M;
+    if (N <= 0 || L <= 0 || H <= 0 || D <= 0) return 0;
+    const int S = key_splits(N, L, H, D);
+    if (S == 1) return 0;
+    const size_t DT = (D + kDTile - 1) / kDTile;
+    return static_cast<size_t>(S) * N * H * (static_cast<size_t>(D) + DT) * sizeof(float);
+}
 
 extern "C" int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
                                     const float* v, int64_t ldv, int64_t N, int64_t L, int H, int M, int D,
-                                    float* out, int64_t ldo, void* /*workspace*/, size_t /*workspace_bytes*/,
+                                    float* out, int64_t ldo, void* workspace, size_t workspace_bytes,
                                     dif_stream_t stream) {
     DIF_REQUIRE(N > 0 && L > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG,
                 "dif_sigmoid_attn_f32: N, L, H, M, D must be positive");
     DIF_REQUIRE(q && k && v && out, DIF_E_BADARG, "dif_sigmoid_attn_f32: null pointer");
     DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D && ldo >= H * D, DIF_E_BADARG,
                 "dif_sigmoid_attn_f32: leading dimension smaller than a row");
-    const int64_t gx = (N + kQTile - 1) / kQTile;
-    const int gz = (D + kDTile - 1) / kDTile;
-    DIF_REQUIRE(gx < (1ll << 31) && H <= 65535 && gz <= 65535, DIF_E_RANGE, "dif_sigmoid_attn_f32: grid too large");
+    const int64_t gx = (N + kQGroup - 1) / kQGroup;
+    const int64_t gy = static_cast<int64_t>(H) * ((D + kDTile - 1) / kDTile);
+    DIF_REQUIRE(gx < (1ll << 31) && gy <= 65535, DIF_E_RANGE, "dif_sigmoid_attn_f32: grid too large");
+    const int S = key_splits(N, L, H, D);
+    const size_t need = dif_sigmoid_workspace_bytes(N, L, H, M, D);
+    DIF_REQUIRE(S == 1 || (workspace && workspace_bytes >= need), DIF_E_WORKSPACE,
+                "dif_sigmoid_attn_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
     const bool vec = (M % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && dif::aligned16(q) && dif::aligned16(k);
     const bool qreg = (M <= 64);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid(static_cast<unsigned>(gx), H, gz), block(512);
+    float* part = static_cast<float*>(workspace);
+    float* pden = (S > 1) ? part + static_cast<size_t>(S) * N * H * D : nullptr;
+    dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), S), block(512);
 #define DIF_LAUNCH_SIG(V, Q) \
-    hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, M, D, out, ldo)
+    hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, ldo, \
+                       part, pden)
     if (vec && qreg) DIF_LAUNCH_SIG(true, true);
     else if (vec) DIF_LAUNCH_SIG(true, false);
     else if (qreg) DIF_LAUNCH_SIG(false, true);
     else DIF_LAUNCH_SIG(false, false);
 #undef DIF_LAUNCH_SIG
-    return dif::launch_status("sigmoid_attn_kernel");
+    if (int rc = dif::launch_status("sigmoid_attn_kernel")) return rc;
+    if (S > 1) {
+        int64_t g = (N * H * D + 255) / 256;
+        if (g > 8 * dif::kCUs) g = 8 * dif::kCUs;
+        hipLaunchKernelGGL(sigmoid_combine_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, part, pden, N, H, D, S,
+                           out, ldo);
+        return dif::launch_status("sigmoid_combine_kernel");
+    }
+    return 0;
 }

@@ -47,7 +47,8 @@ def test_version_and_size_helpers(lib):
     assert lib.dif_simple_workspace_bytes(0, 1, 64, 64) == 0
     small, big = lib.dif_csr_workspace_bytes(1000, 100, 1), lib.dif_csr_workspace_bytes(79255038, 132534, 13)
     assert 0 < small < big and big > 4 * 4 * 79255038
-    assert lib.dif_sigmoid_workspace_bytes(10, 10, 1, 8, 8) == 0
+    assert lib.dif_sigmoid_workspace_bytes(100000, 100000, 1, 64, 64) == 0       # enough query groups: no key split
+    assert lib.dif_sigmoid_workspace_bytes(2708, 2708, 1, 64, 64) > 0            # Cora: keys split over workgroups
 
 
 def test_argument_checks_reject_before_touching_the_device(lib):
