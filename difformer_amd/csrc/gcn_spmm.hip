@@ -206,7 +206,7 @@ constexpr int kBlkLdsBytesPerCU = 147456;  // 144 KiB of the CU's 160 KiB for ac
 constexpr int kBlkPre = 4;             // G-entry chunks of a (row, block) group fetched in one batch
 
 // WPC = workgroups per CU (1: 16 waves/CU, 128-VGPR budget; 2: 32 waves/CU, 64-VGPR budget)
-template <int G, int W, int WPC, int UNROLL>
+template <int G, int W, int WPC, int UNROLL, bool PACE>
 __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_blocked_kernel(
     const int32_t* __restrict__ blkptr, int64_t n_nodes, int n_blocks, const int32_t* __restrict__ src,
     const float* __restrict__ val, const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows,
@@ -230,13 +230,21 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
     const int64_t n_panels = (n_rows + rpw - 1) / rpw;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlkWaves + wave;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlkWaves;
-    for (int64_t panel = first; panel < n_panels; panel += stride) {
-        const int64_t row0 = panel * rpw;
-        const int nrw = (n_rows - row0 < rpw) ? static_cast<int>(n_rows - row0) : rpw;
+    // every wave runs the same number of panel rounds (a wave without a panel only paces the barriers)
+    const int64_t rounds = (n_panels + stride - 1) / stride;
+    for (int64_t rnd = 0; rnd < rounds; ++rnd) {
+        const int64_t panel = first + rnd * stride;
+        const bool has = panel < n_panels;
+        const int64_t row0 = has ? panel * rpw : 0;
+        const int nrw = !has ? 0 : (n_rows - row0 < rpw) ? static_cast<int>(n_rows - row0) : rpw;
         const int nq = (nrw + S - 1) / S;
         for (int i = lane; i < rpw * RW; i += 64) my[i] = 0.f;
 
         for (int b = 0; b < n_blocks; ++b) {
+            // pace the workgroup's 16 waves block by block: without it they drift apart over the sweep, the
+            // XCD's L2 has to hold two source blocks and ~24 % of the gathers miss (PMC FETCH_SIZE per launch
+            // at C4: 5.8 GB unpaced -> 1.34 GB paced, 1.0 GB compulsory; 1.29 -> 1.19 ms)
+            if (PACE) __syncthreads();
             const int32_t* p0 = blkptr + static_cast<int64_t>(b) * n_nodes + row_begin + row0;
             const int32_t e0v = (lane < nrw) ? p0[lane] : 0;
             const int32_t e1v = (lane < nrw) ? p0[n_nodes + lane] : 0;
@@ -349,7 +357,7 @@ int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int
     const int64_t n_panels = (n_rows + rpw - 1) / rpw;
     int64_t grid = (n_panels + kBlkWaves - 1) / kBlkWaves;
     if (grid > dif::kCUs * WPC) grid = dif::kCUs * WPC;
-    hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL>), dim3(static_cast<unsigned>(grid)),
+    hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true>), dim3(static_cast<unsigned>(grid)),
                        dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F,
                        attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
     return dif::launch_status("spmm_blocked_kernel");
