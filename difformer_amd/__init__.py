@@ -10,6 +10,7 @@ call does, and fails loudly if it has not been built.
 """
 from .difformer import DIFFormer, DIFFormerConv, full_attention_conv, gcn_conv  # noqa: F401
 from .dist import RowShard  # noqa: F401
+from .graphs import GraphedForward  # noqa: F401
 
-__all__ = ["DIFFormer", "DIFFormerConv", "full_attention_conv", "gcn_conv", "RowShard"]
+__all__ = ["DIFFormer", "DIFFormerConv", "full_attention_conv", "gcn_conv", "RowShard", "GraphedForward"]
 __version__ = "0.1.0"

@@ -23,9 +23,17 @@ import torch.distributed as dist
 
 
 def split_rows(n_global: int, world: int) -> List[int]:
-    """Contiguous block sizes, first `n_global % world` ranks take one extra row."""
-    base, extra = divmod(n_global, world)
-    return [base + (1 if r < extra else 0) for r in range(world)]
+    """Contiguous block sizes: every rank but the last takes c = ceil(n_global / world) rows, the last the
+    remainder.  All blocks then start at multiples of c, so an all-gather of c-row (zero-padded) blocks lands
+    every node at its global row index -- no compaction copy after the collective."""
+    c = -(-n_global // world)
+    counts = []
+    left = n_global
+    for _ in range(world):
+        take = min(c, left)
+        counts.append(take)
+        left -= take
+    return counts
 
 
 @dataclass
@@ -76,14 +84,21 @@ class RowShard:
             return local
         local = local.contiguous()
         tail = tuple(local.shape[1:])
-        if len(set(self.counts)) == 1:
-            full = torch.empty((self.n_global,) + tail, dtype=local.dtype, device=local.device)
+        c = max(self.counts)
+        uniform = all(self.offsets[r] == r * c for r in range(self.world))
+        if uniform:
+            # blocks start at multiples of c (split_rows): gather c-row blocks straight into place; the rows past
+            # n_global at the end of the buffer are padding that no CSR entry refers to
+            if self.n_local != c:
+                padded = torch.zeros((c,) + tail, dtype=local.dtype, device=local.device)
+                padded[: self.n_local] = local
+                local = padded
+            full = torch.empty((self.world * c,) + tail, dtype=local.dtype, device=local.device)
             dist.all_gather_into_tensor(full, local, group=self.group)
-            return full
-        # uneven blocks (n_global % world != 0): gather equal-sized padded blocks, then compact
-        maxc = max(self.counts)
-        padded = torch.zeros((maxc,) + tail, dtype=local.dtype, device=local.device)
+            return full[: self.n_global]
+        # arbitrary user-supplied blocks: gather equal-sized padded blocks, then compact
+        padded = torch.zeros((c,) + tail, dtype=local.dtype, device=local.device)
         padded[: self.n_local] = local
-        buf = torch.empty((self.world * maxc,) + tail, dtype=local.dtype, device=local.device)
+        buf = torch.empty((self.world * c,) + tail, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(buf, padded, group=self.group)
-        return torch.cat([buf[r * maxc: r * maxc + self.counts[r]] for r in range(self.world)], dim=0)
+        return torch.cat([buf[r * c: r * c + self.counts[r]] for r in range(self.world)], dim=0)

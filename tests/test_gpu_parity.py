@@ -443,3 +443,44 @@ def test_training_step_gradients_match_autograd_of_closed_form(dev):
         p[0, 0] = base
     fd = (lp - lm) / (2 * eps)
     assert abs(fd - grads["convs.0.Wq.weight"][0, 0].item()) < 0.1 * abs(fd) + 1e-4
+
+
+def test_graphed_forward_replays_match_eager(dev):
+    """hipGraph capture of the whole forward: replays equal the eager result, also after the input changes."""
+    from difformer_amd import DIFFormer, GraphedForward
+    torch.manual_seed(3)
+    n = 3000
+    model = DIFFormer(40, 64, 6, num_layers=3, kernel="simple").to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    x1, x2 = torch.randn(n, 40, generator=g).to(dev), torch.randn(n, 40, generator=g).to(dev)
+    ei = torch.cat([torch.randint(0, n, (2, 20000), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    with torch.no_grad():
+        e1, e2 = model(x1, ei).clone(), model(x2, ei).clone()
+    fwd = GraphedForward(model, x1, ei)
+    assert torch.equal(fwd(x1), e1)
+    assert torch.equal(fwd(x2), e2)
+    assert torch.equal(fwd(x1), e1)
+    with pytest.raises(ValueError):
+        fwd(x1[:10])
+
+
+def test_rccl_single_rank_collectives(dev):
+    """The collectives the sharded path uses work on this box (RCCL, one rank; multi-rank logic is covered by the
+    gloo tests)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        t = torch.arange(8, dtype=torch.float32, device=dev)
+        dist.all_reduce(t)
+        out = torch.empty(8, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        dist.barrier()
+        assert torch.equal(out.cpu(), torch.arange(8, dtype=torch.float32))
+    finally:
+        dist.destroy_process_group()

@@ -99,11 +99,12 @@ def test_get_attentions_shape_and_rows_sum(fake_backend):
 
 def test_split_rows_and_row_shard():
     from difformer_amd.dist import RowShard, split_rows
-    assert split_rows(132534, 8) == [16567] * 6 + [16566] * 2
+    assert split_rows(132534, 8) == [16567] * 7 + [16565]       # all but the last take ceil(N / world)
     assert split_rows(5, 8) == [1, 1, 1, 1, 1, 0, 0, 0]
+    assert split_rows(64, 2) == [32, 32]
     s = RowShard(10, rank=2, world=3)
-    assert s.counts == [4, 3, 3] and s.offsets == [0, 4, 7, 10] and (s.row_begin, s.n_local) == (7, 3)
-    assert torch.equal(s.local_rows(torch.arange(10)), torch.tensor([7, 8, 9]))
+    assert s.counts == [4, 4, 2] and s.offsets == [0, 4, 8, 10] and (s.row_begin, s.n_local) == (8, 2)
+    assert torch.equal(s.local_rows(torch.arange(10)), torch.tensor([8, 9]))
     with pytest.raises(ValueError):
         RowShard(10, 0, 2, counts=[4, 4])
     one = RowShard(7)
