@@ -228,7 +228,9 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
     float* my = acc_lds + wave * rpw * RW;
 
     const int64_t n_panels = (n_rows + rpw - 1) / rpw;
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlkWaves + wave;
+    // panels are dealt round-robin over the workgroups (panel p -> workgroup p % grid, wave (p / grid) % 16), so every
+    // CU carries the same number of panels to within one whatever the panel count is
+    const int64_t first = static_cast<int64_t>(wave) * gridDim.x + blockIdx.x;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlkWaves;
     // every wave runs the same number of panel rounds (a wave without a panel only paces the barriers)
     const int64_t rounds = (n_panels + stride - 1) / stride;
@@ -240,25 +242,32 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
         const int nq = (nrw + S - 1) / S;
         for (int i = lane; i < rpw * RW; i += 64) my[i] = 0.f;
 
+        // (row, block) group pointers of the current and of the next block, one lane per row of the panel
+        const int32_t* pb = blkptr + row_begin + row0;
+        int32_t e0v = (lane < nrw) ? pb[lane] : 0;
+        int32_t e1v = (lane < nrw) ? pb[n_nodes + lane] : 0;
+        // entries of the NEXT row-quad (of this block, or the first quad of the next block) are always in flight
+        // while the current quad gathers
+        int32_t e0n = __shfl(e0v, slot, 64), e1n = __shfl(e1v, slot, 64);
+        int32_t sn[kBlkPre];
+        float wn[kBlkPre];
+#pragma unroll
+        for (int c = 0; c < kBlkPre; ++c) {
+            const int32_t idx = e0n + c * G + li;
+            const bool ok = idx < e1n;
+            sn[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
+            wn[c] = ok ? __builtin_nontemporal_load(val + idx) : 0.f;
+        }
         for (int b = 0; b < n_blocks; ++b) {
             // pace the workgroup's 16 waves block by block: without it they drift apart over the sweep, the
             // XCD's L2 has to hold two source blocks and ~24 % of the gathers miss (PMC FETCH_SIZE per launch
             // at C4: 5.8 GB unpaced -> 1.34 GB paced, 1.0 GB compulsory; 1.29 -> 1.19 ms)
             if (PACE) __syncthreads();
-            const int32_t* p0 = blkptr + static_cast<int64_t>(b) * n_nodes + row_begin + row0;
-            const int32_t e0v = (lane < nrw) ? p0[lane] : 0;
-            const int32_t e1v = (lane < nrw) ? p0[n_nodes + lane] : 0;
-
-            // entries of the NEXT quad are fetched while the current one gathers
-            int32_t e0n = __shfl(e0v, slot, 64), e1n = __shfl(e1v, slot, 64);
-            int32_t sn[kBlkPre];
-            float wn[kBlkPre];
-#pragma unroll
-            for (int c = 0; c < kBlkPre; ++c) {
-                const int32_t idx = e0n + c * G + li;
-                const bool ok = idx < e1n;
-                sn[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
-                wn[c] = ok ? __builtin_nontemporal_load(val + idx) : 0.f;
+            int32_t e0x = 0, e1x = 0;     // pointers of block b+1, requested a whole block ahead
+            if (b + 1 < n_blocks) {
+                const int32_t* pn = pb + static_cast<int64_t>(b + 1) * n_nodes;
+                e0x = (lane < nrw) ? pn[lane] : 0;
+                e1x = (lane < nrw) ? pn[n_nodes + lane] : 0;
             }
             for (int q = 0; q < nq; ++q) {
                 const int rl = q * S + slot;
@@ -267,9 +276,14 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                 float wv[kBlkPre];
 #pragma unroll
                 for (int c = 0; c < kBlkPre; ++c) { sv[c] = sn[c]; wv[c] = wn[c]; }
-                if (q + 1 < nq) {
-                    e0n = __shfl(e0v, rl + S, 64);
-                    e1n = __shfl(e1v, rl + S, 64);
+                if (q + 1 < nq || b + 1 < n_blocks) {
+                    if (q + 1 < nq) {
+                        e0n = __shfl(e0v, rl + S, 64);
+                        e1n = __shfl(e1v, rl + S, 64);
+                    } else {
+                        e0n = __shfl(e0x, slot, 64);
+                        e1n = __shfl(e1x, slot, 64);
+                    }
 #pragma unroll
                     for (int c = 0; c < kBlkPre; ++c) {
                         const int32_t idx = e0n + c * G + li;
@@ -324,6 +338,8 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                     vstore<W>(a, vload<W>(a) + acc);
                 }
             }
+            e0v = e0x;
+            e1v = e1x;
         }
         // panel epilogue: S rows per step, each a full contiguous row segment
         for (int q = 0; q < nq; ++q) {
@@ -349,14 +365,27 @@ int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int
     constexpr int S = 64 / G;
     constexpr int RW = G * W;
     constexpr int kLdsFloats = kBlkLdsBytesPerCU / 4 / WPC;
-    const int64_t slots = static_cast<int64_t>(dif::kCUs) * WPC * kBlkWaves;   // waves resident on the chip
+    const int64_t n_wg = static_cast<int64_t>(dif::kCUs) * WPC;               // one persistent workgroup per CU
+    const int64_t slots = n_wg * kBlkWaves;                                      // waves resident on the chip
     const int rpw_max = (kLdsFloats / kBlkWaves / RW < 64) ? kLdsFloats / kBlkWaves / RW : 64;
-    int64_t rpw = (n_rows + slots - 1) / slots;
-    if (rpw < S) rpw = S;
-    if (rpw > rpw_max) rpw = rpw_max / S * S;
+    // rows per wave panel: the busiest CU does ceil(panels / workgroups) panels of ceil(rpw / S) row-quad visits per
+    // block; pick the panel height near n_rows / slots that minimises that product (ties -> shorter panels: more waves busy).
+    // Measured on a 16,567-row shard of C4: 4 rows/wave (two rounds) 0.249 ms, 6-8 rows 0.215 ms, 16 rows 0.371 ms.
+    int64_t lo = (n_rows + slots - 1) / slots;
+    if (lo < 1) lo = 1;
+    int64_t rpw = 0, best = -1;
+    for (int64_t cand = (lo > S ? lo - S + 1 : 1); cand <= lo + 2 * S; ++cand) {
+        if (cand > rpw_max) break;
+        const int64_t panels = (n_rows + cand - 1) / cand;
+        const int64_t wgs = panels < n_wg ? panels : n_wg;
+        // a second round of panels re-runs the whole block sweep (with its barriers) for a few stragglers: avoid
+        const int64_t rounds = (panels + wgs * kBlkWaves - 1) / (wgs * kBlkWaves);
+        const int64_t cost = (rounds - 1) * 1000000 + ((panels + wgs - 1) / wgs) * ((cand + S - 1) / S);
+        if (best < 0 || cost < best) { best = cost; rpw = cand; }
+    }
+    if (rpw == 0) rpw = rpw_max;
     const int64_t n_panels = (n_rows + rpw - 1) / rpw;
-    int64_t grid = (n_panels + kBlkWaves - 1) / kBlkWaves;
-    if (grid > dif::kCUs * WPC) grid = dif::kCUs * WPC;
+    int64_t grid = n_panels < n_wg ? n_panels : n_wg;
     hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true>), dim3(static_cast<unsigned>(grid)),
                        dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F,
                        attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
