@@ -12,7 +12,7 @@ from . import ops
 
 
 def _needs_grad(*tensors):
-    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+    return torch.is_grad_enabled() and any(t is not None and getattr(t, "requires_grad", False) for t in tensors)
 
 
 def _no_sharded_training(shard):

@@ -116,7 +116,7 @@ class DIFFormerConv(nn.Module):
         if not want_qk and self._fusable_projection(query_input, source_input):
             attn, v = ops.project_simple_attention(source_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,
                                                    self.Wk.bias, self.Wv.weight, self.Wv.bias, H,
-                                                   self.out_channels, shard)
+                                                   self.out_channels, shard, gather_values=self.use_graph)
         else:
             q, k, v = self._project(query_input, source_input)
             v_att = v if v.shape[1] == H else v.expand(-1, H, -1).contiguous()

@@ -44,6 +44,9 @@ class RowShard:
     world: int = 1
     group: Optional[object] = None
     counts: List[int] = field(default_factory=list)
+    # second communicator for the small all-reduce, so it can run while the all-gather of the value rows
+    # (issued first, on `group`) is still in flight; None = use `group` for both (serialised)
+    side_group: Optional[object] = None
 
     def __post_init__(self):
         if not self.counts:
@@ -58,7 +61,12 @@ class RowShard:
     def from_process_group(cls, n_global: int, group=None):
         if not dist.is_initialized():
             return cls(n_global)
-        return cls(n_global, dist.get_rank(group), dist.get_world_size(group), group)
+        world = dist.get_world_size(group)
+        side = None
+        if world > 1:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+            side = dist.new_group(ranks=ranks)          # collective: every rank of `group` must get here
+        return cls(n_global, dist.get_rank(group), world, group, side_group=side)
 
     @property
     def row_begin(self) -> int:
@@ -75,30 +83,50 @@ class RowShard:
     def all_reduce_sum(self, buf: torch.Tensor) -> torch.Tensor:
         """In-place sum over ranks of the small `reduced` record of the simple kernel."""
         if self.world > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM,
+                            group=self.side_group if self.side_group is not None else self.group)
         return buf
+
+    def all_gather_rows_async(self, local: torch.Tensor):
+        """Start the all-gather of the value rows and return a handle; `handle.wait()` gives the gathered tensor.
+        Lets the record all-reduce + the apply kernel run while the 4*N*H*D bytes move over xGMI."""
+        return _GatherHandle(self, local)
 
     def all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
         """[n_local, ...] on every rank -> [n_global, ...] everywhere (rank order = row order)."""
-        if self.world == 1:
-            return local
+        return _GatherHandle(self, local).wait()
+
+
+class _GatherHandle:
+    """All-gather of row blocks, possibly still in flight."""
+
+    def __init__(self, shard: RowShard, local: torch.Tensor):
+        self.shard, self.work, self.post = shard, None, None
+        if shard.world == 1:
+            self.result = local
+            return
         local = local.contiguous()
         tail = tuple(local.shape[1:])
-        c = max(self.counts)
-        uniform = all(self.offsets[r] == r * c for r in range(self.world))
+        c = max(shard.counts)
+        uniform = all(shard.offsets[r] == r * c for r in range(shard.world))
+        if shard.n_local != c:
+            padded = torch.zeros((c,) + tail, dtype=local.dtype, device=local.device)
+            padded[: shard.n_local] = local
+            local = padded
+        buf = torch.empty((shard.world * c,) + tail, dtype=local.dtype, device=local.device)
+        self.work = dist.all_gather_into_tensor(buf, local, group=shard.group, async_op=True)
+        self._keep = local
         if uniform:
-            # blocks start at multiples of c (split_rows): gather c-row blocks straight into place; the rows past
-            # n_global at the end of the buffer are padding that no CSR entry refers to
-            if self.n_local != c:
-                padded = torch.zeros((c,) + tail, dtype=local.dtype, device=local.device)
-                padded[: self.n_local] = local
-                local = padded
-            full = torch.empty((self.world * c,) + tail, dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(full, local, group=self.group)
-            return full[: self.n_global]
-        # arbitrary user-supplied blocks: gather equal-sized padded blocks, then compact
-        padded = torch.zeros((c,) + tail, dtype=local.dtype, device=local.device)
-        padded[: self.n_local] = local
-        buf = torch.empty((self.world * c,) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(buf, padded, group=self.group)
-        return torch.cat([buf[r * c: r * c + self.counts[r]] for r in range(self.world)], dim=0)
+            # blocks start at multiples of c (split_rows): every node already sits at its global row index; the rows
+            # past n_global at the end of the buffer are padding that no CSR entry refers to
+            self.post = lambda: buf[: shard.n_global]
+        else:
+            # arbitrary caller-supplied blocks: compact the padded blocks
+            self.post = lambda: torch.cat([buf[r * c: r * c + shard.counts[r]] for r in range(shard.world)], dim=0)
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            self.result = self.post()
+        return self.result

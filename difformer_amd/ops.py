@@ -47,16 +47,29 @@ def simple_attention(qs, ks, vs, shard: Optional[RowShard] = None):
     return be.simple_apply(qs, reduced, n_global, vs.shape[2])
 
 
-def project_simple_attention(x, Wq, bq, Wk, bk, Wv, bv, H, D, shard: Optional[RowShard] = None):
+def project_simple_attention(x, Wq, bq, Wk, bk, Wv, bv, H, D, shard: Optional[RowShard] = None,
+                             gather_values=False):
     """x [n,C] (local rows) -> (attn [n,H,D], v [n,H,D]).  Projections (difformer.py:115-118) fused with
     stage 1 of the simple kernel; k never reaches HBM.  Needs C <= 64 and D <= 64."""
     be = get_backend()
     q, v, reduced = be.project_reduce(x, Wq, bq, Wk, bk, Wv, bv, H, D)
     n_global = x.shape[0]
     if shard is not None and shard.world > 1:
+        if gather_values:
+            # start moving the value rows now: the record all-reduce (second communicator) and the apply kernel
+            # run while they are in flight; gcn_aggregate picks the handle up
+            v = GatheredRows(v, shard.all_gather_rows_async(v.reshape(v.shape[0], H * D)))
         shard.all_reduce_sum(reduced)
         n_global = shard.n_global
     return be.simple_apply(q, reduced, n_global, D), v
+
+
+class GatheredRows:
+    """Local value rows [n,H,D] plus the in-flight all-gather of them (row-sharded runs)."""
+
+    def __init__(self, local, handle):
+        self.local, self.handle = local, handle
+        self.shape = local.shape
 
 
 def sigmoid_attention(qs, ks, vs, shard: Optional[RowShard] = None):
@@ -151,11 +164,15 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
     destination rows.  `tail` (H == 1 only) = dict(x0, prev, alpha, ln_weight, ln_bias, eps) fuses the
     layer tail of :139-140 / :200-203 into the SpMM epilogue; the result is then [n, 1, D]."""
     n, H, D = x.shape
-    x2 = x.reshape(n, H * D)
     row_begin, n_rows = 0, n
-    if shard is not None and shard.world > 1:
-        x2 = shard.all_gather_rows(x2)         # the one exchange step: N*H*D floats
+    if isinstance(x, GatheredRows):            # all-gather already started by project_simple_attention
+        x2 = x.handle.wait()
         row_begin, n_rows = shard.row_begin, shard.n_local
+    else:
+        x2 = x.reshape(n, H * D)
+        if shard is not None and shard.world > 1:
+            x2 = shard.all_gather_rows(x2)     # the one exchange step: N*H*D floats
+            row_begin, n_rows = shard.row_begin, shard.n_local
     a2 = None if attn is None else attn.reshape(n, H * D)
     out = get_backend().spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x2,
                              row_begin, n_rows, a2, attn_scale, gcn_scale, tail)

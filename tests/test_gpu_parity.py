@@ -484,3 +484,34 @@ def test_rccl_single_rank_collectives(dev):
         assert torch.equal(out.cpu(), torch.arange(8, dtype=torch.float32))
     finally:
         dist.destroy_process_group()
+
+
+def _full_config_parity(dev, n, pairs, f_in, classes, layers, tol=TOL):
+    from difformer_amd import DIFFormer
+    from bench import make_graph
+    torch.manual_seed(123)
+    model = DIFFormer(f_in, 64, classes, num_layers=layers, kernel="simple", use_graph=True).eval()
+    gx = torch.Generator().manual_seed(1)
+    x = torch.randn(n, f_in, generator=gx)
+    ei = make_graph(n, pairs, dev)
+    cfg = dict(hidden_channels=64, num_layers=layers, num_heads=1, kernel="simple", alpha=0.5, use_bn=True,
+               use_residual=True, use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    p = {k: v.double().numpy() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(x.to(dev), ei).cpu().numpy()
+    ref = orc.difformer_forward(p, x.double().numpy(), ei.cpu().numpy(), None, cfg)
+    assert np.isfinite(out).all()
+    assert rel_err(out, ref) < tol
+
+
+def test_model_forward_c5_pokec_batch_shape(dev):
+    """BASELINE config C5 shape (one Pokec mini-batch: 100k nodes, ~230k random edge pairs + self loops, F_in=65,
+    C=2, 3 layers) in fp32 against the float64 oracle."""
+    _full_config_parity(dev, 100000, 115000, 65, 2, 3)
+
+
+def test_model_forward_c4_ogbn_proteins_full_size(dev):
+    """BASELINE config C4 at FULL size -- the exact bench.py workload (132,534 nodes, 79,255,038 CSR entries,
+    4 layers) -- against the float64 oracle (OpenMP C gcn_conv + numpy)."""
+    _full_config_parity(dev, 132534, 39561252, 8, 112, 4)
