@@ -41,6 +41,10 @@ WORKLOADS = {
     "cora-s": (2708, 5278, 1433, 7, 64, 2, "simple", True),
     "cora-a": (2708, 5278, 1433, 7, 64, 2, "sigmoid", True),
     "cifar50k-s": (50000, 0, 512, 10, 64, 4, "simple", False),
+    # C5: one Pokec-shaped mini-batch (main-batch.py path), bf16 storage / fp32 accumulate; 8 GPUs = 8 replicas
+    "pokec-batch-s-bf16": (100000, 115000, 65, 2, 64, 3, "simple", True),
+    # not a BASELINE config: the C4 graph in bf16 storage, to show what the gather-bound SpMM does at half the bytes
+    "ogbn-proteins-s-bf16": (132534, 39561252, 8, 112, 64, 4, "simple", True),
 }
 
 
@@ -107,8 +111,10 @@ def main():
     model = DIFFormer(f_in, hidden, classes, num_layers=layers, num_heads=1, kernel=kernel, use_graph=use_graph)
     model.reset_parameters()
     model = model.to(dev).eval()
+    store = torch.bfloat16 if args.workload.endswith("-bf16") else torch.float32
+    model = model.to(store)
     gx = torch.Generator(device=dev).manual_seed(1)
-    x_full = torch.randn(n, f_in, generator=gx, device=dev)
+    x_full = torch.randn(n, f_in, generator=gx, device=dev).to(store)
     edge_index = make_graph(n, pairs, dev) if use_graph else None
     nnz = 0 if edge_index is None else int(edge_index.shape[1])
 
@@ -164,7 +170,8 @@ def main():
 
     # roofline of the dominant kernel on this rank
     if use_graph:
-        dom, alg_bytes = "dif_gcn_spmm_f32", 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * 4
+        esz = 2 if store == torch.bfloat16 else 4
+        dom, alg_bytes = "dif_gcn_spmm_f32", 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * esz
         dom_name = "spmm_blocked_kernel (gcn_conv)"
     elif kernel == "simple":
         dom, alg_bytes = "dif_project_reduce_f32", 3.0 * n_local * hidden * 4
@@ -196,7 +203,7 @@ def main():
                   file=sys.stderr)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and store == torch.float32:
         cfg = dict(hidden_channels=hidden, num_layers=layers, num_heads=1, kernel=kernel, alpha=0.5, use_bn=True,
                    use_residual=True, use_weight=True, use_graph=use_graph, graph_weight=-1, use_source=False)
         cpu = cpu_baseline(model, x_full, edge_index, cfg, layers)
@@ -205,7 +212,7 @@ def main():
         print(json.dumps({
             "metric": "DIFFormer-layer forward nodes/sec", "value": value, "unit": "nodes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if store == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "nodes": n, "csr_entries": nnz, "in_channels": f_in,
                        "hidden": hidden, "heads": 1, "layers": layers, "kernel": kernel, "use_graph": use_graph,
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",

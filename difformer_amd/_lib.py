@@ -40,6 +40,12 @@ SIGNATURES = {
                                       c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp, c_f32,
                                       c_vp, c_i64, c_vp]),
 }
+# bfloat16 storage variants share the argument lists of their float32 twins
+for _n in ("dif_linear", "dif_project_reduce", "dif_simple_reduce", "dif_simple_apply", "dif_layer_tail"):
+    SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f32"]
+SIGNATURES["dif_gcn_spmm_tail_bf16"] = (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64,
+                                                c_int, c_vp, c_i64, c_f32, c_f32, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,
+                                                c_vp, c_vp, c_f32, c_vp, c_i64, c_vp])
 
 _lib = None
 

@@ -44,6 +44,25 @@ def _f32(t, name):
     return t
 
 
+_SUFFIX = {torch.float32: "f32", torch.bfloat16: "bf16"}
+
+
+def _storage(*tensors):
+    """Common storage dtype of the operands -> C-ABI suffix ('f32' | 'bf16')."""
+    dt = None
+    for t in tensors:
+        if t is None:
+            continue
+        if t.dtype not in _SUFFIX:
+            raise TypeError(f"difformer_amd: unsupported dtype {t.dtype}: float32 (reference dtype) or bfloat16 "
+                            "(storage-only variant) expected")
+        if dt is None:
+            dt = t.dtype
+        elif t.dtype != dt:
+            raise TypeError(f"difformer_amd: operands mix {dt} and {t.dtype}")
+    return dt, _SUFFIX[dt]
+
+
 def _row_major(t, width):
     """Return (tensor, leading dimension in elements) with the trailing dims dense so that
     row r starts at data_ptr + r*ld*4 and holds `width` contiguous floats.  Strided row views
@@ -100,44 +119,49 @@ class HipBackend:
         dev = _require_device(q, k, v)
         n, H, M = q.shape
         D = v.shape[2]
-        q, ldq = _row_major(_f32(q, "q"), H * M)
-        k, ldk = _row_major(_f32(k, "k"), H * M)
-        v, ldv = _row_major(_f32(v, "v"), H * D)
+        _, sfx = _storage(q, k, v)
+        q, ldq = _row_major(q, H * M)
+        k, ldk = _row_major(k, H * M)
+        v, ldv = _row_major(v, H * D)
         reduced = torch.empty(self.lib.dif_simple_reduced_len(H, M, D), dtype=torch.float32, device=dev)
         ws_bytes = self.lib.dif_simple_workspace_bytes(n, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        fn = getattr(self.lib, "dif_simple_reduce_" + sfx)
         with _Timed(self, "dif_simple_reduce_f32", dev):
-            rc = self.lib.dif_simple_reduce_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, n, H, M, D,
-                                                _ptr(reduced), _ptr(ws), ws_bytes, _stream(dev))
-        _lib.check(rc, "dif_simple_reduce_f32")
+            rc = fn(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, n, H, M, D, _ptr(reduced), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_simple_reduce_" + sfx)
         return reduced
 
     def project_reduce(self, x, Wq, bq, Wk, bk, Wv, bv, H, D):
         """x [n,C] -> (q [n,H,D], v [n,H,D], reduced): projections fused with stage 1 of the simple kernel."""
         dev = _require_device(x, Wq, bq, Wk, bk, Wv, bv)
         n, C = x.shape
-        x, ldx = _row_major(_f32(x, "x"), C)
-        ws_ = [_f32(t, "projection parameter").contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
-        q = torch.empty((n, H, D), dtype=torch.float32, device=dev)
-        v = torch.empty((n, H, D), dtype=torch.float32, device=dev)
+        dt, sfx = _storage(x, Wq, bq, Wk, bk, Wv, bv)
+        x, ldx = _row_major(x, C)
+        ws_ = [t.contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
+        q = torch.empty((n, H, D), dtype=dt, device=dev)
+        v = torch.empty((n, H, D), dtype=dt, device=dev)
         reduced = torch.empty(self.lib.dif_simple_reduced_len(H, D, D), dtype=torch.float32, device=dev)
         ws_bytes = self.lib.dif_project_reduce_workspace_bytes(n, H, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        fn = getattr(self.lib, "dif_project_reduce_" + sfx)
         with _Timed(self, "dif_project_reduce_f32", dev):
-            rc = self.lib.dif_project_reduce_f32(_ptr(x), ldx, n, C, *[_ptr(t) for t in ws_], H, D, _ptr(q), H * D,
-                                                 _ptr(v), H * D, _ptr(reduced), _ptr(ws), ws_bytes, _stream(dev))
-        _lib.check(rc, "dif_project_reduce_f32")
+            rc = fn(_ptr(x), ldx, n, C, *[_ptr(t) for t in ws_], H, D, _ptr(q), H * D, _ptr(v), H * D, _ptr(reduced),
+                    _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_project_reduce_" + sfx)
         return q, v, reduced
 
     def simple_apply(self, q, reduced, n_global, D):
         dev = _require_device(q, reduced)
         n, H, M = q.shape
-        q, ldq = _row_major(_f32(q, "q"), H * M)
-        out = torch.empty((n, H, D), dtype=torch.float32, device=dev)
+        dt, sfx = _storage(q)
+        _f32(reduced, "reduced")
+        q, ldq = _row_major(q, H * M)
+        out = torch.empty((n, H, D), dtype=dt, device=dev)
+        fn = getattr(self.lib, "dif_simple_apply_" + sfx)
         with _Timed(self, "dif_simple_apply_f32", dev):
-            rc = self.lib.dif_simple_apply_f32(_ptr(q), ldq, _ptr(reduced), n, int(n_global), H, M, D,
-                                               _ptr(out), H * D, _stream(dev))
-        _lib.check(rc, "dif_simple_apply_f32")
+            rc = fn(_ptr(q), ldq, _ptr(reduced), n, int(n_global), H, M, D, _ptr(out), H * D, _stream(dev))
+        _lib.check(rc, "dif_simple_apply_" + sfx)
         return out
 
     # ---- a2 --------------------------------------------------------------------------------
@@ -145,9 +169,13 @@ class HipBackend:
         dev = _require_device(q, k, v)
         N, H, M = q.shape
         L, D = k.shape[0], v.shape[2]
-        q, ldq = _row_major(_f32(q, "q"), H * M)
-        k, ldk = _row_major(_f32(k, "k"), H * M)
-        v, ldv = _row_major(_f32(v, "v"), H * D)
+        for t_, nm in ((q, "q"), (k, "k"), (v, "v")):
+            if t_.dtype != torch.float32:
+                raise TypeError(f"difformer_amd: the sigmoid kernel is float32-only (got {t_.dtype} for {nm}); the "
+                                "bfloat16 storage variant covers the simple kernel path (BASELINE config C5)")
+        q, ldq = _row_major(q, H * M)
+        k, ldk = _row_major(k, H * M)
+        v, ldv = _row_major(v, H * D)
         out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
         ws_bytes = self.lib.dif_sigmoid_workspace_bytes(N, L, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
@@ -191,36 +219,39 @@ class HipBackend:
         """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps): fuse the layer tail (H == 1)."""
         dev = _require_device(rowptr, blkptr, src, val, x, attn)
         F = x.shape[1]
-        x, ldx = _row_major(_f32(x, "x"), F)
+        t = tail or {}
+        x0, prev, lw, lb = t.get("x0"), t.get("prev"), t.get("ln_weight"), t.get("ln_bias")
+        _require_device(x0, prev, lw, lb)
+        dt, sfx = _storage(x, attn, x0, prev, lw, lb)
+        _f32(val, "CSR values")
+        x, ldx = _row_major(x, F)
         if x.shape[0] != n_nodes:
             raise ValueError(f"difformer_amd: spmm needs all {n_nodes} source rows, got {x.shape[0]}")
-        lda = 0
+        lda = ldx0 = ldp = 0
         if attn is not None:
-            attn, lda = _row_major(_f32(attn, "attn"), F)
-        out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
-        if tail is None:
-            with _Timed(self, "dif_gcn_spmm_f32", dev):
-                rc = self.lib.dif_gcn_spmm_f32(_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes, nnz,
-                                               _ptr(x), ldx, row_begin, n_rows, F, _ptr(attn), lda, float(attn_scale),
-                                               float(gcn_scale), _ptr(out), F, _stream(dev))
-            _lib.check(rc, "dif_gcn_spmm_f32")
-            return out
-        x0, prev, lw, lb = tail.get("x0"), tail.get("prev"), tail.get("ln_weight"), tail.get("ln_bias")
-        _require_device(x0, prev, lw, lb)
-        ldx0 = ldp = 0
+            attn, lda = _row_major(attn, F)
         if x0 is not None:
-            x0, ldx0 = _row_major(_f32(x0, "x0"), F)
+            x0, ldx0 = _row_major(x0, F)
         if prev is not None:
-            prev, ldp = _row_major(_f32(prev, "prev"), F)
+            prev, ldp = _row_major(prev, F)
         if lw is not None:
             lw, lb = lw.contiguous(), lb.contiguous()
+        out = torch.empty((n_rows, F), dtype=dt, device=dev)
+        head = (_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes, nnz, _ptr(x), ldx, row_begin, n_rows, F,
+                _ptr(attn), lda, float(attn_scale), float(gcn_scale))
+        tail_args = (_ptr(x0), ldx0, _ptr(prev), ldp, float(t.get("alpha", 0.5)), _ptr(lw), _ptr(lb),
+                     float(t.get("eps", 1e-5)))
         with _Timed(self, "dif_gcn_spmm_f32", dev):
-            rc = self.lib.dif_gcn_spmm_tail_f32(_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes,
-                                                nnz, _ptr(x), ldx, row_begin, n_rows, F, _ptr(attn), lda,
-                                                float(attn_scale), float(gcn_scale), _ptr(x0), ldx0, _ptr(prev), ldp,
-                                                float(tail.get("alpha", 0.5)), _ptr(lw), _ptr(lb),
-                                                float(tail.get("eps", 1e-5)), _ptr(out), F, _stream(dev))
-        _lib.check(rc, "dif_gcn_spmm_tail_f32")
+            if sfx == "bf16":
+                name = "dif_gcn_spmm_tail_bf16"
+                rc = self.lib.dif_gcn_spmm_tail_bf16(*head, int(tail is not None), *tail_args, _ptr(out), F, _stream(dev))
+            elif tail is None:
+                name = "dif_gcn_spmm_f32"
+                rc = self.lib.dif_gcn_spmm_f32(*head, _ptr(out), F, _stream(dev))
+            else:
+                name = "dif_gcn_spmm_tail_f32"
+                rc = self.lib.dif_gcn_spmm_tail_f32(*head, *tail_args, _ptr(out), F, _stream(dev))
+        _lib.check(rc, name)
         return out
 
     # ---- a5 ends: narrow Linear (+ LayerNorm + ReLU) -------------------------------------------
@@ -228,33 +259,36 @@ class HipBackend:
         dev = _require_device(x, weight, bias, ln_weight, ln_bias)
         n, C = x.shape
         Co = weight.shape[0]
-        x, ldx = _row_major(_f32(x, "x"), C)
-        weight, bias = _f32(weight, "weight").contiguous(), _f32(bias, "bias").contiguous()
+        dt, sfx = _storage(x, weight, bias, ln_weight, ln_bias)
+        x, ldx = _row_major(x, C)
+        weight, bias = weight.contiguous(), bias.contiguous()
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
-        out = torch.empty((n, Co), dtype=torch.float32, device=dev)
+        out = torch.empty((n, Co), dtype=dt, device=dev)
+        fn = getattr(self.lib, "dif_linear_" + sfx)
         with _Timed(self, "dif_linear_f32", dev):
-            rc = self.lib.dif_linear_f32(_ptr(x), ldx, n, C, _ptr(weight), _ptr(bias), Co, _ptr(ln_weight), _ptr(ln_bias),
-                                         float(eps), int(bool(relu)), _ptr(out), Co, _stream(dev))
-        _lib.check(rc, "dif_linear_f32")
+            rc = fn(_ptr(x), ldx, n, C, _ptr(weight), _ptr(bias), Co, _ptr(ln_weight), _ptr(ln_bias), float(eps),
+                    int(bool(relu)), _ptr(out), Co, _stream(dev))
+        _lib.check(rc, "dif_linear_" + sfx)
         return out
 
     # ---- a4 / a5 tail ----------------------------------------------------------------------
     def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         dev = _require_device(conv, x0, prev, ln_weight, ln_bias)
         n, H, D = conv.shape
-        conv, ldc = _row_major(_f32(conv, "conv"), H * D)
+        dt, sfx = _storage(conv, x0, prev, ln_weight, ln_bias)
+        conv, ldc = _row_major(conv, H * D)
         ldx0 = ldp = 0
         if x0 is not None:
-            x0, ldx0 = _row_major(_f32(x0, "x0"), D)
+            x0, ldx0 = _row_major(x0, D)
         if prev is not None:
-            prev, ldp = _row_major(_f32(prev, "prev"), D)
+            prev, ldp = _row_major(prev, D)
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
-        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        out = torch.empty((n, D), dtype=dt, device=dev)
+        fn = getattr(self.lib, "dif_layer_tail_" + sfx)
         with _Timed(self, "dif_layer_tail_f32", dev):
-            rc = self.lib.dif_layer_tail_f32(_ptr(conv), ldc, n, H, D, _ptr(x0), ldx0, _ptr(prev), ldp,
-                                             float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
-                                             int(bool(relu)), _ptr(out), D, _stream(dev))
-        _lib.check(rc, "dif_layer_tail_f32")
+            rc = fn(_ptr(conv), ldc, n, H, D, _ptr(x0), ldx0, _ptr(prev), ldp, float(alpha), _ptr(ln_weight),
+                    _ptr(ln_bias), float(eps), int(bool(relu)), _ptr(out), D, _stream(dev))
+        _lib.check(rc, "dif_layer_tail_" + sfx)
         return out

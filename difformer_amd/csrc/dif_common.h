@@ -31,3 +31,56 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 #define DIF_REQUIRE(cond, code, ...) \
     do { if (!(cond)) return dif::fail((code), __VA_ARGS__); } while (0)
+
+// ---- storage types: float32 (the reference's dtype) and bfloat16 (storage only; every accumulation is fp32) ----
+namespace dif {
+
+struct bf16 { uint16_t bits; };
+
+__host__ __device__ __forceinline__ float bf16_to_f32(uint16_t b) {
+    union { uint32_t u; float f; } c;
+    c.u = static_cast<uint32_t>(b) << 16;
+    return c.f;
+}
+
+// round-to-nearest-even, NaN preserved (quiet)
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    union { float f; uint32_t u; } c;
+    c.f = f;
+    if ((c.u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((c.u >> 16) | 0x40u);
+    c.u += 0x7fffu + ((c.u >> 16) & 1u);
+    return static_cast<uint16_t>(c.u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kBytes = 4;
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Elem<bf16> {
+    static constexpr int kBytes = 2;
+    static __device__ __forceinline__ float ld(const bf16* p) { return bf16_to_f32(p->bits); }
+    static __device__ __forceinline__ void st(bf16* p, float v) { p->bits = f32_to_bf16(v); }
+    static __device__ __forceinline__ f32x4 ld4(const bf16* p) {       // one 8-byte load
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        f32x4 v;
+        v[0] = bf16_to_f32(static_cast<uint16_t>(r.x & 0xffffu)); v[1] = bf16_to_f32(static_cast<uint16_t>(r.x >> 16));
+        v[2] = bf16_to_f32(static_cast<uint16_t>(r.y & 0xffffu)); v[3] = bf16_to_f32(static_cast<uint16_t>(r.y >> 16));
+        return v;
+    }
+    static __device__ __forceinline__ void st4(bf16* p, f32x4 v) {     // one 8-byte store
+        uint2 r;
+        r.x = static_cast<uint32_t>(f32_to_bf16(v[0])) | (static_cast<uint32_t>(f32_to_bf16(v[1])) << 16);
+        r.y = static_cast<uint32_t>(f32_to_bf16(v[2])) | (static_cast<uint32_t>(f32_to_bf16(v[3])) << 16);
+        *reinterpret_cast<uint2*>(p) = r;
+    }
+};
+
+// pointer usable with Elem<T>::ld4 / st4 (4 elements wide)
+template <typename T>
+inline bool aligned_v4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
+
+}  // namespace dif

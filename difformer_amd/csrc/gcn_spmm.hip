@@ -20,6 +20,7 @@
 namespace {
 
 using dif::f32x4;
+using dif::Elem;
 
 template <int W> struct Vec;
 template <> struct Vec<4> { using T = f32x4; };
@@ -43,6 +44,19 @@ __device__ __forceinline__ void vstore(float* p, typename Vec<W>::T v) {
     else *p = v;
 }
 
+// global-memory row pieces in the storage type E (float | dif::bf16); registers and LDS stay fp32
+template <int W, typename E>
+__device__ __forceinline__ typename Vec<W>::T gload(const E* p) {
+    if constexpr (W == 4) return Elem<E>::ld4(p);
+    else return Elem<E>::ld(p);
+}
+
+template <int W, typename E>
+__device__ __forceinline__ void gstore(E* p, typename Vec<W>::T v) {
+    if constexpr (W == 4) Elem<E>::st4(p, v);
+    else Elem<E>::st(p, v);
+}
+
 template <int W>
 __device__ __forceinline__ typename Vec<W>::T vshfl_xor(typename Vec<W>::T v, int m) {
     if constexpr (W == 4) {
@@ -57,21 +71,22 @@ __device__ __forceinline__ typename Vec<W>::T vshfl_xor(typename Vec<W>::T v, in
 
 // Optional fused layer tail (H == 1 only; difformer.py:139-140, :200-203): applied to the finished
 // row `o` held by a G-lane group (W floats per lane, lanes with col >= F inactive).
+template <typename E>
 struct Tail {
-    const float* x0;   int64_t ldx0;   // += x_0            (use_source)
-    const float* prev; int64_t ldp;    // alpha-residual    (use_residual)
+    const E* x0;   int64_t ldx0;   // += x_0            (use_source)
+    const E* prev; int64_t ldp;    // alpha-residual    (use_residual)
     float alpha;
-    const float* ln_w; const float* ln_b; float eps;   // LayerNorm (use_bn)
+    const E* ln_w; const E* ln_b; float eps;   // LayerNorm (use_bn)
     int enabled;
 };
 
-template <int G, int W>
-__device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, const Tail& t, int64_t row, int col,
+template <int G, int W, typename E>
+__device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, const Tail<E>& t, int64_t row, int col,
                                                          bool ok, int F) {
     using V = typename Vec<W>::T;
     if (ok) {
-        if (t.x0) o += vload<W>(t.x0 + row * t.ldx0 + col);
-        if (t.prev) o = t.alpha * o + (1.0f - t.alpha) * vload<W>(t.prev + row * t.ldp + col);
+        if (t.x0) o += gload<W, E>(t.x0 + row * t.ldx0 + col);
+        if (t.prev) o = t.alpha * o + (1.0f - t.alpha) * gload<W, E>(t.prev + row * t.ldp + col);
     }
     if (t.ln_w) {   // wave-uniform
         const float inv_d = 1.0f / static_cast<float>(F);
@@ -89,7 +104,7 @@ __device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, c
 #pragma unroll
         for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
         const float rstd = 1.0f / sqrtf(v * inv_d + t.eps);
-        if (ok) o = dz * rstd * vload<W>(t.ln_w + col) + vload<W>(t.ln_b + col);
+        if (ok) o = dz * rstd * gload<W, E>(t.ln_w + col) + gload<W, E>(t.ln_b + col);
     }
     return o;
 }
@@ -98,12 +113,12 @@ constexpr int kGatherUnroll = 8;
 
 // ---- whole wave per destination row ---------------------------------------------------------
 // grid (row blocks, column chunks of G*W floats); 256 threads = 4 rows in flight per block.
-template <int G, int W>
+template <int G, int W, typename E>
 __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const float* __restrict__ val,
-    const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-    const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail tail,
-    float* __restrict__ out, int64_t ldo) {
+    const E* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+    const E* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail<E> tail,
+    E* __restrict__ out, int64_t ldo) {
     using V = typename Vec<W>::T;
     constexpr int EPW = 64 / G;  // entries gathered per wave instruction
     const int lane = threadIdx.x & 63;
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     const bool active = col < F;
     const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     const int64_t nw = static_cast<int64_t>(gridDim.x) * 4;
-    const float* xcol = x + col;
+    const E* xcol = x + col;
 
     for (int64_t row = gw; row < n_rows; row += nw) {
         const int64_t r = row_begin + row;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
                     const int ent = ((j0 + u) * EPW + sub) & 63;
                     const int32_t s = __shfl(my_src, ent, 64);
                     w[u] = (j0 + u < steps) ? __shfl(my_val, ent, 64) : 0.f;
-                    xv[u] = (active && j0 + u < steps) ? vload<W>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
+                    xv[u] = (active && j0 + u < steps) ? gload<W, E>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
                 }
 #pragma unroll
                 for (int u = 0; u < kGatherUnroll; ++u) acc += w[u] * xv[u];
@@ -144,25 +159,25 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
         for (int m = G; m < 64; m <<= 1) acc += vshfl_xor<W>(acc, m);
         const bool ok = (sub == 0 && active);
         V o = gcn_scale * acc;
-        if (ok && attn) o += attn_scale * vload<W>(attn + row * lda + col);
-        if (tail.enabled) o = apply_tail<G, W>(o, tail, row, col, ok, F);
-        if (ok) vstore<W>(out + row * ldo + col, o);
+        if (ok && attn) o += attn_scale * gload<W, E>(attn + row * lda + col);
+        if (tail.enabled) o = apply_tail<G, W, E>(o, tail, row, col, ok, F);
+        if (ok) gstore<W, E>(out + row * ldo + col, o);
     }
 }
 
 // ---- one G-lane group per destination row (low-degree graphs) ---------------------------------
-template <int G, int W>
+template <int G, int W, typename E>
 __global__ __launch_bounds__(256) void spmm_group_row_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const float* __restrict__ val,
-    const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-    const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail tail,
-    float* __restrict__ out, int64_t ldo) {
+    const E* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+    const E* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail<E> tail,
+    E* __restrict__ out, int64_t ldo) {
     using V = typename Vec<W>::T;
     constexpr int RPB = 256 / G;  // rows per block
     const int li = threadIdx.x % G;
     const int col = blockIdx.y * (G * W) + li * W;
     const bool active = col < F;
-    const float* xcol = x + col;
+    const E* xcol = x + col;
     const int64_t nrb = (n_rows + RPB - 1) / RPB;
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         const int64_t row = rb * RPB + threadIdx.x / G;
@@ -178,16 +193,16 @@ __global__ __launch_bounds__(256) void spmm_group_row_kernel(
                 const bool ok = e + u < e1;
                 const int32_t s = ok ? src[e + u] : 0;
                 w[u] = ok ? val[e + u] : 0.f;
-                xv[u] = (ok && active) ? vload<W>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
+                xv[u] = (ok && active) ? gload<W, E>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc += w[u] * xv[u];
         }
         const bool ok = active && rok;
         V o = gcn_scale * acc;
-        if (ok && attn) o += attn_scale * vload<W>(attn + row * lda + col);
-        if (tail.enabled) o = apply_tail<G, W>(o, tail, row, col, ok, F);
-        if (ok) vstore<W>(out + row * ldo + col, o);
+        if (ok && attn) o += attn_scale * gload<W, E>(attn + row * lda + col);
+        if (tail.enabled) o = apply_tail<G, W, E>(o, tail, row, col, ok, F);
+        if (ok) gstore<W, E>(out + row * ldo + col, o);
     }
 }
 
@@ -206,12 +221,12 @@ constexpr int kBlkLdsBytesPerCU = 147456;  // 144 KiB of the CU's 160 KiB for ac
 constexpr int kBlkPre = 4;             // G-entry chunks of a (row, block) group fetched in one batch
 
 // WPC = workgroups per CU (1: 16 waves/CU, 128-VGPR budget; 2: 32 waves/CU, 64-VGPR budget)
-template <int G, int W, int WPC, int UNROLL, bool PACE>
+template <int G, int W, int WPC, int UNROLL, bool PACE, typename E>
 __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_blocked_kernel(
     const int32_t* __restrict__ blkptr, int64_t n_nodes, int n_blocks, const int32_t* __restrict__ src,
-    const float* __restrict__ val, const float* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows,
-    int F, const float* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail tail,
-    float* __restrict__ out, int64_t ldo, int rpw) {
+    const float* __restrict__ val, const E* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows,
+    int F, const E* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail<E> tail,
+    E* __restrict__ out, int64_t ldo, int rpw) {
     using V = typename Vec<W>::T;
     constexpr int S = 64 / G;       // rows walked concurrently by one wave
     constexpr int RW = G * W;       // floats of LDS per accumulator row
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
     const int li = lane % G;
     const int col = li * W;
     const bool active = col < F;
-    const float* xcol = x + col;
+    const E* xcol = x + col;
     float* my = acc_lds + wave * rpw * RW;
 
     const int64_t n_panels = (n_rows + rpw - 1) / rpw;
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                                     w[u] = __shfl(wv[c], from, 64);
                                     const bool take = active && (c0 + c * G + j0 + u < len);
                                     if (!take) w[u] = 0.f;
-                                    xv[u] = take ? vload<W>(xcol + static_cast<int64_t>(sidx) * ldx) : vzero<W>();
+                                    xv[u] = take ? gload<W, E>(xcol + static_cast<int64_t>(sidx) * ldx) : vzero<W>();
                                 }
 #pragma unroll
                                 for (int u = 0; u < UNROLL; ++u) acc += w[u] * xv[u];
@@ -349,19 +364,19 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
             V o = vzero<W>();
             if (ok) {
                 o = gcn_scale * vload<W>(my + rl * RW + col);
-                if (attn) o += attn_scale * vload<W>(attn + row * lda + col);
+                if (attn) o += attn_scale * gload<W, E>(attn + row * lda + col);
             }
-            if (tail.enabled) o = apply_tail<G, W>(o, tail, row, col, ok, F);
-            if (ok) vstore<W>(out + row * ldo + col, o);
+            if (tail.enabled) o = apply_tail<G, W, E>(o, tail, row, col, ok, F);
+            if (ok) gstore<W, E>(out + row * ldo + col, o);
         }
     }
 }
 
-template <int G, int W, int WPC, int UNROLL>
+template <int G, int W, int WPC, int UNROLL, typename E>
 int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
-                     const float* val, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-                     const float* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail& tail, float* out,
-        int64_t ldo) {
+                     const float* val, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                     const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail, E* out,
+                     int64_t ldo) {
     constexpr int S = 64 / G;
     constexpr int RW = G * W;
     constexpr int kLdsFloats = kBlkLdsBytesPerCU / 4 / WPC;
@@ -386,39 +401,39 @@ int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int
     if (rpw == 0) rpw = rpw_max;
     const int64_t n_panels = (n_rows + rpw - 1) / rpw;
     int64_t grid = n_panels < n_wg ? n_panels : n_wg;
-    hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true>), dim3(static_cast<unsigned>(grid)),
+    hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true, E>), dim3(static_cast<unsigned>(grid)),
                        dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F,
                        attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
     return dif::launch_status("spmm_blocked_kernel");
 }
 
-template <int G, int W>
+template <int G, int W, typename E>
 int launch_blocked(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
-                   const float* val, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-                   const float* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail& tail, float* out,
-        int64_t ldo) {
+                   const float* val, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                   const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail, E* out,
+                   int64_t ldo) {
     // 1 workgroup (16 waves) per CU, 8 gathers in flight per wave: best of the measured variants
     // (2 workgroups per CU need a 64-VGPR budget and spill)
-    return launch_blocked_v<G, W, 1, 8>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn,
+    return launch_blocked_v<G, W, 1, 8, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn,
                                         lda, attn_scale, gcn_scale, tail, out, ldo);
 }
 
-template <int G, int W>
+template <int G, int W, typename E>
 int launch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t* src, const float* val,
-           const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
-           float attn_scale, float gcn_scale, const Tail& tail, float* out, int64_t ldo) {
+           const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F, const E* attn, int64_t lda,
+           float attn_scale, float gcn_scale, const Tail<E>& tail, E* out, int64_t ldo) {
     const int gy = (F + G * W - 1) / (G * W);
     const int64_t cap = 8 * dif::kCUs;
     if (wave_mode) {
         int64_t gx = (n_rows + 3) / 4;
         if (gx > cap) gx = cap;
-        hipLaunchKernelGGL((spmm_wave_row_kernel<G, W>), dim3(static_cast<unsigned>(gx), gy), dim3(256), 0, st, rowptr,
+        hipLaunchKernelGGL((spmm_wave_row_kernel<G, W, E>), dim3(static_cast<unsigned>(gx), gy), dim3(256), 0, st, rowptr,
                            src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, tail, out, ldo);
     } else {
         constexpr int RPB = 256 / G;
         int64_t gx = (n_rows + RPB - 1) / RPB;
         if (gx > cap) gx = cap;
-        hipLaunchKernelGGL((spmm_group_row_kernel<G, W>), dim3(static_cast<unsigned>(gx), gy), dim3(256), 0, st,
+        hipLaunchKernelGGL((spmm_group_row_kernel<G, W, E>), dim3(static_cast<unsigned>(gx), gy), dim3(256), 0, st,
                            rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, tail, out, ldo);
     }
     return dif::launch_status("spmm kernel");
@@ -426,12 +441,13 @@ int launch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t*
 
 }  // namespace
 
+template <typename E>
 static int spmm_dispatch(bool wave_mode, hipStream_t st, const int32_t* rowptr, const int32_t* src,
-                         const float* val, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
-                         const float* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail& tail,
-                         float* out, int64_t ldo, bool vec) {
+                         const float* val, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                         const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail,
+                         E* out, int64_t ldo, bool vec) {
 #define DIF_SPMM(G, W) \
-    return launch<G, W>(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, tail, out, ldo)
+    return launch<G, W, E>(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale, gcn_scale, tail, out, ldo)
     if (vec) {
         const int q = F / 4;
         if (q <= 1) DIF_SPMM(1, 4);
@@ -451,10 +467,11 @@ static int spmm_dispatch(bool wave_mode, hipStream_t st, const int32_t* rowptr, 
 #undef DIF_SPMM
 }
 
+template <typename E>
 static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src, const float* val,
-                      int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows,
-                      int F, const float* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail& tail,
-                      float* out, int64_t ldo, dif_stream_t stream) {
+                      int64_t n_nodes, int64_t nnz, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows,
+                      int F, const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail,
+                      E* out, int64_t ldo, dif_stream_t stream) {
     DIF_REQUIRE(n_rows > 0 && F > 0 && row_begin >= 0 && n_nodes > 0 && nnz >= 0 && n_blocks >= 1, DIF_E_BADARG,
                 "dif_gcn_spmm: need n_rows > 0, F > 0, row_begin >= 0, n_nodes > 0, nnz >= 0, n_blocks >= 1");
     DIF_REQUIRE(row_begin + n_rows <= n_nodes, DIF_E_BADARG, "dif_gcn_spmm: row range exceeds n_nodes");
@@ -464,24 +481,24 @@ static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks
                 "dif_gcn_spmm: leading dimension smaller than a row");
     DIF_REQUIRE((F + 255) / 256 <= 65535, DIF_E_RANGE, "dif_gcn_spmm: F too large");
     bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && (!attn || lda % 4 == 0) &&
-               dif::aligned16(x) && dif::aligned16(out) && (!attn || dif::aligned16(attn));
+               dif::aligned_v4<E>(x) && dif::aligned_v4<E>(out) && (!attn || dif::aligned_v4<E>(attn));
     if (tail.enabled) {
         DIF_REQUIRE((tail.ln_w == nullptr) == (tail.ln_b == nullptr), DIF_E_BADARG,
-                    "dif_gcn_spmm_tail_f32: ln_weight and ln_bias must be given together");
+                    "dif_gcn_spmm_tail: ln_weight and ln_bias must be given together");
         DIF_REQUIRE((!tail.x0 || tail.ldx0 >= F) && (!tail.prev || tail.ldp >= F), DIF_E_BADARG,
-                    "dif_gcn_spmm_tail_f32: leading dimension smaller than a row");
-        vec = vec && (!tail.x0 || (tail.ldx0 % 4 == 0 && dif::aligned16(tail.x0))) &&
-              (!tail.prev || (tail.ldp % 4 == 0 && dif::aligned16(tail.prev))) &&
-              (!tail.ln_w || (dif::aligned16(tail.ln_w) && dif::aligned16(tail.ln_b)));
+                    "dif_gcn_spmm_tail: leading dimension smaller than a row");
+        vec = vec && (!tail.x0 || (tail.ldx0 % 4 == 0 && dif::aligned_v4<E>(tail.x0))) &&
+              (!tail.prev || (tail.ldp % 4 == 0 && dif::aligned_v4<E>(tail.prev))) &&
+              (!tail.ln_w || (dif::aligned_v4<E>(tail.ln_w) && dif::aligned_v4<E>(tail.ln_b)));
         // the LayerNorm statistics are folded inside one lane group: the whole row must fit it
-        DIF_REQUIRE(F <= (vec ? 256 : 64), DIF_E_SHAPE, "dif_gcn_spmm_tail_f32: fused tail needs F <= %d here",
+        DIF_REQUIRE(F <= (vec ? 256 : 64), DIF_E_SHAPE, "dif_gcn_spmm_tail: fused tail needs F <= %d here",
                     vec ? 256 : 64);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n_blocks > 1 && vec && F <= 256 && nnz > 0) {
 #define DIF_BLK(G) \
-    return launch_blocked<G, 4>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, \
-                                attn_scale, gcn_scale, tail, out, ldo)
+    return launch_blocked<G, 4, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, \
+                                   attn_scale, gcn_scale, tail, out, ldo)
         if (F <= 64) DIF_BLK(16);
         if (F <= 128) DIF_BLK(32);
         DIF_BLK(64);
@@ -489,17 +506,17 @@ static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks
     }
     // row mapping: a whole wave per row pays off once a row keeps the wave's gather slots busy
     const bool wave_mode = nnz / n_nodes >= 16;
-    return spmm_dispatch(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale,
-                         gcn_scale, tail, out, ldo, vec);
+    return spmm_dispatch<E>(wave_mode, st, rowptr, src, val, x, ldx, row_begin, n_rows, F, attn, lda, attn_scale,
+                            gcn_scale, tail, out, ldo, vec);
 }
 
 extern "C" int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
                                 const float* val, int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
                                 int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
                                 float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream) {
-    Tail tail = {};
-    return spmm_entry(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
-                      attn_scale, gcn_scale, tail, out, ldo, stream);
+    Tail<float> tail = {};
+    return spmm_entry<float>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
+                             attn_scale, gcn_scale, tail, out, ldo, stream);
 }
 
 extern "C" int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
@@ -509,7 +526,23 @@ extern "C" int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkpt
                                      const float* prev, int64_t ldp, float alpha, const float* ln_weight,
                                      const float* ln_bias, float ln_eps, float* out, int64_t ldo,
                                      dif_stream_t stream) {
-    Tail tail = {x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, 1};
-    return spmm_entry(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
-                      attn_scale, gcn_scale, tail, out, ldo, stream);
+    Tail<float> tail = {x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, 1};
+    return spmm_entry<float>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
+                             attn_scale, gcn_scale, tail, out, ldo, stream);
+}
+
+// bfloat16 storage: x / attn / x0 / prev / LayerNorm parameters / out are bf16, `val` and every accumulation fp32.
+// tail_enabled = 0 ignores the tail arguments (plain SpMM + combine).
+extern "C" int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
+                                      const float* val, int64_t n_nodes, int64_t nnz, const void* x, int64_t ldx,
+                                      int64_t row_begin, int64_t n_rows, int F, const void* attn, int64_t lda,
+                                      float attn_scale, float gcn_scale, int tail_enabled, const void* x0, int64_t ldx0,
+                                      const void* prev, int64_t ldp, float alpha, const void* ln_weight,
+                                      const void* ln_bias, float ln_eps, void* out, int64_t ldo, dif_stream_t stream) {
+    using B = dif::bf16;
+    auto c = [](const void* p) { return static_cast<const B*>(p); };
+    Tail<B> tail = {};
+    if (tail_enabled) tail = Tail<B>{c(x0), ldx0, c(prev), ldp, alpha, c(ln_weight), c(ln_bias), ln_eps, 1};
+    return spmm_entry<B>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, c(x), ldx, row_begin, n_rows, F, c(attn), lda,
+                         attn_scale, gcn_scale, tail, static_cast<B*>(out), ldo, stream);
 }

@@ -10,16 +10,17 @@
 namespace {
 
 using dif::f32x4;
+using dif::Elem;
 
-// G lanes x float4 hold one row (D <= 4G, D % 4 == 0); 256/G rows per block.
-template <int G>
-__global__ __launch_bounds__(256) void layer_tail_vec_kernel(const float* __restrict__ conv, int64_t ldc,
+// G lanes x 4 elements hold one row (D <= 4G, D % 4 == 0); 256/G rows per block.  T = float | dif::bf16 (storage).
+template <int G, typename T>
+__global__ __launch_bounds__(256) void layer_tail_vec_kernel(const T* __restrict__ conv, int64_t ldc,
                                                              int64_t n_rows, int H, int D,
-                                                             const float* __restrict__ x0, int64_t ldx0,
-                                                             const float* __restrict__ prev, int64_t ldp, float alpha,
-                                                             const float* __restrict__ ln_w,
-                                                             const float* __restrict__ ln_b, float eps, int relu,
-                                                             float* __restrict__ out, int64_t ldo) {
+                                                             const T* __restrict__ x0, int64_t ldx0,
+                                                             const T* __restrict__ prev, int64_t ldp, float alpha,
+                                                             const T* __restrict__ ln_w,
+                                                             const T* __restrict__ ln_b, float eps, int relu,
+                                                             T* __restrict__ out, int64_t ldo) {
     constexpr int RPB = 256 / G;
     const int li = threadIdx.x % G;
     const int col = 4 * li;
@@ -27,18 +28,18 @@ __global__ __launch_bounds__(256) void layer_tail_vec_kernel(const float* __rest
     const float inv_h = 1.0f / static_cast<float>(H);
     const float inv_d = 1.0f / static_cast<float>(D);
     f32x4 w4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-    if (ln_w && active) { w4 = *reinterpret_cast<const f32x4*>(ln_w + col); b4 = *reinterpret_cast<const f32x4*>(ln_b + col); }
+    if (ln_w && active) { w4 = Elem<T>::ld4(ln_w + col); b4 = Elem<T>::ld4(ln_b + col); }
     const int64_t nrb = (n_rows + RPB - 1) / RPB;
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         const int64_t row = rb * RPB + threadIdx.x / G;
         const bool ok = active && row < n_rows;
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
-            const float* c = conv + row * ldc + col;
-            for (int h = 0; h < H; ++h) z += *reinterpret_cast<const f32x4*>(c + static_cast<int64_t>(h) * D);
+            const T* c = conv + row * ldc + col;
+            for (int h = 0; h < H; ++h) z += Elem<T>::ld4(c + static_cast<int64_t>(h) * D);
             if (H > 1) z *= inv_h;                                                  // :137
-            if (x0) z += *reinterpret_cast<const f32x4*>(x0 + row * ldx0 + col);    // :139-140
-            if (prev) z = alpha * z + (1.0f - alpha) * *reinterpret_cast<const f32x4*>(prev + row * ldp + col);  // :201
+            if (x0) z += Elem<T>::ld4(x0 + row * ldx0 + col);                       // :139-140
+            if (prev) z = alpha * z + (1.0f - alpha) * Elem<T>::ld4(prev + row * ldp + col);  // :201
         }
         if (ln_w) {                                                                 // :202-203
             float s = z[0] + z[1] + z[2] + z[3];
@@ -56,72 +57,81 @@ __global__ __launch_bounds__(256) void layer_tail_vec_kernel(const float* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[i] = fmaxf(z[i], 0.f);
         }
-        if (ok) *reinterpret_cast<f32x4*>(out + row * ldo + col) = z;
+        if (ok) Elem<T>::st4(out + row * ldo + col, z);
     }
 }
 
-// generic shapes: one wave per row, two passes (z parked in `out`)
-__global__ __launch_bounds__(256) void layer_tail_generic_kernel(const float* __restrict__ conv, int64_t ldc,
+// generic shapes: one wave per row; the row is re-derived in each of the three passes (inputs come from L1/L2),
+// so nothing is parked in `out` at reduced precision.
+template <typename T>
+__global__ __launch_bounds__(256) void layer_tail_generic_kernel(const T* __restrict__ conv, int64_t ldc,
                                                                  int64_t n_rows, int H, int D,
-                                                                 const float* __restrict__ x0, int64_t ldx0,
-                                                                 const float* __restrict__ prev, int64_t ldp,
-                                                                 float alpha, const float* __restrict__ ln_w,
-                                                                 const float* __restrict__ ln_b, float eps, int relu,
-                                                                 float* __restrict__ out, int64_t ldo) {
+                                                                 const T* __restrict__ x0, int64_t ldx0,
+                                                                 const T* __restrict__ prev, int64_t ldp,
+                                                                 float alpha, const T* __restrict__ ln_w,
+                                                                 const T* __restrict__ ln_b, float eps, int relu,
+                                                                 T* __restrict__ out, int64_t ldo) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     const int64_t nw = static_cast<int64_t>(gridDim.x) * 4;
     const float inv_h = 1.0f / static_cast<float>(H);
     const float inv_d = 1.0f / static_cast<float>(D);
     for (int64_t row = gw; row < n_rows; row += nw) {
-        float s = 0.f;
-        for (int d = lane; d < D; d += 64) {
+        auto zval = [&](int d) {
             float z = 0.f;
-            for (int h = 0; h < H; ++h) z += conv[row * ldc + static_cast<int64_t>(h) * D + d];
+            for (int h = 0; h < H; ++h) z += Elem<T>::ld(conv + row * ldc + static_cast<int64_t>(h) * D + d);
             if (H > 1) z *= inv_h;
-            if (x0) z += x0[row * ldx0 + d];
-            if (prev) z = alpha * z + (1.0f - alpha) * prev[row * ldp + d];
-            out[row * ldo + d] = (relu && !ln_w) ? fmaxf(z, 0.f) : z;
-            s += z;
+            if (x0) z += Elem<T>::ld(x0 + row * ldx0 + d);
+            if (prev) z = alpha * z + (1.0f - alpha) * Elem<T>::ld(prev + row * ldp + d);
+            return z;
+        };
+        if (!ln_w) {
+            for (int d = lane; d < D; d += 64) {
+                const float z = zval(d);
+                Elem<T>::st(out + row * ldo + d, relu ? fmaxf(z, 0.f) : z);
+            }
+            continue;
         }
-        if (!ln_w) continue;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += zval(d);
         const float mu = dif::wave_sum(s) * inv_d;
         float v = 0.f;
-        for (int d = lane; d < D; d += 64) { const float dz = out[row * ldo + d] - mu; v += dz * dz; }
+        for (int d = lane; d < D; d += 64) { const float dz = zval(d) - mu; v += dz * dz; }
         const float rstd = 1.0f / sqrtf(dif::wave_sum(v) * inv_d + eps);
         for (int d = lane; d < D; d += 64) {
-            const float y = (out[row * ldo + d] - mu) * rstd * ln_w[d] + ln_b[d];
-            out[row * ldo + d] = relu ? fmaxf(y, 0.f) : y;
+            const float y = (zval(d) - mu) * rstd * Elem<T>::ld(ln_w + d) + Elem<T>::ld(ln_b + d);
+            Elem<T>::st(out + row * ldo + d, relu ? fmaxf(y, 0.f) : y);
         }
     }
 }
 
-}  // namespace
-
-extern "C" int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, int D, const float* x0,
-                                  int64_t ldx0, const float* prev, int64_t ldp, float alpha, const float* ln_weight,
-                                  const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo,
-                                  dif_stream_t stream) {
-    DIF_REQUIRE(n_rows > 0 && H > 0 && D > 0, DIF_E_BADARG, "dif_layer_tail_f32: n_rows, H, D must be positive");
-    DIF_REQUIRE(conv && out, DIF_E_BADARG, "dif_layer_tail_f32: null pointer");
+template <typename T>
+int layer_tail_entry(const T* conv, int64_t ldc, int64_t n_rows, int H, int D, const T* x0, int64_t ldx0, const T* prev,
+                     int64_t ldp, float alpha, const T* ln_weight, const T* ln_bias, float ln_eps, int relu, T* out,
+                     int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && H > 0 && D > 0, DIF_E_BADARG, "dif_layer_tail: n_rows, H, D must be positive");
+    DIF_REQUIRE(conv && out, DIF_E_BADARG, "dif_layer_tail: null pointer");
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
-                "dif_layer_tail_f32: ln_weight and ln_bias must be given together");
+                "dif_layer_tail: ln_weight and ln_bias must be given together");
     DIF_REQUIRE(ldc >= static_cast<int64_t>(H) * D && ldo >= D && (!x0 || ldx0 >= D) && (!prev || ldp >= D), DIF_E_BADARG,
-                "dif_layer_tail_f32: leading dimension smaller than a row");
-    DIF_REQUIRE(out != conv || H == 1, DIF_E_BADARG, "dif_layer_tail_f32: in-place only for H == 1");
+                "dif_layer_tail: leading dimension smaller than a row");
+    DIF_REQUIRE(out != conv || H == 1, DIF_E_BADARG, "dif_layer_tail: in-place only for H == 1");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vec = (D % 4 == 0) && D <= 256 && (ldc % 4 == 0) && (ldo % 4 == 0) && (!x0 || ldx0 % 4 == 0) &&
-                     (!prev || ldp % 4 == 0) && dif::aligned16(conv) && dif::aligned16(out) &&
-                     (!x0 || dif::aligned16(x0)) && (!prev || dif::aligned16(prev)) &&
-                     (!ln_weight || (dif::aligned16(ln_weight) && dif::aligned16(ln_bias)));
+                     (!prev || ldp % 4 == 0) && dif::aligned_v4<T>(conv) && dif::aligned_v4<T>(out) &&
+                     (!x0 || dif::aligned_v4<T>(x0)) && (!prev || dif::aligned_v4<T>(prev)) &&
+                     (!ln_weight || (dif::aligned_v4<T>(ln_weight) && dif::aligned_v4<T>(ln_bias)));
+    // the generic kernel re-reads its inputs after writing `out`: no aliasing there
+    DIF_REQUIRE(vec || (out != conv && out != x0 && out != prev), DIF_E_BADARG,
+                "dif_layer_tail: in-place needs D % 4 == 0, D <= 256 and aligned rows");
     const int64_t cap = 8 * dif::kCUs;
     if (vec) {
         const int q = D / 4;
-#define DIF_TAIL(G)                                                                                         \
-    do {                                                                                                    \
-        int64_t gx = (n_rows + (256 / G) - 1) / (256 / G);                                                  \
-        if (gx > cap) gx = cap;                                                                             \
-        hipLaunchKernelGGL((layer_tail_vec_kernel<G>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, \
+#define DIF_TAIL(G)                                                                                            \
+    do {                                                                                                       \
+        int64_t gx = (n_rows + (256 / G) - 1) / (256 / G);                                                     \
+        if (gx > cap) gx = cap;                                                                                \
+        hipLaunchKernelGGL((layer_tail_vec_kernel<G, T>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, \
                            ldc, n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, relu, out, ldo); \
     } while (0)
         if (q <= 1) DIF_TAIL(1);
@@ -135,8 +145,28 @@ extern "C" int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows
     } else {
         int64_t gx = (n_rows + 3) / 4;
         if (gx > cap) gx = cap;
-        hipLaunchKernelGGL(layer_tail_generic_kernel, dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, ldc,
+        hipLaunchKernelGGL((layer_tail_generic_kernel<T>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, ldc,
                            n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, relu, out, ldo);
     }
     return dif::launch_status("layer_tail kernel");
+}
+
+}  // namespace
+
+extern "C" int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, int D, const float* x0,
+                                  int64_t ldx0, const float* prev, int64_t ldp, float alpha, const float* ln_weight,
+                                  const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo,
+                                  dif_stream_t stream) {
+    return layer_tail_entry<float>(conv, ldc, n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, relu,
+                                   out, ldo, stream);
+}
+
+extern "C" int dif_layer_tail_bf16(const void* conv, int64_t ldc, int64_t n_rows, int H, int D, const void* x0,
+                                   int64_t ldx0, const void* prev, int64_t ldp, float alpha, const void* ln_weight,
+                                   const void* ln_bias, float ln_eps, int relu, void* out, int64_t ldo,
+                                   dif_stream_t stream) {
+    using B = dif::bf16;
+    return layer_tail_entry<B>(static_cast<const B*>(conv), ldc, n_rows, H, D, static_cast<const B*>(x0), ldx0,
+                               static_cast<const B*>(prev), ldp, alpha, static_cast<const B*>(ln_weight),
+                               static_cast<const B*>(ln_bias), ln_eps, relu, static_cast<B*>(out), ldo, stream);
 }

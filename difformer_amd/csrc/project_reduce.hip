@@ -22,6 +22,7 @@
 namespace {
 
 using dif::f32x4;
+using dif::Elem;
 
 constexpr int kPRWaves = 4;
 constexpr int kWStride = 68;     // padded LDS row (floats): 16 lanes x b128 land on 64 distinct banks
@@ -33,26 +34,26 @@ struct PRShape {
 };
 
 // X fragment loads.  GUARD = false: full 16-row tile, C == 64, 16-byte aligned rows -> 4 plain dwordx4.
-template <bool GUARD>
-__device__ __forceinline__ void load_tile(f32x4 (&xa)[4], const float* __restrict__ x, int64_t ldx, int64_t r,
+template <bool GUARD, typename T>
+__device__ __forceinline__ void load_tile(f32x4 (&xa)[4], const T* __restrict__ x, int64_t ldx, int64_t r,
                                           int64_t n, int lg, int C, bool vec) {
     if (!GUARD) {
-        const float* p = x + r * ldx + 4 * lg;
+        const T* p = x + r * ldx + 4 * lg;
 #pragma unroll
-        for (int cq = 0; cq < 4; ++cq) xa[cq] = *reinterpret_cast<const f32x4*>(p + 16 * cq);
+        for (int cq = 0; cq < 4; ++cq) xa[cq] = Elem<T>::ld4(p + 16 * cq);
     } else {
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const int c = 16 * cq + 4 * lg;
             if (r < n) {
-                const float* p = x + r * ldx + c;
+                const T* p = x + r * ldx + c;
                 if (vec && c + 3 < C) {
-                    z = *reinterpret_cast<const f32x4*>(p);
+                    z = Elem<T>::ld4(p);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (c + i < C) z[i] = p[i];
+                        if (c + i < C) z[i] = Elem<T>::ld(p + i);
                 }
             }
             xa[cq] = z;
@@ -67,11 +68,11 @@ struct TileState {
 };
 
 // One 16-row tile: three projections, the q / v stores, K^T V and the column sums.
-template <bool GUARD>
+template <bool GUARD, typename T>
 __device__ __forceinline__ void tile_body(TileState& st, const f32x4 (&xa)[4], const float (*sm_w)[64 * kWStride],
                                           const float (*sm_b)[64], int64_t r0, int64_t n_rows, int h, int D,
-                                          int l15, int lg, float* __restrict__ q_out, int64_t ldq,
-                                          float* __restrict__ v_out, int64_t ldv) {
+                                          int l15, int lg, T* __restrict__ q_out, int64_t ldq,
+                                          T* __restrict__ v_out, int64_t ldv) {
     f32x4 kt[4], vt[4];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {            // 0: k, 1: v, 2: q
@@ -113,15 +114,15 @@ __device__ __forceinline__ void tile_body(TileState& st, const f32x4 (&xa)[4], c
                 } else {
                     st.qsq += yy[0] * yy[0] + yy[1] * yy[1] + yy[2] * yy[2] + yy[3] * yy[3];
                 }
-                float* o = (m == 1 ? v_out + (r0 + 4 * lg) * ldv : q_out + (r0 + 4 * lg) * ldq) + h * D + f;
+                T* o = (m == 1 ? v_out + (r0 + 4 * lg) * ldv : q_out + (r0 + 4 * lg) * ldq) + h * D + f;
                 const int64_t ld = (m == 1) ? ldv : ldq;
                 if (!GUARD) {
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) o[reg * ld] = yy[reg];
+                    for (int reg = 0; reg < 4; ++reg) Elem<T>::st(o + reg * ld, yy[reg]);
                 } else if (f < D) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg)
-                        if (r0 + 4 * lg + reg < n_rows) o[reg * ld] = yy[reg];
+                        if (r0 + 4 * lg + reg < n_rows) Elem<T>::st(o + reg * ld, yy[reg]);
                 }
             }
         }
@@ -138,12 +139,12 @@ __device__ __forceinline__ void tile_body(TileState& st, const f32x4 (&xa)[4], c
 
 // grid (row chunks P, heads H); 256 threads.  Record layout identical to simple_attn.hip's.
 // EXACT: C == 64, D == 64, aligned rows -> full tiles run without any guard.
-template <bool EXACT>
+template <bool EXACT, typename T>
 __global__ __launch_bounds__(256, 2) void project_reduce_kernel(
-    const float* __restrict__ x, int64_t ldx, int64_t n_rows, PRShape sh, const float* __restrict__ Wq,
-    const float* __restrict__ bq, const float* __restrict__ Wk, const float* __restrict__ bk,
-    const float* __restrict__ Wv, const float* __restrict__ bv, float* __restrict__ q_out, int64_t ldq,
-    float* __restrict__ v_out, int64_t ldv, float* __restrict__ ws, int64_t ws_stride, int vec) {
+    const T* __restrict__ x, int64_t ldx, int64_t n_rows, PRShape sh, const T* __restrict__ Wq,
+    const T* __restrict__ bq, const T* __restrict__ Wk, const T* __restrict__ bk,
+    const T* __restrict__ Wv, const T* __restrict__ bv, T* __restrict__ q_out, int64_t ldq,
+    T* __restrict__ v_out, int64_t ldv, float* __restrict__ ws, int64_t ws_stride, int vec) {
     __shared__ __attribute__((aligned(16))) float sm_w[3][64 * kWStride];   // Wk, Wv, Wq of this head (zero padded)
     __shared__ float sm_b[3][64];
     __shared__ __attribute__((aligned(16))) float sm_tile[64 * 64];
@@ -160,16 +161,16 @@ __global__ __launch_bounds__(256, 2) void project_reduce_kernel(
 
     // stage this head's three weight blocks [D x C] -> LDS [64 x kWStride], zero padded
     {
-        const float* Ws[3] = {Wk + static_cast<int64_t>(h) * D * C, Wv + static_cast<int64_t>(h) * D * C,
-                              Wq + static_cast<int64_t>(h) * D * C};
-        const float* bs[3] = {bk + h * D, bv + h * D, bq + h * D};
+        const T* Ws[3] = {Wk + static_cast<int64_t>(h) * D * C, Wv + static_cast<int64_t>(h) * D * C,
+                          Wq + static_cast<int64_t>(h) * D * C};
+        const T* bs[3] = {bk + h * D, bv + h * D, bq + h * D};
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             for (int e = threadIdx.x; e < 64 * 64; e += 256) {
                 const int f = e >> 6, c = e & 63;
-                sm_w[m][f * kWStride + c] = (f < D && c < C) ? Ws[m][f * C + c] : 0.f;
+                sm_w[m][f * kWStride + c] = (f < D && c < C) ? Elem<T>::ld(Ws[m] + f * C + c) : 0.f;
             }
-            if (threadIdx.x < 64) sm_b[m][threadIdx.x] = (threadIdx.x < D) ? bs[m][threadIdx.x] : 0.f;
+            if (threadIdx.x < 64) sm_b[m][threadIdx.x] = (threadIdx.x < D) ? Elem<T>::ld(bs[m] + threadIdx.x) : 0.f;
         }
     }
     __syncthreads();
@@ -305,6 +306,43 @@ int pr_chunks(int64_t n_rows) {
     return static_cast<int>(p);
 }
 
+template <typename T>
+int project_reduce_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* Wq, const T* bq, const T* Wk,
+                         const T* bk, const T* Wv, const T* bv, int H, int D, T* q_out, int64_t ldq, T* v_out,
+                         int64_t ldv, float* reduced, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && C_in > 0 && H > 0 && D > 0, DIF_E_BADARG,
+                "dif_project_reduce: n_rows, C_in, H, D must be positive");
+    DIF_REQUIRE(C_in <= 64 && D <= 64, DIF_E_SHAPE,
+                "dif_project_reduce: fused path covers C_in <= 64 and D <= 64 (got %d, %d); use the Linear layers + "
+                "dif_simple_reduce", C_in, D);
+    DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_project_reduce: too many heads");
+    DIF_REQUIRE(x && Wq && bq && Wk && bk && Wv && bv && q_out && v_out && reduced && workspace, DIF_E_BADARG,
+                "dif_project_reduce: null pointer");
+    DIF_REQUIRE(ldx >= C_in && ldq >= H * D && ldv >= H * D, DIF_E_BADARG,
+                "dif_project_reduce: leading dimension smaller than a row");
+    DIF_REQUIRE(workspace_bytes >= dif_project_reduce_workspace_bytes(n_rows, H, D), DIF_E_WORKSPACE,
+                "dif_project_reduce: workspace too small");
+    PRShape sh;
+    sh.H = H; sh.D = D; sh.C = C_in;
+    sh.t_main = H * D * D + 2 * H * D;
+    const int P = pr_chunks(n_rows);
+    const int64_t rec = (static_cast<int64_t>(sh.t_main) + 2 * H + 3) & ~int64_t(3);
+    const int vec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned_v4<T>(x);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* ws = static_cast<float*>(workspace);
+    const bool exact = vec && C_in == 64 && D == 64;
+    if (exact)
+        hipLaunchKernelGGL((project_reduce_kernel<true, T>), dim3(P, H), dim3(256), 0, st, x, ldx, n_rows, sh, Wq, bq, Wk,
+                           bk, Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec);
+    else
+        hipLaunchKernelGGL((project_reduce_kernel<false, T>), dim3(P, H), dim3(256), 0, st, x, ldx, n_rows, sh, Wq, bq,
+                           Wk, bk, Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec);
+    if (int rc = dif::launch_status("project_reduce_kernel")) return rc;
+    const int nb = (sh.t_main + 63) / 64 + 1;
+    hipLaunchKernelGGL(project_finalize_kernel, dim3(nb), dim3(1024), 0, st, ws, P, rec, sh.t_main, H, reduced);
+    return dif::launch_status("project_finalize_kernel");
+}
+
 }  // namespace
 
 extern "C" size_t dif_project_reduce_workspace_bytes(int64_t n_rows, int H, int D) {
@@ -318,35 +356,17 @@ extern "C" int dif_project_reduce_f32(const float* x, int64_t ldx, int64_t n_row
                                       const float* bv, int H, int D, float* q_out, int64_t ldq, float* v_out,
                                       int64_t ldv, float* reduced, void* workspace, size_t workspace_bytes,
                                       dif_stream_t stream) {
-    DIF_REQUIRE(n_rows > 0 && C_in > 0 && H > 0 && D > 0, DIF_E_BADARG,
-                "dif_project_reduce_f32: n_rows, C_in, H, D must be positive");
-    DIF_REQUIRE(C_in <= 64 && D <= 64, DIF_E_SHAPE,
-                "dif_project_reduce_f32: fused path covers C_in <= 64 and D <= 64 (got %d, %d); use the Linear layers + "
-                "dif_simple_reduce_f32", C_in, D);
-    DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_project_reduce_f32: too many heads");
-    DIF_REQUIRE(x && Wq && bq && Wk && bk && Wv && bv && q_out && v_out && reduced && workspace, DIF_E_BADARG,
-                "dif_project_reduce_f32: null pointer");
-    DIF_REQUIRE(ldx >= C_in && ldq >= H * D && ldv >= H * D, DIF_E_BADARG,
-                "dif_project_reduce_f32: leading dimension smaller than a row");
-    DIF_REQUIRE(workspace_bytes >= dif_project_reduce_workspace_bytes(n_rows, H, D), DIF_E_WORKSPACE,
-                "dif_project_reduce_f32: workspace too small");
-    PRShape sh;
-    sh.H = H; sh.D = D; sh.C = C_in;
-    sh.t_main = H * D * D + 2 * H * D;
-    const int P = pr_chunks(n_rows);
-    const int64_t rec = (static_cast<int64_t>(sh.t_main) + 2 * H + 3) & ~int64_t(3);
-    const int vec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned16(x);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    float* ws = static_cast<float*>(workspace);
-    const bool exact = vec && C_in == 64 && D == 64;
-    if (exact)
-        hipLaunchKernelGGL(project_reduce_kernel<true>, dim3(P, H), dim3(256), 0, st, x, ldx, n_rows, sh, Wq, bq, Wk, bk,
-                           Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec);
-    else
-        hipLaunchKernelGGL(project_reduce_kernel<false>, dim3(P, H), dim3(256), 0, st, x, ldx, n_rows, sh, Wq, bq, Wk,
-                           bk, Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec);
-    if (int rc = dif::launch_status("project_reduce_kernel")) return rc;
-    const int nb = (sh.t_main + 63) / 64 + 1;
-    hipLaunchKernelGGL(project_finalize_kernel, dim3(nb), dim3(1024), 0, st, ws, P, rec, sh.t_main, H, reduced);
-    return dif::launch_status("project_finalize_kernel");
+    return project_reduce_entry<float>(x, ldx, n_rows, C_in, Wq, bq, Wk, bk, Wv, bv, H, D, q_out, ldq, v_out, ldv, reduced,
+                                       workspace, workspace_bytes, stream);
+}
+
+extern "C" int dif_project_reduce_bf16(const void* x, int64_t ldx, int64_t n_rows, int C_in, const void* Wq,
+                                       const void* bq, const void* Wk, const void* bk, const void* Wv, const void* bv,
+                                       int H, int D, void* q_out, int64_t ldq, void* v_out, int64_t ldv, float* reduced,
+                                       void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    using B = dif::bf16;
+    auto c = [](const void* p) { return static_cast<const B*>(p); };
+    return project_reduce_entry<B>(c(x), ldx, n_rows, C_in, c(Wq), c(bq), c(Wk), c(bk), c(Wv), c(bv), H, D,
+                                   static_cast<B*>(q_out), ldq, static_cast<B*>(v_out), ldv, reduced, workspace,
+                                   workspace_bytes, stream);
 }

@@ -14,6 +14,7 @@
 namespace {
 
 using dif::f32x4;
+using dif::Elem;
 
 constexpr int kTile = 64;       // m / d extent one workgroup accumulates (16 MFMA tiles of 16x16)
 constexpr int kRedWaves = 4;    // waves per reduce workgroup
@@ -37,18 +38,18 @@ __host__ __device__ inline Shape make_shape(int H, int M, int D) {
 }
 
 // 4 consecutive floats of row r starting at column c (c % 4 == 0); zero outside [0,n) x [0,width).
-template <bool VEC>
-__device__ __forceinline__ f32x4 load_row4(const float* __restrict__ base, int64_t ld, int64_t r,
+template <bool VEC, typename T>
+__device__ __forceinline__ f32x4 load_row4(const T* __restrict__ base, int64_t ld, int64_t r,
                                            int64_t n, int col0, int c, int width) {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     if (r >= n) return z;
-    const float* p = base + r * ld + col0 + c;
+    const T* p = base + r * ld + col0 + c;
     if (VEC) {
-        if (c < width) z = *reinterpret_cast<const f32x4*>(p);
+        if (c < width) z = Elem<T>::ld4(p);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (c + i < width) z[i] = p[i];
+            if (c + i < width) z[i] = Elem<T>::ld(p + i);
     }
     return z;
 }
@@ -59,10 +60,10 @@ __device__ __forceinline__ f32x4 load_row4(const float* __restrict__ base, int64
 // and MFMA (t,u) accumulates  D[i][j] += sum_k A[i][k] B[k][j]  with A[i=lane%16][k=lane/16] =
 // kx[t], B[k][j=lane%16] = vx[u], i.e. KtV[m0 + 4i + t][d0 + 4j + u].
 // ------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, typename T>
 __global__ __launch_bounds__(256) void simple_reduce_kernel(
-    const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
-    const float* __restrict__ v, int64_t ldv, int64_t n_rows, Shape sh, float* __restrict__ ws,
+    const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk,
+    const T* __restrict__ v, int64_t ldv, int64_t n_rows, Shape sh, float* __restrict__ ws,
     int64_t ws_stride) {
     __shared__ __attribute__((aligned(16))) float sm_tile[kTile * kTile];
     __shared__ float sm_k[kRedWaves][kTile];
@@ -222,11 +223,11 @@ __global__ __launch_bounds__(1024) void simple_finalize_kernel(const float* __re
 //   A = s*KtV[16c + 4*(lane/16) + t][16*dtl + lane%16] (register-resident when M,D <= 64).
 //   The lane ends up with out[r0 + lane%16][16*dtl + 4*(lane/16) .. +3]: one float4 store.
 // ------------------------------------------------------------------------------------------
-template <bool VEC, bool SINGLE>
-__global__ __launch_bounds__(256) void simple_apply_kernel(const float* __restrict__ q, int64_t ldq,
+template <bool VEC, bool SINGLE, typename T>
+__global__ __launch_bounds__(256) void simple_apply_kernel(const T* __restrict__ q, int64_t ldq,
                                                            const float* __restrict__ reduced,
                                                            int64_t n_rows, float n_global, Shape sh,
-                                                           float* __restrict__ out, int64_t ldo) {
+                                                           T* __restrict__ out, int64_t ldo) {
     const int h = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -313,16 +314,16 @@ __global__ __launch_bounds__(256) void simple_apply_kernel(const float* __restri
 #pragma unroll
                 for (int dtl = 0; dtl < 4; ++dtl) {
                     const int d0 = dt * kTile + 16 * dtl + 4 * lg;
-                    float* o = out + r * ldo + h * sh.D + d0;
+                    T* o = out + r * ldo + h * sh.D + d0;
                     if (VEC) {
                         if (d0 < sh.D) {
                             const f32x4 vs4 = *reinterpret_cast<const f32x4*>(vsum + d0);
-                            *reinterpret_cast<f32x4*>(o) = (acc[dtl] + vs4) / den;  // :29, :39
+                            Elem<T>::st4(o, (acc[dtl] + vs4) / den);  // :29, :39
                         }
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (d0 + i < sh.D) o[i] = (acc[dtl][i] + vsum[d0 + i]) / den;
+                            if (d0 + i < sh.D) Elem<T>::st(o + i, (acc[dtl][i] + vsum[d0 + i]) / den);
                     }
                 }
             }
@@ -349,6 +350,65 @@ int check_shape(int64_t n_rows, int H, int M, int D) {
     return 0;
 }
 
+template <typename T>
+int simple_reduce_entry(const T* q, int64_t ldq, const T* k, int64_t ldk, const T* v, int64_t ldv, int64_t n_rows, int H,
+                        int M, int D, float* reduced, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    if (int rc = check_shape(n_rows, H, M, D)) return rc;
+    DIF_REQUIRE(q && k && v && reduced && workspace, DIF_E_BADARG, "dif_simple_reduce: null pointer");
+    DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D, DIF_E_BADARG,
+                "dif_simple_reduce: leading dimension smaller than a row");
+    DIF_REQUIRE(workspace_bytes >= dif_simple_workspace_bytes(n_rows, H, M, D), DIF_E_WORKSPACE,
+                "dif_simple_reduce: workspace too small (%zu < %zu)", workspace_bytes,
+                dif_simple_workspace_bytes(n_rows, H, M, D));
+    DIF_REQUIRE(dif::aligned16(workspace), DIF_E_BADARG, "dif_simple_reduce: workspace not 16-byte aligned");
+    const Shape sh = make_shape(H, M, D);
+    const int P = reduce_chunks(n_rows);
+    const int64_t rec = (static_cast<int64_t>(sh.t_main) + 2 * sh.tiles + 3) & ~int64_t(3);
+    const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) &&
+                     dif::aligned_v4<T>(q) && dif::aligned_v4<T>(k) && dif::aligned_v4<T>(v);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* ws = static_cast<float*>(workspace);
+    dim3 grid(P, sh.tiles), block(256);
+    if (vec)
+        hipLaunchKernelGGL((simple_reduce_kernel<true, T>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, n_rows, sh, ws, rec);
+    else
+        hipLaunchKernelGGL((simple_reduce_kernel<false, T>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, n_rows, sh, ws, rec);
+    if (int rc = dif::launch_status("simple_reduce_kernel")) return rc;
+    const int nb = (sh.t_main + 63) / 64 + 1;
+    hipLaunchKernelGGL(simple_finalize_kernel, dim3(nb), dim3(1024), 0, st, ws, P, rec, sh, reduced);
+    return dif::launch_status("simple_finalize_kernel");
+}
+
+template <typename T>
+int simple_apply_entry(const T* q, int64_t ldq, const float* reduced, int64_t n_rows, int64_t n_global, int H, int M,
+                       int D, T* out, int64_t ldo, dif_stream_t stream) {
+    if (int rc = check_shape(n_rows, H, M, D)) return rc;
+    DIF_REQUIRE(q && reduced && out, DIF_E_BADARG, "dif_simple_apply: null pointer");
+    DIF_REQUIRE(ldq >= H * M && ldo >= H * D, DIF_E_BADARG, "dif_simple_apply: leading dimension smaller than a row");
+    DIF_REQUIRE(n_global >= n_rows, DIF_E_BADARG, "dif_simple_apply: n_global < n_rows");
+    DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_simple_apply: too many heads");
+    const Shape sh = make_shape(H, M, D);
+    const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldo % 4 == 0) && dif::aligned_v4<T>(q) &&
+                     dif::aligned_v4<T>(out) && dif::aligned16(reduced) && ((H * M * D + H * M) % 4 == 0);
+    const bool single = (sh.MT == 1 && sh.DT == 1);
+    const int64_t n_steps = (n_rows + 15) / 16;
+    int64_t gx = (n_steps + 3) / 4;
+    const int64_t cap = 2 * dif::kCUs;  // persistent: the per-wave fragment prologue is paid once per ~4+ steps
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(static_cast<unsigned>(gx), H), block(256);
+    const float nf = static_cast<float>(n_global);
+#define DIF_LAUNCH_APPLY(V, S) \
+    hipLaunchKernelGGL((simple_apply_kernel<V, S, T>), grid, block, 0, st, q, ldq, reduced, n_rows, nf, sh, out, ldo)
+    if (vec && single) DIF_LAUNCH_APPLY(true, true);
+    else if (vec) DIF_LAUNCH_APPLY(true, false);
+    else if (single) DIF_LAUNCH_APPLY(false, true);
+    else DIF_LAUNCH_APPLY(false, false);
+#undef DIF_LAUNCH_APPLY
+    return dif::launch_status("simple_apply_kernel");
+}
+
 }  // namespace
 
 extern "C" size_t dif_simple_reduced_len(int H, int M, int D) {
@@ -363,62 +423,28 @@ extern "C" size_t dif_simple_workspace_bytes(int64_t n_rows, int H, int M, int D
     return rec * sizeof(float) * static_cast<size_t>(reduce_chunks(n_rows));
 }
 
-extern "C" int dif_simple_reduce_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
-                                     const float* v, int64_t ldv, int64_t n_rows, int H, int M, int D,
-                                     float* reduced, void* workspace, size_t workspace_bytes,
-                                     dif_stream_t stream) {
-    if (int rc = check_shape(n_rows, H, M, D)) return rc;
-    DIF_REQUIRE(q && k && v && reduced && workspace, DIF_E_BADARG, "dif_simple_reduce_f32: null pointer");
-    DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D, DIF_E_BADARG,
-                "dif_simple_reduce_f32: leading dimension smaller than a row");
-    DIF_REQUIRE(workspace_bytes >= dif_simple_workspace_bytes(n_rows, H, M, D), DIF_E_WORKSPACE,
-                "dif_simple_reduce_f32: workspace too small (%zu < %zu)", workspace_bytes,
-                dif_simple_workspace_bytes(n_rows, H, M, D));
-    DIF_REQUIRE(dif::aligned16(workspace), DIF_E_BADARG, "dif_simple_reduce_f32: workspace not 16-byte aligned");
-    const Shape sh = make_shape(H, M, D);
-    const int P = reduce_chunks(n_rows);
-    const int64_t rec = (static_cast<int64_t>(sh.t_main) + 2 * sh.tiles + 3) & ~int64_t(3);
-    const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) &&
-                     dif::aligned16(q) && dif::aligned16(k) && dif::aligned16(v);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    float* ws = static_cast<float*>(workspace);
-    dim3 grid(P, sh.tiles), block(256);
-    if (vec)
-        hipLaunchKernelGGL(simple_reduce_kernel<true>, grid, block, 0, st, q, ldq, k, ldk, v, ldv, n_rows, sh, ws, rec);
-    else
-        hipLaunchKernelGGL(simple_reduce_kernel<false>, grid, block, 0, st, q, ldq, k, ldk, v, ldv, n_rows, sh, ws, rec);
-    if (int rc = dif::launch_status("simple_reduce_kernel")) return rc;
-    const int nb = (sh.t_main + 63) / 64 + 1;
-    hipLaunchKernelGGL(simple_finalize_kernel, dim3(nb), dim3(1024), 0, st, ws, P, rec, sh, reduced);
-    return dif::launch_status("simple_finalize_kernel");
+extern "C" int dif_simple_reduce_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                     int64_t ldv, int64_t n_rows, int H, int M, int D, float* reduced, void* workspace,
+                                     size_t workspace_bytes, dif_stream_t stream) {
+    return simple_reduce_entry<float>(q, ldq, k, ldk, v, ldv, n_rows, H, M, D, reduced, workspace, workspace_bytes, stream);
 }
 
-extern "C" int dif_simple_apply_f32(const float* q, int64_t ldq, const float* reduced, int64_t n_rows,
-                                    int64_t n_global, int H, int M, int D, float* out, int64_t ldo,
-                                    dif_stream_t stream) {
-    if (int rc = check_shape(n_rows, H, M, D)) return rc;
-    DIF_REQUIRE(q && reduced && out, DIF_E_BADARG, "dif_simple_apply_f32: null pointer");
-    DIF_REQUIRE(ldq >= H * M && ldo >= H * D, DIF_E_BADARG, "dif_simple_apply_f32: leading dimension smaller than a row");
-    DIF_REQUIRE(n_global >= n_rows, DIF_E_BADARG, "dif_simple_apply_f32: n_global < n_rows");
-    DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_simple_apply_f32: too many heads");
-    const Shape sh = make_shape(H, M, D);
-    const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldo % 4 == 0) && dif::aligned16(q) &&
-                     dif::aligned16(out) && dif::aligned16(reduced) && ((H * M * D + H * M) % 4 == 0);
-    const bool single = (sh.MT == 1 && sh.DT == 1);
-    const int64_t n_steps = (n_rows + 15) / 16;
-    int64_t gx = (n_steps + 3) / 4;
-    const int64_t cap = 2 * dif::kCUs;  // persistent: the per-wave fragment prologue is paid once per ~4+ steps
-    if (gx > cap) gx = cap;
-    if (gx < 1) gx = 1;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid(static_cast<unsigned>(gx), H), block(256);
-    const float nf = static_cast<float>(n_global);
-#define DIF_LAUNCH_APPLY(V, S) \
-    hipLaunchKernelGGL((simple_apply_kernel<V, S>), grid, block, 0, st, q, ldq, reduced, n_rows, nf, sh, out, ldo)
-    if (vec && single) DIF_LAUNCH_APPLY(true, true);
-    else if (vec) DIF_LAUNCH_APPLY(true, false);
-    else if (single) DIF_LAUNCH_APPLY(false, true);
-    else DIF_LAUNCH_APPLY(false, false);
-#undef DIF_LAUNCH_APPLY
-    return dif::launch_status("simple_apply_kernel");
+extern "C" int dif_simple_reduce_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                      int64_t n_rows, int H, int M, int D, float* reduced, void* workspace,
+                                      size_t workspace_bytes, dif_stream_t stream) {
+    using B = dif::bf16;
+    return simple_reduce_entry<B>(static_cast<const B*>(q), ldq, static_cast<const B*>(k), ldk, static_cast<const B*>(v),
+                                  ldv, n_rows, H, M, D, reduced, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dif_simple_apply_f32(const float* q, int64_t ldq, const float* reduced, int64_t n_rows, int64_t n_global,
+                                    int H, int M, int D, float* out, int64_t ldo, dif_stream_t stream) {
+    return simple_apply_entry<float>(q, ldq, reduced, n_rows, n_global, H, M, D, out, ldo, stream);
+}
+
+extern "C" int dif_simple_apply_bf16(const void* q, int64_t ldq, const float* reduced, int64_t n_rows, int64_t n_global,
+                                     int H, int M, int D, void* out, int64_t ldo, dif_stream_t stream) {
+    using B = dif::bf16;
+    return simple_apply_entry<B>(static_cast<const B*>(q), ldq, reduced, n_rows, n_global, H, M, D, static_cast<B*>(out),
+                                 ldo, stream);
 }

@@ -13,17 +13,18 @@
 namespace {
 
 using dif::f32x4;
+using dif::Elem;
 
 constexpr int kLinStride = 68;
 
 // grid (row chunks, ceil(C_out/64)); 256 threads.  KQ = number of 16-channel groups of C_in actually used (1..4).
-template <int KQ>
-__global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows,
-                                                            int C_in, const float* __restrict__ W,
-                                                            const float* __restrict__ bias, int C_out,
-                                                            const float* __restrict__ ln_w,
-                                                            const float* __restrict__ ln_b, float eps, int relu,
-                                                            float* __restrict__ out, int64_t ldo, int vec) {
+template <int KQ, typename T>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict__ x, int64_t ldx, int64_t n_rows,
+                                                            int C_in, const T* __restrict__ W,
+                                                            const T* __restrict__ bias, int C_out,
+                                                            const T* __restrict__ ln_w,
+                                                            const T* __restrict__ ln_b, float eps, int relu,
+                                                            T* __restrict__ out, int64_t ldo, int vec) {
     __shared__ __attribute__((aligned(16))) float sm_w[64 * kLinStride];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
 
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         const int f = e >> 6, c = e & 63;
-        sm_w[f * kLinStride + c] = (f0 + f < C_out && c < C_in) ? W[static_cast<int64_t>(f0 + f) * C_in + c] : 0.f;
+        sm_w[f * kLinStride + c] = (f0 + f < C_out && c < C_in) ? Elem<T>::ld(W + static_cast<int64_t>(f0 + f) * C_in + c) : 0.f;
     }
     __syncthreads();
     // weight fragments stay in registers for the whole row sweep
@@ -42,9 +43,9 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
         const int f = f0 + 16 * ft + l15;
-        bfr[ft] = (f < C_out) ? bias[f] : 0.f;
-        lw[ft] = (ln_w && f < C_out) ? ln_w[f] : 0.f;
-        lb[ft] = (ln_w && f < C_out) ? ln_b[f] : 0.f;
+        bfr[ft] = (f < C_out) ? Elem<T>::ld(bias + f) : 0.f;
+        lw[ft] = (ln_w && f < C_out) ? Elem<T>::ld(ln_w + f) : 0.f;
+        lb[ft] = (ln_w && f < C_out) ? Elem<T>::ld(ln_b + f) : 0.f;
 #pragma unroll
         for (int cq = 0; cq < KQ; ++cq)
             wf[ft][cq] = *reinterpret_cast<const f32x4*>(&sm_w[(16 * ft + l15) * kLinStride + 16 * cq + 4 * lg]);
@@ -63,13 +64,13 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const int c = 16 * cq + 4 * lg;
             if (r < n_rows) {
-                const float* p = x + r * ldx + c;
+                const T* p = x + r * ldx + c;
                 if (vec && c + 3 < C_in) {
-                    z = *reinterpret_cast<const f32x4*>(p);
+                    z = Elem<T>::ld4(p);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (c + i < C_in) z[i] = p[i];
+                        if (c + i < C_in) z[i] = Elem<T>::ld(p + i);
                 }
             }
             xa[cq] = z;
@@ -113,28 +114,26 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int64_t rr = r0 + 4 * lg + reg;
-                    if (rr < n_rows) out[rr * ldo + f] = relu ? fmaxf(y[ft][reg], 0.f) : y[ft][reg];
+                    if (rr < n_rows) Elem<T>::st(out + rr * ldo + f, relu ? fmaxf(y[ft][reg], 0.f) : y[ft][reg]);
                 }
             }
         }
     }
 }
 
-}  // namespace
-
-extern "C" int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const float* W, const float* bias,
-                              int C_out, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
-                              float* out, int64_t ldo, dif_stream_t stream) {
-    DIF_REQUIRE(n_rows > 0 && C_in > 0 && C_out > 0, DIF_E_BADARG, "dif_linear_f32: n_rows, C_in, C_out must be positive");
-    DIF_REQUIRE(x && W && bias && out, DIF_E_BADARG, "dif_linear_f32: null pointer");
-    DIF_REQUIRE(C_in <= 64, DIF_E_SHAPE, "dif_linear_f32: covers C_in <= 64 (got %d); use the vendor GEMM", C_in);
+template <typename T>
+int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, const T* bias, int C_out,
+                 const T* ln_weight, const T* ln_bias, float ln_eps, int relu, T* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && C_in > 0 && C_out > 0, DIF_E_BADARG, "dif_linear: n_rows, C_in, C_out must be positive");
+    DIF_REQUIRE(x && W && bias && out, DIF_E_BADARG, "dif_linear: null pointer");
+    DIF_REQUIRE(C_in <= 64, DIF_E_SHAPE, "dif_linear: covers C_in <= 64 (got %d); use the vendor GEMM", C_in);
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
-                "dif_linear_f32: ln_weight and ln_bias must be given together");
-    DIF_REQUIRE(!ln_weight || C_out <= 64, DIF_E_SHAPE, "dif_linear_f32: fused LayerNorm needs C_out <= 64");
-    DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear_f32: leading dimension smaller than a row");
+                "dif_linear: ln_weight and ln_bias must be given together");
+    DIF_REQUIRE(!ln_weight || C_out <= 64, DIF_E_SHAPE, "dif_linear: fused LayerNorm needs C_out <= 64");
+    DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear: leading dimension smaller than a row");
     const int gy = (C_out + 63) / 64;
-    DIF_REQUIRE(gy <= 65535, DIF_E_RANGE, "dif_linear_f32: C_out too large");
-    const int vec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned16(x);
+    DIF_REQUIRE(gy <= 65535, DIF_E_RANGE, "dif_linear: C_out too large");
+    const int vec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned_v4<T>(x);
     const int64_t n_tiles = (n_rows + 15) / 16;
     int64_t gx = (n_tiles + 3) / 4;
     const int64_t cap = 4 * dif::kCUs;
@@ -143,7 +142,7 @@ extern "C" int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C
     dim3 grid(static_cast<unsigned>(gx), gy), block(256);
     const int kq = (C_in + 15) / 16;
 #define DIF_LIN(KQ) \
-    hipLaunchKernelGGL((skinny_linear_kernel<KQ>), grid, block, 0, st, x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, \
+    hipLaunchKernelGGL((skinny_linear_kernel<KQ, T>), grid, block, 0, st, x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, \
                        ln_bias, ln_eps, relu, out, ldo, vec)
     if (kq == 1) DIF_LIN(1);
     else if (kq == 2) DIF_LIN(2);
@@ -151,4 +150,21 @@ extern "C" int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C
     else DIF_LIN(4);
 #undef DIF_LIN
     return dif::launch_status("skinny_linear_kernel");
+}
+
+}  // namespace
+
+extern "C" int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const float* W, const float* bias,
+                              int C_out, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                              float* out, int64_t ldo, dif_stream_t stream) {
+    return linear_entry<float>(x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, ln_bias, ln_eps, relu, out, ldo, stream);
+}
+
+extern "C" int dif_linear_bf16(const void* x, int64_t ldx, int64_t n_rows, int C_in, const void* W, const void* bias,
+                               int C_out, const void* ln_weight, const void* ln_bias, float ln_eps, int relu, void* out,
+                               int64_t ldo, dif_stream_t stream) {
+    using B = dif::bf16;
+    return linear_entry<B>(static_cast<const B*>(x), ldx, n_rows, C_in, static_cast<const B*>(W),
+                           static_cast<const B*>(bias), C_out, static_cast<const B*>(ln_weight),
+                           static_cast<const B*>(ln_bias), ln_eps, relu, static_cast<B*>(out), ldo, stream);
 }

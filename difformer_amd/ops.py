@@ -93,6 +93,8 @@ def choose_source_blocks(num_nodes, row_bytes, nnz):
     if total <= 4 * 2 ** 20 or nnz < 64 * num_nodes:
         return 1
     nb = int(round(total / L2_SLICE_BYTES))
+    # the sweep prefetches up to 64 entries of a (row, block) group; longer groups fall off that fast path
+    nb = max(nb, -(-int(nnz) // (int(num_nodes) * 48)))
     nb = max(2, min(nb, 64))
     # keep >= ~24 entries per (row, block) group on average
     while nb > 2 and nnz / (num_nodes * nb) < 24:

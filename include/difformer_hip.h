@@ -158,6 +158,42 @@ int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const 
                    const float* bias, int C_out, const float* ln_weight, const float* ln_bias,
                    float ln_eps, int relu, float* out, int64_t ldo, dif_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * bfloat16 STORAGE variants (BASELINE config C5: Pokec mini-batches in bf16).  Same semantics as the
+ * _f32 entry points; every tensor the reference would hold in its activation dtype (x, q, k, v, attn,
+ * conv, out, Linear / LayerNorm parameters) is bf16 (uint16 bit patterns behind void*), while the CSR
+ * values, the `reduced` record and all accumulation stay float32.  The reference itself cannot run
+ * bf16 (difformer.py:27 raises), so parity is against the float64 oracle on the bf16-rounded inputs
+ * at a bf16-appropriate tolerance.  dif_gcn_spmm_tail_bf16: tail_enabled = 0 gives the plain SpMM.
+ * ------------------------------------------------------------------------------------- */
+int dif_linear_bf16(const void* x, int64_t ldx, int64_t n_rows, int C_in, const void* W,
+                    const void* bias, int C_out, const void* ln_weight, const void* ln_bias,
+                    float ln_eps, int relu, void* out, int64_t ldo, dif_stream_t stream);
+int dif_project_reduce_bf16(const void* x, int64_t ldx, int64_t n_rows, int C_in,
+                            const void* Wq, const void* bq, const void* Wk, const void* bk,
+                            const void* Wv, const void* bv, int H, int D,
+                            void* q_out, int64_t ldq, void* v_out, int64_t ldv,
+                            float* reduced, void* workspace, size_t workspace_bytes,
+                            dif_stream_t stream);
+int dif_simple_reduce_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk,
+                           const void* v, int64_t ldv, int64_t n_rows, int H, int M, int D,
+                           float* reduced, void* workspace, size_t workspace_bytes,
+                           dif_stream_t stream);
+int dif_simple_apply_bf16(const void* q, int64_t ldq, const float* reduced, int64_t n_rows,
+                          int64_t n_global, int H, int M, int D, void* out, int64_t ldo,
+                          dif_stream_t stream);
+int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
+                           const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
+                           const void* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                           const void* attn, int64_t lda, float attn_scale, float gcn_scale,
+                           int tail_enabled, const void* x0, int64_t ldx0, const void* prev,
+                           int64_t ldp, float alpha, const void* ln_weight, const void* ln_bias,
+                           float ln_eps, void* out, int64_t ldo, dif_stream_t stream);
+int dif_layer_tail_bf16(const void* conv, int64_t ldc, int64_t n_rows, int H, int D,
+                        const void* x0, int64_t ldx0, const void* prev, int64_t ldp,
+                        float alpha, const void* ln_weight, const void* ln_bias, float ln_eps,
+                        int relu, void* out, int64_t ldo, dif_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

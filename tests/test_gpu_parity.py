@@ -515,3 +515,85 @@ def test_model_forward_c4_ogbn_proteins_full_size(dev):
     """BASELINE config C4 at FULL size -- the exact bench.py workload (132,534 nodes, 79,255,038 CSR entries,
     4 layers) -- against the float64 oracle (OpenMP C gcn_conv + numpy)."""
     _full_config_parity(dev, 132534, 39561252, 8, 112, 4)
+
+
+# ------------------------------------------------------------------ bfloat16 storage variants (config C5)
+BF16_TOL = 1e-2      # SURVEY.md section 8d: bf16 storage / fp32 accumulate against the fp32-or-better oracle
+
+
+def _bf(t):
+    """Round to bfloat16 and return (bf16 tensor, its exact float64 numpy value)."""
+    b = t.to(torch.bfloat16)
+    return b, b.to(torch.float64).numpy()
+
+
+def test_bf16_operators_vs_oracle(dev):
+    from difformer_amd import ops
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(77)
+    n, c, h, d = 3000, 64, 1, 64
+    x, x64 = _bf(torch.randn(n, c, generator=g))
+    W = [_bf(torch.randn(h * d, c, generator=g) / 8) for _ in range(3)]
+    b = [_bf(torch.randn(h * d, generator=g) * 0.3) for _ in range(3)]
+    lw, lw64 = _bf(torch.rand(d, generator=g) + 0.5)
+    lb, lb64 = _bf(torch.randn(d, generator=g))
+    # Linear + LayerNorm + ReLU
+    out = ops.linear(x.to(dev), W[0][0].to(dev), b[0][0].to(dev), lw.to(dev), lb.to(dev), 1e-5, True)
+    assert out.dtype == torch.bfloat16
+    ref = np.maximum(orc.layer_norm(x64 @ W[0][1].T + b[0][1], lw64, lb64), 0)
+    assert rel_err(out.float().cpu().numpy(), ref) < BF16_TOL
+    # projection + reduce, apply
+    q, v, rec = be.project_reduce(x.to(dev), W[0][0].to(dev), b[0][0].to(dev), W[1][0].to(dev), b[1][0].to(dev),
+                                  W[2][0].to(dev), b[2][0].to(dev), h, d)
+    q64, k64, v64 = ((x64 @ W[i][1].T + b[i][1]).reshape(n, h, d) for i in range(3))
+    assert q.dtype == torch.bfloat16 and rec.dtype == torch.float32
+    assert rel_err(q.float().cpu().numpy(), q64) < BF16_TOL and rel_err(v.float().cpu().numpy(), v64) < BF16_TOL
+    assert rel_err(rec[: d * d].cpu().numpy(), np.einsum("lhm,lhd->hmd", k64, v64).ravel()) < 1e-4
+    attn = be.simple_apply(q, rec, n, d)
+    q_r, v_r = q.double().cpu().numpy(), v64
+    ref_attn = orc.simple_attention(q_r, k64, v_r)
+    assert rel_err(attn.float().cpu().numpy(), ref_attn) < BF16_TOL
+    # stand-alone reduce on bf16 q, k, v
+    k_b, _ = _bf(torch.from_numpy(k64))
+    rec2 = be.simple_reduce(q, k_b.to(dev), v)
+    assert rel_err(rec2[: d * d].cpu().numpy(), np.einsum("lhm,lhd->hmd", k_b.double().numpy(), v.double().cpu().numpy()).ravel()) < 1e-4
+    # SpMM (+ combine, + fused tail) with bf16 rows, blocked and plain
+    ei = torch.randint(0, n, (2, 200000), generator=g)
+    prev, prev64 = _bf(torch.randn(n, d, generator=g))
+    gref = orc.gcn_conv(v.double().cpu().numpy(), ei.numpy(), None)
+    for n_blocks in (1, 3):
+        csr = ops.GraphCSR.build(ei.to(dev), None, n, n_blocks)
+        plain = ops.gcn_aggregate(csr, v, attn, 1.0, 1.0)
+        assert plain.dtype == torch.bfloat16
+        assert rel_err(plain.float().cpu().numpy(), gref + attn.double().cpu().numpy()) < BF16_TOL
+        tail = dict(x0=None, prev=prev.to(dev), alpha=0.5, ln_weight=lw.to(dev), ln_bias=lb.to(dev), eps=1e-5)
+        fused = ops.gcn_aggregate(csr, v, attn, 1.0, 1.0, None, tail)[:, 0, :]
+        z = 0.5 * (gref + attn.double().cpu().numpy())[:, 0, :] + 0.5 * prev64
+        assert rel_err(fused.float().cpu().numpy(), orc.layer_norm(z, lw64, lb64)) < BF16_TOL
+    # stand-alone tail
+    t = ops.layer_tail(plain, None, prev.to(dev), 0.5, lw.to(dev), lb.to(dev), 1e-5)
+    z = 0.5 * plain.double().cpu().numpy()[:, 0, :] + 0.5 * prev64
+    assert rel_err(t.float().cpu().numpy(), orc.layer_norm(z, lw64, lb64)) < BF16_TOL
+
+
+def test_bf16_model_forward_c5_shape(dev):
+    """BASELINE config C5: one Pokec-shaped mini-batch in bfloat16 storage (model.to(bfloat16), x bfloat16) against the
+    float64 oracle evaluated with the bf16-rounded parameters and inputs."""
+    from difformer_amd import DIFFormer
+    from bench import make_graph
+    n, f_in, classes, layers = 100000, 65, 2, 3
+    torch.manual_seed(123)
+    model = DIFFormer(f_in, 64, classes, num_layers=layers, kernel="simple", use_graph=True).eval()
+    gx = torch.Generator().manual_seed(1)
+    x = torch.randn(n, f_in, generator=gx).to(torch.bfloat16)
+    ei = make_graph(n, 115000, dev)
+    model = model.to(torch.bfloat16)
+    cfg = dict(hidden_channels=64, num_layers=layers, num_heads=1, kernel="simple", alpha=0.5, use_bn=True,
+               use_residual=True, use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    p = {k: v.double().numpy() for k, v in model.state_dict().items()}
+    ref = orc.difformer_forward(p, x.double().numpy(), ei.cpu().numpy(), None, cfg)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(x.to(dev), ei)
+    assert out.dtype == torch.bfloat16
+    assert rel_err(out.float().cpu().numpy(), ref) < 2 * BF16_TOL     # 4 LayerNorm-separated bf16 round trips
