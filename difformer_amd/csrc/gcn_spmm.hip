@@ -111,6 +111,14 @@ __device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, c
 
 constexpr int kGatherUnroll = 8;
 
+// Element offset of source row `s`: 32-bit arithmetic (one v_mul_lo_u32) when the whole matrix spans < 2^31 elements
+// -- the 64-bit form costs five extra VALU instructions per gather.
+template <bool WIDE>
+__device__ __forceinline__ int64_t row_off(int32_t s, int64_t ldx) {
+    if (WIDE) return static_cast<int64_t>(s) * ldx;
+    return static_cast<int64_t>(static_cast<uint32_t>(s) * static_cast<uint32_t>(ldx));
+}
+
 // ---- whole wave per destination row ---------------------------------------------------------
 // grid (row blocks, column chunks of G*W floats); 256 threads = 4 rows in flight per block.
 template <int G, int W, typename E>
@@ -221,7 +229,7 @@ constexpr int kBlkLdsBytesPerCU = 147456;  // 144 KiB of the CU's 160 KiB for ac
 constexpr int kBlkPre = 4;             // G-entry chunks of a (row, block) group fetched in one batch
 
 // WPC = workgroups per CU (1: 16 waves/CU, 128-VGPR budget; 2: 32 waves/CU, 64-VGPR budget)
-template <int G, int W, int WPC, int UNROLL, bool PACE, typename E>
+template <int G, int W, int WPC, int UNROLL, bool PACE, bool WIDE, typename E>
 __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_blocked_kernel(
     const int32_t* __restrict__ blkptr, int64_t n_nodes, int n_blocks, const int32_t* __restrict__ src,
     const float* __restrict__ val, const E* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows,
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
     const int li = lane % G;
     const int col = li * W;
     const bool active = col < F;
-    const E* xcol = x + col;
+    const E* xcol = x + (active ? col : 0);     // inactive column lanes read (and discard) column 0
     float* my = acc_lds + wave * rpw * RW;
 
     const int64_t n_panels = (n_rows + rpw - 1) / rpw;
@@ -316,6 +324,7 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                 }
                 if (maxlen <= 0) continue;
                 V acc = vzero<W>();
+                const int32_t sidx_first = __shfl(sv[0], slot * G, 64);
                 for (int c0 = 0; c0 < maxlen; c0 += kBlkPre * G) {
                     if (c0 > 0) {  // rare: a group longer than kBlkPre*G entries
 #pragma unroll
@@ -336,11 +345,15 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
 #pragma unroll
                                 for (int u = 0; u < UNROLL; ++u) {
                                     const int from = slot * G + j0 + u;
-                                    const int32_t sidx = __shfl(sv[c], from, 64);
-                                    w[u] = __shfl(wv[c], from, 64);
+                                    // branch-free: lanes past the end of their group carry source 0 / weight 0
+                                    // (masked at the entry load) and fetch a valid row unconditionally, so the
+                                    // eight gathers issue back to back; the select keeps a NaN in that row out
                                     const bool take = active && (c0 + c * G + j0 + u < len);
-                                    if (!take) w[u] = 0.f;
-                                    xv[u] = take ? gload<W, E>(xcol + static_cast<int64_t>(sidx) * ldx) : vzero<W>();
+                                    int32_t sidx = __shfl(sv[c], from, 64);
+                                    w[u] = __shfl(wv[c], from, 64);
+                                    if (!take) sidx = sidx_first;      // a row this lane group has just fetched (L1-hot)
+                                    const V t = gload<W, E>(xcol + row_off<WIDE>(sidx, ldx));
+                                    xv[u] = take ? t : vzero<W>();
                                 }
 #pragma unroll
                                 for (int u = 0; u < UNROLL; ++u) acc += w[u] * xv[u];
@@ -401,9 +414,14 @@ int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int
     if (rpw == 0) rpw = rpw_max;
     const int64_t n_panels = (n_rows + rpw - 1) / rpw;
     int64_t grid = n_panels < n_wg ? n_panels : n_wg;
-    hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true, E>), dim3(static_cast<unsigned>(grid)),
-                       dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F,
-                       attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
+    if (n_nodes * ldx < (int64_t(1) << 31))
+        hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true, false, E>), dim3(static_cast<unsigned>(grid)),
+                           dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows,
+                           F, attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
+    else
+        hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true, true, E>), dim3(static_cast<unsigned>(grid)),
+                           dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows,
+                           F, attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
     return dif::launch_status("spmm_blocked_kernel");
 }
 
@@ -414,7 +432,7 @@ int launch_blocked(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n
                    int64_t ldo) {
     // 1 workgroup (16 waves) per CU, 8 gathers in flight per wave: best of the measured variants
     // (2 workgroups per CU need a 64-VGPR budget and spill)
-    return launch_blocked_v<G, W, 1, 8, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn,
+    return launch_blocked_v<G, W, 1, 4, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn,
                                         lda, attn_scale, gcn_scale, tail, out, ldo);
 }
 
