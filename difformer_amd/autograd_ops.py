@@ -89,20 +89,8 @@ class _GcnAggregate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        csr = ctx.csr
-        n, H, D = g.shape
-        g2 = g.reshape(n, H * D)
-        # transposed product: grad_x[src_e] += val_e * g[dst_e]
-        counts = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
-        dst = torch.repeat_interleave(torch.arange(n, device=g.device), counts)
-        gx = torch.zeros_like(g2)
-        src = csr.src[: csr.nnz].long()
-        val = csr.val[: csr.nnz]
-        step = max(1, (1 << 26) // max(H * D, 1))  # bound the [chunk, F] temporary
-        for s in range(0, csr.nnz, step):
-            e = slice(s, min(s + step, csr.nnz))
-            gx.index_add_(0, src[e], g2[dst[e]] * val[e].unsqueeze(1))
-        gx = (ctx.gcn_scale * gx).reshape(n, H, D)
+        # adjoint product on the same blocked SpMM kernel: grad_x = gcn_scale * A_hat^T g
+        gx = ops.gcn_aggregate(ctx.csr.adjoint(), g.contiguous(), None, 1.0, ctx.gcn_scale)
         return None, gx, (ctx.attn_scale * g if ctx.has_attn else None), None, None
 
 

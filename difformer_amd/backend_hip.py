@@ -186,7 +186,7 @@ class HipBackend:
         return out
 
     # ---- a3 --------------------------------------------------------------------------------
-    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1):
+    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
         dev = _require_device(edge_index, edge_weight)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise TypeError("difformer_amd: edge_index must be an int64 tensor of shape [2, E]")
@@ -207,7 +207,8 @@ class HipBackend:
         ws_bytes = self.lib.dif_csr_workspace_bytes(E, num_nodes, n_blocks)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _Timed(self, "dif_csr_build", dev):
-            rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), n_blocks, _ptr(rowptr), _ptr(blkptr),
+            rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), n_blocks, int(bool(transpose)), _ptr(rowptr),
+                                        _ptr(blkptr),
                                         _ptr(src), _ptr(val), _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_csr_build")
         if int(status.item()) != 0:  # one sync per (cold) build

@@ -40,7 +40,7 @@ struct Plan {
     int64_t n_chunks;      // sort chunks (waves)
     int64_t table_len;     // kRadix * n_chunks
     int passes;            // radix passes over the destination id
-    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_deg, off_dinv, off_table, off_bsum, total;
+    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_deg, off_dinv, off_degc, off_table, off_bsum, total;
 };
 
 Plan make_plan(int64_t E, int64_t N, int64_t NB) {
@@ -64,6 +64,7 @@ Plan make_plan(int64_t E, int64_t N, int64_t NB) {
     p.off_vals_b = o; o += align256(e * 4);
     p.off_deg = o;    o += align256(static_cast<size_t>(p.n_keys + 1) * 4);   // per-key counts, then key pointers
     p.off_dinv = o;   o += align256(static_cast<size_t>(N + 1) * 4);
+    p.off_degc = o;   o += align256(static_cast<size_t>(N + 1) * 4);   // in-degree over `col` (transposed build)
     p.off_table = o;  o += align256(static_cast<size_t>(p.table_len) * 4);
     p.off_bsum = o;   o += align256(static_cast<size_t>((scan_n + kScanTile - 1) / kScanTile + 1) * 4);
     p.total = o;
@@ -72,9 +73,10 @@ Plan make_plan(int64_t E, int64_t N, int64_t NB) {
 
 // ---- degree count + sort keys (destination) / values (edge id) ------------------------------
 __global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ edge_index, int64_t E,
-                                                        int64_t N, int64_t NB, int64_t block_rows,
+                                                        int64_t N, int64_t NB, int64_t block_rows, int transpose,
                                                         uint32_t* __restrict__ keys,
                                                         uint32_t* __restrict__ vals, int32_t* __restrict__ deg,
+                                                        int32_t* __restrict__ degc,
                                                         int32_t* __restrict__ status) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < E; e += stride) {
@@ -84,10 +86,13 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restric
             atomicOr(status, 1);
             r = 0; c = 0;  // keep the build memory-safe; the host rejects the result
         }
-        const int64_t key = c * NB + r / block_rows;
+        // forward: entries grouped by destination (col), blocked by source; transposed (backward of the aggregation):
+        // grouped by source (row), blocked by destination
+        const int64_t key = transpose ? r * NB + c / block_rows : c * NB + r / block_rows;
         keys[e] = static_cast<uint32_t>(key);
         vals[e] = static_cast<uint32_t>(e);
-        atomicAdd(&deg[key], 1);               // summed over a row's blocks: in-degree over `col` (:66)
+        atomicAdd(&deg[key], 1);               // forward: summed over a row's blocks = in-degree over `col` (:66)
+        if (transpose) atomicAdd(&degc[c], 1); // the normalisation always uses the in-degree over `col`
     }
 }
 
@@ -185,14 +190,14 @@ int exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* out_tota
 // dinv[n] = sqrt(1/deg[n])  (float32, correctly rounded: difformer.py:67-68); deg 0 -> inf
 __global__ __launch_bounds__(256) void csr_ptrs_kernel(const int32_t* __restrict__ kptr, int64_t N, int64_t NB,
                                                        int32_t* __restrict__ rowptr, int32_t* __restrict__ blkptr,
-                                                       float* __restrict__ dinv) {
+                                                       const int32_t* __restrict__ degc, float* __restrict__ dinv) {
     const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r > N) return;
     const int32_t start = kptr[r * NB];
     rowptr[r] = start;                         // r == N: kptr[N*NB] = E
     if (r == N) return;
     const int32_t end = kptr[(r + 1) * NB];
-    dinv[r] = sqrtf(1.0f / static_cast<float>(end - start));
+    dinv[r] = sqrtf(1.0f / static_cast<float>(degc ? degc[r] : end - start));
     if (blkptr) {
         for (int64_t b = 0; b < NB; ++b) blkptr[b * N + r] = kptr[r * NB + b];
         blkptr[NB * N + r] = end;
@@ -271,7 +276,8 @@ __global__ __launch_bounds__(64 * kSortWaves) void radix_scatter_kernel(
 
 // ---- per-entry source id and normalised value ---------------------------------------------------
 __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
-                                                       uint32_t NB, const float* __restrict__ edge_weight,
+                                                       uint32_t NB, int transpose,
+                                                       const float* __restrict__ edge_weight,
                                                        const uint32_t* __restrict__ key_sorted,
                                                        const uint32_t* __restrict__ eid_sorted,
                                                        const float* __restrict__ dinv, int32_t* __restrict__ src,
@@ -279,15 +285,17 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < E; k += stride) {
         const uint32_t e = eid_sorted[k];
-        int64_t r = edge_index[e];
-        if (r < 0 || r >= N) r = 0;            // flagged in status by csr_count_kernel
-        const uint32_t c = key_sorted[k] / NB;
+        const uint32_t grp = key_sorted[k] / NB;          // the row this entry is filed under
+        int64_t other = edge_index[transpose ? E + e : e];
+        if (other < 0 || other >= N) other = 0;           // flagged in status by csr_count_kernel
+        const int64_t r = transpose ? grp : other;        // source      (difformer.py:65 `row`)
+        const int64_t c = transpose ? other : grp;        // destination (`col`)
         const float dn_in = dinv[c];
         const float dn_out = dinv[r];
         // :71 / :73 -- (w * d_norm_in) * d_norm_out, float32, no contraction
         float v = edge_weight ? __fmul_rn(__fmul_rn(edge_weight[e], dn_in), dn_out) : __fmul_rn(dn_in, dn_out);
         if (!isfinite(v)) v = 0.f;             // :74 nan_to_num(nan=0, posinf=0, neginf=0)
-        src[k] = static_cast<int32_t>(r);
+        src[k] = static_cast<int32_t>(other);             // the row to gather when this entry is applied
         val[k] = v;
     }
 }
@@ -300,7 +308,7 @@ extern "C" size_t dif_csr_workspace_bytes(int64_t E, int64_t N, int n_blocks) {
 }
 
 extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, const float* edge_weight,
-                             int n_blocks, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
+                             int n_blocks, int transpose, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
                              int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
     DIF_REQUIRE(N > 0 && E >= 0 && n_blocks >= 1, DIF_E_BADARG, "dif_csr_build: need N > 0, E >= 0, n_blocks >= 1");
     DIF_REQUIRE(E < (int64_t(1) << 31) - 4096 && N < (int64_t(1) << 31) - 1, DIF_E_RANGE,
@@ -324,11 +332,13 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     uint32_t* vals_b = reinterpret_cast<uint32_t*>(ws + p.off_vals_b);
     int32_t* kcnt = reinterpret_cast<int32_t*>(ws + p.off_deg);   // per-key counts -> key pointers (in place)
     float* dinv = reinterpret_cast<float*>(ws + p.off_dinv);
+    int32_t* degc = transpose ? reinterpret_cast<int32_t*>(ws + p.off_degc) : nullptr;
     int32_t* table = reinterpret_cast<int32_t*>(ws + p.off_table);
     int32_t* bsum = reinterpret_cast<int32_t*>(ws + p.off_bsum);
 
     hipError_t he = hipMemsetAsync(kcnt, 0, static_cast<size_t>(p.n_keys + 1) * 4, st);
     if (he == hipSuccess) he = hipMemsetAsync(status, 0, 4, st);
+    if (he == hipSuccess && transpose) he = hipMemsetAsync(degc, 0, static_cast<size_t>(N + 1) * 4, st);
     if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_csr_build: memset: %s", hipGetErrorString(he));
 
     const int64_t cap = 8 * dif::kCUs;
@@ -336,13 +346,13 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
         int64_t g = (E + 255) / 256;
         if (g > cap) g = cap;
         hipLaunchKernelGGL(csr_count_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N, p.NB,
-                           p.block_rows, keys_a, vals_a, kcnt, status);
+                           p.block_rows, transpose, keys_a, vals_a, kcnt, degc, status);
         if (int rc = dif::launch_status("csr_count_kernel")) return rc;
     }
     // kptr[0..N*NB] = exclusive scan of the per-key counts (kcnt[N*NB] == 0, so kptr[N*NB] = E)
     if (int rc = exclusive_scan(kcnt, p.n_keys + 1, kcnt, nullptr, bsum, st)) return rc;
     hipLaunchKernelGGL(csr_ptrs_kernel, dim3(static_cast<unsigned>((N + 256) / 256)), dim3(256), 0, st, kcnt, N, p.NB,
-                       rowptr, n_blocks > 1 ? blkptr : nullptr, dinv);
+                       rowptr, n_blocks > 1 ? blkptr : nullptr, degc, dinv);
     if (int rc = dif::launch_status("csr_ptrs_kernel")) return rc;
     if (E == 0) return 0;
 
@@ -363,6 +373,6 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     int64_t g = (E + 255) / 256;
     if (g > cap) g = cap;
     hipLaunchKernelGGL(csr_fill_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N,
-                       static_cast<uint32_t>(p.NB), edge_weight, kin, vin, dinv, src, val);
+                       static_cast<uint32_t>(p.NB), transpose, edge_weight, kin, vin, dinv, src, val);
     return dif::launch_status("csr_fill_kernel");
 }

@@ -108,11 +108,29 @@ class GraphCSR:
     def __init__(self, rowptr, blkptr, n_blocks, src, val, num_nodes, nnz):
         self.rowptr, self.blkptr, self.n_blocks, self.src, self.val = rowptr, blkptr, int(n_blocks), src, val
         self.num_nodes, self.nnz = int(num_nodes), int(nnz)
+        self._edges = None          # weak references to (edge_index, edge_weight) for the lazily built adjoint
+        self._adjoint = None
 
     @classmethod
-    def build(cls, edge_index, edge_weight, num_nodes, n_blocks=1):
-        rowptr, blkptr, src, val = get_backend().csr_build(edge_index, edge_weight, int(num_nodes), int(n_blocks))
-        return cls(rowptr, blkptr, n_blocks, src, val, num_nodes, edge_index.shape[1])
+    def build(cls, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
+        rowptr, blkptr, src, val = get_backend().csr_build(edge_index, edge_weight, int(num_nodes), int(n_blocks),
+                                                           transpose)
+        csr = cls(rowptr, blkptr, n_blocks, src, val, num_nodes, edge_index.shape[1])
+        if not transpose:
+            csr._edges = (weakref.ref(edge_index), None if edge_weight is None else weakref.ref(edge_weight))
+        return csr
+
+    def adjoint(self):
+        """CSR of A_hat^T (entries filed under their source row): the SpMM over it is the gradient of the
+        aggregation.  Built on first use (training only) from the same edge tensors."""
+        if self._adjoint is None:
+            ei = self._edges[0]() if self._edges else None
+            ew = self._edges[1]() if self._edges and self._edges[1] is not None else None
+            if ei is None or (self._edges[1] is not None and ew is None):
+                raise RuntimeError("difformer_amd: the edge_index this CSR was built from has been freed; keep it alive "
+                                   "until backward()")
+            self._adjoint = GraphCSR.build(ei, ew, self.num_nodes, self.n_blocks, transpose=True)
+        return self._adjoint
 
 
 class _CSRCache:

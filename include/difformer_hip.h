@@ -104,7 +104,9 @@ int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ld
  * [(n_blocks+1) x N] int32 (block-major) receives the start of every (row, block) group and the
  * SpMM sweeps the blocks in order so the gathered slice of x stays L2-resident (choose
  * n_blocks ~ N*F*4 / 2.5 MiB; 1 = plain CSR).  status[0] (device int32) is set non-zero if any
- * index is outside [0,N).
+ * index is outside [0,N).  transpose = 1 files every entry under its SOURCE row instead (same values,
+ * `src` then holds the destination): the SpMM over that CSR is the adjoint A_hat^T g, i.e. the gradient
+ * of gcn_conv with respect to x (loss.backward() in main.py:130).
  * dif_gcn_spmm_f32: out[r, :] = gcn_scale * sum_{e in row r} val_e * x[src_e, :]
  *                                (+ attn_scale * attn[r, :] when attn != NULL)
  * for r in [row_begin, row_begin + n_rows): the adjacency product of :75-78 over all H*D
@@ -115,7 +117,7 @@ int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ld
  * ------------------------------------------------------------------------------------- */
 size_t dif_csr_workspace_bytes(int64_t E, int64_t N, int n_blocks);
 int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, const float* edge_weight,
-                  int n_blocks, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
+                  int n_blocks, int transpose, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
                   int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream);
 int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
                      const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,

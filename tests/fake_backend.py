@@ -44,9 +44,11 @@ class OracleBackend:
     def sigmoid_attention(self, q, k, v):
         return torch.from_numpy(orc.sigmoid_attention(*(_np(t).astype(np.float64) for t in (q, k, v))).astype(np.float32))
 
-    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1):
+    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
         ei = _np(edge_index)
         row, col, val = orc.gcn_edge_values(ei, num_nodes, _np(edge_weight), dtype=np.float32)
+        if transpose:
+            row, col = col, row
         block_rows = -(-num_nodes // n_blocks)
         key = col * n_blocks + row // block_rows
         order = np.argsort(key, kind="stable")

@@ -59,9 +59,9 @@ def test_argument_checks_reject_before_touching_the_device(lib):
     assert rc == -1 and b"positive" in lib.dif_last_error()
     rc = lib.dif_sigmoid_attn_f32(None, 8, None, 8, None, 8, 4, 4, 1, 8, 8, None, 8, None, 0, None)
     assert rc == -1
-    rc = lib.dif_csr_build(None, 10, 0, None, 1, None, None, None, None, None, None, 0, None)
+    rc = lib.dif_csr_build(None, 10, 0, None, 1, 0, None, None, None, None, None, None, 0, None)
     assert rc == -1
-    rc = lib.dif_csr_build(None, 2 ** 31, 10, None, 1, None, None, None, None, None, None, 0, None)
+    rc = lib.dif_csr_build(None, 2 ** 31, 10, None, 1, 0, None, None, None, None, None, None, 0, None)
     assert rc == -4                                                                    # DIF_E_RANGE
     rc = lib.dif_gcn_spmm_f32(None, None, 1, None, None, 10, 5, None, 8, 0, 20, 8, None, 0, 1.0, 1.0, None, 8, None)
     assert rc == -1 and b"row range" in lib.dif_last_error()

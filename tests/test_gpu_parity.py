@@ -597,3 +597,26 @@ def test_bf16_model_forward_c5_shape(dev):
         out = model(x.to(dev), ei)
     assert out.dtype == torch.bfloat16
     assert rel_err(out.float().cpu().numpy(), ref) < 2 * BF16_TOL     # 4 LayerNorm-separated bf16 round trips
+
+
+@pytest.mark.parametrize("n,e,weighted,n_blocks", [(500, 6000, True, 1), (20000, 3000000, False, 4)])
+def test_gcn_conv_adjoint_and_backward(n, e, weighted, n_blocks, dev):
+    """The transposed CSR (entries filed under their source) gives A_hat^T g, and x.grad of gcn_conv is exactly that."""
+    from difformer_amd import ops, autograd_ops as ag
+    g = torch.Generator().manual_seed(n)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[1, : e // 4] = torch.randint(0, max(n // 20, 1), (e // 4,), generator=g)      # asymmetric, skewed
+    w = (torch.rand(e, generator=g) + 0.1) if weighted else None
+    go = torch.randn(n, 1, 64, generator=g)
+    row, col, val = orc.gcn_edge_values(ei.numpy(), n, None if w is None else w.numpy(), dtype=np.float64)
+    ref = np.zeros((n, 64))
+    np.add.at(ref, row, val[:, None] * go.double().numpy()[col, 0])                    # A^T g
+    eid, wd = ei.to(dev), None if w is None else w.to(dev)
+    csr = ops.GraphCSR.build(eid, wd, n, n_blocks)
+    adj = csr.adjoint()
+    out = ops.gcn_aggregate(adj, go.to(dev)).cpu().numpy()[:, 0]
+    assert rel_err(out, ref) < 1e-5
+    x = torch.randn(n, 1, 64, generator=g).to(dev).requires_grad_(True)
+    y = ag.gcn_aggregate(csr, x, None, 1.0, 0.7)
+    y.backward(go.to(dev))
+    assert rel_err(x.grad.cpu().numpy()[:, 0], 0.7 * ref) < 1e-5
