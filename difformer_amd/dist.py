@@ -64,8 +64,11 @@ class RowShard:
         world = dist.get_world_size(group)
         side = None
         if world > 1:
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
-            side = dist.new_group(ranks=ranks)          # collective: every rank of `group` must get here
+            try:
+                ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+                side = dist.new_group(ranks=ranks)      # collective: every rank of `group` must get here
+            except Exception:                           # no second communicator: both collectives share `group`
+                side = None
         return cls(n_global, dist.get_rank(group), world, group, side_group=side)
 
     @property
