@@ -27,8 +27,8 @@ constexpr int kScanItems = 4;
 constexpr int kScanTile = kScanBlock * kScanItems;  // 1024 values per block
 
 constexpr int kSortWaves = 4;       // independent waves per block
-constexpr int kSortRounds = 64;     // 64 lanes x 64 rounds = 4096 keys per wave chunk
-constexpr int kSortChunk = 64 * kSortRounds;
+constexpr int kSortRoundsMax = 64;  // 64 lanes x 64 rounds = 4096 keys per wave chunk on large graphs
+constexpr int kSortRoundsMin = 8;   // small graphs (mini-batches): shorter chunks so that >= ~1000 waves share the sort
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 
@@ -37,6 +37,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 struct Plan {
     int64_t E, N;
     int64_t NB, block_rows, n_keys;  // source blocks, nodes per block, N * NB sort keys
+    int rounds;            // 64-key rounds per wave chunk
     int64_t n_chunks;      // sort chunks (waves)
     int64_t table_len;     // kRadix * n_chunks
     int passes;            // radix passes over the destination id
@@ -49,7 +50,12 @@ Plan make_plan(int64_t E, int64_t N, int64_t NB) {
     p.NB = NB < 1 ? 1 : NB;
     p.block_rows = (N + p.NB - 1) / p.NB;
     p.n_keys = N * p.NB;
-    p.n_chunks = (E + kSortChunk - 1) / kSortChunk;
+    int64_t rounds = (E + 64 * 4096 - 1) / (64 * 4096);     // aim at ~4096 waves
+    if (rounds < kSortRoundsMin) rounds = kSortRoundsMin;
+    if (rounds > kSortRoundsMax) rounds = kSortRoundsMax;
+    p.rounds = static_cast<int>(rounds);
+    const int64_t chunk = 64 * rounds;
+    p.n_chunks = (E + chunk - 1) / chunk;
     if (p.n_chunks < 1) p.n_chunks = 1;
     p.table_len = p.n_chunks * kRadix;
     int bits = 1;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void csr_ptrs_kernel(const int32_t* __restrict
 
 // ---- stable LSD radix sort, 8 bits per pass; each WAVE owns a 4096-key chunk -------------------
 __global__ __launch_bounds__(64 * kSortWaves) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
-                                                                    int shift, int64_t n_chunks,
+                                                                    int shift, int64_t n_chunks, int rounds,
                                                                     int32_t* __restrict__ table) {
     __shared__ int32_t hist[kSortWaves][kRadix];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,9 +221,9 @@ __global__ __launch_bounds__(64 * kSortWaves) void radix_hist_kernel(const uint3
     for (int i = 0; i < kRadix / 64; ++i) hist[wave][lane + 64 * i] = 0;
     __builtin_amdgcn_wave_barrier();
     if (chunk < n_chunks) {
-        const int64_t base = chunk * kSortChunk;
+        const int64_t base = chunk * 64 * rounds;
 #pragma unroll 8
-        for (int i = 0; i < kSortRounds; ++i) {
+        for (int i = 0; i < rounds; ++i) {
             const int64_t idx = base + i * 64 + lane;
             if (idx < n) atomicAdd(&hist[wave][(keys[idx] >> shift) & (kRadix - 1)], 1);
         }
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void radix_hist_kernel(const uint3
 
 __global__ __launch_bounds__(64 * kSortWaves) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n, int shift,
-    int64_t n_chunks, const int32_t* __restrict__ table, uint32_t* __restrict__ keys_out,
+    int64_t n_chunks, int rounds, const int32_t* __restrict__ table, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out) {
     __shared__ int32_t base_s[kSortWaves][kRadix];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -246,8 +252,8 @@ __global__ __launch_bounds__(64 * kSortWaves) void radix_scatter_kernel(
     }
     __builtin_amdgcn_wave_barrier();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int64_t cbase = chunk * kSortChunk;
-    for (int i = 0; i < kSortRounds; ++i) {
+    const int64_t cbase = chunk * 64 * rounds;
+    for (int i = 0; i < rounds; ++i) {
         const int64_t idx = cbase + i * 64 + lane;
         const bool valid = idx < n;
         if (!__any(valid)) break;
@@ -361,11 +367,11 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     for (int pass = 0; pass < p.passes; ++pass) {
         const int shift = pass * kRadixBits;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, E, shift,
-                           p.n_chunks, table);
+                           p.n_chunks, p.rounds, table);
         if (int rc = dif::launch_status("radix_hist_kernel")) return rc;
         if (int rc = exclusive_scan(table, p.table_len, table, nullptr, bsum, st)) return rc;
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, vin, E, shift,
-                           p.n_chunks, table, kout, vout);
+                           p.n_chunks, p.rounds, table, kout, vout);
         if (int rc = dif::launch_status("radix_scatter_kernel")) return rc;
         uint32_t* t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;

@@ -280,6 +280,55 @@ __global__ __launch_bounds__(256) void simple_apply_kernel(const T* __restrict__
     const int64_t n_steps = (n_rows + 15) / 16;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
+    if (SINGLE) {
+        // M, D <= 64: one fragment set for the whole sweep; the next step's 16 rows of q are requested before the
+        // current step's 64 MFMAs so the HBM latency hides under them
+        f32x4 qn[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qn[c] = load_row4<VEC>(q, ldq, first * 16 + l15, n_rows, h * sh.M, 16 * c + 4 * lg, sh.M);
+        for (int64_t st = first; st < n_steps; st += stride) {
+            const int64_t r = st * 16 + l15;
+            f32x4 qv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qv[c] = qn[c];
+            if (st + stride < n_steps) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    qn[c] = load_row4<VEC>(q, ldq, (st + stride) * 16 + l15, n_rows, h * sh.M, 16 * c + 4 * lg, sh.M);
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int dtl = 0; dtl < 4; ++dtl) acc[dtl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float dpart = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int dtl = 0; dtl < 4; ++dtl)
+                        acc[dtl] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[dtl][c][t], qv[c][t], acc[dtl], 0, 0, 0);
+                    dpart += qv[c][t] * kfrag[c][t];
+                }
+            dpart += __shfl_xor(dpart, 16, 64);
+            dpart += __shfl_xor(dpart, 32, 64);
+            const float den = dpart + n_global;  // difformer.py:37-38
+            if (r < n_rows) {
+#pragma unroll
+                for (int dtl = 0; dtl < 4; ++dtl) {
+                    const int d0 = 16 * dtl + 4 * lg;
+                    T* o = out + r * ldo + h * sh.D + d0;
+                    if (VEC) {
+                        if (d0 < sh.D) Elem<T>::st4(o, (acc[dtl] + *reinterpret_cast<const f32x4*>(vsum + d0)) / den);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (d0 + i < sh.D) Elem<T>::st(o + i, (acc[dtl][i] + vsum[d0 + i]) / den);
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int64_t st = first; st < n_steps; st += stride) {
         const int64_t r = st * 16 + l15;
         float den = 0.f;
@@ -393,7 +442,7 @@ int simple_apply_entry(const T* q, int64_t ldq, const float* reduced, int64_t n_
     const bool single = (sh.MT == 1 && sh.DT == 1);
     const int64_t n_steps = (n_rows + 15) / 16;
     int64_t gx = (n_steps + 3) / 4;
-    const int64_t cap = 2 * dif::kCUs;  // persistent: the per-wave fragment prologue is paid once per ~4+ steps
+    const int64_t cap = 3 * dif::kCUs;  // persistent: the per-wave fragment prologue is paid once per ~3+ steps
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
