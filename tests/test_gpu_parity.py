@@ -620,3 +620,42 @@ def test_gcn_conv_adjoint_and_backward(n, e, weighted, n_blocks, dev):
     y = ag.gcn_aggregate(csr, x, None, 1.0, 0.7)
     y.backward(go.to(dev))
     assert rel_err(x.grad.cpu().numpy()[:, 0], 0.7 * ref) < 1e-5
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_row_sharded_kernels_match_unsharded(world, dev):
+    """What each of `world` ranks would run -- its rows of the fused projection+reduce, the summed record (the
+    all-reduce), apply with the GLOBAL N, the SpMM over its destination rows of the full CSR with the gathered V --
+    done rank after rank in one process on the GPU, must reproduce the unsharded layer."""
+    from difformer_amd import ops
+    from difformer_amd.dist import split_rows
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(world)
+    n, d = 20011, 64
+    x = torch.randn(n, d, generator=g).to(dev)
+    W = [(torch.randn(d, d, generator=g) / 8).to(dev) for _ in range(3)]
+    b = [(torch.randn(d, generator=g) * 0.2).to(dev) for _ in range(3)]
+    prev = torch.randn(n, d, generator=g).to(dev)
+    lw, lb = (torch.rand(d, generator=g) + 0.5).to(dev), torch.randn(d, generator=g).to(dev)
+    ei = torch.randint(0, n, (2, 2500000), generator=g).to(dev)
+    csr = ops.GraphCSR.build(ei, None, n, 3)
+    tail = lambda lo, hi: dict(x0=None, prev=prev[lo:hi], alpha=0.5, ln_weight=lw, ln_bias=lb, eps=1e-5)
+    # unsharded
+    q, v, rec = be.project_reduce(x, W[0], b[0], W[1], b[1], W[2], b[2], 1, d)
+    attn = be.simple_apply(q, rec, n, d)
+    full = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, n, csr.nnz, v.reshape(n, d), 0, n,
+                   attn.reshape(n, d), 1.0, 1.0, tail(0, n))
+    # sharded, rank by rank
+    counts = split_rows(n, world)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    parts = [be.project_reduce(x[offs[r]:offs[r + 1]].contiguous(), W[0], b[0], W[1], b[1], W[2], b[2], 1, d)
+             for r in range(world)]
+    rec_sum = torch.stack([p[2] for p in parts]).sum(dim=0)                 # the all-reduce
+    v_all = torch.cat([p[1] for p in parts]).reshape(n, d)                  # the all-gather
+    assert rel_err(rec_sum.cpu().numpy(), rec.cpu().numpy()) < 1e-5
+    for r in range(world):
+        lo, hi = int(offs[r]), int(offs[r + 1])
+        attn_r = be.simple_apply(parts[r][0], rec_sum, n, d)                # n_global = N, not the shard size
+        out_r = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, n, csr.nnz, v_all, lo, hi - lo,
+                        attn_r.reshape(hi - lo, d), 1.0, 1.0, tail(lo, hi))
+        assert rel_err(out_r.cpu().numpy(), full[lo:hi].cpu().numpy()) < 1e-5, (world, r)
