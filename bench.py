@@ -193,8 +193,6 @@ def main():
         tj = json.load(open(tpath))
         if tj.get("workload") == args.workload:
             traffic = tj["kernels"].get("spmm_blocked_kernel", {}).get("hbm_bytes_per_launch")
-    if dom == "dif_sigmoid_attn_f32" and False:
-        pass
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": "profiles/r01_pmc_traffic_c4.json (rocprofv3 PMC, separate passes)" if traffic else None,

@@ -16,6 +16,10 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Post-launch check: hipGetLastError only (never synchronises).
 int launch_status(const char* what);
 
+// record_finalize.hip: column-sum the P partial records of the simple kernel's stage 1 into `reduced`
+int launch_record_finalize(const float* ws, int P, int64_t ws_stride, int t_main, int tiles, float* reduced,
+                           hipStream_t st);
+
 constexpr int kWave = 64;         // CDNA wavefront
 constexpr int kCUs = 256;         // MI355X
 

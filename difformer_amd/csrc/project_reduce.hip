@@ -255,47 +255,6 @@ __global__ __launch_bounds__(256, 2) void project_reduce_kernel(
     }
 }
 
-// column sums of the P partial records (same scheme as simple_finalize_kernel)
-constexpr int kFinSlices = 16;
-__global__ __launch_bounds__(1024) void project_finalize_kernel(const float* __restrict__ ws, int P, int64_t ws_stride,
-                                                                int t_main, int tiles, float* __restrict__ reduced) {
-    __shared__ float sm[kFinSlices][64];
-    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    if (blockIdx.x + 1 < gridDim.x) {
-        const int col = blockIdx.x * 64 + c;
-        float a = 0.f;
-        if (col < t_main)
-            for (int p = sl; p < P; p += kFinSlices) a += ws[p * ws_stride + col];
-        sm[sl][c] = a;
-        __syncthreads();
-        if (sl == 0 && col < t_main) {
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < kFinSlices; ++i) t += sm[i][c];
-            reduced[col] = t;
-        }
-    } else {
-        float a0 = 0.f, a1 = 0.f;
-        const int total = P * tiles;
-        for (int i = threadIdx.x; i < total; i += 1024) {
-            const int p = i / tiles, yy = i % tiles;
-            a0 += ws[p * ws_stride + t_main + 2 * yy];
-            a1 += ws[p * ws_stride + t_main + 2 * yy + 1];
-        }
-        a0 = dif::wave_sum(a0);
-        a1 = dif::wave_sum(a1);
-        if (c == 0) { sm[sl][0] = a0; sm[sl][1] = a1; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < kFinSlices; ++i) { t0 += sm[i][0]; t1 += sm[i][1]; }
-            reduced[t_main] = t0;
-            reduced[t_main + 1] = t1;
-        }
-    }
-}
-
 int pr_chunks(int64_t n_rows) {
     const int64_t tiles = (n_rows + 15) / 16;
     int64_t p = (tiles + kPRWaves - 1) / kPRWaves;     // at least one tile per wave
@@ -338,9 +297,7 @@ int project_reduce_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, cons
         hipLaunchKernelGGL((project_reduce_kernel<false, T>), dim3(P, H), dim3(256), 0, st, x, ldx, n_rows, sh, Wq, bq,
                            Wk, bk, Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec);
     if (int rc = dif::launch_status("project_reduce_kernel")) return rc;
-    const int nb = (sh.t_main + 63) / 64 + 1;
-    hipLaunchKernelGGL(project_finalize_kernel, dim3(nb), dim3(1024), 0, st, ws, P, rec, sh.t_main, H, reduced);
-    return dif::launch_status("project_finalize_kernel");
+    return dif::launch_record_finalize(ws, P, rec, sh.t_main, H, reduced, st);
 }
 
 }  // namespace

@@ -172,50 +172,6 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     }
 }
 
-// Column-sum of the P partial records -> `reduced`.  Blocks 0..nb-2: 64 columns x 16 record
-// slices each; last block: the two Frobenius scalars (P x tiles entries each).
-constexpr int kFinSlices = 16;
-__global__ __launch_bounds__(1024) void simple_finalize_kernel(const float* __restrict__ ws, int P,
-                                                               int64_t ws_stride, Shape sh,
-                                                               float* __restrict__ reduced) {
-    __shared__ float sm[kFinSlices][64];
-    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    if (blockIdx.x + 1 < gridDim.x) {
-        const int col = blockIdx.x * 64 + c;
-        float a = 0.f;
-        if (col < sh.t_main)
-            for (int p = sl; p < P; p += kFinSlices) a += ws[p * ws_stride + col];
-        sm[sl][c] = a;
-        __syncthreads();
-        if (sl == 0 && col < sh.t_main) {
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < kFinSlices; ++i) t += sm[i][c];
-            reduced[col] = t;
-        }
-    } else {
-        // scalars: thread tid strides over (p, tile) pairs; which = 0 (q) / 1 (k)
-        float a0 = 0.f, a1 = 0.f;
-        const int total = P * sh.tiles;
-        for (int i = threadIdx.x; i < total; i += 1024) {
-            const int p = i / sh.tiles, yy = i % sh.tiles;
-            a0 += ws[p * ws_stride + sh.t_main + 2 * yy];
-            a1 += ws[p * ws_stride + sh.t_main + 2 * yy + 1];
-        }
-        a0 = dif::wave_sum(a0);
-        a1 = dif::wave_sum(a1);
-        if (c == 0) { sm[sl][0] = a0; sm[sl][1] = a1; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < kFinSlices; ++i) { t0 += sm[i][0]; t1 += sm[i][1]; }
-            reduced[sh.t_main] = t0;
-            reduced[sh.t_main + 1] = t1;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // apply: out^T tile = (s KtV)^T . Q^T on the MFMA:  D[i][j] = sum_k A[i][k] B[k][j] with
 //   i <-> d, j <-> row, k <-> m.  Per 16-row step lane holds qv[c] = Q[r0 + lane%16][16c +
@@ -423,9 +379,7 @@ int simple_reduce_entry(const T* q, int64_t ldq, const T* k, int64_t ldk, const 
     else
         hipLaunchKernelGGL((simple_reduce_kernel<false, T>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, n_rows, sh, ws, rec);
     if (int rc = dif::launch_status("simple_reduce_kernel")) return rc;
-    const int nb = (sh.t_main + 63) / 64 + 1;
-    hipLaunchKernelGGL(simple_finalize_kernel, dim3(nb), dim3(1024), 0, st, ws, P, rec, sh, reduced);
-    return dif::launch_status("simple_finalize_kernel");
+    return dif::launch_record_finalize(ws, P, rec, sh.t_main, sh.tiles, reduced, st);
 }
 
 template <typename T>

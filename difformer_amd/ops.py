@@ -13,8 +13,6 @@ import weakref
 from collections import OrderedDict
 from typing import Optional
 
-import torch
-
 from .dist import RowShard
 
 _BACKEND = None
