@@ -26,6 +26,11 @@ SIGNATURES = {
     "dif_project_reduce_workspace_bytes": (c_sz, [c_i64, c_int, c_int]),
     "dif_project_reduce_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
                                        c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "dif_simple_bwd_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int]),
+    "dif_simple_bwd_prep_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int,
+                                        c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dif_rowgemm_f32": (c_int, [c_vp, c_i64, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64,
+                                c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp]),
     "dif_sigmoid_workspace_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
     "dif_sigmoid_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int,
                                      c_vp, c_i64, c_vp, c_sz, c_vp]),

@@ -60,14 +60,25 @@ def _tail_expr(alpha, eps, has_ln):
 
 
 class _SimpleAttention(torch.autograd.Function):
+    """Forward and (for fp32, M, D <= 64) backward on the HIP kernels; other shapes re-derive the gradient with
+    differentiable device ops."""
+
     @staticmethod
     def forward(ctx, q, k, v):
-        ctx.save_for_backward(q, k, v)
-        return ops.simple_attention(q, k, v)
+        be = ops.get_backend()
+        reduced = be.simple_reduce(q, k, v)
+        out = be.simple_apply(q, reduced, q.shape[0], v.shape[2])
+        ctx.save_for_backward(q, k, v, reduced, out)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        return _grad_by_recompute(_simple_expr, ctx.saved_tensors, g.contiguous())
+        q, k, v, reduced, out = ctx.saved_tensors
+        hip_ok = (q.dtype == torch.float32 and q.shape[2] <= 64 and v.shape[2] <= 64 and
+                  hasattr(ops.get_backend(), "simple_backward"))
+        if hip_ok:
+            return ops.get_backend().simple_backward(q, k, v, reduced, out, g)
+        return _grad_by_recompute(_simple_expr, (q, k, v), g.contiguous())
 
 
 class _SigmoidAttention(torch.autograd.Function):

@@ -1,0 +1,201 @@
+// a1 backward: gradient of full_attention_conv(..., 'simple')
+// (node classification/difformer.py:18-39) with respect to q, k, v -- what loss.backward() in
+// main.py:130 / main-batch.py:141 needs.  The reference leaves this to autograd over ~17 ATen ops.
+//
+// With s = 1/(|Q||K|), num = s q KtV + vs, den = s q.ks + N, out = num/den and g = dL/dout:
+//   gn = g / den                      gd = -(g . out) / den                         (per row, head)
+//   dKtV = s sum_n q_n^T gn_n         dks = s sum_n q_n gd_n        dvs = sum_n gn_n
+//   T    = -(sum_h vs_h . dvs_h) - N sum gd          ( = s * dL/ds )
+//   dq = gn (s KtV)^T + gd (s ks) - (T / sum q^2) q
+//   dk = v dKtV^T + dks - (T / sum k^2) k           dv = k dKtV + dvs
+// Pass structure:  bwd_prep (rows -> gn, gd; partial sums of q*gd and gd)  ->  the forward's reduce kernel on
+// (q, q, gn) gives q^T gn and sum gn  ->  three row-GEMMs  out = A Mat + bias + r (x) u + beta C  (this file).
+#include "dif_common.h"
+
+namespace {
+
+using dif::f32x4;
+
+// ---- prep: one 16-lane group per (row, head); D, M <= 64*4... handled by striding ------------------------------
+// Writes gn [n,H,D], gd [n,H]; per-block partial of  sum_n q[n,h,m]*gd[n,h]  ([H*M]) and  sum gd  (1) into `part`.
+__global__ __launch_bounds__(256) void simple_bwd_prep_kernel(const float* __restrict__ q, int64_t ldq,
+                                                              const float* __restrict__ g, int64_t ldg,
+                                                              const float* __restrict__ out, int64_t ldo,
+                                                              const float* __restrict__ reduced, int64_t n_rows,
+                                                              float n_global, int H, int M, int D,
+                                                              float* __restrict__ gn, float* __restrict__ gd,
+                                                              float* __restrict__ part, int part_stride) {
+    extern __shared__ float sm[];   // [H*M + 1] block accumulators
+    const int t_ks = H * M * D, t_main = H * M * D + H * M + H * D;
+    const float s = 1.0f / (sqrtf(reduced[t_main]) * sqrtf(reduced[t_main + 1]));
+    for (int i = threadIdx.x; i <= H * M; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int lane16 = threadIdx.x & 15;
+    const int64_t groups = n_rows * H;
+    const int64_t gstride = static_cast<int64_t>(gridDim.x) * 16;
+    float gd_acc = 0.f;
+    for (int64_t gi = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4); gi < groups; gi += gstride) {
+        const int64_t n = gi / H;
+        const int h = static_cast<int>(gi % H);
+        const float* qr = q + n * ldq + h * M;
+        const float* gr = g + n * ldg + h * D;
+        const float* orow = out + n * ldo + h * D;
+        const float* ks = reduced + t_ks + h * M;
+        float dot = 0.f, go = 0.f;
+        for (int m = lane16; m < M; m += 16) dot += qr[m] * ks[m];
+        for (int d = lane16; d < D; d += 16) go += gr[d] * orow[d];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { dot += __shfl_xor(dot, o, 64); go += __shfl_xor(go, o, 64); }
+        const float den = s * dot + n_global;
+        const float gdv = -go / den;
+        for (int d = lane16; d < D; d += 16) gn[(n * H + h) * D + d] = gr[d] / den;
+        if (lane16 == 0) { gd[n * H + h] = gdv; gd_acc += gdv; }
+        for (int m = lane16; m < M; m += 16) atomicAdd(&sm[h * M + m], qr[m] * gdv);   // LDS atomics
+    }
+    if (lane16 == 0) atomicAdd(&sm[H * M], gd_acc);
+    __syncthreads();
+    for (int i = threadIdx.x; i <= H * M; i += 256) part[static_cast<int64_t>(blockIdx.x) * part_stride + i] = sm[i];
+}
+
+// column sums of the prep partials -> sums [H*M + 1]
+__global__ __launch_bounds__(256) void simple_bwd_sum_kernel(const float* __restrict__ part, int P, int part_stride,
+                                                             int len, float* __restrict__ sums) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= len) return;
+    float a = 0.f;
+    for (int p = 0; p < P; ++p) a += part[static_cast<int64_t>(p) * part_stride + c];
+    sums[c] = a;
+}
+
+// ---- row-GEMM: out[n, :C] = A[n, :K] Mat[K x C] + bias[C] + r[n] u[C] + beta Cin[n, :C]   (K, C <= 64, per head) ----
+// Same transposed MFMA formulation as simple_apply_kernel: D[i <-> c][j <-> row] = sum_k Mat[k][c] A[row][k].
+// mat_t != 0: Mat is given transposed in memory (Mat[k][c] = mem[c * ldm + k]).
+__global__ __launch_bounds__(256) void rowgemm_kernel(const float* __restrict__ A, int64_t lda, int a_head_stride,
+                                                      const float* __restrict__ Mat, int ldm, int mat_head_stride,
+                                                      int mat_t, float mat_scale, const float* __restrict__ bias,
+                                                      int bias_head_stride, const float* __restrict__ r, int H,
+                                                      const float* __restrict__ u, int u_head_stride, float u_scale,
+                                                      const float* __restrict__ Cin, int64_t ldc,
+                                                      const float* __restrict__ beta_dev,
+                                                      int64_t n_rows, int K, int C, float* __restrict__ out,
+                                                      int64_t ldo) {
+    __shared__ float sm_m[64 * 68];
+    const int h = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const float* mat = Mat + static_cast<int64_t>(h) * mat_head_stride;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int k = e >> 6, c = e & 63;
+        float v = 0.f;
+        if (k < K && c < C) v = mat_scale * (mat_t ? mat[c * ldm + k] : mat[k * ldm + c]);
+        sm_m[k * 68 + c] = v;
+    }
+    __syncthreads();
+    float afrag[4][4][4];   // [ctile][kq][t] = Mat[16kq + 4lg + t][16 ctile + l15]
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) afrag[ct][kq][t] = sm_m[(16 * kq + 4 * lg + t) * 68 + 16 * ct + l15];
+
+    const float beta = (Cin && beta_dev) ? *beta_dev : 1.0f;
+    const int64_t n_steps = (n_rows + 15) / 16;
+    for (int64_t st = static_cast<int64_t>(blockIdx.x) * 4 + wave; st < n_steps; st += static_cast<int64_t>(gridDim.x) * 4) {
+        const int64_t row = st * 16 + l15;
+        const bool rok = row < n_rows;
+        f32x4 av[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (rok) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = 16 * kq + 4 * lg + i;
+                    if (kk < K) z[i] = A[row * lda + h * a_head_stride + kk];
+                }
+            }
+            av[kq] = z;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ct][kq][t], av[kq][t], acc[ct], 0, 0, 0);
+        if (rok) {
+            const float rv = r ? r[row * H + h] : 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 16 * ct + 4 * lg + i;      // lane holds out^T[c = 16ct + 4lg + i][row]
+                    if (c < C) {
+                        float o = acc[ct][i];
+                        if (bias) o += bias[h * bias_head_stride + c];
+                        if (r) o += rv * u_scale * u[h * u_head_stride + c];
+                        if (Cin) o += beta * Cin[row * ldc + h * C + c];
+                        out[row * ldo + h * C + c] = o;
+                    }
+                }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dif_simple_bwd_workspace_bytes(int64_t n_rows, int H, int M, int D) {
+    if (n_rows <= 0 || H <= 0 || M <= 0 || D <= 0) return 0;
+    const size_t P = 512;
+    const size_t len = static_cast<size_t>(H) * M + 1;
+    return (P * ((len + 3) & ~size_t(3)) + ((len + 3) & ~size_t(3))) * sizeof(float);
+}
+
+// gn [n,H,D], gd [n,H] and sums [H*M + 1] = { sum_n q*gd per (h,m), sum gd }.
+extern "C" int dif_simple_bwd_prep_f32(const float* q, int64_t ldq, const float* g, int64_t ldg, const float* out,
+                                       int64_t ldo, const float* reduced, int64_t n_rows, int64_t n_global, int H,
+                                       int M, int D, float* gn, float* gd, float* sums, void* workspace,
+                                       size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG, "dif_simple_bwd_prep_f32: sizes must be positive");
+    DIF_REQUIRE(q && g && out && reduced && gn && gd && sums && workspace, DIF_E_BADARG,
+                "dif_simple_bwd_prep_f32: null pointer");
+    DIF_REQUIRE(workspace_bytes >= dif_simple_bwd_workspace_bytes(n_rows, H, M, D), DIF_E_WORKSPACE,
+                "dif_simple_bwd_prep_f32: workspace too small");
+    DIF_REQUIRE(static_cast<size_t>(H) * M + 1 <= 12000, DIF_E_SHAPE, "dif_simple_bwd_prep_f32: H*M too large for LDS");
+    const int len = H * M + 1;
+    const int stride = (len + 3) & ~3;
+    int64_t P = (n_rows * H + 15) / 16;
+    if (P > 512) P = 512;
+    float* part = static_cast<float*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(simple_bwd_prep_kernel, dim3(static_cast<unsigned>(P)), dim3(256), sizeof(float) * (len + 1), st, q,
+                       ldq, g, ldg, out, ldo, reduced, n_rows, static_cast<float>(n_global), H, M, D, gn, gd, part, stride);
+    if (int rc = dif::launch_status("simple_bwd_prep_kernel")) return rc;
+    hipLaunchKernelGGL(simple_bwd_sum_kernel, dim3((len + 255) / 256), dim3(256), 0, st, part, static_cast<int>(P), stride,
+                       len, sums);
+    return dif::launch_status("simple_bwd_sum_kernel");
+}
+
+// out[n,h,:C] = A[n,h,:K] Mat_h + bias_h + r[n,h] * u_scale * u_h + (*beta_dev) * Cin[n,h,:C]    (K, C <= 64)
+// beta_dev: DEVICE scalar (the backward's coefficients are computed on the device; no host round trip); NULL = 1.
+extern "C" int dif_rowgemm_f32(const float* A, int64_t lda, const float* Mat, int ldm, int mat_head_stride, int mat_t,
+                               float mat_scale, const float* bias, const float* r, const float* u, float u_scale,
+                               const float* Cin, int64_t ldc, const float* beta_dev, int64_t n_rows, int H, int K,
+                               int C, float* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && H > 0 && K > 0 && C > 0, DIF_E_BADARG, "dif_rowgemm_f32: sizes must be positive");
+    DIF_REQUIRE(K <= 64 && C <= 64, DIF_E_SHAPE, "dif_rowgemm_f32: covers K, C <= 64 (got %d, %d)", K, C);
+    DIF_REQUIRE(A && Mat && out && ((r == nullptr) == (u == nullptr)), DIF_E_BADARG, "dif_rowgemm_f32: null pointer");
+    DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_rowgemm_f32: too many heads");
+    const int64_t n_steps = (n_rows + 15) / 16;
+    int64_t gx = (n_steps + 3) / 4;
+    if (gx > 3 * dif::kCUs) gx = 3 * dif::kCUs;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rowgemm_kernel, dim3(static_cast<unsigned>(gx), H), dim3(256), 0, st, A, lda, K, Mat, ldm,
+                       mat_head_stride, mat_t, mat_scale, bias, C, r, H, u, C, u_scale, Cin, ldc, beta_dev, n_rows, K, C, out,
+                       ldo);
+    return dif::launch_status("rowgemm_kernel");
+}

@@ -161,6 +161,24 @@ int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const 
                    float ln_eps, int relu, float* out, int64_t ldo, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a1 backward: gradient of full_attention_conv(..., 'simple') (difformer.py:18-39) w.r.t. q, k, v -- what
+ * loss.backward() (main.py:130) needs; the reference leaves it to autograd.  With gn = g/den and
+ * gd = -(g.out)/den per (row, head):  dif_simple_bwd_prep_f32 writes gn [n,H,D], gd [n,H] and
+ * sums [H*M+1] = { sum_n q*gd per (h,m), sum gd };  dif_simple_reduce_f32(q, q, gn) then gives q^T gn and
+ * sum gn;  dif_rowgemm_f32 (out = A Mat + bias + r (x) u + beta Cin per head, K, C <= 64, beta a DEVICE scalar)
+ * forms dq, dk, dv (formulas in csrc/simple_attn_bwd.hip).
+ * ------------------------------------------------------------------------------------- */
+size_t dif_simple_bwd_workspace_bytes(int64_t n_rows, int H, int M, int D);
+int dif_simple_bwd_prep_f32(const float* q, int64_t ldq, const float* g, int64_t ldg,
+                            const float* out, int64_t ldo, const float* reduced, int64_t n_rows,
+                            int64_t n_global, int H, int M, int D, float* gn, float* gd, float* sums,
+                            void* workspace, size_t workspace_bytes, dif_stream_t stream);
+int dif_rowgemm_f32(const float* A, int64_t lda, const float* Mat, int ldm, int mat_head_stride,
+                    int mat_t, float mat_scale, const float* bias, const float* r, const float* u,
+                    float u_scale, const float* Cin, int64_t ldc, const float* beta_dev,
+                    int64_t n_rows, int H, int K, int C, float* out, int64_t ldo, dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * bfloat16 STORAGE variants (BASELINE config C5: Pokec mini-batches in bf16).  Same semantics as the
  * _f32 entry points; every tensor the reference would hold in its activation dtype (x, q, k, v, attn,
  * conv, out, Linear / LayerNorm parameters) is bf16 (uint16 bit patterns behind void*), while the CSR

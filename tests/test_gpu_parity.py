@@ -659,3 +659,20 @@ def test_row_sharded_kernels_match_unsharded(world, dev):
         out_r = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, n, csr.nnz, v_all, lo, hi - lo,
                         attn_r.reshape(hi - lo, d), 1.0, 1.0, tail(lo, hi))
         assert rel_err(out_r.cpu().numpy(), full[lo:hi].cpu().numpy()) < 1e-5, (world, r)
+
+
+@pytest.mark.parametrize("n,h,d", [(300, 1, 64), (1000, 2, 32), (257, 3, 20), (50000, 1, 64)])
+def test_simple_attention_backward_kernels(n, h, d, dev):
+    """dq, dk, dv from the HIP backward (bwd_prep + reduce + row-GEMMs) against float64 autograd of the closed form
+    of difformer.py:18-39 (the reference itself relies on autograd)."""
+    from difformer_amd import autograd_ops as ag
+    g = torch.Generator().manual_seed(n + d)
+    q, k, v = (torch.randn(n, h, d, generator=g) for _ in range(3))
+    go = torch.randn(n, h, d, generator=g)
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = ag.simple_attention(qd, kd, vd)
+    out.backward(go.to(dev))
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    ag._simple_expr(q64, k64, v64).backward(go.double())
+    for got, ref, name in ((qd.grad, q64.grad, "dq"), (kd.grad, k64.grad, "dk"), (vd.grad, v64.grad, "dv")):
+        assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-4, name
