@@ -262,6 +262,31 @@ class HipBackend:
             raise IndexError(f"difformer_amd: edge_index holds node ids outside [0, {num_nodes})")
         return rowptr, blkptr, src, val
 
+    def subgraph(self, subset, edge_index, edge_weight, num_nodes):
+        """Induced subgraph with relabelling (main-batch.py:131) -> (edge_index [2,E'], edge_weight [E'] | None)."""
+        dev = _require_device(subset, edge_index, edge_weight)
+        if edge_index.dtype != torch.int64 or subset.dtype != torch.int64:
+            raise TypeError("difformer_amd: subset and edge_index must be int64")
+        ei = edge_index.contiguous()
+        sub = subset.contiguous()
+        E, B = int(ei.shape[1]), int(sub.numel())
+        ew = None if edge_weight is None else _f32(edge_weight, "edge_weight").contiguous()
+        out_ei = torch.empty((2, max(E, 1)), dtype=torch.int64, device=dev)
+        out_w = None if ew is None else torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        ws_bytes = self.lib.dif_subgraph_workspace_bytes(E, num_nodes)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_subgraph", dev):
+            rc = self.lib.dif_subgraph(_ptr(ei), E, num_nodes, _ptr(sub), B, _ptr(ew), _ptr(out_ei), _ptr(out_w),
+                                       _ptr(count), _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_subgraph")
+        kept, bad = int(count.item()), int(status.item())       # one sync: the result size is data dependent
+        if bad:
+            raise IndexError(f"difformer_amd: subset / edge_index hold node ids outside [0, {num_nodes})")
+        out = torch.stack([out_ei[0, :kept], out_ei[1, :kept]])
+        return out, (None if out_w is None else out_w[:kept].clone())
+
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
              gcn_scale=1.0, tail=None):
         """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps): fuse the layer tail (H == 1)."""

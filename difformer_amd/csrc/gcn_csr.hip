@@ -306,6 +306,49 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict
     }
 }
 
+// ---- induced subgraph of a node subset with relabelling (f2: the per-batch graph step of the mini-batch path) ----
+// node classification/main-batch.py:131  subgraph(idx_i, edge_index, num_nodes=n, relabel_nodes=True)  (torch_geometric
+// 1.7.2, un-vendored: node_mask[subset] = True; keep edges whose two ends are in the subset, in their original order;
+// new id of subset[i] is i).  The reference runs it on the CPU over the whole edge list for every batch.
+__global__ __launch_bounds__(256) void subgraph_mark_kernel(const int64_t* __restrict__ subset, int64_t B, int64_t N,
+                                                            int32_t* __restrict__ newid, int32_t* __restrict__ status) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int64_t v = subset[i];
+    if (v < 0 || v >= N) { atomicOr(status, 1); return; }
+    newid[v] = static_cast<int32_t>(i) + 1;          // 0 = not in the subset
+}
+
+__global__ __launch_bounds__(256) void subgraph_flag_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
+                                                            const int32_t* __restrict__ newid,
+                                                            int32_t* __restrict__ keep, int32_t* __restrict__ status) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e <= E; e += stride) {
+        if (e == E) { keep[e] = 0; continue; }        // sentinel so the scan's last entry is the kept count
+        const int64_t r = edge_index[e], c = edge_index[E + e];
+        if (r < 0 || r >= N || c < 0 || c >= N) { atomicOr(status, 1); keep[e] = 0; continue; }
+        keep[e] = (newid[r] != 0 && newid[c] != 0) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void subgraph_emit_kernel(const int64_t* __restrict__ edge_index, int64_t E,
+                                                            const float* __restrict__ edge_weight,
+                                                            const int32_t* __restrict__ newid,
+                                                            const int32_t* __restrict__ pos, int64_t cap,
+                                                            int64_t* __restrict__ out_ei, float* __restrict__ out_w,
+                                                            int64_t* __restrict__ out_count) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < E; e += stride) {
+        const int32_t p = pos[e];
+        if (pos[e + 1] != p) {                        // kept: exclusive scan advanced
+            out_ei[p] = newid[edge_index[e]] - 1;
+            out_ei[cap + p] = newid[edge_index[E + e]] - 1;
+            if (out_w) out_w[p] = edge_weight[e];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = pos[E];
+}
+
 }  // namespace
 
 extern "C" size_t dif_csr_workspace_bytes(int64_t E, int64_t N, int n_blocks) {
@@ -381,4 +424,48 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     hipLaunchKernelGGL(csr_fill_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N,
                        static_cast<uint32_t>(p.NB), transpose, edge_weight, kin, vin, dinv, src, val);
     return dif::launch_status("csr_fill_kernel");
+}
+
+extern "C" size_t dif_subgraph_workspace_bytes(int64_t E, int64_t N) {
+    if (E < 0 || N <= 0) return 0;
+    return align256(static_cast<size_t>(N) * 4) + align256(static_cast<size_t>(E + 1) * 4) +
+           align256(static_cast<size_t>((E + 1 + kScanTile - 1) / kScanTile + 1) * 4);
+}
+
+extern "C" int dif_subgraph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* subset, int64_t B,
+                            const float* edge_weight, int64_t* out_edge_index, float* out_weight, int64_t* out_count,
+                            int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && E >= 0 && B >= 0, DIF_E_BADARG, "dif_subgraph: need N > 0, E >= 0, B >= 0");
+    DIF_REQUIRE(E < (int64_t(1) << 31) - 4096 && N < (int64_t(1) << 31) - 1 && B < (int64_t(1) << 31) - 1, DIF_E_RANGE,
+                "dif_subgraph: sizes must fit int32");
+    DIF_REQUIRE(out_count && status && workspace && (E == 0 || (edge_index && out_edge_index)) && (B == 0 || subset),
+                DIF_E_BADARG, "dif_subgraph: null pointer");
+    DIF_REQUIRE((edge_weight == nullptr) == (out_weight == nullptr), DIF_E_BADARG,
+                "dif_subgraph: edge_weight and out_weight must be given together");
+    DIF_REQUIRE(workspace_bytes >= dif_subgraph_workspace_bytes(E, N), DIF_E_WORKSPACE, "dif_subgraph: workspace too small");
+    DIF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DIF_E_BADARG,
+                "dif_subgraph: workspace must be 256-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    int32_t* newid = reinterpret_cast<int32_t*>(ws);
+    int32_t* keep = reinterpret_cast<int32_t*>(ws + align256(static_cast<size_t>(N) * 4));
+    int32_t* bsum = reinterpret_cast<int32_t*>(ws + align256(static_cast<size_t>(N) * 4) + align256(static_cast<size_t>(E + 1) * 4));
+    hipError_t he = hipMemsetAsync(newid, 0, static_cast<size_t>(N) * 4, st);
+    if (he == hipSuccess) he = hipMemsetAsync(status, 0, 4, st);
+    if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_subgraph: memset: %s", hipGetErrorString(he));
+    if (B > 0) {
+        hipLaunchKernelGGL(subgraph_mark_kernel, dim3(static_cast<unsigned>((B + 255) / 256)), dim3(256), 0, st, subset, B,
+                           N, newid, status);
+        if (int rc = dif::launch_status("subgraph_mark_kernel")) return rc;
+    }
+    const int64_t cap = 8 * dif::kCUs;
+    int64_t g = (E + 1 + 255) / 256;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(subgraph_flag_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N, newid,
+                       keep, status);
+    if (int rc = dif::launch_status("subgraph_flag_kernel")) return rc;
+    if (int rc = exclusive_scan(keep, E + 1, keep, nullptr, bsum, st)) return rc;
+    hipLaunchKernelGGL(subgraph_emit_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, edge_weight,
+                       newid, keep, E, out_edge_index, out_weight, out_count);
+    return dif::launch_status("subgraph_emit_kernel");
 }

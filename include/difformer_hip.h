@@ -126,6 +126,18 @@ int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
                      float* out, int64_t ldo, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f2  induced subgraph of a node subset with relabelling -- the per-batch graph step of the mini-batch path,
+ *     node classification/main-batch.py:131  subgraph(idx_i, edge_index, num_nodes=n, relabel_nodes=True)
+ *     (torch_geometric 1.7.2 semantics: keep the edges whose two ends are in `subset`, in their original order;
+ *     subset[i] becomes node i).  out_edge_index has capacity [2, E] (row r at offset r*E); out_count (device int64)
+ *     receives the number of kept edges; status[0] != 0 flags ids outside [0, N).  `subset` must not repeat ids.
+ * ------------------------------------------------------------------------------------- */
+size_t dif_subgraph_workspace_bytes(int64_t E, int64_t N);
+int dif_subgraph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* subset, int64_t B,
+                 const float* edge_weight, int64_t* out_edge_index, float* out_weight, int64_t* out_count,
+                 int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a4/a5  tail of DIFFormerConv.forward + the per-layer tail of DIFFormer.forward
  *        node classification/difformer.py:137 (mean over heads), :139-140 (+= x_0),
  *        :200-201 (alpha residual), :202-203 (LayerNorm, eps 1e-5, affine)

@@ -241,3 +241,22 @@ def difformer_forward(p, x, edge_index, edge_weight, cfg, return_layers=False):
 
 def cast_params(p, dtype):
     return {k: np.asarray(v).astype(dtype) for k, v in p.items()}
+
+
+# --------------------------------------------------------------------------
+# f2: induced subgraph with relabelling (caller side of the mini-batch path)
+#     node classification/main-batch.py:131  subgraph(idx_i, edge_index, num_nodes=n, relabel_nodes=True)
+#     torch_geometric 1.7.2 (un-vendored): node_mask[subset] = True; edge_mask = mask[row] & mask[col];
+#     kept edges stay in their original order; node_idx[subset] = arange(len(subset)) relabels them.
+# --------------------------------------------------------------------------
+def subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes=None):
+    subset = np.asarray(subset, dtype=np.int64)
+    edge_index = np.asarray(edge_index, dtype=np.int64)
+    n = int(num_nodes) if num_nodes is not None else int(edge_index.max()) + 1
+    newid = np.full(n, -1, dtype=np.int64)
+    newid[subset] = np.arange(subset.shape[0])
+    keep = (newid[edge_index[0]] >= 0) & (newid[edge_index[1]] >= 0)
+    out = edge_index[:, keep]
+    if relabel_nodes:
+        out = newid[out]
+    return out, (None if edge_attr is None else np.asarray(edge_attr)[keep])

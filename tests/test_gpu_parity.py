@@ -676,3 +676,30 @@ def test_simple_attention_backward_kernels(n, h, d, dev):
     ag._simple_expr(q64, k64, v64).backward(go.double())
     for got, ref, name in ((qd.grad, q64.grad, "dq"), (kd.grad, k64.grad, "dk"), (vd.grad, v64.grad, "dv")):
         assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-4, name
+
+
+def test_subgraph_relabel_matches_numpy(dev):
+    """dif_subgraph (main-batch.py:131 semantics): kept edges in original order, relabelled; integer work -> exact."""
+    from difformer_amd import graph_utils as gu
+    g = torch.Generator().manual_seed(4)
+    n, e, bsz = 50000, 1200000, 10000
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = torch.rand(e, generator=g)
+    subset = torch.randperm(n, generator=g)[:bsz]
+    ref, ref_w = orc.subgraph(subset.numpy(), ei.numpy(), w.numpy(), relabel_nodes=True, num_nodes=n)
+    out, ow = gu.subgraph(subset.to(dev), ei.to(dev), w.to(dev), relabel_nodes=True, num_nodes=n)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(ow.cpu().numpy(), ref_w)
+    out2, _ = gu.subgraph(subset.to(dev), ei.to(dev), None, relabel_nodes=False, num_nodes=n)
+    assert np.array_equal(out2.cpu().numpy(), orc.subgraph(subset.numpy(), ei.numpy(), None, False, n)[0])
+    empty, _ = gu.subgraph(torch.zeros(0, dtype=torch.long, device=dev), ei.to(dev), None, True, n)
+    assert empty.shape == (2, 0)
+    with pytest.raises(IndexError):
+        gu.subgraph(torch.tensor([n + 5], device=dev), ei.to(dev), None, True, n)
+    # the small helpers
+    a, _ = gu.remove_self_loops(torch.tensor([[0, 1, 2], [0, 2, 2]], device=dev))
+    assert a.tolist() == [[1], [2]]
+    b, _ = gu.add_self_loops(a, num_nodes=3)
+    assert b.tolist() == [[1, 0, 1, 2], [2, 0, 1, 2]]
+    u = gu.to_undirected(torch.tensor([[0, 1, 1], [1, 0, 2]], device=dev), num_nodes=3)
+    assert u.tolist() == [[0, 1, 1, 2], [1, 0, 2, 1]]

@@ -89,3 +89,12 @@ def test_model_forward(name):
         conv0 = orc.difformer_conv(p, "convs.0.", layers[0], layers[0], ei,
                                    None if w is None else w.astype(dt), layers[0], cfg)
         assert rel_err(conv0, c["conv0_" + suffix]) < tol
+
+
+def test_subgraph_restatement_small_case():
+    """oracle.subgraph against a hand-checked case (torch_geometric.utils.subgraph semantics, main-batch.py:131)."""
+    ei = np.array([[0, 1, 2, 3, 3, 4], [1, 2, 3, 4, 0, 4]])
+    out, w = orc.subgraph(np.array([3, 0, 4]), ei, np.arange(6.0), relabel_nodes=True, num_nodes=5)
+    assert out.tolist() == [[0, 0, 2], [2, 1, 2]] and w.tolist() == [3.0, 4.0, 5.0]
+    out2, _ = orc.subgraph(np.array([3, 0, 4]), ei, None, relabel_nodes=False, num_nodes=5)
+    assert out2.tolist() == [[3, 3, 4], [4, 0, 4]]
