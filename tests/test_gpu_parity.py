@@ -703,3 +703,41 @@ def test_subgraph_relabel_matches_numpy(dev):
     assert b.tolist() == [[1, 0, 1, 2], [2, 0, 1, 2]]
     u = gu.to_undirected(torch.tensor([[0, 1, 1], [1, 0, 2]], device=dev), num_nodes=3)
     assert u.tolist() == [[0, 1, 1, 2], [1, 0, 2, 1]]
+
+
+def _random_cfgs(count, seed):
+    rng = np.random.default_rng(seed)
+    cfgs = []
+    while len(cfgs) < count:
+        c = dict(hidden_channels=int(rng.choice([8, 16, 20, 64, 96])), num_layers=int(rng.integers(1, 4)),
+                 num_heads=int(rng.choice([1, 1, 2, 3])), kernel=str(rng.choice(["simple", "simple", "sigmoid"])),
+                 alpha=float(rng.choice([0.5, 0.2])), use_bn=bool(rng.integers(0, 2)), use_residual=bool(rng.integers(0, 2)),
+                 use_weight=bool(rng.integers(0, 4) > 0), use_graph=bool(rng.integers(0, 4) > 0),
+                 graph_weight=float(rng.choice([-1, -1, 0.3])), use_source=bool(rng.integers(0, 2)))
+        c["weighted"] = bool(rng.integers(0, 2)) and c["use_graph"]
+        c["n"] = int(rng.integers(50, 600))
+        c["f_in"] = int(rng.choice([5, 32, 64, 130]))
+        cfgs.append(c)
+    return cfgs
+
+
+@pytest.mark.parametrize("idx,cfg", list(enumerate(_random_cfgs(28, 2024))))
+def test_model_forward_random_flag_combinations(idx, cfg, dev):
+    """Every constructor switch of difformer.py:154-155 in random combinations (incl. the CLI defaults of parse.py:48-52,
+    several heads, odd widths, use_weight=False, graph_weight > 0, edge weights) against the float64 oracle."""
+    from difformer_amd import DIFFormer
+    cfg = dict(cfg)
+    n, f_in, weighted = cfg.pop("n"), cfg.pop("f_in"), cfg.pop("weighted")
+    torch.manual_seed(1000 + idx)
+    model = DIFFormer(f_in, cfg["hidden_channels"], 6, **{k: v for k, v in cfg.items() if k != "hidden_channels"}).eval()
+    g = torch.Generator().manual_seed(idx)
+    x = torch.randn(n, f_in, generator=g)
+    ei = torch.cat([torch.randint(0, n, (2, 5 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+    w = (torch.rand(ei.shape[1], generator=g) + 0.05) if weighted else None
+    p = {k: v.double().numpy() for k, v in model.state_dict().items()}
+    ref = orc.difformer_forward(p, x.double().numpy(), ei.numpy() if cfg["use_graph"] else None,
+                                None if w is None else w.double().numpy(), cfg)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(x.to(dev), ei.to(dev) if cfg["use_graph"] else None, None if w is None else w.to(dev))
+    assert rel_err(out.cpu().numpy(), ref) < TOL, cfg
