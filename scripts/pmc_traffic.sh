@@ -15,13 +15,13 @@ def load(d):
     f = glob.glob(f"$OUT/{d}/*counter_collection.csv")[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        agg[(r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 res = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     for d in (f"cal_{C}", f"bench_{C}"):
         for (k, c), v in load(d).items():
-            if any(s in k for s in ("read_dword", "write_dwordx4", "spmm", "project_reduce", "simple_apply")):
+            if any(s in k for s in ("read_dword", "write_dwordx4", "spmm", "project_reduce", "simple_apply", "skinny_linear")):
                 res.setdefault(k, {})[c] = v
 print(json.dumps(res, indent=1))
 json.dump(res, open("$OUT/pmc_traffic_raw.json", "w"), indent=1)
