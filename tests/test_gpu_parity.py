@@ -741,3 +741,39 @@ def test_model_forward_random_flag_combinations(idx, cfg, dev):
     with torch.no_grad():
         out = model(x.to(dev), ei.to(dev) if cfg["use_graph"] else None, None if w is None else w.to(dev))
     assert rel_err(out.cpu().numpy(), ref) < TOL, cfg
+
+
+_SCRIPT_SHAPES = [
+    # (name, n, f_in, classes, cfg): widths the reference's run.sh files actually pass
+    ("cifar-script hidden 300 no graph", 3000, 512, 10,
+     dict(hidden_channels=300, num_layers=2, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+          use_weight=True, use_graph=False, graph_weight=-1, use_source=False)),
+    ("pokec-script hidden 128", 4000, 65, 2,
+     dict(hidden_channels=128, num_layers=3, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+          use_weight=True, use_graph=True, graph_weight=-1, use_source=False)),
+    ("hidden 256 sigmoid, 2 heads", 1500, 100, 5,
+     dict(hidden_channels=256, num_layers=2, num_heads=2, kernel="sigmoid", alpha=0.5, use_bn=True, use_residual=True,
+          use_weight=True, use_graph=True, graph_weight=-1, use_source=True)),
+    ("hidden 32, 4 heads, graph_weight", 2500, 40, 7,
+     dict(hidden_channels=32, num_layers=2, num_heads=4, kernel="simple", alpha=0.3, use_bn=False, use_residual=True,
+          use_weight=True, use_graph=True, graph_weight=0.7, use_source=False)),
+]
+
+
+@pytest.mark.parametrize("name,n,f_in,classes,cfg", _SCRIPT_SHAPES, ids=[s[0] for s in _SCRIPT_SHAPES])
+def test_model_forward_script_widths(name, n, f_in, classes, cfg, dev):
+    """Hidden widths of the shipped scripts (image and text/run.sh:27 hidden 300; node classification/run.sh:42-44
+    hidden 128) and wide multi-head cases, against the float64 oracle."""
+    from difformer_amd import DIFFormer
+    torch.manual_seed(7)
+    model = DIFFormer(f_in, cfg["hidden_channels"], classes,
+                      **{k: v for k, v in cfg.items() if k != "hidden_channels"}).eval()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, f_in, generator=g)
+    ei = torch.cat([torch.randint(0, n, (2, 6 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+    p = {k: v.double().numpy() for k, v in model.state_dict().items()}
+    ref = orc.difformer_forward(p, x.double().numpy(), ei.numpy() if cfg["use_graph"] else None, None, cfg)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(x.to(dev), ei.to(dev) if cfg["use_graph"] else None)
+    assert rel_err(out.cpu().numpy(), ref) < TOL, name
