@@ -260,3 +260,86 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes=
     if relabel_nodes:
         out = newid[out]
     return out, (None if edge_attr is None else np.asarray(edge_attr)[keep])
+
+
+# --------------------------------------------------------------------------
+# f4: DIFFormer_v2 (physical particle/difformer-v2.py) - a batch of B independent graphs whose nodes are
+#     stored back to back; n_nodes[b] = node count of graph b.  The reference pads to [B, max_node, H, D]
+#     (:8-27); here the same sums are restated per graph / per position without padding.
+# --------------------------------------------------------------------------
+def v2_simple_attention(qs, ks, vs, n_nodes):
+    """TransConv.full_attention, kernel 'simple' (difformer-v2.py:80-111).
+
+    :82-83  q, k divided by the Frobenius norm over the WHOLE batch (all graphs together)
+    :93     per-graph K^T V                      :95-98   per-graph sum of v (UNscaled values)
+    :100-101 numerator = q.KtV_b + vsum_b        :103-109 denominator = q.ksum_b + n_b
+    """
+    qs, ks, vs = (np.asarray(a) for a in (qs, ks, vs))
+    n_nodes = np.asarray(n_nodes, dtype=np.int64)
+    dt = qs.dtype.type
+    qn = qs / np.sqrt((qs * qs).sum(dtype=qs.dtype))
+    kn = ks / np.sqrt((ks * ks).sum(dtype=ks.dtype))
+    out = np.empty(vs.shape, dtype=vs.dtype)
+    off = 0
+    for nb in n_nodes.tolist():
+        q, k, v = qn[off:off + nb], kn[off:off + nb], vs[off:off + nb]
+        ktv = np.einsum("lhm,lhd->hmd", k, v)
+        num = np.einsum("nhm,hmd->nhd", q, ktv) + v.sum(axis=0)[None]
+        den = np.einsum("nhm,hm->nh", q, k.sum(axis=0)) + dt(nb)
+        out[off:off + nb] = num / den[..., None]
+        off += nb
+    return out
+
+
+def v2_sigmoid_attention(qs, ks, vs, n_nodes):
+    """TransConv.full_attention, kernel 'sigmoid' (difformer-v2.py:113-135).
+
+    :124 einsum("abcd,ebcd->aebc"): the node at POSITION b of graph a scores against the node at the SAME
+    position b of every graph e (not against the other nodes of its own graph).  Graphs shorter than b+1
+    contribute a padded zero key: sigma(0) = 0.5 to the denominator (:127-129, + 1e-9) and a zero value (:134).
+    """
+    qs, ks, vs = (np.asarray(a) for a in (qs, ks, vs))
+    n_nodes = np.asarray(n_nodes, dtype=np.int64)
+    dt = qs.dtype.type
+    B = n_nodes.shape[0]
+    offs = np.concatenate([[0], np.cumsum(n_nodes)])
+    out = np.empty(vs.shape, dtype=vs.dtype)
+    for p in range(int(n_nodes.max()) if B else 0):
+        idx = offs[:-1][n_nodes > p] + p                       # the nodes at position p
+        q, k, v = qs[idx], ks[idx], vs[idx]
+        s = 1.0 / (1.0 + np.exp(-np.einsum("nhm,lhm->nlh", q, k)))
+        den = s.sum(axis=1) + dt(0.5) * dt(B - idx.shape[0]) + dt(1e-9)
+        out[idx] = np.einsum("nlh,lhd->nhd", s, v) / den[..., None]
+    return out
+
+
+def difformer_v2_forward(p, x, edge_index, n_nodes, cfg):
+    """DIFFormer_v2.forward in eval mode (difformer-v2.py:193-223): as DIFFormer.forward but one head, no
+    use_source, attention per graph (above), and ReLU AFTER each layer's LayerNorm (:216-217)."""
+    dt = x.dtype.type
+    d = cfg["hidden_channels"]
+    alpha = dt(cfg.get("alpha", 0.5))
+    h = linear(x, p["fcs.0.weight"], p["fcs.0.bias"])                  # :197
+    if cfg.get("use_bn", True):
+        h = layer_norm(h, p["bns.0.weight"], p["bns.0.bias"])          # :198-199
+    h = np.maximum(h, dt(0))                                           # :200
+    layers = [h]
+    attend = v2_simple_attention if cfg.get("kernel", "simple") == "simple" else v2_sigmoid_attention
+    for i in range(cfg["num_layers"]):
+        pre = f"convs.{i}."
+        q = linear(h, p[pre + "Wq.weight"], p[pre + "Wq.bias"]).reshape(-1, 1, d)      # :143
+        k = linear(h, p[pre + "Wk.weight"], p[pre + "Wk.bias"]).reshape(-1, 1, d)      # :144
+        v = linear(h, p[pre + "Wv.weight"], p[pre + "Wv.bias"]).reshape(-1, 1, d)      # :145-146 (use_weight)
+        att = attend(q, k, v, n_nodes)                                                 # :148
+        if cfg.get("use_graph", True):
+            g = gcn_conv(v, edge_index, None)
+            gw = cfg.get("graph_weight", -1)
+            att = (dt(1 - gw) * att + dt(gw) * g) if gw > 0 else (att + g)             # :150-154
+        hh = att.mean(axis=1).astype(x.dtype)                                          # :157
+        if cfg.get("use_residual", True):
+            hh = alpha * hh + (dt(1) - alpha) * layers[i]                              # :212-213
+        if cfg.get("use_bn", True):
+            hh = layer_norm(hh, p[f"bns.{i + 1}.weight"], p[f"bns.{i + 1}.bias"])      # :214-215
+        h = np.maximum(hh, dt(0))                                                      # :217
+        layers.append(h)
+    return linear(h, p["fcs.1.weight"], p["fcs.1.bias"])                               # :221

@@ -98,3 +98,34 @@ def test_subgraph_restatement_small_case():
     assert out.tolist() == [[0, 0, 2], [2, 1, 2]] and w.tolist() == [3.0, 4.0, 5.0]
     out2, _ = orc.subgraph(np.array([3, 0, 4]), ei, None, relabel_nodes=False, num_nodes=5)
     assert out2.tolist() == [[3, 3, 4], [4, 0, 4]]
+
+
+# ---- f4: DIFFormer_v2 (physical particle/difformer-v2.py), fixtures from tests/golden/make_golden_v2.py ----------
+V2 = load_golden("v2")
+
+
+@pytest.mark.parametrize("name", sorted(n for n in V2 if n.startswith("attn/")))
+def test_v2_full_attention(name):
+    c = V2[name]
+    fn = orc.v2_simple_attention if str(c["kernel"]) == "simple" else orc.v2_sigmoid_attention
+    for suffix, dt, tol in (("f64", np.float64, 1e-12), ("f32", np.float32, 1e-5)):
+        out = fn(c["q"].astype(dt), c["k"].astype(dt), c["v"].astype(dt), c["n_nodes"])
+        assert out.dtype == dt and out.shape == c["out_" + suffix].shape
+        assert rel_err(out, c["out_" + suffix]) < tol
+
+
+def test_v2_single_graph_is_a1():
+    """One graph in the batch: difformer-v2.py:80-111 reduces to difformer.py:18-39."""
+    rng = np.random.default_rng(0)
+    q, k, v = (rng.standard_normal((50, 2, 16)) for _ in range(3))
+    assert rel_err(orc.v2_simple_attention(q, k, v, [50]), orc.simple_attention(q, k, v)) < 1e-13
+
+
+@pytest.mark.parametrize("name", sorted(n for n in V2 if n.startswith("model/")))
+def test_v2_model_forward(name):
+    c = V2[name]
+    cfg, sd = split_model_case(c)
+    ei = c["edge_index"] if cfg["use_graph"] else None
+    for suffix, dt, tol in (("f64", np.float64, 1e-11), ("f32", np.float32, 2e-5)):
+        out = orc.difformer_v2_forward(orc.cast_params(sd, dt), c["x"].astype(dt), ei, c["n_nodes"], cfg)
+        assert rel_err(out, c["out_" + suffix]) < tol
