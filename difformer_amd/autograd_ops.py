@@ -135,6 +135,65 @@ def sigmoid_attention(q, k, v, shard=None):
     return ops.sigmoid_attention(q, k, v, shard)
 
 
+# ---- f4: batch of graphs (physical particle/difformer-v2.py:71-137) -------------------------------
+def _pad(t, layout):
+    """[N,H,D] -> [B, max_nodes, H, D] (zeros beyond each graph) -- backward-only helper."""
+    ptr = layout.graph_ptr.long()
+    batch = torch.repeat_interleave(torch.arange(layout.n_graphs, device=t.device), ptr[1:] - ptr[:-1])
+    pos = torch.arange(layout.n_rows, device=t.device) - ptr[:-1][batch]
+    out = t.new_zeros((layout.n_graphs, layout.max_nodes) + tuple(t.shape[1:]))
+    out[batch, pos] = t
+    return out, batch, pos
+
+
+def _batched_simple_expr(layout):
+    def fn(q, k, v):
+        s = 1.0 / (torch.linalg.vector_norm(q) * torch.linalg.vector_norm(k))
+        qp, batch, pos = _pad(q, layout)
+        kp, _, _ = _pad(k, layout)
+        vp, _, _ = _pad(v, layout)
+        ktv = torch.einsum("blhm,blhd->bhmd", kp, vp)
+        num = s * torch.einsum("bnhm,bhmd->bnhd", qp, ktv) + vp.sum(dim=1, keepdim=True)
+        n_b = (layout.graph_ptr[1:] - layout.graph_ptr[:-1]).to(q.dtype).view(-1, 1, 1)
+        den = s * torch.einsum("bnhm,bhm->bnh", qp, kp.sum(dim=1)) + n_b
+        return (num / den.unsqueeze(-1))[batch, pos]
+    return fn
+
+
+def _batched_sigmoid_expr(layout):
+    def fn(q, k, v):
+        qp, batch, pos = _pad(q, layout)
+        kp, _, _ = _pad(k, layout)
+        vp, _, _ = _pad(v, layout)
+        sg = torch.sigmoid(torch.einsum("aphm,ephm->aeph", qp, kp))
+        att = sg / (sg.sum(dim=1, keepdim=True) + 1e-9)
+        return torch.einsum("aeph,ephd->aphd", att, vp)[batch, pos]
+    return fn
+
+
+class _BatchedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, layout, kernel):
+        ctx.save_for_backward(q, k, v)
+        ctx.layout, ctx.kernel = layout, kernel
+        fwd = ops.batched_simple_attention if kernel == "simple" else ops.batched_sigmoid_attention
+        return fwd(q, k, v, layout)
+
+    @staticmethod
+    def backward(ctx, g):
+        expr = _batched_simple_expr if ctx.kernel == "simple" else _batched_sigmoid_expr
+        return _grad_by_recompute(expr(ctx.layout), ctx.saved_tensors, g.contiguous()) + (None, None)
+
+
+def batched_attention(q, k, v, layout, kernel):
+    if kernel not in ("simple", "sigmoid"):
+        raise ValueError(f"unknown attention kernel {kernel!r} (expected 'simple' or 'sigmoid')")
+    if _needs_grad(q, k, v):
+        return _BatchedAttention.apply(q, k, v, layout, kernel)
+    fwd = ops.batched_simple_attention if kernel == "simple" else ops.batched_sigmoid_attention
+    return fwd(q, k, v, layout)
+
+
 def gcn_aggregate(csr, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard=None):
     if _needs_grad(x, attn):
         _no_sharded_training(shard)
@@ -142,23 +201,25 @@ def gcn_aggregate(csr, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard=None):
     return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard)
 
 
-def gcn_aggregate_tail(csr, x, attn, attn_scale, gcn_scale, shard, x0, prev, alpha, ln_weight, ln_bias, eps):
+def gcn_aggregate_tail(csr, x, attn, attn_scale, gcn_scale, shard, x0, prev, alpha, ln_weight, ln_bias, eps,
+                       relu=False):
     """SpMM + combine + layer tail -> [n, D].  One fused kernel when nothing needs a gradient and the
     layer has a single head; otherwise the two operators run back to back."""
     d = x.shape[2]
     fused = (x.shape[1] == 1 and (d <= 64 or (d % 4 == 0 and d <= 256)) and
              not _needs_grad(x, attn, x0, prev, ln_weight, ln_bias))
     if fused:
-        tail = dict(x0=x0, prev=prev, alpha=alpha, ln_weight=ln_weight, ln_bias=ln_bias, eps=eps)
+        tail = dict(x0=x0, prev=prev, alpha=alpha, ln_weight=ln_weight, ln_bias=ln_bias, eps=eps, relu=relu)
         return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard, tail)[:, 0, :]
     conv = gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard)
-    return layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
+    return layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu)
 
 
-def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5):
+def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
     if _needs_grad(conv, x0, prev, ln_weight, ln_bias):
-        return _LayerTail.apply(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
-    return ops.layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
+        y = _LayerTail.apply(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
+        return torch.relu(y) if relu else y
+    return ops.layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu)
 
 
 def norm_relu(x, ln_weight, ln_bias, eps):

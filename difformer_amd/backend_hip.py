@@ -232,6 +232,50 @@ class HipBackend:
         _lib.check(rc, "dif_sigmoid_attn_f32")
         return out
 
+    # ---- f4: batch of graphs (physical particle/difformer-v2.py:71-137) ---------------------
+    def batched_simple_attention(self, q, k, v, graph_ptr):
+        """graph_ptr: int32 [B+1] device tensor, graph b = rows [graph_ptr[b], graph_ptr[b+1])."""
+        dev = _require_device(q, k, v, graph_ptr)
+        N, H, M = q.shape
+        D = v.shape[2]
+        for t_, nm in ((q, "q"), (k, "k"), (v, "v")):
+            _f32(t_, nm)
+        if graph_ptr.dtype != torch.int32 or not graph_ptr.is_contiguous():
+            raise TypeError("difformer_amd: graph_ptr must be a contiguous int32 tensor [B+1]")
+        q, ldq = _row_major(q, H * M)
+        k, ldk = _row_major(k, H * M)
+        v, ldv = _row_major(v, H * D)
+        out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.dif_batched_simple_workspace_bytes()
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_batched_simple_attn_f32", dev):
+            rc = self.lib.dif_batched_simple_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(graph_ptr),
+                                                      graph_ptr.numel() - 1, N, H, M, D, _ptr(out), H * D, _ptr(ws),
+                                                      ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_batched_simple_attn_f32")
+        return out
+
+    def batched_sigmoid_attention(self, q, k, v, ranked_first, pos_count):
+        """ranked_first: int32 [B] first row of the r-th largest graph; pos_count: int32 [max_nodes]."""
+        dev = _require_device(q, k, v, ranked_first, pos_count)
+        N, H, M = q.shape
+        D = v.shape[2]
+        for t_, nm in ((q, "q"), (k, "k"), (v, "v")):
+            _f32(t_, nm)
+        for t_ in (ranked_first, pos_count):
+            if t_.dtype != torch.int32 or not t_.is_contiguous():
+                raise TypeError("difformer_amd: ranked_first / pos_count must be contiguous int32 tensors")
+        q, ldq = _row_major(q, H * M)
+        k, ldk = _row_major(k, H * M)
+        v, ldv = _row_major(v, H * D)
+        out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_batched_sigmoid_attn_f32", dev):
+            rc = self.lib.dif_batched_sigmoid_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(ranked_first),
+                                                       _ptr(pos_count), ranked_first.numel(), pos_count.numel(), H, M, D,
+                                                       _ptr(out), H * D, _stream(dev))
+        _lib.check(rc, "dif_batched_sigmoid_attn_f32")
+        return out
+
     # ---- a3 --------------------------------------------------------------------------------
     def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
         dev = _require_device(edge_index, edge_weight)
@@ -289,7 +333,7 @@ class HipBackend:
 
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
              gcn_scale=1.0, tail=None):
-        """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps): fuse the layer tail (H == 1)."""
+        """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps[, relu]): fuse the layer tail (H == 1)."""
         dev = _require_device(rowptr, blkptr, src, val, x, attn)
         F = x.shape[1]
         t = tail or {}
@@ -313,7 +357,7 @@ class HipBackend:
         head = (_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes, nnz, _ptr(x), ldx, row_begin, n_rows, F,
                 _ptr(attn), lda, float(attn_scale), float(gcn_scale))
         tail_args = (_ptr(x0), ldx0, _ptr(prev), ldp, float(t.get("alpha", 0.5)), _ptr(lw), _ptr(lb),
-                     float(t.get("eps", 1e-5)))
+                     float(t.get("eps", 1e-5)), int(bool(t.get("relu", False))))
         with _Timed(self, "dif_gcn_spmm_f32", dev):
             if sfx == "bf16":
                 name = "dif_gcn_spmm_tail_bf16"

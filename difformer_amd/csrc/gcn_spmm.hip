@@ -78,6 +78,7 @@ struct Tail {
     float alpha;
     const E* ln_w; const E* ln_b; float eps;   // LayerNorm (use_bn)
     int enabled;
+    int relu;                                   // ReLU after the norm (difformer-v2.py:217)
 };
 
 template <int G, int W, typename E>
@@ -105,6 +106,9 @@ __device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, c
         for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
         const float rstd = 1.0f / sqrtf(v * inv_d + t.eps);
         if (ok) o = dz * rstd * gload<W, E>(t.ln_w + col) + gload<W, E>(t.ln_b + col);
+    }
+    if (t.relu) {
+        if constexpr (W == 4) { for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f); } else o = fmaxf(o, 0.f);
     }
     return o;
 }
@@ -540,9 +544,9 @@ extern "C" int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkpt
                                      int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
                                      float attn_scale, float gcn_scale, const float* x0, int64_t ldx0,
                                      const float* prev, int64_t ldp, float alpha, const float* ln_weight,
-                                     const float* ln_bias, float ln_eps, float* out, int64_t ldo,
+                                     const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo,
                                      dif_stream_t stream) {
-    Tail<float> tail = {x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, 1};
+    Tail<float> tail = {x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, 1, relu};
     return spmm_entry<float>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
                              attn_scale, gcn_scale, tail, out, ldo, stream);
 }
@@ -554,11 +558,12 @@ extern "C" int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkp
                                       int64_t row_begin, int64_t n_rows, int F, const void* attn, int64_t lda,
                                       float attn_scale, float gcn_scale, int tail_enabled, const void* x0, int64_t ldx0,
                                       const void* prev, int64_t ldp, float alpha, const void* ln_weight,
-                                      const void* ln_bias, float ln_eps, void* out, int64_t ldo, dif_stream_t stream) {
+                                      const void* ln_bias, float ln_eps, int relu, void* out, int64_t ldo,
+                                      dif_stream_t stream) {
     using B = dif::bf16;
     auto c = [](const void* p) { return static_cast<const B*>(p); };
     Tail<B> tail = {};
-    if (tail_enabled) tail = Tail<B>{c(x0), ldx0, c(prev), ldp, alpha, c(ln_weight), c(ln_bias), ln_eps, 1};
+    if (tail_enabled) tail = Tail<B>{c(x0), ldx0, c(prev), ldp, alpha, c(ln_weight), c(ln_bias), ln_eps, 1, relu};
     return spmm_entry<B>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, c(x), ldx, row_begin, n_rows, F, c(attn), lda,
                          attn_scale, gcn_scale, tail, static_cast<B*>(out), ldo, stream);
 }

@@ -26,10 +26,8 @@ constexpr int kDTile = 64;    // output columns per workgroup (grid.y covers hea
 // zeroed afterwards, so the compiler can issue all of a tile's loads back to back (a guarded load is
 // its own exec-masked branch region and serialises).
 template <bool VEC>
-__device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld, int64_t r, int64_t n,
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld, int64_t rc, bool rok,
                                      int col0, int c, int width) {
-    const bool rok = r < n;
-    const int64_t rc = rok ? r : n - 1;
     f32x4 z;
     if (VEC) {
         const bool cok = c < width;                       // width % 4 == 0 here
@@ -56,21 +54,43 @@ __device__ __forceinline__ float sigmoidf(float x) {
 // S == 1: writes the normalised output.  S > 1 (small N: not enough query groups to fill 256 CUs): writes
 // un-normalised partial sums and row sums to `part` [S][N][H*D] / `pden` [S][N][H*DT]; sigmoid_combine_kernel
 // finishes.
-template <bool VEC, bool QREG>
+//
+// SEG (f4, physical particle/difformer-v2.py:113-135): blockIdx.z is a POSITION p inside the graphs of a batch; the
+// attention runs among the seg_cnt[p] nodes that sit at position p of their graph.  Graphs are ranked by size
+// (descending), so those are exactly ranks 0 .. seg_cnt[p]-1 and local row r is node seg_first[r] + p
+// (seg_first[r] = first node of the r-th largest graph).  The n_graphs - seg_cnt[p] shorter graphs are the
+// reference's zero padding: sigma(0) = 0.5 each in the denominator (+1e-9), nothing in the numerator.
+template <bool VEC, bool QREG, bool SEG>
 __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restrict__ q, int64_t ldq,
                                                            const float* __restrict__ k, int64_t ldk,
                                                            const float* __restrict__ v, int64_t ldv,
                                                            int64_t N, int64_t L, int H, int M, int D,
                                                            float* __restrict__ out, int64_t ldo,
-                                                           float* __restrict__ part, float* __restrict__ pden) {
+                                                           float* __restrict__ part, float* __restrict__ pden,
+                                                           const int32_t* __restrict__ seg_first,
+                                                           const int32_t* __restrict__ seg_cnt, int n_graphs) {
     __shared__ __attribute__((aligned(16))) float sm_o[kWaves][kQGroup * kDTile];   // 64 KiB
     __shared__ float sm_den[kWaves][kQGroup];
 
     const int DT = (D + kDTile - 1) / kDTile;
     const int h = blockIdx.y / DT;
     const int dt = blockIdx.y % DT;
-    const int S = gridDim.z;
-    const int split = blockIdx.z;
+    const int S = SEG ? 1 : gridDim.z;
+    const int split = SEG ? 0 : blockIdx.z;
+    const int pos = SEG ? blockIdx.z : 0;
+    if (SEG) {
+        N = L = seg_cnt[pos];
+        if (static_cast<int64_t>(blockIdx.x) * kQGroup >= N) return;       // uniform: before any barrier
+    }
+    // local row -> row in memory (clamped to the last valid row; callers mask with `r < n`)
+    auto qrow = [&](int64_t r) -> int64_t {
+        const int64_t rc = r < N ? r : N - 1;
+        return SEG ? static_cast<int64_t>(seg_first[rc]) + pos : rc;
+    };
+    auto krow = [&](int64_t r) -> int64_t {
+        const int64_t rc = r < L ? r : L - 1;
+        return SEG ? static_cast<int64_t>(seg_first[rc]) + pos : rc;
+    };
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l15 = lane & 15;
@@ -84,7 +104,8 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restri
 #pragma unroll
         for (int t = 0; t < kQT; ++t)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) qv[t][c] = ld4<VEC>(q, ldq, q0 + 16 * t + l15, N, h * M, 16 * c + 4 * lg, M);
+            for (int c = 0; c < 4; ++c)
+                qv[t][c] = ld4<VEC>(q, ldq, qrow(q0 + 16 * t + l15), q0 + 16 * t + l15 < N, h * M, 16 * c + 4 * lg, M);
     }
 
     f32x4 acc_o[kQT][4];
@@ -109,14 +130,16 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restri
         for (int t = 0; t < kQT; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int mc = 0; mc < m_chunks; ++mc) {
             f32x4 kx[4];
+            const int64_t kr = krow(kbase + l15);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) kx[c] = ld4<VEC>(k, ldk, kbase + l15, L, h * M, mc * 64 + 16 * c + 4 * lg, M);
+            for (int c = 0; c < 4; ++c) kx[c] = ld4<VEC>(k, ldk, kr, kbase + l15 < L, h * M, mc * 64 + 16 * c + 4 * lg, M);
             if (!QREG) {
 #pragma unroll
                 for (int t = 0; t < kQT; ++t)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        qv[t][c] = ld4<VEC>(q, ldq, q0 + 16 * t + l15, N, h * M, mc * 64 + 16 * c + 4 * lg, M);
+                        qv[t][c] = ld4<VEC>(q, ldq, qrow(q0 + 16 * t + l15), q0 + 16 * t + l15 < N, h * M,
+                                            mc * 64 + 16 * c + 4 * lg, M);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -132,7 +155,7 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restri
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t key = kbase + 4 * lg + reg;
             const bool kok = key < L;
-            const float* vrow = v + (kok ? key : L - 1) * ldv + h * D;
+            const float* vrow = v + krow(key) * ldv + h * D;
 #pragma unroll
             for (int dtl = 0; dtl < 4; ++dtl) {
                 const int d = dt * kDTile + 16 * dtl + l15;
@@ -181,7 +204,10 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restri
         const int64_t row = q0 + qi;
         const int d = dt * kDTile + dl;
         if (row < N && d < D) {
-            if (S == 1) {
+            if (SEG) {
+                // difformer-v2.py:127-134: padded graphs add sigma(0) each, then + epsilon
+                out[qrow(row) * ldo + h * D + d] = o / (dn + 0.5f * static_cast<float>(n_graphs - N) + 1e-9f);
+            } else if (S == 1) {
                 out[row * ldo + h * D + d] = o / dn;                       // :55-56
             } else {
                 part[(static_cast<int64_t>(split) * N + row) * (H * D) + h * D + d] = o;
@@ -256,8 +282,8 @@ extern "C" int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k,
     float* pden = (S > 1) ? part + static_cast<size_t>(S) * N * H * D : nullptr;
     dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), S), block(512);
 #define DIF_LAUNCH_SIG(V, Q) \
-    hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, ldo, \
-                       part, pden)
+    hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q, false>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, \
+                       ldo, part, pden, nullptr, nullptr, 0)
     if (vec && qreg) DIF_LAUNCH_SIG(true, true);
     else if (vec) DIF_LAUNCH_SIG(true, false);
     else if (qreg) DIF_LAUNCH_SIG(false, true);
@@ -272,4 +298,34 @@ extern "C" int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k,
         return dif::launch_status("sigmoid_combine_kernel");
     }
     return 0;
+}
+
+// f4: TransConv.full_attention(kernel='sigmoid') over a batch of graphs -- physical particle/difformer-v2.py:113-135.
+extern "C" int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                            int64_t ldv, const int32_t* ranked_first, const int32_t* pos_count,
+                                            int n_graphs, int max_nodes, int H, int M, int D, float* out, int64_t ldo,
+                                            dif_stream_t stream) {
+    DIF_REQUIRE(n_graphs > 0 && max_nodes > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG,
+                "dif_batched_sigmoid_attn_f32: n_graphs, max_nodes, H, M, D must be positive");
+    DIF_REQUIRE(q && k && v && out && ranked_first && pos_count, DIF_E_BADARG, "dif_batched_sigmoid_attn_f32: null pointer");
+    DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D && ldo >= H * D, DIF_E_BADARG,
+                "dif_batched_sigmoid_attn_f32: leading dimension smaller than a row");
+    const int64_t gx = (static_cast<int64_t>(n_graphs) + kQGroup - 1) / kQGroup;
+    const int64_t gy = static_cast<int64_t>(H) * ((D + kDTile - 1) / kDTile);
+    DIF_REQUIRE(gy <= 65535 && max_nodes <= 65535, DIF_E_RANGE,
+                "dif_batched_sigmoid_attn_f32: grid too large (heads x column tiles %lld, max_nodes %d; limit 65535)",
+                static_cast<long long>(gy), max_nodes);
+    const bool vec = (M % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && dif::aligned16(q) && dif::aligned16(k);
+    const bool qreg = (M <= 64);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), static_cast<unsigned>(max_nodes)), block(512);
+#define DIF_LAUNCH_SEG(V, Q) \
+    hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, int64_t{0}, \
+                       int64_t{0}, H, M, D, out, ldo, nullptr, nullptr, ranked_first, pos_count, n_graphs)
+    if (vec && qreg) DIF_LAUNCH_SEG(true, true);
+    else if (vec) DIF_LAUNCH_SEG(true, false);
+    else if (qreg) DIF_LAUNCH_SEG(false, true);
+    else DIF_LAUNCH_SEG(false, false);
+#undef DIF_LAUNCH_SEG
+    return dif::launch_status("sigmoid_attn_kernel<batched>");
 }

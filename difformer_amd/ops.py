@@ -198,6 +198,90 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
 
 
 # ------------------------------------------------------------------------------------------
+# f4: batch of graphs stored back to back (physical particle/difformer-v2.py:71-137)
+# ------------------------------------------------------------------------------------------
+class BatchLayout:
+    """Index tables of a batch, derived once from `n_nodes` [B] (node count per graph), all on the device:
+        graph_ptr    int32 [B+1]   graph b = rows [graph_ptr[b], graph_ptr[b+1])
+        ranked_first int32 [B]     first row of the r-th largest graph        (sigmoid kernel)
+        pos_count    int32 [maxn]  number of graphs with more than p nodes    (sigmoid kernel)
+    They replace the reference's padding machinery (make_batch_mask / make_batch / to_pad, difformer-v2.py:8-27).
+    Only B-sized integer bookkeeping happens here; the node-sized work is in the kernels."""
+
+    def __init__(self, n_nodes, device):
+        import torch
+        n = n_nodes.to(device=device, dtype=torch.int64).reshape(-1)
+        if n.numel() == 0:
+            raise ValueError("difformer_amd: n_nodes is empty")
+        ptr = torch.zeros(n.numel() + 1, dtype=torch.int64, device=device)
+        torch.cumsum(n, 0, out=ptr[1:])
+        self.n_graphs = int(n.numel())
+        total, biggest, smallest = (int(v) for v in torch.stack([ptr[-1], n.max(), n.min()]).tolist())   # one sync
+        if smallest < 0:
+            raise ValueError("difformer_amd: negative entry in n_nodes")
+        if total >= 2 ** 31:
+            raise ValueError("difformer_amd: batches are limited to 2^31 - 1 nodes")
+        self.n_rows, self.max_nodes = total, biggest
+        self.graph_ptr = ptr.to(torch.int32)
+        order = torch.argsort(n, descending=True, stable=True)
+        self.ranked_first = ptr[:-1][order].to(torch.int32).contiguous()
+        le = torch.cumsum(torch.bincount(n, minlength=biggest + 1), 0)        # le[p] = #{graphs with n <= p}
+        self.pos_count = (self.n_graphs - le[:biggest]).to(torch.int32).contiguous()
+
+
+class _LayoutCache:
+    """One BatchLayout per `n_nodes` tensor (identity + version), so the per-layer calls of one forward and
+    repeated forwards over the same batch do the bookkeeping (and its host sync) once."""
+
+    def __init__(self, capacity=16):
+        self.capacity = capacity
+        self.entries = OrderedDict()
+
+    def get(self, n_nodes, device):
+        import torch
+        if not torch.is_tensor(n_nodes):
+            n_nodes = torch.as_tensor(n_nodes)
+            return BatchLayout(n_nodes, device)
+        key = (id(n_nodes), n_nodes.data_ptr(), tuple(n_nodes.shape), n_nodes._version, str(device))
+        hit = self.entries.get(key)
+        if hit is not None:
+            ref, lay = hit
+            if ref() is n_nodes:
+                self.entries.move_to_end(key)
+                return lay
+            del self.entries[key]
+        lay = BatchLayout(n_nodes, device)
+        self.entries[key] = (weakref.ref(n_nodes), lay)
+        while len(self.entries) > self.capacity:
+            self.entries.popitem(last=False)
+        return lay
+
+    def clear(self):
+        self.entries.clear()
+
+
+layout_cache = _LayoutCache()
+
+
+def _check_batch(qs, ks, vs, layout):
+    if not (qs.shape[0] == ks.shape[0] == vs.shape[0] == layout.n_rows):
+        raise RuntimeError(f"difformer_amd: n_nodes sums to {layout.n_rows} but q/k/v have "
+                           f"{qs.shape[0]}/{ks.shape[0]}/{vs.shape[0]} rows (difformer-v2.py:26 would raise too)")
+
+
+def batched_simple_attention(qs, ks, vs, layout: BatchLayout):
+    """qs, ks [N,H,M], vs [N,H,D] -> [N,H,D]; attention inside each graph.  difformer-v2.py:80-111."""
+    _check_batch(qs, ks, vs, layout)
+    return get_backend().batched_simple_attention(qs, ks, vs, layout.graph_ptr)
+
+
+def batched_sigmoid_attention(qs, ks, vs, layout: BatchLayout):
+    """Attention among the nodes at equal positions of the graphs.  difformer-v2.py:113-135."""
+    _check_batch(qs, ks, vs, layout)
+    return get_backend().batched_sigmoid_attention(qs, ks, vs, layout.ranked_first, layout.pos_count)
+
+
+# ------------------------------------------------------------------------------------------
 # a4 / a5 tail
 # ------------------------------------------------------------------------------------------
 def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):

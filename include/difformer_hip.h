@@ -91,6 +91,28 @@ int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ld
                          dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f4  TransConv.full_attention over a batch of graphs    physical particle/difformer-v2.py:71-137
+ *     The batch stores its graphs back to back: graph b owns rows [graph_ptr[b], graph_ptr[b+1]).
+ *     Nothing is padded (the reference pads to [B, max_node, H, D], :8-27, :87-91).
+ *
+ * 'simple' (:80-111):  out_i = (s q_i KtV_b + vsum_b) / (s q_i.ksum_b + n_b),  s = 1/(|Q|_F |K|_F) over the whole
+ *     batch, the sums over graph b only.  M <= 256 per head (DIF_E_SHAPE beyond).  workspace: partial norms.
+ * 'sigmoid' (:113-135): the node at position p of a graph attends the nodes at the SAME position p of all graphs
+ *     (einsum "abcd,ebcd->aebc"); shorter graphs count sigma(0) = 0.5 in the denominator, + 1e-9.
+ *     ranked_first[r] = first row of the r-th largest graph (any order among equal sizes), pos_count[p] = number of
+ *     graphs with more than p nodes, p < max_nodes = size of the largest graph.
+ * ------------------------------------------------------------------------------------- */
+size_t dif_batched_simple_workspace_bytes(void);
+int dif_batched_simple_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                                const float* v, int64_t ldv, const int32_t* graph_ptr, int n_graphs,
+                                int64_t n_rows, int H, int M, int D, float* out, int64_t ldo,
+                                void* workspace, size_t workspace_bytes, dif_stream_t stream);
+int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                                 const float* v, int64_t ldv, const int32_t* ranked_first,
+                                 const int32_t* pos_count, int n_graphs, int max_nodes, int H, int M, int D,
+                                 float* out, int64_t ldo, dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a3  gcn_conv(x, edge_index, edge_weight)          node classification/difformer.py:63-79
  *     (replaces torch_geometric.utils.degree :66, torch_sparse.SparseTensor :75 and
  *      torch_sparse.matmul :77)
@@ -153,13 +175,14 @@ int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, in
 
 /* dif_gcn_spmm_f32 with the tail above fused into its epilogue (H == 1 layers: conv row = feature
  * row, F = D <= 256): out = tail(gcn_scale * A_hat x (+ attn_scale * attn)).  Saves the [n,D] round
- * trip between the two kernels.  Returns DIF_E_SHAPE when the row does not fit one lane group. */
+ * trip between the two kernels.  relu = 1 appends max(., 0) (DIFFormer_v2: norm -> ReLU, difformer-v2.py:214-217).
+ * Returns DIF_E_SHAPE when the row does not fit one lane group. */
 int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
                           const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
                           const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                           const float* attn, int64_t lda, float attn_scale, float gcn_scale,
                           const float* x0, int64_t ldx0, const float* prev, int64_t ldp, float alpha,
-                          const float* ln_weight, const float* ln_bias, float ln_eps,
+                          const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
                           float* out, int64_t ldo, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -220,7 +243,7 @@ int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_b
                            const void* attn, int64_t lda, float attn_scale, float gcn_scale,
                            int tail_enabled, const void* x0, int64_t ldx0, const void* prev,
                            int64_t ldp, float alpha, const void* ln_weight, const void* ln_bias,
-                           float ln_eps, void* out, int64_t ldo, dif_stream_t stream);
+                           float ln_eps, int relu, void* out, int64_t ldo, dif_stream_t stream);
 int dif_layer_tail_bf16(const void* conv, int64_t ldc, int64_t n_rows, int H, int D,
                         const void* x0, int64_t ldx0, const void* prev, int64_t ldp,
                         float alpha, const void* ln_weight, const void* ln_bias, float ln_eps,

@@ -44,6 +44,18 @@ class OracleBackend:
     def sigmoid_attention(self, q, k, v):
         return torch.from_numpy(orc.sigmoid_attention(*(_np(t).astype(np.float64) for t in (q, k, v))).astype(np.float32))
 
+    def batched_simple_attention(self, q, k, v, graph_ptr):
+        n_nodes = np.diff(_np(graph_ptr).astype(np.int64))
+        return torch.from_numpy(orc.v2_simple_attention(_np(q), _np(k), _np(v), n_nodes))
+
+    def batched_sigmoid_attention(self, q, k, v, ranked_first, pos_count):
+        # rebuild n_nodes from the layout tables: graph r (by rank) has #{p : pos_count[p] > r} nodes
+        first, cnt = _np(ranked_first).astype(np.int64), _np(pos_count).astype(np.int64)
+        sizes = (cnt[None, :] > np.arange(first.shape[0])[:, None]).sum(axis=1)
+        order = np.argsort(first, kind="stable")                  # memory order of the graphs
+        assert np.array_equal(np.cumsum(sizes[order]) - sizes[order], first[order])
+        return torch.from_numpy(orc.v2_sigmoid_attention(_np(q), _np(k), _np(v), sizes[order]))
+
     def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
         ei = _np(edge_index)
         row, col, val = orc.gcn_edge_values(ei, num_nodes, _np(edge_weight), dtype=np.float32)
@@ -74,7 +86,8 @@ class OracleBackend:
         out = torch.from_numpy(out.astype(np.float32))
         if tail is not None:
             out = self.layer_tail(out[:, None, :], tail.get("x0"), tail.get("prev"), tail.get("alpha", 0.5),
-                                  tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5))
+                                  tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5),
+                                  tail.get("relu", False))
         return out
 
     def linear(self, x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):

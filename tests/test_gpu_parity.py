@@ -777,3 +777,99 @@ def test_model_forward_script_widths(name, n, f_in, classes, cfg, dev):
     with torch.no_grad():
         out = model(x.to(dev), ei.to(dev) if cfg["use_graph"] else None)
     assert rel_err(out.cpu().numpy(), ref) < TOL, name
+
+
+# ------------------------------------------------------------------ f4: DIFFormer_v2 (batches of graphs)
+V2 = load_golden("v2")
+
+
+def _v2_attention(q, k, v, n_nodes, kernel, dev):
+    from difformer_amd import TransConv
+    conv = TransConv(q.shape[2], q.shape[2], num_heads=q.shape[1], kernel=kernel)
+    return conv.full_attention(t(q, dev), t(k, dev), t(v, dev), kernel, torch.as_tensor(n_nodes).to(dev))
+
+
+@pytest.mark.parametrize("name", sorted(n for n in V2 if n.startswith("attn/")))
+def test_v2_full_attention_golden(name, dev):
+    c = V2[name]
+    out = _v2_attention(c["q"], c["k"], c["v"], c["n_nodes"], str(c["kernel"]), dev)
+    assert out.shape == c["out_f64"].shape and out.dtype == torch.float32
+    assert rel_err(out.cpu().numpy(), c["out_f64"]) < TOL
+
+
+@pytest.mark.parametrize("name", sorted(n for n in V2 if n.startswith("model/")))
+def test_v2_model_forward_golden(name, dev):
+    from difformer_amd import DIFFormer_v2
+    c = V2[name]
+    cfg, sd = split_model_case(c)
+    kw = {k: cfg[k] for k in ("num_layers", "kernel", "alpha", "use_bn", "use_residual", "use_weight", "use_graph",
+                              "graph_weight")}
+    kw["kernel"] = str(kw["kernel"])
+    h = int(cfg["hidden_channels"])
+    model = DIFFormer_v2(int(cfg["in_channels"]), h, h, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        out = model(t(c["x"], dev), t(c["edge_index"], dev) if cfg["use_graph"] else None, t(c["n_nodes"], dev))
+    assert rel_err(out.cpu().numpy(), c["out_f64"]) < TOL
+
+
+_V2_RANDOM = [  # (B, max graph size, H, D, kernel)
+    (300, 60, 1, 64, "simple"), (300, 60, 2, 16, "simple"), (64, 200, 1, 10, "simple"), (100, 40, 1, 128, "simple"),
+    (50, 30, 2, 200, "simple"), (40, 25, 1, 256, "simple"), (7, 1500, 1, 64, "simple"),
+    (300, 30, 1, 64, "sigmoid"), (200, 20, 2, 16, "sigmoid"), (150, 12, 1, 10, "sigmoid"), (90, 9, 1, 96, "sigmoid"),
+]
+
+
+@pytest.mark.parametrize("B,mx,H,D,kernel", _V2_RANDOM)
+def test_v2_attention_random_batches(B, mx, H, D, kernel, dev):
+    """Ragged batches incl. empty and single-node graphs, several heads, odd / wide widths, vs the float64 oracle."""
+    rng = np.random.default_rng(B * 1000 + D)
+    n_nodes = rng.integers(1, mx + 1, size=B)
+    n_nodes[rng.integers(0, B, size=max(B // 20, 1))] = 0            # empty graphs
+    n_nodes[rng.integers(0, B, size=max(B // 20, 1))] = 1
+    n = int(n_nodes.sum())
+    q, k, v = (rng.standard_normal((n, H, D)).astype(np.float32) for _ in range(3))
+    out = _v2_attention(q, k, v, n_nodes, kernel, dev)
+    fn = orc.v2_simple_attention if kernel == "simple" else orc.v2_sigmoid_attention
+    ref = fn(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), n_nodes)
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+def test_v2_single_graph_equals_a1(dev):
+    """B = 1: difformer-v2.py:80-111 is difformer.py:18-39."""
+    from difformer_amd import full_attention_conv
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(5000, 1, 64, generator=g).to(dev) for _ in range(3))
+    a = _v2_attention(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), [5000], "simple", dev)
+    b = full_attention_conv(q, k, v, "simple")
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def test_v2_particle_scale_batch(dev):
+    """Shape of the shipped scripts (physical particle/run.sh: batch_size 8192, hidden 64, 2 layers): 8192 graphs of
+    ~20 nodes, whole model against the float64 oracle; the same batch under a permutation of its graphs gives
+    the same rows (graphs are independent in the simple kernel)."""
+    from difformer_amd import DIFFormer_v2
+    rng = np.random.default_rng(42)
+    B = 8192
+    n_nodes = rng.integers(8, 33, size=B)
+    offs = np.concatenate([[0], np.cumsum(n_nodes)])
+    n = int(offs[-1])
+    src, dst = [], []
+    for b in range(B):                                        # ~3 random edges per node inside each graph + self loops
+        e = 3 * n_nodes[b]
+        src.append(rng.integers(0, n_nodes[b], size=e) + offs[b]); dst.append(rng.integers(0, n_nodes[b], size=e) + offs[b])
+    loops = np.arange(n)
+    ei = np.stack([np.concatenate(src + [loops]), np.concatenate(dst + [loops])]).astype(np.int64)
+    x = rng.standard_normal((n, 7)).astype(np.float32)
+    cfg = dict(hidden_channels=64, num_layers=2, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=True, use_graph=True, graph_weight=-1)
+    torch.manual_seed(9)
+    model = DIFFormer_v2(7, 64, 64, **{k: v for k, v in cfg.items() if k != "hidden_channels"}).eval()
+    p = {k: v.double().numpy() for k, v in model.state_dict().items()}
+    ref = orc.difformer_v2_forward(p, x.astype(np.float64), ei, n_nodes, cfg)
+    model = model.to(dev)
+    with torch.no_grad():
+        out = model(t(x, dev), t(ei, dev), t(n_nodes, dev))
+    assert rel_err(out.cpu().numpy(), ref) < TOL
