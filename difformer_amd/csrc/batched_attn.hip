@@ -83,8 +83,10 @@ __global__ __launch_bounds__(64) void sumsq_fold_kernel(const float* __restrict_
     if (lane == 0) { out2[0] = a; out2[1] = b; }
 }
 
-// ---- one wave per (graph, head, 64-column tile) ------------------------------------------------------------------
-template <int MT, bool VEC>
+// ---- one wave (WAVES == 1) or one 4-wave workgroup (WAVES == 4) per (graph, head, 64-column tile) ------------------
+// WAVES == 4 serves batches of few, larger graphs (not enough items to fill the chip with one wave each): the four
+// waves split the graph's rows in both phases and fold their K^T V accumulators through LDS in a fixed order.
+template <int MT, bool VEC, int WAVES>
 __global__ __launch_bounds__(256) void batched_simple_kernel(const float* __restrict__ q, int64_t ldq,
                                                              const float* __restrict__ k, int64_t ldk,
                                                              const float* __restrict__ v, int64_t ldv,
@@ -95,8 +97,9 @@ __global__ __launch_bounds__(256) void batched_simple_kernel(const float* __rest
     const int l15 = lane & 15;
     const int lg = lane >> 4;
     const int DT = (D + 63) / 64;
-    const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (item >= static_cast<int64_t>(n_graphs) * H * DT) return;             // wave-uniform; the kernel has no barrier
+    const int wv = (WAVES == 1) ? 0 : (threadIdx.x >> 6);                    // this wave's share of the item
+    const int64_t item = (WAVES == 1) ? static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6) : blockIdx.x;
+    if (item >= static_cast<int64_t>(n_graphs) * H * DT) return;             // uniform over everything that syncs
     const int g = static_cast<int>(item % n_graphs);
     const int hd = static_cast<int>(item / n_graphs);
     const int h = hd / DT, dt = hd % DT;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void batched_simple_kernel(const float* __rest
 
     // ---- phase 1: KtV_b, ksum_b, vsum_b over the graph's rows (:93-106) ----------------------------------------
     constexpr int kU = (MT == 1) ? 4 : (MT == 2) ? 2 : 1;                                    // 4-row steps in flight
-    for (int64_t rb = r0; rb < r1; rb += 4 * kU) {
+    for (int64_t rb = r0 + 4 * kU * wv; rb < r1; rb += 4 * kU * WAVES) {
         f32x4 kx[kU][MT], vx[kU];
 #pragma unroll
         for (int st = 0; st < kU; ++st) {
@@ -151,9 +154,43 @@ __global__ __launch_bounds__(256) void batched_simple_kernel(const float* __rest
         a += __shfl_xor(a, 32, 64);
         vs[u] = a;
     }
+    if (WAVES > 1) {
+        // slot-major [slot][lane] float4: every lane reads back exactly the registers it wrote
+        __shared__ __attribute__((aligned(16))) float sm[(WAVES > 1) ? (20 * MT + 1) * 256 : 4];
+        f32x4* base = reinterpret_cast<f32x4*>(sm) + lane;
+        for (int w = 0; w < WAVES; ++w) {
+            if (wv == w) {
+                int slot = 0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u, ++slot) {
+                            if (w == 0) base[slot * 64] = acc[mt][t][u]; else base[slot * 64] += acc[mt][t][u];
+                        }
+                        if (w == 0) base[slot * 64] = acck[mt][t]; else base[slot * 64] += acck[mt][t];
+                        ++slot;
+                    }
+                if (w == 0) base[slot * 64] = vs; else base[slot * 64] += vs;
+            }
+            __syncthreads();
+        }
+        int slot = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u, ++slot) acc[mt][t][u] = base[slot * 64];
+                acck[mt][t] = base[slot * 64];
+                ++slot;
+            }
+        vs = base[slot * 64];
+    }
 
     // ---- phase 2: apply to the graph's own queries (:100-111) --------------------------------------------------
-    for (int64_t rb = r0; rb < r1; rb += 16) {
+    for (int64_t rb = r0 + 16 * wv; rb < r1; rb += 16 * WAVES) {
         f32x4 qf[MT][4];
         const int64_t rq = rb + l15;
 #pragma unroll
@@ -229,14 +266,20 @@ extern "C" int dif_batched_simple_attn_f32(const float* q, int64_t ldq, const fl
 
     const int DT = (D + 63) / 64;
     const int64_t items = static_cast<int64_t>(n_graphs) * H * DT;
-    const int64_t grid = (items + 3) / 4;
+    // few items of many rows: a 4-wave workgroup per item (>= ~16 rows per wave and phase to be worth the fold)
+    const bool wide = items < 8 * dif::kCUs && n_rows >= 64 * static_cast<int64_t>(n_graphs);
+    const int64_t grid = wide ? items : (items + 3) / 4;
     DIF_REQUIRE(grid < (1ll << 31), DIF_E_RANGE, "dif_batched_simple_attn_f32: grid too large");
     const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) && (ldo % 4 == 0) &&
                      dif::aligned16(q) && dif::aligned16(k) && dif::aligned16(v) && dif::aligned16(out);
     const int MT = (M + 63) / 64;
 #define DIF_LAUNCH_BS(MTV, V) \
-    hipLaunchKernelGGL((batched_simple_kernel<MTV, V>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, q, ldq, k, ldk, \
-                       v, ldv, graph_ptr, n_graphs, H, M, D, sumsq, out, ldo)
+    do { \
+        if (wide) hipLaunchKernelGGL((batched_simple_kernel<MTV, V, 4>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, q, \
+                                     ldq, k, ldk, v, ldv, graph_ptr, n_graphs, H, M, D, sumsq, out, ldo); \
+        else hipLaunchKernelGGL((batched_simple_kernel<MTV, V, 1>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, q, \
+                                ldq, k, ldk, v, ldv, graph_ptr, n_graphs, H, M, D, sumsq, out, ldo); \
+    } while (0)
     if (MT == 1) { if (vec) DIF_LAUNCH_BS(1, true); else DIF_LAUNCH_BS(1, false); }
     else if (MT == 2) { if (vec) DIF_LAUNCH_BS(2, true); else DIF_LAUNCH_BS(2, false); }
     else { if (vec) DIF_LAUNCH_BS(4, true); else DIF_LAUNCH_BS(4, false); }

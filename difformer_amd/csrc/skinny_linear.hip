@@ -3,10 +3,14 @@
 // 64->112).  One pass: x read once, y written once, LayerNorm/ReLU applied in registers.  Vendor GEMMs are
 // tuned for large K and spend ~100 us on these (K = 8: 4 MB in, 34 MB out).
 //
-// MFMA plan (v_mfma_f32_16x16x4_f32, exact fp32), per wave and 16-row tile, 64 output features per
-// workgroup column (grid.y):  D[i <-> row][j <-> feature] = sum_c X[row][c] W[feature][c]
-//   A[i=lane%16][k=lane/16] = X[r0 + lane%16][16cq + 4*(lane/16) + t]   (dwordx4 loads)
-//   B[k=lane/16][j=lane%16] = W[f0 + 16ft + lane%16][16cq + 4*(lane/16) + t]   (registers; <= 64 per wave)
+// MFMA plan (v_mfma_f32_16x16x4_f32, exact fp32), per wave and 16-row tile.  A workgroup keeps up to 256 output
+// features of W in LDS (grid.y covers wider layers) and sweeps them in blocks of 64 per row tile, so x is read once.
+// Inside a block the four 16x16 output tiles INTERLEAVE the features (tile ft owns features 4j + ft): a lane holds 4
+// consecutive features of a row across its four accumulators and 16 lanes store one whole 256-B row.
+//   D[i <-> row][j <-> feature fb + 4j + ft] = sum_c X[row][c] W[feature][c]
+//   A[i=lane%16][k=lane/16] = X[r0 + lane%16][16cq + 4*(lane/16) + t]                 (dwordx4 loads, next tile prefetched)
+//   B[k=lane/16][j=lane%16] = W[fb + 4*(lane%16) + ft][16cq + 4*(lane/16) + t]        (LDS row 16 ft + lane%16 of the block)
+//   lane then holds out[r0 + 4*(lane/16) + reg][fb + 4*(lane%16) + ft]: one 16-byte store per reg.
 // HBM-bound: (C_in + C_out) * 4 bytes per row.
 #include "dif_common.h"
 
@@ -15,50 +19,50 @@ namespace {
 using dif::f32x4;
 using dif::Elem;
 
-constexpr int kLinStride = 68;
+constexpr int kLinStride = 68;          // floats per LDS weight row (64 + 4: b128 reads of 16 rows hit all banks)
+constexpr int kLinMaxBlocks = 4;        // 64-feature blocks per workgroup
 
-// grid (row chunks, ceil(C_out/64)); 256 threads.  KQ = number of 16-channel groups of C_in actually used (1..4).
+// grid (row chunks, ceil(C_out/256)); 256 threads; dynamic LDS = blocks * 64 * (kLinStride + 1) floats.
+// KQ = number of 16-channel groups of C_in actually used (1..4).
 template <int KQ, typename T>
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict__ x, int64_t ldx, int64_t n_rows,
                                                             int C_in, const T* __restrict__ W,
                                                             const T* __restrict__ bias, int C_out,
                                                             const T* __restrict__ ln_w,
                                                             const T* __restrict__ ln_b, float eps, int relu,
-                                                            T* __restrict__ out, int64_t ldo, int vec) {
-    __shared__ __attribute__((aligned(16))) float sm_w[64 * kLinStride];
+                                                            T* __restrict__ out, int64_t ldo, int vec, int ovec) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l15 = lane & 15;
     const int lg = lane >> 4;
-    const int f0 = blockIdx.y * 64;
+    const int f0 = blockIdx.y * 64 * kLinMaxBlocks;
+    int nblk = (C_out - f0 + 63) / 64;
+    if (nblk > kLinMaxBlocks) nblk = kLinMaxBlocks;
+    float* sm_w = sm;                                       // [nblk*64][kLinStride], block-local row 16 (f%4) + (f%64)/4
+    float* sm_b = sm + nblk * 64 * kLinStride;              // [nblk*64] bias in feature order
 
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    for (int e = threadIdx.x; e < nblk * 64 * 64; e += 256) {
         const int f = e >> 6, c = e & 63;
-        sm_w[f * kLinStride + c] = (f0 + f < C_out && c < C_in) ? Elem<T>::ld(W + static_cast<int64_t>(f0 + f) * C_in + c) : 0.f;
+        const int row = (f & ~63) + 16 * (f & 3) + ((f & 63) >> 2);
+        sm_w[row * kLinStride + c] =
+            (f0 + f < C_out && c < C_in) ? Elem<T>::ld(W + static_cast<int64_t>(f0 + f) * C_in + c) : 0.f;
     }
+    for (int f = threadIdx.x; f < nblk * 64; f += 256) sm_b[f] = (f0 + f < C_out) ? Elem<T>::ld(bias + f0 + f) : 0.f;
     __syncthreads();
-    // weight fragments stay in registers for the whole row sweep
-    f32x4 wf[4][KQ];
-    float bfr[4], lw[4], lb[4];
+
+    f32x4 lw = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};   // LayerNorm: C_out <= 64, one block
+    if (ln_w) {
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-        const int f = f0 + 16 * ft + l15;
-        bfr[ft] = (f < C_out) ? Elem<T>::ld(bias + f) : 0.f;
-        lw[ft] = (ln_w && f < C_out) ? Elem<T>::ld(ln_w + f) : 0.f;
-        lb[ft] = (ln_w && f < C_out) ? Elem<T>::ld(ln_b + f) : 0.f;
-#pragma unroll
-        for (int cq = 0; cq < KQ; ++cq)
-            wf[ft][cq] = *reinterpret_cast<const f32x4*>(&sm_w[(16 * ft + l15) * kLinStride + 16 * cq + 4 * lg]);
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f = 4 * l15 + ft;
+            if (f < C_out) { lw[ft] = Elem<T>::ld(ln_w + f); lb[ft] = Elem<T>::ld(ln_b + f); }
+        }
     }
     const float inv_c = 1.0f / static_cast<float>(C_out);
 
-    const int64_t n_tiles = (n_rows + 15) / 16;
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
-    for (int64_t tile = first; tile < n_tiles; tile += stride) {
-        const int64_t r0 = tile * 16;
-        const int64_t r = r0 + l15;
-        f32x4 xa[KQ];
+    auto load_x = [&](int64_t tile, f32x4 (&xa)[KQ]) {
+        const int64_t r = tile * 16 + l15;
 #pragma unroll
         for (int cq = 0; cq < KQ; ++cq) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -75,49 +79,75 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
             }
             xa[cq] = z;
         }
-        f32x4 y[4];
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) y[ft] = f32x4{bfr[ft], bfr[ft], bfr[ft], bfr[ft]};
-#pragma unroll
-        for (int cq = 0; cq < KQ; ++cq)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int ft = 0; ft < 4; ++ft)
-                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cq][t], wf[ft][cq][t], y[ft], 0, 0, 0);
+    };
 
-        if (ln_w) {   // LayerNorm over the C_out <= 64 features of each row (row = 4*lg + reg)
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
+    f32x4 xa[KQ], xn[KQ];
+    if (first < n_tiles) load_x(first, xa);
+    for (int64_t tile = first; tile < n_tiles; tile += stride) {
+        const int64_t r0 = tile * 16;
+        if (tile + stride < n_tiles) load_x(tile + stride, xn);               // in flight under this tile's work
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int fb = f0 + 64 * blk;
+            const float* wrow = sm_w + (64 * blk + l15) * kLinStride + 4 * lg;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sm_b + 64 * blk + 4 * l15);
+            f32x4 y[4];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                float s = 0.f;
+            for (int ft = 0; ft < 4; ++ft) y[ft] = f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft)
-                    if (16 * ft + l15 < C_out) s += y[ft][reg];
+            for (int cq = 0; cq < KQ; ++cq)
 #pragma unroll
-                for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
-                const float mu = s * inv_c;
-                float v = 0.f;
+                for (int ft = 0; ft < 4; ++ft) {
+                    const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + 16 * ft * kLinStride + 16 * cq);
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft)
-                    if (16 * ft + l15 < C_out) { const float dz = y[ft][reg] - mu; v += dz * dz; }
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
-                const float rstd = 1.0f / sqrtf(v * inv_c + eps);
-#pragma unroll
-                for (int ft = 0; ft < 4; ++ft) y[ft][reg] = (y[ft][reg] - mu) * rstd * lw[ft] + lb[ft];
-            }
-        }
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            const int f = f0 + 16 * ft + l15;
-            if (f < C_out) {
+                    for (int t = 0; t < 4; ++t)
+                        y[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cq][t], wf[t], y[ft], 0, 0, 0);
+                }
+            if (ln_w) {   // LayerNorm over the features of each row (row = 4*lg + reg; features over 16 lanes x 4 tiles)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int64_t rr = r0 + 4 * lg + reg;
-                    if (rr < n_rows) Elem<T>::st(out + rr * ldo + f, relu ? fmaxf(y[ft][reg], 0.f) : y[ft][reg]);
+                    float s = 0.f;
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft)
+                        if (4 * l15 + ft < C_out) s += y[ft][reg];
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+                    const float mu = s * inv_c;
+                    float v = 0.f;
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft)
+                        if (4 * l15 + ft < C_out) { const float dz = y[ft][reg] - mu; v += dz * dz; }
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+                    const float rstd = 1.0f / sqrtf(v * inv_c + eps);
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft) y[ft][reg] = (y[ft][reg] - mu) * rstd * lw[ft] + lb[ft];
+                }
+            }
+            const bool vst = ovec && (fb + 4 * l15 + 3 < C_out);   // this lane's 4 features are all real
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t rr = r0 + 4 * lg + reg;
+                if (rr >= n_rows) continue;
+                f32x4 o = {y[0][reg], y[1][reg], y[2][reg], y[3][reg]};
+                if (relu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
+                }
+                T* dst = out + rr * ldo + fb + 4 * l15;
+                if (vst) {
+                    Elem<T>::st4(dst, o);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (fb + 4 * l15 + i < C_out) Elem<T>::st(dst + i, o[i]);
                 }
             }
         }
+#pragma unroll
+        for (int cq = 0; cq < KQ; ++cq) xa[cq] = xn[cq];
     }
 }
 
@@ -131,19 +161,23 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
                 "dif_linear: ln_weight and ln_bias must be given together");
     DIF_REQUIRE(!ln_weight || C_out <= 64, DIF_E_SHAPE, "dif_linear: fused LayerNorm needs C_out <= 64");
     DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear: leading dimension smaller than a row");
-    const int gy = (C_out + 63) / 64;
+    const int gy = (C_out + 64 * kLinMaxBlocks - 1) / (64 * kLinMaxBlocks);
     DIF_REQUIRE(gy <= 65535, DIF_E_RANGE, "dif_linear: C_out too large");
+    const int nblk = (C_out >= 64 * kLinMaxBlocks) ? kLinMaxBlocks : (C_out + 63) / 64;
+    const size_t lds = static_cast<size_t>(nblk) * 64 * (kLinStride + 1) * sizeof(float);
     const int vec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned_v4<T>(x);
+    const int ovec = (ldo % 4 == 0) && dif::aligned_v4<T>(out);
     const int64_t n_tiles = (n_rows + 15) / 16;
-    int64_t gx = (n_tiles + 3) / 4;
-    const int64_t cap = 4 * dif::kCUs;
+    int64_t gx = (n_tiles + 15) / 16;                       // >= 4 row tiles per wave: the weight staging is amortised
+    const int64_t cap = (nblk <= 2 ? 4 : 2) * dif::kCUs;    // what the LDS footprint lets a CU hold
     if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(static_cast<unsigned>(gx), gy), block(256);
     const int kq = (C_in + 15) / 16;
 #define DIF_LIN(KQ) \
-    hipLaunchKernelGGL((skinny_linear_kernel<KQ, T>), grid, block, 0, st, x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, \
-                       ln_bias, ln_eps, relu, out, ldo, vec)
+    hipLaunchKernelGGL((skinny_linear_kernel<KQ, T>), grid, block, lds, st, x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, \
+                       ln_bias, ln_eps, relu, out, ldo, vec, ovec)
     if (kq == 1) DIF_LIN(1);
     else if (kq == 2) DIF_LIN(2);
     else if (kq == 3) DIF_LIN(3);

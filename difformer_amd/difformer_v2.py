@@ -63,6 +63,24 @@ class TransConv(nn.Module):
         if self.use_weight:
             self.Wv.reset_parameters()
 
+    def _project(self, query_input, source_input):
+        """Wq / Wk / Wv (:143-146).  Same input and nothing to differentiate: ONE narrow-Linear launch over the
+        concatenated weights (x read once); q, k, v are then column slices of its [n, 3*H*D] result."""
+        H, D = self.num_heads, self.out_channels
+        params = (self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, self.Wv.weight, self.Wv.bias)
+        if query_input is source_input and source_input.shape[1] <= 64 and not ag._needs_grad(source_input, *params):
+            key = tuple((p.data_ptr(), p._version) for p in params)
+            if getattr(self, "_cat_key", None) != key:
+                self._cat_w = torch.cat([self.Wq.weight, self.Wk.weight, self.Wv.weight], dim=0).detach().contiguous()
+                self._cat_b = torch.cat([self.Wq.bias, self.Wk.bias, self.Wv.bias], dim=0).detach().contiguous()
+                self._cat_key = key
+            qkv = ops.linear(source_input, self._cat_w, self._cat_b)
+            return (qkv[:, : H * D].reshape(-1, H, D), qkv[:, H * D: 2 * H * D].reshape(-1, H, D),
+                    qkv[:, 2 * H * D:].reshape(-1, H, D))
+        return (ag.linear(query_input, self.Wq.weight, self.Wq.bias).reshape(-1, H, D),
+                ag.linear(source_input, self.Wk.weight, self.Wk.bias).reshape(-1, H, D),
+                ag.linear(source_input, self.Wv.weight, self.Wv.bias).reshape(-1, H, D))
+
     def full_attention(self, qs, ks, vs, kernel, n_nodes):
         """qs, ks, vs [N,H,D]; n_nodes [B] -> [N,H,D]  (:71-137)."""
         return ag.batched_attention(qs, ks, vs, ops.layout_cache.get(n_nodes, qs.device), kernel)
@@ -75,9 +93,7 @@ class TransConv(nn.Module):
             # UnboundLocalError right here
             raise UnboundLocalError("TransConv needs use_weight=True: difformer-v2.py:145-148 leaves `value` unbound "
                                     "otherwise")
-        q = ag.linear(query_input, self.Wq.weight, self.Wq.bias).reshape(-1, H, D)       # :143
-        k = ag.linear(source_input, self.Wk.weight, self.Wk.bias).reshape(-1, H, D)      # :144
-        v = ag.linear(source_input, self.Wv.weight, self.Wv.bias).reshape(-1, H, D)      # :146
+        q, k, v = self._project(query_input, source_input)                               # :143-146
         attn = self.full_attention(q, k, v, self.kernel, n_nodes)                        # :148
         if not self.use_graph:
             return ag.layer_tail(attn, None, prev, alpha, ln_weight, ln_bias, eps, relu)

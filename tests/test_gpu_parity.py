@@ -841,8 +841,12 @@ def test_v2_single_graph_equals_a1(dev):
     from difformer_amd import full_attention_conv
     g = torch.Generator().manual_seed(5)
     q, k, v = (torch.randn(5000, 1, 64, generator=g).to(dev) for _ in range(3))
-    a = _v2_attention(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), [5000], "simple", dev)
+    from difformer_amd import ops
+    ptr = torch.tensor([0, 5000], dtype=torch.int32, device=dev)
+    a = ops.get_backend().batched_simple_attention(q, k, v, ptr)           # the batched kernel itself
     b = full_attention_conv(q, k, v, "simple")
+    c = _v2_attention(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), [5000], "simple", dev)   # routed to a1
+    assert torch.equal(b, c)
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
 
