@@ -45,13 +45,24 @@ WORKLOADS = {
     "pokec-batch-s-bf16": (100000, 115000, 65, 2, 64, 3, "simple", True),
     # not a BASELINE config: the C4 graph in bf16 storage, to show what the gather-bound SpMM does at half the bytes
     "ogbn-proteins-s-bf16": (132534, 39561252, 8, 112, 64, 4, "simple", True),
+    # the C4 graph with a skewed (Zipf-like) degree profile, max / mean degree ~13 as in the real
+    # ogbn-proteins (7750 / 597), to exercise the SpMM's load balance; not the headline line
+    "ogbn-proteins-zipf-s": (132534, 39561252, 8, 112, 64, 4, "simple", True),
 }
 
 
-def make_graph(n, pairs, dev):
+def make_graph(n, pairs, dev, zipf=False):
     g = torch.Generator(device=dev).manual_seed(0)
-    a = torch.randint(0, n, (pairs,), generator=g, device=dev)
-    b = torch.randint(0, n, (pairs,), generator=g, device=dev)
+    if zipf:
+        # endpoint probability ~ (rank + 1100)^-0.75 over randomly permuted node ids: max / mean degree ~ 13
+        w = (torch.arange(n, device=dev, dtype=torch.float64) + 1100.0) ** -0.75
+        cdf = torch.cumsum(w, 0) / w.sum()
+        perm = torch.randperm(n, generator=g, device=dev)
+        a, b = (perm[torch.searchsorted(cdf, torch.rand(pairs, generator=g, device=dev, dtype=torch.float64)).clamp_(max=n - 1)]
+                for _ in range(2))
+    else:
+        a = torch.randint(0, n, (pairs,), generator=g, device=dev)
+        b = torch.randint(0, n, (pairs,), generator=g, device=dev)
     loops = torch.arange(n, device=dev)
     return torch.stack([torch.cat([a, b, loops]), torch.cat([b, a, loops])]).contiguous()
 
@@ -115,7 +126,7 @@ def main():
     model = model.to(store)
     gx = torch.Generator(device=dev).manual_seed(1)
     x_full = torch.randn(n, f_in, generator=gx, device=dev).to(store)
-    edge_index = make_graph(n, pairs, dev) if use_graph else None
+    edge_index = make_graph(n, pairs, dev, zipf="-zipf" in args.workload) if use_graph else None
     nnz = 0 if edge_index is None else int(edge_index.shape[1])
 
     shard = RowShard.from_process_group(n) if world > 1 else None

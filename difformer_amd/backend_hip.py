@@ -332,9 +332,14 @@ class HipBackend:
         return out, (None if out_w is None else out_w[:kept].clone())
 
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
-             gcn_scale=1.0, tail=None):
-        """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps[, relu]): fuse the layer tail (H == 1)."""
-        dev = _require_device(rowptr, blkptr, src, val, x, attn)
+             gcn_scale=1.0, tail=None, order=None):
+        """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps[, relu]): fuse the layer tail (H == 1).
+        order = None | (int32 [n_rows], n_split) from row_order(): degree-sorted rows (the first n_split of them split
+        over a whole quad) for the blocked kernel's load balance."""
+        order, n_split = order if order is not None else (None, 0)
+        dev = _require_device(rowptr, blkptr, src, val, x, attn, order)
+        if order is not None and (order.dtype != torch.int32 or order.numel() != n_rows or not order.is_contiguous()):
+            raise TypeError("difformer_amd: order must be a contiguous int32 tensor with one entry per local row")
         F = x.shape[1]
         t = tail or {}
         x0, prev, lw, lb = t.get("x0"), t.get("prev"), t.get("ln_weight"), t.get("ln_bias")
@@ -355,7 +360,7 @@ class HipBackend:
             lw, lb = lw.contiguous(), lb.contiguous()
         out = torch.empty((n_rows, F), dtype=dt, device=dev)
         head = (_ptr(rowptr), _ptr(blkptr), n_blocks, _ptr(src), _ptr(val), n_nodes, nnz, _ptr(x), ldx, row_begin, n_rows, F,
-                _ptr(attn), lda, float(attn_scale), float(gcn_scale))
+                _ptr(attn), lda, float(attn_scale), float(gcn_scale), _ptr(order), int(n_split))
         tail_args = (_ptr(x0), ldx0, _ptr(prev), ldp, float(t.get("alpha", 0.5)), _ptr(lw), _ptr(lb),
                      float(t.get("eps", 1e-5)), int(bool(t.get("relu", False))))
         with _Timed(self, "dif_gcn_spmm_f32", dev):
@@ -370,6 +375,20 @@ class HipBackend:
                 rc = self.lib.dif_gcn_spmm_tail_f32(*head, *tail_args, _ptr(out), F, _stream(dev))
         _lib.check(rc, name)
         return out
+
+    def row_order(self, rowptr, row_begin, n_rows):
+        """Rows [row_begin, row_begin + n_rows) by descending degree (indices inside the shard) ->
+        (order int32 [n_rows], stats int32 [2] = {rows with degree > 4x mean, max degree}), both on the device."""
+        dev = _require_device(rowptr)
+        order = torch.empty(n_rows, dtype=torch.int32, device=dev)
+        stats = torch.empty(2, dtype=torch.int32, device=dev)
+        ws_bytes = self.lib.dif_row_order_workspace_bytes(n_rows)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_row_order", dev):
+            rc = self.lib.dif_row_order(_ptr(rowptr), row_begin, n_rows, _ptr(order), _ptr(stats), _ptr(ws), ws_bytes,
+                                        _stream(dev))
+        _lib.check(rc, "dif_row_order")
+        return order, stats
 
     # ---- a5 ends: narrow Linear (+ LayerNorm + ReLU) -------------------------------------------
     def linear(self, x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):

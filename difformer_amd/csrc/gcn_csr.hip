@@ -280,6 +280,21 @@ __global__ __launch_bounds__(64 * kSortWaves) void radix_scatter_kernel(
     }
 }
 
+// ---- rows of a shard by descending degree (load balance of the blocked SpMM) ----------------------
+// stats[0] = rows with degree > 4 * mean degree of the shard (they come first in the order), stats[1] = max degree
+__global__ __launch_bounds__(256) void order_keys_kernel(const int32_t* __restrict__ rowptr, int64_t row_begin,
+                                                         int64_t n_rows, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals, int32_t* __restrict__ stats) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t d = static_cast<uint32_t>(rowptr[row_begin + i + 1] - rowptr[row_begin + i]);
+    const int64_t total = static_cast<int64_t>(rowptr[row_begin + n_rows]) - rowptr[row_begin];
+    if (static_cast<int64_t>(d) * n_rows > 4 * total) atomicAdd(stats, 1);
+    atomicMax(stats + 1, static_cast<int32_t>(d));
+    keys[i] = 0xFFFFFFu - (d < 0xFFFFFFu ? d : 0xFFFFFFu);      // ascending key = descending degree (24 bits)
+    vals[i] = static_cast<uint32_t>(i);                         // row inside the shard
+}
+
 // ---- per-entry source id and normalised value ---------------------------------------------------
 __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
                                                        uint32_t NB, int transpose,
@@ -424,6 +439,73 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     hipLaunchKernelGGL(csr_fill_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N,
                        static_cast<uint32_t>(p.NB), transpose, edge_weight, kin, vin, dinv, src, val);
     return dif::launch_status("csr_fill_kernel");
+}
+
+namespace {
+struct OrderPlan { int64_t n_chunks, table_len; size_t off_keys_a, off_keys_b, off_vals_a, off_table, off_bsum, total; };
+OrderPlan make_order_plan(int64_t n) {
+    OrderPlan p;
+    const int64_t chunk = 64 * kSortRoundsMin;
+    p.n_chunks = (n + chunk - 1) / chunk;
+    if (p.n_chunks < 1) p.n_chunks = 1;
+    p.table_len = p.n_chunks * kRadix;
+    const size_t e = static_cast<size_t>(n > 0 ? n : 1);
+    size_t o = 0;
+    p.off_keys_a = o; o += align256(e * 4);
+    p.off_keys_b = o; o += align256(e * 4);
+    p.off_vals_a = o; o += align256(e * 4);
+    p.off_table = o;  o += align256(static_cast<size_t>(p.table_len) * 4);
+    p.off_bsum = o;   o += align256(static_cast<size_t>((p.table_len + kScanTile - 1) / kScanTile + 1) * 4);
+    p.total = o;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t dif_row_order_workspace_bytes(int64_t n_rows) {
+    if (n_rows <= 0) return 0;
+    return make_order_plan(n_rows).total;
+}
+
+// order[i] = i-th row of the shard [row_begin, row_begin + n_rows) by descending degree (ties: ascending row), as an
+// index INSIDE the shard; stats[0] = number of rows whose degree exceeds 4x the shard's mean (a prefix of the order: the
+// rows the blocked SpMM splits over a whole quad), stats[1] = largest degree.  Stable 3-pass LSD radix sort on 24 bits of (2^24 - 1 - degree) with the CSR build's kernels.
+extern "C" int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int32_t* order, int32_t* stats,
+                             void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && row_begin >= 0 && n_rows < (int64_t(1) << 31) - 4096, DIF_E_BADARG,
+                "dif_row_order: need 0 < n_rows < 2^31, row_begin >= 0");
+    DIF_REQUIRE(rowptr && order && stats && workspace, DIF_E_BADARG, "dif_row_order: null pointer");
+    const OrderPlan p = make_order_plan(n_rows);
+    DIF_REQUIRE(workspace_bytes >= p.total, DIF_E_WORKSPACE, "dif_row_order: workspace too small (%zu < %zu)",
+                workspace_bytes, p.total);
+    DIF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DIF_E_BADARG,
+                "dif_row_order: workspace must be 256-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    uint32_t* kin = reinterpret_cast<uint32_t*>(ws + p.off_keys_a);
+    uint32_t* kout = reinterpret_cast<uint32_t*>(ws + p.off_keys_b);
+    uint32_t* vin = reinterpret_cast<uint32_t*>(ws + p.off_vals_a);
+    uint32_t* vout = reinterpret_cast<uint32_t*>(order);            // 3 passes: a -> order -> a -> order
+    int32_t* table = reinterpret_cast<int32_t*>(ws + p.off_table);
+    int32_t* bsum = reinterpret_cast<int32_t*>(ws + p.off_bsum);
+    hipError_t he = hipMemsetAsync(stats, 0, 8, st);
+    if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_row_order: memset: %s", hipGetErrorString(he));
+    hipLaunchKernelGGL(order_keys_kernel, dim3(static_cast<unsigned>((n_rows + 255) / 256)), dim3(256), 0, st, rowptr,
+                       row_begin, n_rows, kin, vin, stats);
+    if (int rc = dif::launch_status("order_keys_kernel")) return rc;
+    const unsigned sort_grid = static_cast<unsigned>((p.n_chunks + kSortWaves - 1) / kSortWaves);
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass * kRadixBits;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, n_rows, shift, p.n_chunks,
+                           kSortRoundsMin, table);
+        if (int rc = dif::launch_status("radix_hist_kernel")) return rc;
+        if (int rc = exclusive_scan(table, p.table_len, table, nullptr, bsum, st)) return rc;
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, vin, n_rows, shift,
+                           p.n_chunks, kSortRoundsMin, table, kout, vout);
+        if (int rc = dif::launch_status("radix_scatter_kernel")) return rc;
+        uint32_t* t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    return 0;
 }
 
 extern "C" size_t dif_subgraph_workspace_bytes(int64_t E, int64_t N) {

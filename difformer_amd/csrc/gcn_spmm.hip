@@ -233,12 +233,14 @@ constexpr int kBlkLdsBytesPerCU = 147456;  // 144 KiB of the CU's 160 KiB for ac
 constexpr int kBlkPre = 4;             // G-entry chunks of a (row, block) group fetched in one batch
 
 // WPC = workgroups per CU (1: 16 waves/CU, 128-VGPR budget; 2: 32 waves/CU, 64-VGPR budget)
-template <int G, int W, int WPC, int UNROLL, bool PACE, bool WIDE, typename E>
+// ORD: walk the rows through `order` (degree-sorted, hub rows split) -- a separate instantiation, so graphs that do
+// not need it run the plain contiguous-panel code.
+template <int G, int W, int WPC, int UNROLL, bool PACE, bool WIDE, bool ORD, typename E>
 __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_blocked_kernel(
     const int32_t* __restrict__ blkptr, int64_t n_nodes, int n_blocks, const int32_t* __restrict__ src,
     const float* __restrict__ val, const E* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows,
     int F, const E* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail<E> tail,
-    E* __restrict__ out, int64_t ldo, int rpw) {
+    E* __restrict__ out, int64_t ldo, int rpw, const int32_t* __restrict__ order, int64_t n_split) {
     using V = typename Vec<W>::T;
     constexpr int S = 64 / G;       // rows walked concurrently by one wave
     constexpr int RW = G * W;       // floats of LDS per accumulator row
@@ -254,7 +256,18 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
     const E* xcol = x + (active ? col : 0);     // inactive column lanes read (and discard) column 0
     float* my = acc_lds + wave * rpw * RW;
 
-    const int64_t n_panels = (n_rows + rpw - 1) / rpw;
+    // Panels.  A "quad" is the S rows a wave walks side by side; a panel is rpw / S quads.
+    //  * order == nullptr (degrees about equal): panel p = rows [p*rpw, (p+1)*rpw) -- contiguous CSR, fewest TLB entries.
+    //  * order != nullptr (skewed degrees; real graphs: ogbn-proteins has max / mean degree ~13): a quad costs the
+    //    LONGEST of its groups and the block barrier costs the slowest wave, so `order` lists the shard's rows by
+    //    descending degree (dif_row_order), a quad is S consecutive entries of it (similar lengths) and the quads are
+    //    dealt round-robin over the panels (every wave gets one quad of each degree stratum).  The first n_split rows of
+    //    the order (degree > 4x mean) each take a WHOLE quad: every lane group walks a quarter of each of the row's
+    //    groups and the epilogue adds the S partial rows.  Zipf-profile C4: 3.05 ms natural order, see
+    //    profiles/r01_experiments.md for the ordered / split figures.
+    const int qpp = rpw / S;                                    // ORD: quads per panel (rpw is a multiple of S then)
+    const int64_t n_quads = n_split + (n_rows - n_split + S - 1) / S;
+    const int64_t n_panels = ORD ? (n_quads + qpp - 1) / qpp : (n_rows + rpw - 1) / rpw;
     // panels are dealt round-robin over the workgroups (panel p -> workgroup p % grid, wave (p / grid) % 16), so every
     // CU carries the same number of panels to within one whatever the panel count is (vs 16 consecutive panels per
     // workgroup: 1.165 -> 1.125 ms at C4, 0.271 -> 0.181 ms on a 16.5k-row shard; PMC fetch 1.4 -> 2.1 GB per launch)
@@ -265,15 +278,39 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
     for (int64_t rnd = 0; rnd < rounds; ++rnd) {
         const int64_t panel = first + rnd * stride;
         const bool has = panel < n_panels;
-        const int64_t row0 = has ? panel * rpw : 0;
-        const int nrw = !has ? 0 : (n_rows - row0 < rpw) ? static_cast<int>(n_rows - row0) : rpw;
-        const int nq = (nrw + S - 1) / S;
+        // lane i <-> panel slot i: member i % S of the panel's quad i / S
+        const int64_t myquad = static_cast<int64_t>(lane / S) * n_panels + panel;      // ORD only
+        const bool split = ORD && myquad < n_split;             // this slot holds a quarter of a split row
+        const int64_t mypos = !ORD ? panel * rpw + lane : split ? myquad : n_split + (myquad - n_split) * S + (lane % S);
+        const bool mine = has && lane < rpw && (!ORD || myquad < n_quads) && mypos < n_rows;
+        const int32_t lrow = mine ? (ORD ? order[mypos] : static_cast<int32_t>(mypos)) : 0;   // row inside the shard
+        // the part of a (row, block) group [e0, e1) this slot walks
+        auto part_of = [&](int32_t& e0, int32_t& e1) {
+            if (ORD && split) {
+                const int32_t len = e1 - e0;
+                const int32_t chunk = ((len + S * G - 1) / (S * G)) * G;
+                e0 += (lane % S) * chunk;
+                if (e0 > e1) e0 = e1;
+                if (e1 - e0 > chunk) e1 = e0 + chunk;
+            }
+        };
+        int nq = 0;
+        if (has) {
+            if (ORD) {
+                const int64_t left = (n_quads - panel + n_panels - 1) / n_panels;   // q with q*n_panels + panel < n_quads
+                nq = left < qpp ? static_cast<int>(left) : qpp;
+            } else {
+                const int64_t left = n_rows - panel * rpw;
+                nq = static_cast<int>(((left < rpw ? left : rpw) + S - 1) / S);
+            }
+        }
         for (int i = lane; i < rpw * RW; i += 64) my[i] = 0.f;
 
         // (row, block) group pointers of the current and of the next block, one lane per row of the panel
-        const int32_t* pb = blkptr + row_begin + row0;
-        int32_t e0v = (lane < nrw) ? pb[lane] : 0;
-        int32_t e1v = (lane < nrw) ? pb[n_nodes + lane] : 0;
+        const int32_t* pb = blkptr + row_begin + lrow;
+        int32_t e0v = mine ? pb[0] : 0;
+        int32_t e1v = mine ? pb[n_nodes] : 0;
+        part_of(e0v, e1v);
         // entries of the NEXT row-quad (of this block, or the first quad of the next block) are always in flight
         // while the current quad gathers
         int32_t e0n = __shfl(e0v, slot, 64), e1n = __shfl(e1v, slot, 64);
@@ -294,8 +331,9 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
             int32_t e0x = 0, e1x = 0;     // pointers of block b+1, requested a whole block ahead
             if (b + 1 < n_blocks) {
                 const int32_t* pn = pb + static_cast<int64_t>(b + 1) * n_nodes;
-                e0x = (lane < nrw) ? pn[lane] : 0;
-                e1x = (lane < nrw) ? pn[n_nodes + lane] : 0;
+                e0x = mine ? pn[0] : 0;
+                e1x = mine ? pn[n_nodes] : 0;
+                part_of(e0x, e1x);
             }
             for (int q = 0; q < nq; ++q) {
                 const int rl = q * S + slot;
@@ -374,15 +412,23 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
         // panel epilogue: S rows per step, each a full contiguous row segment
         for (int q = 0; q < nq; ++q) {
             const int rl = q * S + slot;
-            const bool ok = rl < nrw && active;
-            const int64_t row = row0 + rl;
+            const int flags = __shfl(static_cast<int>(mine) | (static_cast<int>(split) << 1), rl, 64);
+            const bool ok = (flags & 1) && active;
+            const int64_t row = __shfl(lrow, rl, 64);
             V o = vzero<W>();
             if (ok) {
-                o = gcn_scale * vload<W>(my + rl * RW + col);
+                if (ORD && (flags & 2)) {       // split row: the S lane groups each hold a partial sum; all add them, group 0 stores
+                    V t = vload<W>(my + (q * S) * RW + col);
+#pragma unroll
+                    for (int p2 = 1; p2 < S; ++p2) t += vload<W>(my + (q * S + p2) * RW + col);
+                    o = gcn_scale * t;
+                } else {
+                    o = gcn_scale * vload<W>(my + rl * RW + col);
+                }
                 if (attn) o += attn_scale * gload<W, E>(attn + row * lda + col);
             }
             if (tail.enabled) o = apply_tail<G, W, E>(o, tail, row, col, ok, F);
-            if (ok) gstore<W, E>(out + row * ldo + col, o);
+            if (ok && (!ORD || !(flags & 2) || slot == 0)) gstore<W, E>(out + row * ldo + col, o);
         }
     }
 }
@@ -391,7 +437,7 @@ template <int G, int W, int WPC, int UNROLL, typename E>
 int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
                      const float* val, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                      const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail, E* out,
-                     int64_t ldo) {
+                     int64_t ldo, const int32_t* order, int64_t n_split) {
     constexpr int S = 64 / G;
     constexpr int RW = G * W;
     constexpr int kLdsFloats = kBlkLdsBytesPerCU / 4 / WPC;
@@ -401,29 +447,32 @@ int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int
     // rows per wave panel: the busiest CU does ceil(panels / workgroups) panels of ceil(rpw / S) row-quad visits per
     // block; pick the panel height near n_rows / slots that minimises that product (ties -> shorter panels: more waves busy).
     // Measured on a 16,567-row shard of C4: 4 rows/wave (two rounds) 0.249 ms, 6-8 rows 0.215 ms, 16 rows 0.371 ms.
-    int64_t lo = (n_rows + slots - 1) / slots;
+    int64_t lo = (n_rows + 3 * (order ? n_split : 0) + slots - 1) / slots;   // a split row fills S slots
     if (lo < 1) lo = 1;
     int64_t rpw = 0, best = -1;
-    for (int64_t cand = (lo > S ? lo - S + 1 : 1); cand <= lo + 2 * S; ++cand) {
+    if (!order) n_split = 0;
+    const int64_t n_quads = n_split + (n_rows - n_split + S - 1) / S;
+    const int64_t step = order ? S : 1;                       // ordered walk: whole quads only
+    for (int64_t cand = order ? ((lo + S - 1) / S) * S : (lo > S ? lo - S + 1 : 1); cand <= lo + 3 * S; cand += step) {
         if (cand > rpw_max) break;
-        const int64_t panels = (n_rows + cand - 1) / cand;
+        const int64_t panels = order ? (n_quads + cand / S - 1) / (cand / S) : (n_rows + cand - 1) / cand;
         const int64_t wgs = panels < n_wg ? panels : n_wg;
         // a second round of panels re-runs the whole block sweep (with its barriers) for a few stragglers: avoid
         const int64_t rounds = (panels + wgs * kBlkWaves - 1) / (wgs * kBlkWaves);
         const int64_t cost = (rounds - 1) * 1000000 + ((panels + wgs - 1) / wgs) * ((cand + S - 1) / S);
         if (best < 0 || cost < best) { best = cost; rpw = cand; }
     }
-    if (rpw == 0) rpw = rpw_max;
-    const int64_t n_panels = (n_rows + rpw - 1) / rpw;
+    if (rpw == 0) rpw = (rpw_max / S) * S;
+    const int64_t n_panels = order ? (n_quads + rpw / S - 1) / (rpw / S) : (n_rows + rpw - 1) / rpw;
     int64_t grid = n_panels < n_wg ? n_panels : n_wg;
-    if (n_nodes * ldx < (int64_t(1) << 31))
-        hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true, false, E>), dim3(static_cast<unsigned>(grid)),
-                           dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows,
-                           F, attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
-    else
-        hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true, true, E>), dim3(static_cast<unsigned>(grid)),
-                           dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows,
-                           F, attn, lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw));
+    const bool wide = n_nodes * ldx >= (int64_t(1) << 31);
+#define DIF_BLK_LAUNCH(WIDEV, ORDV) \
+    hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true, WIDEV, ORDV, E>), dim3(static_cast<unsigned>(grid)), \
+                       dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, \
+                       lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw), order, n_split)
+    if (order) { if (wide) DIF_BLK_LAUNCH(true, true); else DIF_BLK_LAUNCH(false, true); }
+    else { if (wide) DIF_BLK_LAUNCH(true, false); else DIF_BLK_LAUNCH(false, false); }
+#undef DIF_BLK_LAUNCH
     return dif::launch_status("spmm_blocked_kernel");
 }
 
@@ -431,11 +480,11 @@ template <int G, int W, typename E>
 int launch_blocked(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
                    const float* val, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                    const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail, E* out,
-                   int64_t ldo) {
+                   int64_t ldo, const int32_t* order, int64_t n_split) {
     // 1 workgroup (16 waves) per CU, 8 gathers in flight per wave: best of the measured variants
     // (2 workgroups per CU need a 64-VGPR budget and spill)
     return launch_blocked_v<G, W, 1, 8, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn,
-                                        lda, attn_scale, gcn_scale, tail, out, ldo);
+                                        lda, attn_scale, gcn_scale, tail, out, ldo, order, n_split);
 }
 
 template <int G, int W, typename E>
@@ -491,12 +540,14 @@ template <typename E>
 static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src, const float* val,
                       int64_t n_nodes, int64_t nnz, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows,
                       int F, const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail,
-                      E* out, int64_t ldo, dif_stream_t stream) {
+                      E* out, int64_t ldo, const int32_t* order, int64_t n_split, dif_stream_t stream) {
     DIF_REQUIRE(n_rows > 0 && F > 0 && row_begin >= 0 && n_nodes > 0 && nnz >= 0 && n_blocks >= 1, DIF_E_BADARG,
                 "dif_gcn_spmm: need n_rows > 0, F > 0, row_begin >= 0, n_nodes > 0, nnz >= 0, n_blocks >= 1");
     DIF_REQUIRE(row_begin + n_rows <= n_nodes, DIF_E_BADARG, "dif_gcn_spmm: row range exceeds n_nodes");
     DIF_REQUIRE(rowptr && x && out && (nnz == 0 || (src && val)), DIF_E_BADARG, "dif_gcn_spmm: null pointer");
     DIF_REQUIRE(n_blocks == 1 || blkptr, DIF_E_BADARG, "dif_gcn_spmm: n_blocks > 1 needs blkptr");
+    DIF_REQUIRE(n_split >= 0 && n_split <= n_rows && (order || n_split == 0), DIF_E_BADARG,
+                "dif_gcn_spmm: n_split_rows must lie in [0, n_rows] and needs row_order");
     DIF_REQUIRE(ldx >= F && ldo >= F && (!attn || lda >= F), DIF_E_BADARG,
                 "dif_gcn_spmm: leading dimension smaller than a row");
     DIF_REQUIRE((F + 255) / 256 <= 65535, DIF_E_RANGE, "dif_gcn_spmm: F too large");
@@ -518,7 +569,7 @@ static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks
     if (n_blocks > 1 && vec && F <= 256 && nnz > 0) {
 #define DIF_BLK(G) \
     return launch_blocked<G, 4, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, \
-                                   attn_scale, gcn_scale, tail, out, ldo)
+                                   attn_scale, gcn_scale, tail, out, ldo, order, n_split)
         if (F <= 64) DIF_BLK(16);
         if (F <= 128) DIF_BLK(32);
         DIF_BLK(64);
@@ -533,22 +584,24 @@ static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks
 extern "C" int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
                                 const float* val, int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
                                 int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
-                                float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream) {
+                                float attn_scale, float gcn_scale, const int32_t* row_order, int64_t n_split_rows,
+                                float* out, int64_t ldo, dif_stream_t stream) {
     Tail<float> tail = {};
     return spmm_entry<float>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
-                             attn_scale, gcn_scale, tail, out, ldo, stream);
+                             attn_scale, gcn_scale, tail, out, ldo, row_order, n_split_rows, stream);
 }
 
 extern "C" int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
                                      const float* val, int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
                                      int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
-                                     float attn_scale, float gcn_scale, const float* x0, int64_t ldx0,
+                                     float attn_scale, float gcn_scale, const int32_t* row_order, int64_t n_split_rows,
+                                     const float* x0, int64_t ldx0,
                                      const float* prev, int64_t ldp, float alpha, const float* ln_weight,
                                      const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo,
                                      dif_stream_t stream) {
     Tail<float> tail = {x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, 1, relu};
     return spmm_entry<float>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
-                             attn_scale, gcn_scale, tail, out, ldo, stream);
+                             attn_scale, gcn_scale, tail, out, ldo, row_order, n_split_rows, stream);
 }
 
 // bfloat16 storage: x / attn / x0 / prev / LayerNorm parameters / out are bf16, `val` and every accumulation fp32.
@@ -556,7 +609,8 @@ extern "C" int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkpt
 extern "C" int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
                                       const float* val, int64_t n_nodes, int64_t nnz, const void* x, int64_t ldx,
                                       int64_t row_begin, int64_t n_rows, int F, const void* attn, int64_t lda,
-                                      float attn_scale, float gcn_scale, int tail_enabled, const void* x0, int64_t ldx0,
+                                      float attn_scale, float gcn_scale, const int32_t* row_order, int64_t n_split_rows,
+                                      int tail_enabled, const void* x0, int64_t ldx0,
                                       const void* prev, int64_t ldp, float alpha, const void* ln_weight,
                                       const void* ln_bias, float ln_eps, int relu, void* out, int64_t ldo,
                                       dif_stream_t stream) {
@@ -565,5 +619,5 @@ extern "C" int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkp
     Tail<B> tail = {};
     if (tail_enabled) tail = Tail<B>{c(x0), ldx0, c(prev), ldp, alpha, c(ln_weight), c(ln_bias), ln_eps, 1, relu};
     return spmm_entry<B>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, c(x), ldx, row_begin, n_rows, F, c(attn), lda,
-                         attn_scale, gcn_scale, tail, static_cast<B*>(out), ldo, stream);
+                         attn_scale, gcn_scale, tail, static_cast<B*>(out), ldo, row_order, n_split_rows, stream);
 }

@@ -108,6 +108,23 @@ class GraphCSR:
         self.num_nodes, self.nnz = int(num_nodes), int(nnz)
         self._edges = None          # weak references to (edge_index, edge_weight) for the lazily built adjoint
         self._adjoint = None
+        self._orders = {}           # (row_begin, n_rows) -> rows by descending degree (blocked SpMM load balance)
+
+    def row_order(self, row_begin, n_rows):
+        """(order, n_split) for the blocked SpMM over a shard: its rows by descending degree, the first n_split of them
+        (degree > 4x mean) to be split over a whole quad.  Built once per shard on the device (one host sync for the two
+        statistics).  None when the order would not help: unblocked kernels (they map rows to waves / lane groups one by
+        one), or degrees about equal (max <= 2x mean: contiguous panels are faster then)."""
+        if self.n_blocks <= 1 or self.nnz == 0:
+            return None
+        key = (int(row_begin), int(n_rows))
+        if key not in self._orders:
+            order, stats = get_backend().row_order(self.rowptr, *key)
+            n_split, max_deg = (int(v) for v in stats.tolist())
+            total = int(self.rowptr[key[0] + key[1]]) - int(self.rowptr[key[0]])
+            skewed = max_deg * key[1] > 2 * total
+            self._orders[key] = (order, n_split) if skewed else None
+        return self._orders[key]
 
     @classmethod
     def build(cls, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
@@ -193,7 +210,7 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
             row_begin, n_rows = shard.row_begin, shard.n_local
     a2 = None if attn is None else attn.reshape(n, H * D)
     out = get_backend().spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x2,
-                             row_begin, n_rows, a2, attn_scale, gcn_scale, tail)
+                             row_begin, n_rows, a2, attn_scale, gcn_scale, tail, csr.row_order(row_begin, n_rows))
     return out.reshape(n_rows, H, D)
 
 

@@ -145,7 +145,18 @@ int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
                      const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
                      const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                      const float* attn, int64_t lda, float attn_scale, float gcn_scale,
-                     float* out, int64_t ldo, dif_stream_t stream);
+                     const int32_t* row_order, int64_t n_split_rows, float* out, int64_t ldo,
+                     dif_stream_t stream);
+/* row_order (optional; NULL with n_split_rows = 0 = natural order): the rows of [row_begin, row_begin + n_rows) by
+ * descending degree, as produced by dif_row_order (indices inside the shard).  It only changes which rows the blocked
+ * kernel walks side by side and in which wave (similar degrees together, every wave a share of each degree stratum):
+ * the load balance on graphs with skewed degrees.  The first n_split_rows rows of the order (dif_row_order's stats[0]:
+ * degree > 4x the mean) are each split over the wave's four lane groups, whose partial rows are added in a fixed order;
+ * every other row is summed exactly as without the order.  Ignored by the unblocked kernels.
+ * dif_row_order: order int32 [n_rows]; stats int32 [2] (device) = {rows with degree > 4x mean, max degree}. */
+size_t dif_row_order_workspace_bytes(int64_t n_rows);
+int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int32_t* order, int32_t* stats,
+                  void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * f2  induced subgraph of a node subset with relabelling -- the per-batch graph step of the mini-batch path,
@@ -181,7 +192,7 @@ int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_bl
                           const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
                           const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                           const float* attn, int64_t lda, float attn_scale, float gcn_scale,
-                          const float* x0, int64_t ldx0, const float* prev, int64_t ldp, float alpha,
+                          const int32_t* row_order, int64_t n_split_rows, const float* x0, int64_t ldx0, const float* prev, int64_t ldp, float alpha,
                           const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
                           float* out, int64_t ldo, dif_stream_t stream);
 
@@ -241,7 +252,7 @@ int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_b
                            const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
                            const void* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                            const void* attn, int64_t lda, float attn_scale, float gcn_scale,
-                           int tail_enabled, const void* x0, int64_t ldx0, const void* prev,
+                           const int32_t* row_order, int64_t n_split_rows, int tail_enabled, const void* x0, int64_t ldx0, const void* prev,
                            int64_t ldp, float alpha, const void* ln_weight, const void* ln_bias,
                            float ln_eps, int relu, void* out, int64_t ldo, dif_stream_t stream);
 int dif_layer_tail_bf16(const void* conv, int64_t ldc, int64_t n_rows, int H, int D,

@@ -74,7 +74,7 @@ class OracleBackend:
                 torch.from_numpy(val[order]))
 
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
-             gcn_scale=1.0, tail=None):
+             gcn_scale=1.0, tail=None, order=None):
         rp, s, w, xx = _np(rowptr), _np(src)[:nnz], _np(val)[:nnz].astype(np.float64), _np(x).astype(np.float64)
         assert xx.shape[0] == n_nodes
         dst = np.repeat(np.arange(n_nodes), np.diff(rp))
@@ -89,6 +89,11 @@ class OracleBackend:
                                   tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5),
                                   tail.get("relu", False))
         return out
+
+    def row_order(self, rowptr, row_begin, n_rows):
+        deg = np.diff(_np(rowptr).astype(np.int64))[row_begin: row_begin + n_rows]
+        stats = np.array([(deg * n_rows > 4 * deg.sum()).sum(), deg.max()], dtype=np.int32)
+        return torch.from_numpy(np.argsort(-deg, kind="stable").astype(np.int32)), torch.from_numpy(stats)
 
     def linear(self, x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
         y = torch.nn.functional.linear(x, weight, bias)
