@@ -96,6 +96,7 @@ class _GcnAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, csr, x, attn, attn_scale, gcn_scale):
         ctx.csr, ctx.attn_scale, ctx.gcn_scale, ctx.has_attn = csr, attn_scale, gcn_scale, attn is not None
+        ctx.edges = csr.hold_edges() if csr._adjoint is None else None    # the adjoint CSR is built from them in backward
         return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale)
 
     @staticmethod

@@ -135,6 +135,13 @@ class GraphCSR:
             csr._edges = (weakref.ref(edge_index), None if edge_weight is None else weakref.ref(edge_weight))
         return csr
 
+    def hold_edges(self):
+        """Strong references to the tensors this CSR was built from (None if already freed).  The autograd node of the
+        aggregation keeps them until backward(), so callers may pass temporaries (`model(x, ei.to(dev))`)."""
+        if not self._edges:
+            return None
+        return (self._edges[0](), self._edges[1]() if self._edges[1] is not None else None)
+
     def adjoint(self):
         """CSR of A_hat^T (entries filed under their source row): the SpMM over it is the gradient of the
         aggregation.  Built on first use (training only) from the same edge tensors."""
