@@ -17,7 +17,13 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(dev):
+    """Raw handle of torch's current HIP stream on `dev` (the fast accessor when this torch has it)."""
+    if _raw_stream is not None and dev.index is not None:
+        return ctypes.c_void_p(_raw_stream(dev.index))
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
@@ -86,8 +92,11 @@ class _Timed:
         self.name, self.dev = name, dev
 
     def __enter__(self):
-        self.ctx = torch.cuda.device(self.dev)
-        self.ctx.__enter__()
+        # device guard only when the operands live on another device than the current one
+        self.ctx = None
+        if self.dev.index is None or torch.cuda.current_device() != self.dev.index:
+            self.ctx = torch.cuda.device(self.dev)
+            self.ctx.__enter__()
         if self.rec is not None:
             self.start = torch.cuda.Event(enable_timing=True)
             self.start.record(torch.cuda.current_stream(self.dev))
@@ -98,7 +107,7 @@ class _Timed:
             end = torch.cuda.Event(enable_timing=True)
             end.record(torch.cuda.current_stream(self.dev))
             self.rec.setdefault(self.name, []).append((self.start, end))
-        return self.ctx.__exit__(*exc)
+        return self.ctx.__exit__(*exc) if self.ctx is not None else False
 
 
 class HipBackend:
