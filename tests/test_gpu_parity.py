@@ -989,3 +989,56 @@ def test_v2_training_step_gradients(kernel, dev):
     (out * w.to(dev)).sum().backward()
     for name, p in model.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), ref[name].grad.numpy()) < 2e-4, name
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 17, 63, 65])
+@pytest.mark.parametrize("kernel", ["simple", "sigmoid"])
+def test_attention_tiny_inputs(n, kernel, dev):
+    """Fewer rows than one MFMA tile / one wave step, down to a single node."""
+    from difformer_amd import full_attention_conv
+    rng = np.random.default_rng(n)
+    q, k, v = (rng.standard_normal((n, 2, 24)).astype(np.float32) for _ in range(3))
+    out = full_attention_conv(t(q, dev), t(k, dev), t(v, dev), kernel)
+    ref = orc.full_attention_conv(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), kernel)
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+def test_simple_attention_zero_norm_is_non_finite_like_the_reference(dev):
+    """difformer.py:20-21 divides by the Frobenius norms: all-zero queries give 0/0 there, and here."""
+    from difformer_amd import full_attention_conv
+    q = torch.zeros(40, 1, 16, device=dev)
+    k, v = torch.randn(40, 1, 16, device=dev), torch.randn(40, 1, 16, device=dev)
+    ref = orc.simple_attention(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy())
+    out = full_attention_conv(q, k, v, "simple")
+    assert not np.isfinite(ref).any() and not torch.isfinite(out).any()
+
+
+def test_gcn_conv_edge_free_and_single_node_graphs(dev):
+    """E = 0 (every degree 0 -> every value dropped, difformer.py:73-74) and N = 1 with a self loop."""
+    from difformer_amd import DIFFormer, gcn_conv
+    x = torch.randn(9, 1, 8, device=dev)
+    out = gcn_conv(x, torch.zeros(2, 0, dtype=torch.long, device=dev), None)
+    assert out.shape == x.shape and not out.any()
+    one = gcn_conv(x[:1], torch.zeros(2, 1, dtype=torch.long, device=dev), None)
+    assert rel_err(one.cpu().numpy(), x[:1].cpu().numpy()) < 1e-6
+    torch.manual_seed(0)
+    model = DIFFormer(5, 8, 3).eval()
+    xs = torch.randn(1, 5)
+    p = {k: v.double().numpy() for k, v in model.state_dict().items()}
+    cfg = dict(hidden_channels=8, num_layers=2, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    ei = torch.zeros(2, 1, dtype=torch.long)
+    ref = orc.difformer_forward(p, xs.double().numpy(), ei.numpy(), None, cfg)
+    with torch.no_grad():
+        out = model.to(dev)(xs.to(dev), ei.to(dev))
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+def test_empty_inputs_raise(dev):
+    """Zero nodes: the C ABI refuses (DIF_E_BADARG) and the host raises; nothing is launched."""
+    from difformer_amd import full_attention_conv
+    from difformer_amd._lib import DifformerHipError
+    q = torch.zeros(0, 1, 8, device=dev)
+    with pytest.raises(DifformerHipError):
+        full_attention_conv(q, q, q, "simple")
