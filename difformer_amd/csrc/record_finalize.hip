@@ -15,8 +15,19 @@ __global__ __launch_bounds__(1024) void record_finalize_kernel(const float* __re
     if (blockIdx.x + 1 < gridDim.x) {
         const int col = blockIdx.x * 64 + c;
         float a = 0.f;
-        if (col < t_main)
-            for (int p = sl; p < P; p += kFinSlices) a += ws[p * ws_stride + col];
+        if (col < t_main) {
+            // the partials come from other XCDs' workgroups (MALL / HBM latency): 8 loads in flight, summed in the
+            // same fixed order as a plain loop would
+            int p = sl;
+            for (; p + 7 * kFinSlices < P; p += 8 * kFinSlices) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ws[static_cast<int64_t>(p + u * kFinSlices) * ws_stride + col];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+            for (; p < P; p += kFinSlices) a += ws[static_cast<int64_t>(p) * ws_stride + col];
+        }
         sm[sl][c] = a;
         __syncthreads();
         if (sl == 0 && col < t_main) {
