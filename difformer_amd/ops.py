@@ -13,6 +13,8 @@ import weakref
 from collections import OrderedDict
 from typing import Optional
 
+import torch
+
 from .dist import RowShard
 
 _BACKEND = None
@@ -233,7 +235,6 @@ class BatchLayout:
     Only B-sized integer bookkeeping happens here; the node-sized work is in the kernels."""
 
     def __init__(self, n_nodes, device):
-        import torch
         n = n_nodes.to(device=device, dtype=torch.int64).reshape(-1)
         if n.numel() == 0:
             raise ValueError("difformer_amd: n_nodes is empty")
@@ -262,7 +263,6 @@ class _LayoutCache:
         self.entries = OrderedDict()
 
     def get(self, n_nodes, device):
-        import torch
         if not torch.is_tensor(n_nodes):
             n_nodes = torch.as_tensor(n_nodes)
             return BatchLayout(n_nodes, device)
