@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void project_reduce_kernel(
     const T* __restrict__ x, int64_t ldx, int64_t n_rows, PRShape sh, const T* __restrict__ Wq,
     const T* __restrict__ bq, const T* __restrict__ Wk, const T* __restrict__ bk,
     const T* __restrict__ Wv, const T* __restrict__ bv, T* __restrict__ q_out, int64_t ldq,
-    T* __restrict__ v_out, int64_t ldv, float* __restrict__ ws, int64_t ws_stride, int vec) {
+    T* __restrict__ v_out, int64_t ldv, float* __restrict__ ws, int64_t ws_stride, int vec, int wvec) {
     __shared__ __attribute__((aligned(16))) float sm_w[3][64 * kWStride];   // Wk, Wv, Wq of this head (zero padded)
     __shared__ float sm_b[3][64];
     __shared__ __attribute__((aligned(16))) float sm_tile[64 * 64];
@@ -164,14 +164,32 @@ __global__ __launch_bounds__(256, 2) void project_reduce_kernel(
         const T* Ws[3] = {Wk + static_cast<int64_t>(h) * D * C, Wv + static_cast<int64_t>(h) * D * C,
                           Wq + static_cast<int64_t>(h) * D * C};
         const T* bs[3] = {bk + h * D, bv + h * D, bq + h * D};
+        if (EXACT && wvec) {
+            // 64 x 64 blocks, 4-element aligned: all twelve 4-wide loads of a thread are issued before the first LDS
+            // store (the element-wise loop below runs 48 load -> store round trips back to back: ~10 us of prologue)
+            f32x4 wreg[3][4];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-                const int f = e >> 6, c = e & 63;
-                sm_w[m][f * kWStride + c] = (f < D && c < C) ? Elem<T>::ld(Ws[m] + f * C + c) : 0.f;
-            }
-            if (threadIdx.x < 64) sm_b[m][threadIdx.x] = (threadIdx.x < D) ? Elem<T>::ld(bs[m] + threadIdx.x) : 0.f;
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wreg[m][i] = Elem<T>::ld4(Ws[m] + 4 * (threadIdx.x + 256 * i));
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * (threadIdx.x + 256 * i);
+                    *reinterpret_cast<f32x4*>(&sm_w[m][(e >> 6) * kWStride + (e & 63)]) = wreg[m][i];
+                }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+                    const int f = e >> 6, c = e & 63;
+                    sm_w[m][f * kWStride + c] = (f < D && c < C) ? Elem<T>::ld(Ws[m] + f * C + c) : 0.f;
+                }
         }
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            if (threadIdx.x < 64) sm_b[m][threadIdx.x] = (threadIdx.x < D) ? Elem<T>::ld(bs[m] + threadIdx.x) : 0.f;
     }
     __syncthreads();
 
@@ -211,20 +229,19 @@ __global__ __launch_bounds__(256, 2) void project_reduce_kernel(
     float ksq = st.ksq, qsq = st.qsq;
 
     // ---- fold the 4 waves (fixed order) ------------------------------------------------------
+    // every wave parks its 64 x 64 tile in LDS at once -- waves 0..2 in the weight region (3 x 64 x kWStride floats, no
+    // longer needed), wave 3 in sm_tile -- and after ONE barrier the record write below adds the four copies in the
+    // order ((w0 + w1) + w2) + w3
+    __syncthreads();                                  // all waves are done reading the weights
+    {
+        float* mine = (wave < 3) ? &sm_w[wave][0] : sm_tile;
 #pragma unroll
-    for (int w = 0; w < kPRWaves; ++w) {
-        if (wave == w) {
+        for (int fk = 0; fk < 4; ++fk)
 #pragma unroll
-            for (int fk = 0; fk < 4; ++fk)
+            for (int fv = 0; fv < 4; ++fv)
 #pragma unroll
-                for (int fv = 0; fv < 4; ++fv)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        float* dst = &sm_tile[(16 * fk + 4 * lg + reg) * 64 + 16 * fv + l15];
-                        if (w == 0) *dst = acc[fk][fv][reg]; else *dst += acc[fk][fv][reg];
-                    }
-        }
-        __syncthreads();
+                for (int reg = 0; reg < 4; ++reg)
+                    mine[(16 * fk + 4 * lg + reg) * 64 + 16 * fv + l15] = acc[fk][fv][reg];
     }
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void project_reduce_kernel(
     float* rec_ktv = rec + static_cast<int64_t>(h) * D * D;
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         const int m = e >> 6, d = e & 63;
-        if (m < D && d < D) rec_ktv[m * D + d] = sm_tile[e];
+        if (m < D && d < D) rec_ktv[m * D + d] = ((sm_w[0][e] + sm_w[1][e]) + sm_w[2][e]) + sm_tile[e];
     }
     if (threadIdx.x < 64 && threadIdx.x < D) {
         const int c = threadIdx.x;
@@ -290,12 +307,13 @@ int project_reduce_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* ws = static_cast<float*>(workspace);
     const bool exact = vec && C_in == 64 && D == 64;
+    const int wvec = dif::aligned_v4<T>(Wq) && dif::aligned_v4<T>(Wk) && dif::aligned_v4<T>(Wv);   // H*D*C is a multiple of 4096 here
     if (exact)
         hipLaunchKernelGGL((project_reduce_kernel<true, T>), dim3(P, H), dim3(256), 0, st, x, ldx, n_rows, sh, Wq, bq, Wk,
-                           bk, Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec);
+                           bk, Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec, wvec);
     else
         hipLaunchKernelGGL((project_reduce_kernel<false, T>), dim3(P, H), dim3(256), 0, st, x, ldx, n_rows, sh, Wq, bq,
-                           Wk, bk, Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec);
+                           Wk, bk, Wv, bv, q_out, ldq, v_out, ldv, ws, rec, vec, wvec);
     if (int rc = dif::launch_status("project_reduce_kernel")) return rc;
     return dif::launch_record_finalize(ws, P, rec, sh.t_main, H, reduced, st);
 }
