@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk,
     const T* __restrict__ v, int64_t ldv, int64_t n_rows, Shape sh, float* __restrict__ ws,
     int64_t ws_stride) {
-    __shared__ __attribute__((aligned(16))) float sm_tile[kTile * kTile];
+    __shared__ __attribute__((aligned(16))) float sm_tile[kRedWaves][kTile * kTile];
     __shared__ float sm_k[kRedWaves][kTile];
     __shared__ float sm_v[kRedWaves][kTile];
     __shared__ float sm_s[kRedWaves][2];
@@ -123,21 +123,16 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     }
 
     // ---- fold the 4 waves (fixed order: deterministic) ---------------------------------
-    // lane owns KtV_local[16*lg + 4*reg + t][4*l15 + u]: for fixed (t,reg) the 4 u's are one float4
+    // lane owns KtV_local[16*lg + 4*reg + t][4*l15 + u]: for fixed (t,reg) the 4 u's are one float4.  Every wave parks
+    // its tile in its own LDS slab at once; after the barrier below the record write adds the four slabs in the order
+    // ((w0 + w1) + w2) + w3.
 #pragma unroll
-    for (int w = 0; w < kRedWaves; ++w) {
-        if (wave == w) {
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    f32x4 val = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
-                    f32x4* dst = reinterpret_cast<f32x4*>(&sm_tile[(16 * lg + 4 * reg + t) * kTile + 4 * l15]);
-                    if (w == 0) *dst = val; else *dst += val;
-                }
+        for (int reg = 0; reg < 4; ++reg) {
+            const f32x4 val = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+            *reinterpret_cast<f32x4*>(&sm_tile[wave][(16 * lg + 4 * reg + t) * kTile + 4 * l15]) = val;
         }
-        __syncthreads();
-    }
     // column sums: fold the four 16-lane row groups, then the waves
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -155,7 +150,8 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     float* rec_ktv = rec + static_cast<int64_t>(h) * sh.M * sh.D;
     for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
         const int m = mt * kTile + e / kTile, d = dt * kTile + e % kTile;
-        if (m < sh.M && d < sh.D) rec_ktv[static_cast<int64_t>(m) * sh.D + d] = sm_tile[e];
+        if (m < sh.M && d < sh.D)
+            rec_ktv[static_cast<int64_t>(m) * sh.D + d] = ((sm_tile[0][e] + sm_tile[1][e]) + sm_tile[2][e]) + sm_tile[3][e];
     }
     if (threadIdx.x < kTile) {
         const int c = threadIdx.x;
@@ -214,11 +210,24 @@ __global__ __launch_bounds__(256) void simple_apply_kernel(const T* __restrict__
     if (SINGLE) {
         // the 64x64 record tile is fetched once per workgroup (coalesced) and handed to the lanes'
         // fragment registers through LDS; each wave then streams many 16-row steps with it
-        __shared__ float sm_ktv[kTile * (kTile + 4)];
+        __shared__ __attribute__((aligned(16))) float sm_ktv[kTile * (kTile + 4)];
         __shared__ float sm_ks[kTile];
-        for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
-            const int m = e / kTile, d = e % kTile;
-            sm_ktv[m * (kTile + 4) + d] = (m < sh.M && d < sh.D) ? s * ktv[static_cast<int64_t>(m) * sh.D + d] : 0.f;
+        if (sh.M == kTile && sh.D == kTile) {
+            // full tile: four 16-byte loads per thread, all in flight before the first LDS store (the element loop
+            // below is 16 load -> store round trips)
+            f32x4 r4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r4[i] = *reinterpret_cast<const f32x4*>(ktv + 4 * (threadIdx.x + 256 * i));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * (threadIdx.x + 256 * i);
+                *reinterpret_cast<f32x4*>(&sm_ktv[(e / kTile) * (kTile + 4) + e % kTile]) = s * r4[i];
+            }
+        } else {
+            for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
+                const int m = e / kTile, d = e % kTile;
+                sm_ktv[m * (kTile + 4) + d] = (m < sh.M && d < sh.D) ? s * ktv[static_cast<int64_t>(m) * sh.D + d] : 0.f;
+            }
         }
         if (threadIdx.x < kTile) sm_ks[threadIdx.x] = (threadIdx.x < sh.M) ? s * ksum[threadIdx.x] : 0.f;
         __syncthreads();

@@ -42,11 +42,21 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
     float* sm_w = sm;                                       // [nblk*64][kLinStride], block-local row 16 (f%4) + (f%64)/4
     float* sm_b = sm + nblk * 64 * kLinStride;              // [nblk*64] bias in feature order
 
-    for (int e = threadIdx.x; e < nblk * 64 * 64; e += 256) {
-        const int f = e >> 6, c = e & 63;
-        const int row = (f & ~63) + 16 * (f & 3) + ((f & 63) >> 2);
-        sm_w[row * kLinStride + c] =
-            (f0 + f < C_out && c < C_in) ? Elem<T>::ld(W + static_cast<int64_t>(f0 + f) * C_in + c) : 0.f;
+    // 8 loads in flight per thread before their LDS stores (a plain load -> store loop is 16 round trips per block)
+    for (int base = threadIdx.x; base < nblk * 64 * 64; base += 256 * 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + 256 * u;                      // nblk * 4096 is a multiple of 2048: e stays in range
+            const int f = e >> 6, c = e & 63;
+            wv[u] = (f0 + f < C_out && c < C_in) ? Elem<T>::ld(W + static_cast<int64_t>(f0 + f) * C_in + c) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + 256 * u;
+            const int f = e >> 6, c = e & 63;
+            sm_w[((f & ~63) + 16 * (f & 3) + ((f & 63) >> 2)) * kLinStride + c] = wv[u];
+        }
     }
     for (int f = threadIdx.x; f < nblk * 64; f += 256) sm_b[f] = (f0 + f < C_out) ? Elem<T>::ld(bias + f0 + f) : 0.f;
     __syncthreads();
