@@ -9,8 +9,9 @@ it.  Nothing under `difformer_amd/` imports it.
 Parity pinning: the reference ships no golden vectors / KATs for this path
 (SURVEY.md section 8c).  The oracle is therefore pinned against outputs of the
 reference *itself*, generated in the build container by importing the
-reference source verbatim (`tests/golden/make_golden.py`, fixtures under
-`tests/golden/*.npz`).  `tests/test_oracle_golden.py` checks every function
+reference source verbatim (`tests/golden/make_golden.py` for
+`node classification/difformer.py`, `tests/golden/make_golden_v2.py` for
+`physical particle/difformer-v2.py`; fixtures under `tests/golden/*.npz`).  `tests/test_oracle_golden.py` checks every function
 here against those fixtures.
 
 Every function cites the reference lines it restates.  All arithmetic runs in
