@@ -22,52 +22,136 @@ namespace {
 using dif::f32x4;
 using dif::Elem;
 
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// W floats of a feature row per lane.  W = 8 serves bfloat16 storage in the blocked kernel: 8 elements are one
+// 16-byte load, so a 64-wide row is 8 lanes x 16 B = ONE 128-byte line (W = 4 would fetch it with 8-byte loads,
+// which the texture path runs at ~0.6x the rate).
 template <int W> struct Vec;
+template <> struct Vec<8> { using T = f32x8; };
 template <> struct Vec<4> { using T = f32x4; };
 template <> struct Vec<1> { using T = float; };
 
 template <int W>
 __device__ __forceinline__ typename Vec<W>::T vzero() {
-    if constexpr (W == 4) return f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (W == 8) return f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    else if constexpr (W == 4) return f32x4{0.f, 0.f, 0.f, 0.f};
     else return 0.f;
 }
 
 template <int W>
 __device__ __forceinline__ typename Vec<W>::T vload(const float* p) {
-    if constexpr (W == 4) return *reinterpret_cast<const f32x4*>(p);
+    if constexpr (W == 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    } else if constexpr (W == 4) return *reinterpret_cast<const f32x4*>(p);
     else return *p;
 }
 
 template <int W>
 __device__ __forceinline__ void vstore(float* p, typename Vec<W>::T v) {
-    if constexpr (W == 4) *reinterpret_cast<f32x4*>(p) = v;
+    if constexpr (W == 8) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else if constexpr (W == 4) *reinterpret_cast<f32x4*>(p) = v;
     else *p = v;
 }
 
 // global-memory row pieces in the storage type E (float | dif::bf16); registers and LDS stay fp32
 template <int W, typename E>
 __device__ __forceinline__ typename Vec<W>::T gload(const E* p) {
-    if constexpr (W == 4) return Elem<E>::ld4(p);
+    if constexpr (W == 8) {
+        if constexpr (sizeof(E) == 2) {                       // 8 bfloat16 = one 16-byte load
+            const uint4 r = *reinterpret_cast<const uint4*>(p);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+            f32x8 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = __uint_as_float(w[i] << 16);
+                v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            }
+            return v;
+        } else {
+            const f32x4 a = Elem<E>::ld4(p), b = Elem<E>::ld4(p + 4);
+            return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        }
+    } else if constexpr (W == 4) return Elem<E>::ld4(p);
     else return Elem<E>::ld(p);
 }
 
 template <int W, typename E>
 __device__ __forceinline__ void gstore(E* p, typename Vec<W>::T v) {
-    if constexpr (W == 4) Elem<E>::st4(p, v);
+    if constexpr (W == 8) {
+        Elem<E>::st4(p, f32x4{v[0], v[1], v[2], v[3]});
+        Elem<E>::st4(p + 4, f32x4{v[4], v[5], v[6], v[7]});
+    } else if constexpr (W == 4) Elem<E>::st4(p, v);
     else Elem<E>::st(p, v);
 }
 
 template <int W>
 __device__ __forceinline__ typename Vec<W>::T vshfl_xor(typename Vec<W>::T v, int m) {
-    if constexpr (W == 4) {
-        f32x4 r;
+    if constexpr (W > 1) {
+        typename Vec<W>::T r;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = __shfl_xor(v[i], m, 64);
+        for (int i = 0; i < W; ++i) r[i] = __shfl_xor(v[i], m, 64);
         return r;
     } else {
         return __shfl_xor(v, m, 64);
     }
 }
+
+// sum of the W components (left to right) / of their squares
+template <int W>
+__device__ __forceinline__ float vsum(typename Vec<W>::T v) {
+    if constexpr (W > 1) {
+        float s = v[0];
+#pragma unroll
+        for (int i = 1; i < W; ++i) s += v[i];
+        return s;
+    } else {
+        return v;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ float vsumsq(typename Vec<W>::T v) {
+    if constexpr (W > 1) {
+        float s = v[0] * v[0];
+#pragma unroll
+        for (int i = 1; i < W; ++i) s += v[i] * v[i];
+        return s;
+    } else {
+        return v * v;
+    }
+}
+
+// A gathered row piece as it sits in registers between the load and the FMA.  bfloat16 x 8 stays PACKED (4 registers
+// instead of 8): eight gathers in flight then cost the same 32 registers as in fp32 -- the blocked kernel is bound by
+// the gathers a wave keeps in flight, so unpacking at load time (and halving the unroll to fit the register budget)
+// gave no gain over fp32 rows (1.16 ms at C4).
+template <int W, typename E>
+struct Packed {
+    using T = typename Vec<W>::T;
+    static __device__ __forceinline__ T load(const E* p) { return gload<W, E>(p); }
+    static __device__ __forceinline__ T zero() { return vzero<W>(); }
+    static __device__ __forceinline__ typename Vec<W>::T unpack(T r) { return r; }
+};
+template <>
+struct Packed<8, dif::bf16> {
+    using T = uint4;
+    static __device__ __forceinline__ T load(const dif::bf16* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ T zero() { return uint4{0u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ f32x8 unpack(T r) {
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        f32x8 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+        return v;
+    }
+};
 
 // Optional fused layer tail (H == 1 only; difformer.py:139-140, :200-203): applied to the finished
 // row `o` held by a G-lane group (W floats per lane, lanes with col >= F inactive).
@@ -92,7 +176,7 @@ __device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, c
     if (t.ln_w) {   // wave-uniform
         const float inv_d = 1.0f / static_cast<float>(F);
         float s = 0.f;
-        if (ok) { if constexpr (W == 4) s = o[0] + o[1] + o[2] + o[3]; else s = o; }
+        if (ok) s = vsum<W>(o);
 #pragma unroll
         for (int m = 1; m < G; m <<= 1) s += __shfl_xor(s, m, 64);
         const float mu = s * inv_d;
@@ -100,7 +184,7 @@ __device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, c
         float v = 0.f;
         if (ok) {
             dz = o - mu;
-            if constexpr (W == 4) v = dz[0] * dz[0] + dz[1] * dz[1] + dz[2] * dz[2] + dz[3] * dz[3]; else v = dz * dz;
+            v = vsumsq<W>(dz);
         }
 #pragma unroll
         for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
@@ -108,7 +192,7 @@ __device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, c
         if (ok) o = dz * rstd * gload<W, E>(t.ln_w + col) + gload<W, E>(t.ln_b + col);
     }
     if (t.relu) {
-        if constexpr (W == 4) { for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f); } else o = fmaxf(o, 0.f);
+        if constexpr (W > 1) { for (int i = 0; i < W; ++i) o[i] = fmaxf(o[i], 0.f); } else o = fmaxf(o, 0.f);
     }
     return o;
 }
@@ -243,6 +327,7 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
     E* __restrict__ out, int64_t ldo, int rpw, const int32_t* __restrict__ order, int64_t n_split) {
     using V = typename Vec<W>::T;
     constexpr int S = 64 / G;       // rows walked concurrently by one wave
+    constexpr int kPre = (G >= 16) ? kBlkPre : 64 / G;   // chunks prefetched per group: >= 64 entries (6 chunks: +3 %)
     constexpr int RW = G * W;       // floats of LDS per accumulator row
     constexpr int kLdsFloats = kBlkLdsBytesPerCU / 4 / WPC;
     __shared__ __attribute__((aligned(16))) float acc_lds[kLdsFloats];
@@ -314,10 +399,10 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
         // entries of the NEXT row-quad (of this block, or the first quad of the next block) are always in flight
         // while the current quad gathers
         int32_t e0n = __shfl(e0v, slot, 64), e1n = __shfl(e1v, slot, 64);
-        int32_t sn[kBlkPre];
-        float wn[kBlkPre];
+        int32_t sn[kPre];
+        float wn[kPre];
 #pragma unroll
-        for (int c = 0; c < kBlkPre; ++c) {
+        for (int c = 0; c < kPre; ++c) {
             const int32_t idx = e0n + c * G + li;
             const bool ok = idx < e1n;
             sn[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
@@ -338,10 +423,10 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
             for (int q = 0; q < nq; ++q) {
                 const int rl = q * S + slot;
                 const int32_t e0 = e0n, e1 = e1n;
-                int32_t sv[kBlkPre];
-                float wv[kBlkPre];
+                int32_t sv[kPre];
+                float wv[kPre];
 #pragma unroll
-                for (int c = 0; c < kBlkPre; ++c) { sv[c] = sn[c]; wv[c] = wn[c]; }
+                for (int c = 0; c < kPre; ++c) { sv[c] = sn[c]; wv[c] = wn[c]; }
                 if (q + 1 < nq || b + 1 < n_blocks) {
                     if (q + 1 < nq) {
                         e0n = __shfl(e0v, rl + S, 64);
@@ -351,7 +436,7 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                         e1n = __shfl(e1x, slot, 64);
                     }
 #pragma unroll
-                    for (int c = 0; c < kBlkPre; ++c) {
+                    for (int c = 0; c < kPre; ++c) {
                         const int32_t idx = e0n + c * G + li;
                         const bool ok = idx < e1n;
                         sn[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
@@ -367,10 +452,10 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                 }
                 if (maxlen <= 0) continue;
                 V acc = vzero<W>();
-                for (int c0 = 0; c0 < maxlen; c0 += kBlkPre * G) {
-                    if (c0 > 0) {  // rare: a group longer than kBlkPre*G entries
+                for (int c0 = 0; c0 < maxlen; c0 += kPre * G) {
+                    if (c0 > 0) {  // rare: a group longer than kPre*G entries
 #pragma unroll
-                        for (int c = 0; c < kBlkPre; ++c) {
+                        for (int c = 0; c < kPre; ++c) {
                             const int32_t idx = e0 + c0 + c * G + li;
                             const bool ok = idx < e1;
                             sv[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
@@ -378,11 +463,11 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                         }
                     }
 #pragma unroll
-                    for (int c = 0; c < kBlkPre; ++c) {
+                    for (int c = 0; c < kPre; ++c) {
 #pragma unroll
                         for (int j0 = 0; j0 < G; j0 += UNROLL) {
                             if (c0 + c * G + j0 < maxlen) {        // wave-uniform
-                                V xv[UNROLL];
+                                typename Packed<W, E>::T xv[UNROLL];
                                 float w[UNROLL];
 #pragma unroll
                                 for (int u = 0; u < UNROLL; ++u) {
@@ -393,10 +478,10 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                                     const bool take = active && (c0 + c * G + j0 + u < len);
                                     const int32_t sidx = __shfl(sv[c], from, 64);
                                     w[u] = __shfl(wv[c], from, 64);
-                                    xv[u] = take ? gload<W, E>(xcol + row_off<WIDE>(sidx, ldx)) : vzero<W>();
+                                    xv[u] = take ? Packed<W, E>::load(xcol + row_off<WIDE>(sidx, ldx)) : Packed<W, E>::zero();
                                 }
 #pragma unroll
-                                for (int u = 0; u < UNROLL; ++u) acc += w[u] * xv[u];
+                                for (int u = 0; u < UNROLL; ++u) acc += w[u] * Packed<W, E>::unpack(xv[u]);
                             }
                         }
                     }
@@ -567,12 +652,25 @@ static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n_blocks > 1 && vec && F <= 256 && nnz > 0) {
-#define DIF_BLK(G) \
-    return launch_blocked<G, 4, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, \
+#define DIF_BLK(G, W) \
+    return launch_blocked<G, W, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, \
                                    attn_scale, gcn_scale, tail, out, ldo, order, n_split)
-        if (F <= 64) DIF_BLK(16);
-        if (F <= 128) DIF_BLK(32);
-        DIF_BLK(64);
+        if constexpr (sizeof(E) == 2) {
+            // bfloat16 rows: 8 elements per lane = 16-byte gathers (a 64-wide row is one 128-byte line)
+            auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+            const bool v8 = (F % 8 == 0) && (ldx % 8 == 0) && (ldo % 8 == 0) && (!attn || lda % 8 == 0) && a16(x) &&
+                            a16(out) && (!attn || a16(attn)) && (!tail.x0 || (tail.ldx0 % 8 == 0 && a16(tail.x0))) &&
+                            (!tail.prev || (tail.ldp % 8 == 0 && a16(tail.prev))) &&
+                            (!tail.ln_w || (a16(tail.ln_w) && a16(tail.ln_b)));
+            if (v8) {
+                if (F <= 64) DIF_BLK(8, 8);
+                if (F <= 128) DIF_BLK(16, 8);
+                DIF_BLK(32, 8);
+            }
+        }
+        if (F <= 64) DIF_BLK(16, 4);
+        if (F <= 128) DIF_BLK(32, 4);
+        DIF_BLK(64, 4);
 #undef DIF_BLK
     }
     // row mapping: a whole wave per row pays off once a row keeps the wave's gather slots busy

@@ -1042,3 +1042,25 @@ def test_empty_inputs_raise(dev):
     q = torch.zeros(0, 1, 8, device=dev)
     with pytest.raises(DifformerHipError):
         full_attention_conv(q, q, q, "simple")
+
+
+@pytest.mark.parametrize("d,nb", [(64, 4), (128, 3), (256, 2), (72, 3)])
+def test_bf16_blocked_spmm_wide_lanes_and_row_order(d, nb, dev):
+    """bfloat16 rows in the blocked kernel (8 elements = 16 bytes per lane when the width allows; d = 72 keeps the 4-wide
+    mapping), natural and degree-ordered walks with split hub rows, against the oracle on the bf16-rounded operands."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    n, e = 20000, 1500000
+    ei = _zipf_graph(n, e, d, dev)
+    csr = ops.GraphCSR.build(ei, None, n, nb)
+    g = torch.Generator().manual_seed(d)
+    x, x64 = _bf(torch.randn(n, d, generator=g))
+    a, a64 = _bf(torch.randn(n, d, generator=g))
+    args = (csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, n, csr.nnz, x.to(dev))
+    ref = 2.0 * orc.gcn_conv(x64[:, None, :], ei.cpu().numpy(), None)[:, 0, :] + 0.5 * a64
+    order = csr.row_order(0, n)
+    assert order is not None and order[1] > 0
+    for o in (None, order):
+        out = be.spmm(*args, 0, n, a.to(dev), 0.5, 2.0, None, o)
+        assert out.dtype == torch.bfloat16
+        assert rel_err(out.float().cpu().numpy(), ref) < BF16_TOL
