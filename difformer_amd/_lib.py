@@ -40,7 +40,12 @@ SIGNATURES = {
     "dif_batched_sigmoid_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                              c_int, c_vp, c_i64, c_vp]),
     "dif_csr_workspace_bytes": (c_sz, [c_i64, c_i64, c_int]),
-    "dif_csr_build": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dif_csr_build": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+                              c_vp]),
+    "dif_gcn_spmm_part_scratch_bytes": (c_sz, [c_i64, c_i64, c_int]),
+    "dif_gcn_spmm_part_f32": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int,
+                                      c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,
+                                      c_vp, c_vp, c_f32, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp, c_i64, c_vp]),
     "dif_subgraph_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "dif_subgraph": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_gcn_spmm_f32": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int,
@@ -57,6 +62,7 @@ SIGNATURES = {
 # bfloat16 storage variants share the argument lists of their float32 twins
 for _n in ("dif_linear", "dif_project_reduce", "dif_simple_reduce", "dif_simple_apply", "dif_layer_tail"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f32"]
+SIGNATURES["dif_gcn_spmm_part_bf16"] = SIGNATURES["dif_gcn_spmm_part_f32"]
 SIGNATURES["dif_gcn_spmm_tail_bf16"] = (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64,
                                                 c_int, c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,
                                                 c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp])

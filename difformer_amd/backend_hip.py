@@ -286,7 +286,7 @@ class HipBackend:
         return out
 
     # ---- a3 --------------------------------------------------------------------------------
-    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
+    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False, block_rows=0):
         dev = _require_device(edge_index, edge_weight)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise TypeError("difformer_amd: edge_index must be an int64 tensor of shape [2, E]")
@@ -307,7 +307,7 @@ class HipBackend:
         ws_bytes = self.lib.dif_csr_workspace_bytes(E, num_nodes, n_blocks)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _Timed(self, "dif_csr_build", dev):
-            rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), n_blocks, int(bool(transpose)), _ptr(rowptr),
+            rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), n_blocks, int(block_rows), int(bool(transpose)), _ptr(rowptr),
                                         _ptr(blkptr),
                                         _ptr(src), _ptr(val), _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_csr_build")
@@ -341,8 +341,12 @@ class HipBackend:
         return out, (None if out_w is None else out_w[:kept].clone())
 
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
-             gcn_scale=1.0, tail=None, order=None):
+             gcn_scale=1.0, tail=None, order=None, part=None):
         """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps[, relu]): fuse the layer tail (H == 1).
+        part = None | (0 | 1, own_blk_begin, own_blk_end, scratch | None, x_row0): one half of a split product
+        (row-sharded runs).  Part 0 takes `x` = this rank's OWN value rows, whose first row is source row x_row0 (the
+        sources of blocks own_blk_begin .. own_blk_end-1), parks the accumulators and returns the scratch tensor; part 1
+        takes all n_nodes gathered rows plus that scratch and returns the finished rows.
         order = None | (int32 [n_rows], n_split) from row_order(): degree-sorted rows (the first n_split of them split
         over a whole quad) for the blocked kernel's load balance."""
         order, n_split = order if order is not None else (None, 0)
@@ -356,7 +360,8 @@ class HipBackend:
         dt, sfx = _storage(x, attn, x0, prev, lw, lb)
         _f32(val, "CSR values")
         x, ldx = _row_major(x, F)
-        if x.shape[0] != n_nodes:
+        phase, own_lo, own_hi, scratch, x_row0 = part if part is not None else (None, 0, 0, None, 0)
+        if phase != 0 and x.shape[0] != n_nodes:
             raise ValueError(f"difformer_amd: spmm needs all {n_nodes} source rows, got {x.shape[0]}")
         lda = ldx0 = ldp = 0
         if attn is not None:
@@ -372,6 +377,20 @@ class HipBackend:
                 _ptr(attn), lda, float(attn_scale), float(gcn_scale), _ptr(order), int(n_split))
         tail_args = (_ptr(x0), ldx0, _ptr(prev), ldp, float(t.get("alpha", 0.5)), _ptr(lw), _ptr(lb),
                      float(t.get("eps", 1e-5)), int(bool(t.get("relu", False))))
+        if part is not None:
+            sbytes = self.lib.dif_gcn_spmm_part_scratch_bytes(n_rows, int(n_split), F)
+            if scratch is None:
+                scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+            # part 0 indexes x by GLOBAL source row but only ever touches this rank's own rows: hand it the pointer
+            # the first own row would have inside a full [n_nodes, F] array
+            xp = ctypes.c_void_p(x.data_ptr() - int(x_row0) * ldx * x.element_size())
+            head = head[:7] + (xp,) + head[8:]
+            fn = self.lib.dif_gcn_spmm_part_bf16 if sfx == "bf16" else self.lib.dif_gcn_spmm_part_f32
+            with _Timed(self, "dif_gcn_spmm_f32", dev):
+                rc = fn(*head, int(tail is not None), *tail_args, int(phase), int(own_lo), int(own_hi), _ptr(scratch), sbytes,
+                        _ptr(out), F, _stream(dev))
+            _lib.check(rc, "dif_gcn_spmm_part")
+            return scratch if phase == 0 else out
         with _Timed(self, "dif_gcn_spmm_f32", dev):
             if sfx == "bf16":
                 name = "dif_gcn_spmm_tail_bf16"

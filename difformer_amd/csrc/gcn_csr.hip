@@ -44,11 +44,11 @@ struct Plan {
     size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_deg, off_dinv, off_degc, off_table, off_bsum, total;
 };
 
-Plan make_plan(int64_t E, int64_t N, int64_t NB) {
+Plan make_plan(int64_t E, int64_t N, int64_t NB, int64_t block_rows = 0) {
     Plan p;
     p.E = E; p.N = N;
     p.NB = NB < 1 ? 1 : NB;
-    p.block_rows = (N + p.NB - 1) / p.NB;
+    p.block_rows = block_rows > 0 ? block_rows : (N + p.NB - 1) / p.NB;
     p.n_keys = N * p.NB;
     int64_t rounds = (E + 64 * 4096 - 1) / (64 * 4096);     // aim at ~4096 waves
     if (rounds < kSortRoundsMin) rounds = kSortRoundsMin;
@@ -372,7 +372,7 @@ extern "C" size_t dif_csr_workspace_bytes(int64_t E, int64_t N, int n_blocks) {
 }
 
 extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, const float* edge_weight,
-                             int n_blocks, int transpose, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
+                             int n_blocks, int64_t block_rows, int transpose, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
                              int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
     DIF_REQUIRE(N > 0 && E >= 0 && n_blocks >= 1, DIF_E_BADARG, "dif_csr_build: need N > 0, E >= 0, n_blocks >= 1");
     DIF_REQUIRE(E < (int64_t(1) << 31) - 4096 && N < (int64_t(1) << 31) - 1, DIF_E_RANGE,
@@ -383,7 +383,9 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     DIF_REQUIRE(rowptr && status && workspace && (E == 0 || (edge_index && src && val)), DIF_E_BADARG,
                 "dif_csr_build: null pointer");
     DIF_REQUIRE(n_blocks == 1 || blkptr, DIF_E_BADARG, "dif_csr_build: n_blocks > 1 needs blkptr");
-    const Plan p = make_plan(E, N, n_blocks);
+    DIF_REQUIRE(block_rows >= 0 && (block_rows == 0 || block_rows * n_blocks >= N), DIF_E_BADARG,
+                "dif_csr_build: block_rows * n_blocks must cover N (block_rows = 0: ceil(N / n_blocks))");
+    const Plan p = make_plan(E, N, n_blocks, block_rows);
     DIF_REQUIRE(workspace_bytes >= p.total, DIF_E_WORKSPACE, "dif_csr_build: workspace too small (%zu < %zu)",
                 workspace_bytes, p.total);
     DIF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DIF_E_BADARG,

@@ -312,6 +312,18 @@ __global__ __launch_bounds__(256) void spmm_group_row_kernel(
 // Inside a block visit the wave's S = 64/G lane groups each walk one row's group of entries:
 // G entries are fetched per lane group with one coalesced (non-temporal) load of src/val, then
 // handed out by ds_bpermute, so there is no per-entry index load and no cross-lane reduction.
+// Which source blocks a launch sweeps, and where its accumulators start / end up.  A row-sharded run (dist.py) splits
+// the product in two launches so that the all-gather of the value rows hides behind the first one:
+//   part 0: only the blocks [first, end) whose sources are this rank's OWN rows (available before the collective),
+//           accumulators dumped to `acc_out` (the LDS image of every panel, fp32) instead of the epilogue;
+//   part 1: all other blocks (skip_lo..skip_hi-1 left out), accumulators preloaded from `acc_in`, normal epilogue.
+// A whole product is {0, -1, -1, n_blocks, nullptr, nullptr}.
+struct Sweep {
+    int first, skip_lo, skip_hi, end;
+    const float* acc_in;
+    float* acc_out;
+};
+
 constexpr int kBlkWaves = 16;          // waves per workgroup
 constexpr int kBlkLdsBytesPerCU = 147456;  // 144 KiB of the CU's 160 KiB for accumulators
 constexpr int kBlkPre = 4;             // G-entry chunks of a (row, block) group fetched in one batch
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
     const int32_t* __restrict__ blkptr, int64_t n_nodes, int n_blocks, const int32_t* __restrict__ src,
     const float* __restrict__ val, const E* __restrict__ x, int64_t ldx, int64_t row_begin, int64_t n_rows,
     int F, const E* __restrict__ attn, int64_t lda, float attn_scale, float gcn_scale, Tail<E> tail,
-    E* __restrict__ out, int64_t ldo, int rpw, const int32_t* __restrict__ order, int64_t n_split) {
+    E* __restrict__ out, int64_t ldo, int rpw, const int32_t* __restrict__ order, int64_t n_split, Sweep sw) {
     using V = typename Vec<W>::T;
     constexpr int S = 64 / G;       // rows walked concurrently by one wave
     constexpr int kPre = (G >= 16) ? kBlkPre : 64 / G;   // chunks prefetched per group: >= 64 entries (6 chunks: +3 %)
@@ -389,12 +401,21 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                 nq = static_cast<int>(((left < rpw ? left : rpw) + S - 1) / S);
             }
         }
-        for (int i = lane; i < rpw * RW; i += 64) my[i] = 0.f;
+        if (sw.acc_in && has) {
+            const float* img = sw.acc_in + panel * (rpw * RW);
+            for (int i = lane; i < rpw * RW; i += 64) my[i] = img[i];
+        } else {
+            for (int i = lane; i < rpw * RW; i += 64) my[i] = 0.f;
+        }
 
         // (row, block) group pointers of the current and of the next block, one lane per row of the panel
         const int32_t* pb = blkptr + row_begin + lrow;
-        int32_t e0v = mine ? pb[0] : 0;
-        int32_t e1v = mine ? pb[n_nodes] : 0;
+        int32_t e0v = 0, e1v = 0;
+        if (sw.first < sw.end) {
+            const int32_t* p0 = pb + static_cast<int64_t>(sw.first) * n_nodes;
+            e0v = mine ? p0[0] : 0;
+            e1v = mine ? p0[n_nodes] : 0;
+        }
         part_of(e0v, e1v);
         // entries of the NEXT row-quad (of this block, or the first quad of the next block) are always in flight
         // while the current quad gathers
@@ -408,14 +429,15 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
             sn[c] = ok ? __builtin_nontemporal_load(src + idx) : 0;
             wn[c] = ok ? __builtin_nontemporal_load(val + idx) : 0.f;
         }
-        for (int b = 0; b < n_blocks; ++b) {
+        for (int b = sw.first, nb; b < sw.end; b = nb) {
+            nb = (b + 1 == sw.skip_lo) ? sw.skip_hi : b + 1;       // next block of this launch's sweep
             // pace the workgroup's 16 waves block by block: without it they drift apart over the sweep, the
             // XCD's L2 has to hold two source blocks and ~24 % of the gathers miss (PMC FETCH_SIZE per launch
             // at C4: 5.8 GB unpaced -> 1.34 GB paced, 1.0 GB compulsory; 1.29 -> 1.19 ms)
             if (PACE) __syncthreads();
             int32_t e0x = 0, e1x = 0;     // pointers of block b+1, requested a whole block ahead
-            if (b + 1 < n_blocks) {
-                const int32_t* pn = pb + static_cast<int64_t>(b + 1) * n_nodes;
+            if (nb < sw.end) {
+                const int32_t* pn = pb + static_cast<int64_t>(nb) * n_nodes;
                 e0x = mine ? pn[0] : 0;
                 e1x = mine ? pn[n_nodes] : 0;
                 part_of(e0x, e1x);
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                 float wv[kPre];
 #pragma unroll
                 for (int c = 0; c < kPre; ++c) { sv[c] = sn[c]; wv[c] = wn[c]; }
-                if (q + 1 < nq || b + 1 < n_blocks) {
+                if (q + 1 < nq || nb < sw.end) {
                     if (q + 1 < nq) {
                         e0n = __shfl(e0v, rl + S, 64);
                         e1n = __shfl(e1v, rl + S, 64);
@@ -494,6 +516,13 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
             e0v = e0x;
             e1v = e1x;
         }
+        if (sw.acc_out) {       // part 0 of a split product: park the accumulators, no epilogue
+            if (has) {
+                float* img = sw.acc_out + panel * (rpw * RW);
+                for (int i = lane; i < rpw * RW; i += 64) img[i] = my[i];
+            }
+            continue;
+        }
         // panel epilogue: S rows per step, each a full contiguous row segment
         for (int q = 0; q < nq; ++q) {
             const int rl = q * S + slot;
@@ -522,7 +551,7 @@ template <int G, int W, int WPC, int UNROLL, typename E>
 int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
                      const float* val, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                      const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail, E* out,
-                     int64_t ldo, const int32_t* order, int64_t n_split) {
+                     int64_t ldo, const int32_t* order, int64_t n_split, const Sweep& sw) {
     constexpr int S = 64 / G;
     constexpr int RW = G * W;
     constexpr int kLdsFloats = kBlkLdsBytesPerCU / 4 / WPC;
@@ -554,7 +583,7 @@ int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int
 #define DIF_BLK_LAUNCH(WIDEV, ORDV) \
     hipLaunchKernelGGL((spmm_blocked_kernel<G, W, WPC, UNROLL, true, WIDEV, ORDV, E>), dim3(static_cast<unsigned>(grid)), \
                        dim3(64 * kBlkWaves), 0, st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, \
-                       lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw), order, n_split)
+                       lda, attn_scale, gcn_scale, tail, out, ldo, static_cast<int>(rpw), order, n_split, sw)
     if (order) { if (wide) DIF_BLK_LAUNCH(true, true); else DIF_BLK_LAUNCH(false, true); }
     else { if (wide) DIF_BLK_LAUNCH(true, false); else DIF_BLK_LAUNCH(false, false); }
 #undef DIF_BLK_LAUNCH
@@ -565,11 +594,11 @@ template <int G, int W, typename E>
 int launch_blocked(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int n_blocks, const int32_t* src,
                    const float* val, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                    const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail, E* out,
-                   int64_t ldo, const int32_t* order, int64_t n_split) {
+                   int64_t ldo, const int32_t* order, int64_t n_split, const Sweep& sw) {
     // 1 workgroup (16 waves) per CU, 8 gathers in flight per wave: best of the measured variants
     // (2 workgroups per CU need a 64-VGPR budget and spill)
     return launch_blocked_v<G, W, 1, 8, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn,
-                                        lda, attn_scale, gcn_scale, tail, out, ldo, order, n_split);
+                                        lda, attn_scale, gcn_scale, tail, out, ldo, order, n_split, sw);
 }
 
 template <int G, int W, typename E>
@@ -625,7 +654,8 @@ template <typename E>
 static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src, const float* val,
                       int64_t n_nodes, int64_t nnz, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows,
                       int F, const E* attn, int64_t lda, float attn_scale, float gcn_scale, const Tail<E>& tail,
-                      E* out, int64_t ldo, const int32_t* order, int64_t n_split, dif_stream_t stream) {
+                      E* out, int64_t ldo, const int32_t* order, int64_t n_split, dif_stream_t stream,
+                      const Sweep* part = nullptr) {
     DIF_REQUIRE(n_rows > 0 && F > 0 && row_begin >= 0 && n_nodes > 0 && nnz >= 0 && n_blocks >= 1, DIF_E_BADARG,
                 "dif_gcn_spmm: need n_rows > 0, F > 0, row_begin >= 0, n_nodes > 0, nnz >= 0, n_blocks >= 1");
     DIF_REQUIRE(row_begin + n_rows <= n_nodes, DIF_E_BADARG, "dif_gcn_spmm: row range exceeds n_nodes");
@@ -651,10 +681,13 @@ static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks
                     vec ? 256 : 64);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const Sweep sw = part ? *part : Sweep{0, -1, -1, n_blocks, nullptr, nullptr};
+    DIF_REQUIRE(!part || (n_blocks > 1 && vec && F <= 256 && nnz > 0), DIF_E_SHAPE,
+                "dif_gcn_spmm_part: split products run on the blocked kernel only (n_blocks > 1, F %% 4 == 0, F <= 256, aligned)");
     if (n_blocks > 1 && vec && F <= 256 && nnz > 0) {
 #define DIF_BLK(G, W) \
     return launch_blocked<G, W, E>(st, blkptr, n_nodes, n_blocks, src, val, x, ldx, row_begin, n_rows, F, attn, lda, \
-                                   attn_scale, gcn_scale, tail, out, ldo, order, n_split)
+                                   attn_scale, gcn_scale, tail, out, ldo, order, n_split, sw)
         if constexpr (sizeof(E) == 2) {
             // bfloat16 rows: 8 elements per lane = 16-byte gathers (a 64-wide row is one 128-byte line)
             auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
@@ -718,4 +751,72 @@ extern "C" int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkp
     if (tail_enabled) tail = Tail<B>{c(x0), ldx0, c(prev), ldp, alpha, c(ln_weight), c(ln_bias), ln_eps, 1, relu};
     return spmm_entry<B>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, c(x), ldx, row_begin, n_rows, F, c(attn), lda,
                          attn_scale, gcn_scale, tail, static_cast<B*>(out), ldo, row_order, n_split_rows, stream);
+}
+
+// ---- split product for row-sharded runs (dist.py): part 0 = the blocks whose sources are this rank's own rows (run
+// ---- while the all-gather of the value rows is in flight), part 1 = everything else + the epilogue -----------------
+extern "C" size_t dif_gcn_spmm_part_scratch_bytes(int64_t n_rows, int64_t n_split_rows, int F) {
+    if (n_rows <= 0 || F <= 0 || n_split_rows < 0) return 0;
+    int rw = 64;                                   // floats per accumulator row: G * W of the blocked kernel
+    while (rw < F) rw *= 2;
+    // panels * rows-per-panel <= rows + 3 per split row + one panel (<= 64 rows) + one quad of padding
+    return static_cast<size_t>(n_rows + 3 * n_split_rows + 128) * rw * sizeof(float);
+}
+
+template <typename E>
+static int spmm_part_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src, const float* val,
+                           int64_t n_nodes, int64_t nnz, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                           const E* attn, int64_t lda, float attn_scale, float gcn_scale, const int32_t* row_order,
+                           int64_t n_split_rows, const Tail<E>& tail, int part, int own_blk_begin, int own_blk_end,
+                           float* scratch, size_t scratch_bytes, E* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(part == 0 || part == 1, DIF_E_BADARG, "dif_gcn_spmm_part: part must be 0 or 1");
+    DIF_REQUIRE(0 <= own_blk_begin && own_blk_begin <= own_blk_end && own_blk_end <= n_blocks, DIF_E_BADARG,
+                "dif_gcn_spmm_part: own block range [%d, %d) outside [0, %d]", own_blk_begin, own_blk_end, n_blocks);
+    DIF_REQUIRE(scratch && scratch_bytes >= dif_gcn_spmm_part_scratch_bytes(n_rows, n_split_rows, F), DIF_E_WORKSPACE,
+                "dif_gcn_spmm_part: scratch too small");
+    Sweep sw;
+    if (part == 0) {
+        sw = Sweep{own_blk_begin, -1, -1, own_blk_end, nullptr, scratch};
+    } else {
+        const bool none = own_blk_begin == own_blk_end;
+        sw = Sweep{(!none && own_blk_begin == 0) ? own_blk_end : 0, none ? -1 : own_blk_begin, none ? -1 : own_blk_end,
+                   n_blocks, scratch, nullptr};
+    }
+    Tail<E> t = tail;
+    if (part == 0) t = Tail<E>{};
+    return spmm_entry<E>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F,
+                         part == 0 ? nullptr : attn, lda, attn_scale, gcn_scale, t, out, ldo, row_order, n_split_rows, stream,
+                         &sw);
+}
+
+extern "C" int dif_gcn_spmm_part_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
+                                     const float* val, int64_t n_nodes, int64_t nnz, const float* x, int64_t ldx,
+                                     int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
+                                     float attn_scale, float gcn_scale, const int32_t* row_order, int64_t n_split_rows,
+                                     int tail_enabled, const float* x0, int64_t ldx0, const float* prev, int64_t ldp,
+                                     float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                                     int part, int own_blk_begin, int own_blk_end, float* scratch, size_t scratch_bytes,
+                                     float* out, int64_t ldo, dif_stream_t stream) {
+    Tail<float> tail = {};
+    if (tail_enabled) tail = Tail<float>{x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, 1, relu};
+    return spmm_part_entry<float>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
+                                  attn_scale, gcn_scale, row_order, n_split_rows, tail, part, own_blk_begin, own_blk_end,
+                                  scratch, scratch_bytes, out, ldo, stream);
+}
+
+extern "C" int dif_gcn_spmm_part_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
+                                      const float* val, int64_t n_nodes, int64_t nnz, const void* x, int64_t ldx,
+                                      int64_t row_begin, int64_t n_rows, int F, const void* attn, int64_t lda,
+                                      float attn_scale, float gcn_scale, const int32_t* row_order, int64_t n_split_rows,
+                                      int tail_enabled, const void* x0, int64_t ldx0, const void* prev, int64_t ldp,
+                                      float alpha, const void* ln_weight, const void* ln_bias, float ln_eps, int relu,
+                                      int part, int own_blk_begin, int own_blk_end, float* scratch, size_t scratch_bytes,
+                                      void* out, int64_t ldo, dif_stream_t stream) {
+    using B = dif::bf16;
+    auto c = [](const void* p) { return static_cast<const B*>(p); };
+    Tail<B> tail = {};
+    if (tail_enabled) tail = Tail<B>{c(x0), ldx0, c(prev), ldp, alpha, c(ln_weight), c(ln_bias), ln_eps, 1, relu};
+    return spmm_part_entry<B>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, c(x), ldx, row_begin, n_rows, F, c(attn), lda,
+                              attn_scale, gcn_scale, row_order, n_split_rows, tail, part, own_blk_begin, own_blk_end,
+                              scratch, scratch_bytes, static_cast<B*>(out), ldo, stream);
 }

@@ -134,7 +134,7 @@ class DIFFormerConv(nn.Module):
             raise ValueError("use_graph=True needs an edge_index")
         n_global = shard.n_global if shard is not None else v.shape[0]
         esize = (v.local if isinstance(v, ops.GatheredRows) else v).element_size()
-        csr = ops.csr_cache.get(edge_index, edge_weight, n_global, v.shape[1] * v.shape[2] * esize)
+        csr = ops.csr_cache.get(edge_index, edge_weight, n_global, v.shape[1] * v.shape[2] * esize, shard)
         if self.graph_weight > 0:                              # difformer.py:130-132
             a_s, g_s = 1.0 - self.graph_weight, float(self.graph_weight)
         else:                                                  # difformer.py:134

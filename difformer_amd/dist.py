@@ -27,6 +27,10 @@ def split_rows(n_global: int, world: int) -> List[int]:
     remainder.  All blocks then start at multiples of c, so an all-gather of c-row (zero-padded) blocks lands
     every node at its global row index -- no compaction copy after the collective."""
     c = -(-n_global // world)
+    if n_global >= 64 * world * world:
+        # a multiple of 8, so that the blocked SpMM can cut every rank's rows into 1, 2, 4 or 8 whole source blocks
+        # (block boundaries on rank boundaries: the product over a rank's OWN value rows runs before the all-gather lands)
+        c = -(-c // 8) * 8
     counts = []
     left = n_global
     for _ in range(world):

@@ -102,12 +102,33 @@ def choose_source_blocks(num_nodes, row_bytes, nnz):
     return nb
 
 
+def choose_shard_blocks(num_nodes, row_bytes, nnz, shard):
+    """(n_blocks, block_rows) whose block boundaries fall on the rank boundaries of `shard`, or None.  The blocked SpMM
+    of a row-sharded run can then sweep the blocks holding this rank's OWN value rows while the all-gather of the
+    others is still in flight (gcn_aggregate).  Every rank's c rows (a multiple of 8, dist.split_rows) are cut into
+    m in {1, 2, 4, 8} blocks of c / m rows, ~2.5 MiB of x each."""
+    if shard is None or shard.world <= 1 or choose_source_blocks(num_nodes, row_bytes, nnz) <= 1:
+        return None
+    c = shard.counts[0]
+    if any(shard.offsets[r] != r * c for r in range(shard.world)) or c % 8 != 0:
+        return None
+    for m in (1, 2, 4, 8):
+        rows = c // m
+        n_blocks = -(-int(num_nodes) // rows)
+        if rows * row_bytes <= 1.15 * L2_SLICE_BYTES and n_blocks <= 64:
+            # the sweep prefetches up to 64 entries of a (row, block) group: keep the average group at <= ~48 entries
+            if nnz / (float(num_nodes) * n_blocks) <= 48 or m == 8:
+                return n_blocks, rows
+    return None
+
+
 class GraphCSR:
     """Normalised adjacency in CSR over destination rows (built once per graph, on device)."""
 
-    def __init__(self, rowptr, blkptr, n_blocks, src, val, num_nodes, nnz):
+    def __init__(self, rowptr, blkptr, n_blocks, src, val, num_nodes, nnz, block_rows=0):
         self.rowptr, self.blkptr, self.n_blocks, self.src, self.val = rowptr, blkptr, int(n_blocks), src, val
         self.num_nodes, self.nnz = int(num_nodes), int(nnz)
+        self.block_rows = int(block_rows) or -(-int(num_nodes) // int(n_blocks))     # source rows per block
         self._edges = None          # weak references to (edge_index, edge_weight) for the lazily built adjoint
         self._adjoint = None
         self._orders = {}           # (row_begin, n_rows) -> rows by descending degree (blocked SpMM load balance)
@@ -129,10 +150,10 @@ class GraphCSR:
         return self._orders[key]
 
     @classmethod
-    def build(cls, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
+    def build(cls, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False, block_rows=0):
         rowptr, blkptr, src, val = get_backend().csr_build(edge_index, edge_weight, int(num_nodes), int(n_blocks),
-                                                           transpose)
-        csr = cls(rowptr, blkptr, n_blocks, src, val, num_nodes, edge_index.shape[1])
+                                                           transpose, int(block_rows))
+        csr = cls(rowptr, blkptr, n_blocks, src, val, num_nodes, edge_index.shape[1], block_rows)
         if not transpose:
             csr._edges = (weakref.ref(edge_index), None if edge_weight is None else weakref.ref(edge_weight))
         return csr
@@ -153,7 +174,8 @@ class GraphCSR:
             if ei is None or (self._edges[1] is not None and ew is None):
                 raise RuntimeError("difformer_amd: the edge_index this CSR was built from has been freed; keep it alive "
                                    "until backward()")
-            self._adjoint = GraphCSR.build(ei, ew, self.num_nodes, self.n_blocks, transpose=True)
+            self._adjoint = GraphCSR.build(ei, ew, self.num_nodes, self.n_blocks, transpose=True,
+                                           block_rows=self.block_rows)
         return self._adjoint
 
 
@@ -168,17 +190,19 @@ class _CSRCache:
         self.entries = OrderedDict()
 
     @staticmethod
-    def _key(edge_index, edge_weight, num_nodes, n_blocks):
+    def _key(edge_index, edge_weight, num_nodes, n_blocks, block_rows=0):
         k = (id(edge_index), edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes),
-             int(n_blocks), str(edge_index.device))
+             int(n_blocks), int(block_rows), str(edge_index.device))
         if edge_weight is not None:
             k += (id(edge_weight), edge_weight.data_ptr(), edge_weight._version)
         return k
 
-    def get(self, edge_index, edge_weight, num_nodes, row_bytes=256):
-        """`row_bytes` = bytes of one feature row the SpMM will gather (H*D*4); picks the blocking."""
-        n_blocks = choose_source_blocks(num_nodes, row_bytes, edge_index.shape[1])
-        key = self._key(edge_index, edge_weight, num_nodes, n_blocks)
+    def get(self, edge_index, edge_weight, num_nodes, row_bytes=256, shard=None):
+        """`row_bytes` = bytes of one feature row the SpMM will gather (H*D*4); picks the blocking -- aligned with the
+        rank boundaries of `shard` when the run is row-sharded."""
+        aligned = choose_shard_blocks(num_nodes, row_bytes, edge_index.shape[1], shard)
+        n_blocks, block_rows = aligned if aligned else (choose_source_blocks(num_nodes, row_bytes, edge_index.shape[1]), 0)
+        key = self._key(edge_index, edge_weight, num_nodes, n_blocks, block_rows)
         hit = self.entries.get(key)
         if hit is not None:
             ei_ref, ew_ref, csr = hit
@@ -186,7 +210,7 @@ class _CSRCache:
                 self.entries.move_to_end(key)
                 return csr
             del self.entries[key]
-        csr = GraphCSR.build(edge_index, edge_weight, num_nodes, n_blocks)
+        csr = GraphCSR.build(edge_index, edge_weight, num_nodes, n_blocks, block_rows=block_rows)
         self.entries[key] = (weakref.ref(edge_index), weakref.ref(edge_weight) if edge_weight is not None else None,
                              csr)
         while len(self.entries) > self.capacity:
@@ -208,18 +232,38 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
     destination rows.  `tail` (H == 1 only) = dict(x0, prev, alpha, ln_weight, ln_bias, eps) fuses the
     layer tail of :139-140 / :200-203 into the SpMM epilogue; the result is then [n, 1, D]."""
     n, H, D = x.shape
-    row_begin, n_rows = 0, n
-    if isinstance(x, GatheredRows):            # all-gather already started by project_simple_attention
-        x2 = x.handle.wait()
-        row_begin, n_rows = shard.row_begin, shard.n_local
-    else:
-        x2 = x.reshape(n, H * D)
-        if shard is not None and shard.world > 1:
-            x2 = shard.all_gather_rows(x2)     # the one exchange step: N*H*D floats
-            row_begin, n_rows = shard.row_begin, shard.n_local
     a2 = None if attn is None else attn.reshape(n, H * D)
-    out = get_backend().spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x2,
-                             row_begin, n_rows, a2, attn_scale, gcn_scale, tail, csr.row_order(row_begin, n_rows))
+    be = get_backend()
+    args = (csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz)
+    if shard is None or shard.world <= 1:
+        x2 = x.reshape(n, H * D)
+        out = be.spmm(*args, x2, 0, n, a2, attn_scale, gcn_scale, tail, csr.row_order(0, n))
+        return out.reshape(n, H, D)
+    # row-sharded: the one exchange step of this operator is the all-gather of the value rows (N*H*D elements)
+    if isinstance(x, GatheredRows):            # already started by project_simple_attention
+        local, handle = x.local.reshape(n, H * D), x.handle
+    else:
+        local = x.reshape(n, H * D)
+        handle = shard.all_gather_rows_async(local)
+    row_begin, n_rows = shard.row_begin, shard.n_local
+    order = csr.row_order(row_begin, n_rows)
+    F = H * D
+    rows = csr.block_rows
+    split = (csr.n_blocks > 1 and csr.nnz > 0 and F % 4 == 0 and F <= 256 and row_begin % rows == 0 and
+             (row_begin + n_rows == csr.num_nodes or (row_begin + n_rows) % rows == 0))
+    if split:
+        # blocks [own_lo, own_hi) hold exactly this rank's own value rows: sweep them now, under the collective, and
+        # park the accumulators; the rest of the sweep and the epilogue follow once the other ranks' rows have landed
+        own_lo, own_hi = row_begin // rows, -(-(row_begin + n_rows) // rows)
+        local = local if local.is_contiguous() else local.contiguous()
+        scratch = be.spmm(*args, local, row_begin, n_rows, None, attn_scale, gcn_scale, None, order,
+                          (0, own_lo, own_hi, None, row_begin))
+        x2 = handle.wait()
+        out = be.spmm(*args, x2, row_begin, n_rows, a2, attn_scale, gcn_scale, tail, order,
+                      (1, own_lo, own_hi, scratch, 0))
+    else:
+        x2 = handle.wait()
+        out = be.spmm(*args, x2, row_begin, n_rows, a2, attn_scale, gcn_scale, tail, order)
     return out.reshape(n_rows, H, D)
 
 

@@ -125,7 +125,8 @@ int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, in
  * sources into contiguous blocks of ceil(N/n_blocks) nodes; with n_blocks > 1, blkptr
  * [(n_blocks+1) x N] int32 (block-major) receives the start of every (row, block) group and the
  * SpMM sweeps the blocks in order so the gathered slice of x stays L2-resident (choose
- * n_blocks ~ N*F*4 / 2.5 MiB; 1 = plain CSR).  status[0] (device int32) is set non-zero if any
+ * n_blocks ~ N*F*4 / 2.5 MiB; 1 = plain CSR).  block_rows = 0 means ceil(N/n_blocks); a row-sharded run passes the
+ * rows per rank divided by a small integer so that block boundaries coincide with rank boundaries.  status[0] (device int32) is set non-zero if any
  * index is outside [0,N).  transpose = 1 files every entry under its SOURCE row instead (same values,
  * `src` then holds the destination): the SpMM over that CSR is the adjoint A_hat^T g, i.e. the gradient
  * of gcn_conv with respect to x (loss.backward() in main.py:130).
@@ -139,7 +140,7 @@ int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, in
  * ------------------------------------------------------------------------------------- */
 size_t dif_csr_workspace_bytes(int64_t E, int64_t N, int n_blocks);
 int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, const float* edge_weight,
-                  int n_blocks, int transpose, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
+                  int n_blocks, int64_t block_rows, int transpose, int32_t* rowptr, int32_t* blkptr, int32_t* src, float* val,
                   int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream);
 int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
                      const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
@@ -157,6 +158,34 @@ int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
 size_t dif_row_order_workspace_bytes(int64_t n_rows);
 int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int32_t* order, int32_t* stats,
                   void* workspace, size_t workspace_bytes, dif_stream_t stream);
+
+/* Split product for row-sharded runs (one process per GPU): a rank owns the source rows of the blocks
+ * [own_blk_begin, own_blk_end) before the all-gather of the value rows has delivered the others.
+ *   part 0: sweeps only those blocks and parks the fp32 accumulators in `scratch` (no epilogue, `out` untouched).  `x` may
+ *           be a pointer such that x + s*ldx is valid only for the rank's own source rows s (local rows minus
+ *           row offset): no other row is read.
+ *   part 1: sweeps all other blocks on top of `scratch` and finishes with the combine / tail epilogue.
+ * Same launch geometry in both parts (same n_rows, row_order, n_split_rows).  Blocked kernel only: n_blocks > 1,
+ * F % 4 == 0, F <= 256, 16-byte aligned rows (DIF_E_SHAPE otherwise).  tail_enabled = 0 ignores the tail arguments. */
+size_t dif_gcn_spmm_part_scratch_bytes(int64_t n_rows, int64_t n_split_rows, int F);
+int dif_gcn_spmm_part_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
+                          const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
+                          const float* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                          const float* attn, int64_t lda, float attn_scale, float gcn_scale,
+                          const int32_t* row_order, int64_t n_split_rows, int tail_enabled,
+                          const float* x0, int64_t ldx0, const float* prev, int64_t ldp, float alpha,
+                          const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                          int part, int own_blk_begin, int own_blk_end, float* scratch,
+                          size_t scratch_bytes, float* out, int64_t ldo, dif_stream_t stream);
+int dif_gcn_spmm_part_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
+                           const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
+                           const void* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
+                           const void* attn, int64_t lda, float attn_scale, float gcn_scale,
+                           const int32_t* row_order, int64_t n_split_rows, int tail_enabled,
+                           const void* x0, int64_t ldx0, const void* prev, int64_t ldp, float alpha,
+                           const void* ln_weight, const void* ln_bias, float ln_eps, int relu,
+                           int part, int own_blk_begin, int own_blk_end, float* scratch,
+                           size_t scratch_bytes, void* out, int64_t ldo, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * f2  induced subgraph of a node subset with relabelling -- the per-batch graph step of the mini-batch path,

@@ -56,12 +56,13 @@ class OracleBackend:
         assert np.array_equal(np.cumsum(sizes[order]) - sizes[order], first[order])
         return torch.from_numpy(orc.v2_sigmoid_attention(_np(q), _np(k), _np(v), sizes[order]))
 
-    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False):
+    def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False, block_rows=0):
         ei = _np(edge_index)
         row, col, val = orc.gcn_edge_values(ei, num_nodes, _np(edge_weight), dtype=np.float32)
         if transpose:
             row, col = col, row
-        block_rows = -(-num_nodes // n_blocks)
+        block_rows = block_rows or -(-num_nodes // n_blocks)
+        assert block_rows * n_blocks >= num_nodes
         key = col * n_blocks + row // block_rows
         order = np.argsort(key, kind="stable")
         kptr = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=num_nodes * n_blocks))]).astype(np.int32)
@@ -74,12 +75,34 @@ class OracleBackend:
                 torch.from_numpy(val[order]))
 
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
-             gcn_scale=1.0, tail=None, order=None):
+             gcn_scale=1.0, tail=None, order=None, part=None):
         rp, s, w, xx = _np(rowptr), _np(src)[:nnz], _np(val)[:nnz].astype(np.float64), _np(x).astype(np.float64)
-        assert xx.shape[0] == n_nodes
         dst = np.repeat(np.arange(n_nodes), np.diff(rp))
         full = np.zeros((n_nodes, xx.shape[1]))
-        np.add.at(full, dst, w[:, None] * xx[s])
+        if part is None:
+            assert xx.shape[0] == n_nodes
+            np.add.at(full, dst, w[:, None] * xx[s])
+        else:
+            # split product (row-sharded runs): part 0 sees ONLY this rank's own value rows and must not need any other
+            phase, own_lo, own_hi, scratch, x_row0 = part
+            self.part_calls = getattr(self, "part_calls", {})
+            self.part_calls[phase] = self.part_calls.get(phase, 0) + 1
+            own = (s >= x_row0) & (s < x_row0 + xx.shape[0]) if phase == 0 else None
+            if phase == 0:
+                blk = _np(blkptr).reshape(n_blocks + 1, n_nodes)
+                in_own_blocks = np.zeros(nnz, dtype=bool)
+                for r in range(n_nodes):
+                    in_own_blocks[blk[own_lo, r]: blk[own_hi, r]] = True
+                assert np.array_equal(own, in_own_blocks), "own blocks and own value rows must coincide"
+                np.add.at(full, dst[own], w[own, None] * xx[s[own] - x_row0])
+                return torch.from_numpy(full[row_begin:row_begin + n_rows].copy())          # the parked accumulators
+            assert xx.shape[0] == n_nodes
+            blk = _np(blkptr).reshape(n_blocks + 1, n_nodes)
+            rest = np.ones(nnz, dtype=bool)
+            for r in range(n_nodes):
+                rest[blk[own_lo, r]: blk[own_hi, r]] = False
+            np.add.at(full, dst[rest], w[rest, None] * xx[s[rest]])
+            full[row_begin:row_begin + n_rows] += _np(scratch)
         out = gcn_scale * full[row_begin:row_begin + n_rows]
         if attn is not None:
             out = out + attn_scale * _np(attn).astype(np.float64)

@@ -25,7 +25,7 @@ def lib():
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and len(names) == 32
+    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and len(names) == 35
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -59,9 +59,9 @@ def test_argument_checks_reject_before_touching_the_device(lib):
     assert rc == -1 and b"positive" in lib.dif_last_error()
     rc = lib.dif_sigmoid_attn_f32(None, 8, None, 8, None, 8, 4, 4, 1, 8, 8, None, 8, None, 0, None)
     assert rc == -1
-    rc = lib.dif_csr_build(None, 10, 0, None, 1, 0, None, None, None, None, None, None, 0, None)
+    rc = lib.dif_csr_build(None, 10, 0, None, 1, 0, 0, None, None, None, None, None, None, 0, None)
     assert rc == -1
-    rc = lib.dif_csr_build(None, 2 ** 31, 10, None, 1, 0, None, None, None, None, None, None, 0, None)
+    rc = lib.dif_csr_build(None, 2 ** 31, 10, None, 1, 0, 0, None, None, None, None, None, None, 0, None)
     assert rc == -4                                                                    # DIF_E_RANGE
     rc = lib.dif_gcn_spmm_f32(None, None, 1, None, None, 10, 5, None, 8, 0, 20, 8, None, 0, 1.0, 1.0, None, 0, None, 8, None)
     assert rc == -1 and b"row range" in lib.dif_last_error()

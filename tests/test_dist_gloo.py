@@ -32,6 +32,11 @@ def _worker(rank, world, port, kernel, n, out_q):
         from difformer_amd import DIFFormer, RowShard, ops
         from fake_backend import OracleBackend
         ops._BACKEND = OracleBackend()
+        if n >= 64 * world * world:
+            # force the source-blocked layout at test size, so that the split product of the sharded SpMM (own blocks
+            # under the all-gather, the rest after it) runs: 2 blocks per rank
+            ops.choose_source_blocks = lambda num_nodes, row_bytes, nnz: 4
+            ops.L2_SLICE_BYTES = (-(-n // world) + 7) // 8 * 8 // 2 * 128 / 1.1
         torch.manual_seed(7)
         model = DIFFormer(12, 16, 5, num_layers=2, num_heads=2, kernel=kernel, use_source=True).eval()
         g = torch.Generator().manual_seed(3)
@@ -53,12 +58,16 @@ def _worker(rank, world, port, kernel, n, out_q):
             from difformer_amd.dist import RowShard as RS
             odd = RS(n, rank, world, None, counts=[n - 30, 7, 23])
             ok = ok and bool(torch.equal(odd.all_gather_rows(odd.local_rows(x).contiguous()), x))
+        if n >= 64 * world * world:
+            csr = list(ops.csr_cache.entries.values())[-1][2]
+            ok = ok and csr.n_blocks == 2 * world and ops._BACKEND.part_calls == {0: 2, 1: 2}     # 2 layers x 2 parts
         out_q.put((rank, err, tuple(local.shape), ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kernel,world,n", [("simple", 2, 64), ("simple", 3, 50), ("sigmoid", 2, 41)])
+@pytest.mark.parametrize("kernel,world,n", [("simple", 2, 64), ("simple", 3, 50), ("sigmoid", 2, 41), ("simple", 2, 300),
+                                            ("simple", 3, 620)])
 def test_row_sharded_forward_matches_single_process(kernel, world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

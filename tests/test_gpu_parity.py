@@ -1064,3 +1064,39 @@ def test_bf16_blocked_spmm_wide_lanes_and_row_order(d, nb, dev):
         out = be.spmm(*args, 0, n, a.to(dev), 0.5, 2.0, None, o)
         assert out.dtype == torch.bfloat16
         assert rel_err(out.float().cpu().numpy(), ref) < BF16_TOL
+
+
+@pytest.mark.parametrize("world,zipf,dt", [(2, False, torch.float32), (4, True, torch.float32), (8, False, torch.float32),
+                                           (8, True, torch.float32), (4, False, torch.bfloat16)])
+def test_split_product_own_blocks_then_the_rest(world, zipf, dt, dev):
+    """Row-sharded SpMM as gcn_aggregate runs it: source blocks aligned with the rank boundaries, part 0 over a tensor
+    that holds ONLY the rank's own value rows (what exists before the all-gather lands), part 1 over the gathered rows
+    on top of the parked accumulators, with combine and fused tail -- rank after rank against the unsharded launch."""
+    from difformer_amd import ops
+    from difformer_amd.dist import RowShard
+    be = ops.get_backend()
+    n, e, d = (24000 if dt == torch.float32 else 40000), 1600000, 64      # bf16 rows: x must still exceed the L2
+    g = torch.Generator().manual_seed(world)
+    ei = _zipf_graph(n, e, world, dev) if zipf else torch.randint(0, n, (2, 2 * e), generator=g).to(dev)
+    shards = [RowShard(n, rank=r, world=world) for r in range(world)]
+    nb, rows = ops.choose_shard_blocks(n, d * (2 if dt == torch.bfloat16 else 4), ei.shape[1], shards[0])
+    assert shards[0].counts[0] % rows == 0
+    csr = ops.GraphCSR.build(ei, None, n, nb, block_rows=rows)
+    v = torch.randn(n, d, generator=g).to(dev).to(dt)
+    a = torch.randn(n, d, generator=g).to(dev).to(dt)
+    prev = torch.randn(n, d, generator=g).to(dev).to(dt)
+    lw, lb = (torch.rand(d, generator=g) + 0.5).to(dev).to(dt), torch.randn(d, generator=g).to(dev).to(dt)
+    tail = lambda lo, hi: dict(x0=None, prev=prev[lo:hi], alpha=0.5, ln_weight=lw, ln_bias=lb, eps=1e-5)
+    args = (csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, n, csr.nnz)
+    full = be.spmm(*args, v, 0, n, a, 1.0, 1.0, tail(0, n), csr.row_order(0, n)).float()
+    tol = 2e-2 if dt == torch.bfloat16 else 1e-5
+    for s in shards:
+        lo, cnt = s.row_begin, s.n_local
+        own_lo, own_hi = lo // rows, -(-(lo + cnt) // rows)
+        order = csr.row_order(lo, cnt)
+        assert zipf == (order is not None)
+        own = v[lo: lo + cnt].clone()                                        # nothing but this rank's rows
+        scratch = be.spmm(*args, own, lo, cnt, None, 1.0, 1.0, None, order, (0, own_lo, own_hi, None, lo))
+        out = be.spmm(*args, v, lo, cnt, a[lo: lo + cnt], 1.0, 1.0, tail(lo, lo + cnt), order,
+                      (1, own_lo, own_hi, scratch, 0))
+        assert rel_err(out.float().cpu().numpy(), full[lo: lo + cnt].cpu().numpy()) < tol, (world, s.rank)

@@ -99,7 +99,8 @@ def test_get_attentions_shape_and_rows_sum(fake_backend):
 
 def test_split_rows_and_row_shard():
     from difformer_amd.dist import RowShard, split_rows
-    assert split_rows(132534, 8) == [16567] * 7 + [16565]       # all but the last take ceil(N / world)
+    assert split_rows(132534, 8) == [16568] * 7 + [16558]       # ceil(N / world) rounded up to a multiple of 8
+    assert split_rows(1000, 8) == [125] * 8                     # small graphs: plain ceil(N / world)
     assert split_rows(5, 8) == [1, 1, 1, 1, 1, 0, 0, 0]
     assert split_rows(64, 2) == [32, 32]
     s = RowShard(10, rank=2, world=3)
