@@ -7,6 +7,7 @@ the package has no CPU or eager path.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -16,6 +17,11 @@ from . import _lib
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
+
+# Part 0 of the row-sharded SpMM runs while the all-gather of the value rows is in flight.  A workgroup of the blocked
+# kernel owns a whole CU, so it is launched on fewer workgroups than the 256 CUs and the collective's kernel keeps CUs
+# of its own (RCCL uses up to ~32 channels = workgroups).
+PART0_WORKGROUPS = int(os.environ.get("DIFFORMER_SPMM_PART0_WGS", "224"))
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
@@ -387,8 +393,8 @@ class HipBackend:
             head = head[:7] + (xp,) + head[8:]
             fn = self.lib.dif_gcn_spmm_part_bf16 if sfx == "bf16" else self.lib.dif_gcn_spmm_part_f32
             with _Timed(self, "dif_gcn_spmm_f32", dev):
-                rc = fn(*head, int(tail is not None), *tail_args, int(phase), int(own_lo), int(own_hi), _ptr(scratch), sbytes,
-                        _ptr(out), F, _stream(dev))
+                rc = fn(*head, int(tail is not None), *tail_args, int(phase), int(own_lo), int(own_hi),
+                        PART0_WORKGROUPS if phase == 0 else 0, _ptr(scratch), sbytes, _ptr(out), F, _stream(dev))
             _lib.check(rc, "dif_gcn_spmm_part")
             return scratch if phase == 0 else out
         with _Timed(self, "dif_gcn_spmm_f32", dev):

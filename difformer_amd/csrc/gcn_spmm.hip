@@ -315,13 +315,17 @@ __global__ __launch_bounds__(256) void spmm_group_row_kernel(
 // Which source blocks a launch sweeps, and where its accumulators start / end up.  A row-sharded run (dist.py) splits
 // the product in two launches so that the all-gather of the value rows hides behind the first one:
 //   part 0: only the blocks [first, end) whose sources are this rank's OWN rows (available before the collective),
-//           accumulators dumped to `acc_out` (the LDS image of every panel, fp32) instead of the epilogue;
+//           sums written to `acc_out` (one fp32 row of G*W floats per shard row) instead of the epilogue;
 //   part 1: all other blocks (skip_lo..skip_hi-1 left out), accumulators preloaded from `acc_in`, normal epilogue.
-// A whole product is {0, -1, -1, n_blocks, nullptr, nullptr}.
+// The two parts may use different launch geometries (rows are parked by row index).  A persistent workgroup of this
+// kernel takes a whole CU (16 waves x 128 VGPRs, 144 KiB LDS): nothing else can share it, so part 0 runs on fewer
+// workgroups than there are CUs and the all-gather's kernel keeps (or finds) CUs of its own.
+// A whole product is {0, -1, -1, n_blocks, nullptr, nullptr, 0}.
 struct Sweep {
     int first, skip_lo, skip_hi, end;
     const float* acc_in;
     float* acc_out;
+    int max_wgs;      // 0 = one workgroup per CU; part 0 leaves CUs free for the collective's own kernel (see below)
 };
 
 constexpr int kBlkWaves = 16;          // waves per workgroup
@@ -401,11 +405,16 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
                 nq = static_cast<int>(((left < rpw ? left : rpw) + S - 1) / S);
             }
         }
-        if (sw.acc_in && has) {
-            const float* img = sw.acc_in + panel * (rpw * RW);
-            for (int i = lane; i < rpw * RW; i += 64) my[i] = img[i];
-        } else {
-            for (int i = lane; i < rpw * RW; i += 64) my[i] = 0.f;
+        for (int i = lane; i < rpw * RW; i += 64) my[i] = 0.f;
+        if (sw.acc_in) {        // part 1 of a split product: start from the sums part 0 parked, one fp32 row per shard row
+            for (int q = 0; q < nq; ++q) {
+                const int rl = q * S + slot;
+                const int flags = __shfl(static_cast<int>(mine) | (static_cast<int>(split) << 1), rl, 64);
+                const int64_t row = __shfl(lrow, rl, 64);
+                // a split row keeps S partial sums: the parked total goes to lane group 0, the others start at zero
+                if ((flags & 1) && active && (!(flags & 2) || slot == 0))
+                    vstore<W>(my + rl * RW + col, vload<W>(sw.acc_in + row * RW + col));
+            }
         }
 
         // (row, block) group pointers of the current and of the next block, one lane per row of the panel
@@ -516,10 +525,19 @@ __global__ __launch_bounds__(64 * kBlkWaves, WPC * kBlkWaves / 4) void spmm_bloc
             e0v = e0x;
             e1v = e1x;
         }
-        if (sw.acc_out) {       // part 0 of a split product: park the accumulators, no epilogue
-            if (has) {
-                float* img = sw.acc_out + panel * (rpw * RW);
-                for (int i = lane; i < rpw * RW; i += 64) img[i] = my[i];
+        if (sw.acc_out) {       // part 0 of a split product: park the sums row by row (fp32), no epilogue
+            for (int q = 0; q < nq; ++q) {
+                const int rl = q * S + slot;
+                const int flags = __shfl(static_cast<int>(mine) | (static_cast<int>(split) << 1), rl, 64);
+                const int64_t row = __shfl(lrow, rl, 64);
+                if (!((flags & 1) && active)) continue;
+                V t = vload<W>(my + rl * RW + col);
+                if (ORD && (flags & 2)) {
+                    t = vload<W>(my + (q * S) * RW + col);
+#pragma unroll
+                    for (int p2 = 1; p2 < S; ++p2) t += vload<W>(my + (q * S + p2) * RW + col);
+                }
+                if (!(flags & 2) || slot == 0) vstore<W>(sw.acc_out + row * RW + col, t);
             }
             continue;
         }
@@ -555,7 +573,8 @@ int launch_blocked_v(hipStream_t st, const int32_t* blkptr, int64_t n_nodes, int
     constexpr int S = 64 / G;
     constexpr int RW = G * W;
     constexpr int kLdsFloats = kBlkLdsBytesPerCU / 4 / WPC;
-    const int64_t n_wg = static_cast<int64_t>(dif::kCUs) * WPC;               // one persistent workgroup per CU
+    int64_t n_wg = static_cast<int64_t>(dif::kCUs) * WPC;                     // one persistent workgroup per CU
+    if (sw.max_wgs > 0 && sw.max_wgs < n_wg) n_wg = sw.max_wgs;
     const int64_t slots = n_wg * kBlkWaves;                                      // waves resident on the chip
     const int rpw_max = (kLdsFloats / kBlkWaves / RW < 64) ? kLdsFloats / kBlkWaves / RW : 64;
     // rows per wave panel: the busiest CU does ceil(panels / workgroups) panels of ceil(rpw / S) row-quad visits per
@@ -681,7 +700,7 @@ static int spmm_entry(const int32_t* rowptr, const int32_t* blkptr, int n_blocks
                     vec ? 256 : 64);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Sweep sw = part ? *part : Sweep{0, -1, -1, n_blocks, nullptr, nullptr};
+    const Sweep sw = part ? *part : Sweep{0, -1, -1, n_blocks, nullptr, nullptr, 0};
     DIF_REQUIRE(!part || (n_blocks > 1 && vec && F <= 256 && nnz > 0), DIF_E_SHAPE,
                 "dif_gcn_spmm_part: split products run on the blocked kernel only (n_blocks > 1, F %% 4 == 0, F <= 256, aligned)");
     if (n_blocks > 1 && vec && F <= 256 && nnz > 0) {
@@ -759,8 +778,8 @@ extern "C" size_t dif_gcn_spmm_part_scratch_bytes(int64_t n_rows, int64_t n_spli
     if (n_rows <= 0 || F <= 0 || n_split_rows < 0) return 0;
     int rw = 64;                                   // floats per accumulator row: G * W of the blocked kernel
     while (rw < F) rw *= 2;
-    // panels * rows-per-panel <= rows + 3 per split row + one panel (<= 64 rows) + one quad of padding
-    return static_cast<size_t>(n_rows + 3 * n_split_rows + 128) * rw * sizeof(float);
+    (void)n_split_rows;                            // one parked fp32 row per shard row, whatever the walk order
+    return static_cast<size_t>(n_rows) * rw * sizeof(float);
 }
 
 template <typename E>
@@ -768,19 +787,21 @@ static int spmm_part_entry(const int32_t* rowptr, const int32_t* blkptr, int n_b
                            int64_t n_nodes, int64_t nnz, const E* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
                            const E* attn, int64_t lda, float attn_scale, float gcn_scale, const int32_t* row_order,
                            int64_t n_split_rows, const Tail<E>& tail, int part, int own_blk_begin, int own_blk_end,
-                           float* scratch, size_t scratch_bytes, E* out, int64_t ldo, dif_stream_t stream) {
+                           int max_workgroups, float* scratch, size_t scratch_bytes, E* out, int64_t ldo,
+                           dif_stream_t stream) {
     DIF_REQUIRE(part == 0 || part == 1, DIF_E_BADARG, "dif_gcn_spmm_part: part must be 0 or 1");
+    DIF_REQUIRE(max_workgroups >= 0, DIF_E_BADARG, "dif_gcn_spmm_part: max_workgroups must be >= 0 (0 = one per CU)");
     DIF_REQUIRE(0 <= own_blk_begin && own_blk_begin <= own_blk_end && own_blk_end <= n_blocks, DIF_E_BADARG,
                 "dif_gcn_spmm_part: own block range [%d, %d) outside [0, %d]", own_blk_begin, own_blk_end, n_blocks);
     DIF_REQUIRE(scratch && scratch_bytes >= dif_gcn_spmm_part_scratch_bytes(n_rows, n_split_rows, F), DIF_E_WORKSPACE,
                 "dif_gcn_spmm_part: scratch too small");
     Sweep sw;
     if (part == 0) {
-        sw = Sweep{own_blk_begin, -1, -1, own_blk_end, nullptr, scratch};
+        sw = Sweep{own_blk_begin, -1, -1, own_blk_end, nullptr, scratch, max_workgroups};
     } else {
         const bool none = own_blk_begin == own_blk_end;
         sw = Sweep{(!none && own_blk_begin == 0) ? own_blk_end : 0, none ? -1 : own_blk_begin, none ? -1 : own_blk_end,
-                   n_blocks, scratch, nullptr};
+                   n_blocks, scratch, nullptr, max_workgroups};
     }
     Tail<E> t = tail;
     if (part == 0) t = Tail<E>{};
@@ -795,13 +816,13 @@ extern "C" int dif_gcn_spmm_part_f32(const int32_t* rowptr, const int32_t* blkpt
                                      float attn_scale, float gcn_scale, const int32_t* row_order, int64_t n_split_rows,
                                      int tail_enabled, const float* x0, int64_t ldx0, const float* prev, int64_t ldp,
                                      float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
-                                     int part, int own_blk_begin, int own_blk_end, float* scratch, size_t scratch_bytes,
-                                     float* out, int64_t ldo, dif_stream_t stream) {
+                                     int part, int own_blk_begin, int own_blk_end, int max_workgroups, float* scratch,
+                                     size_t scratch_bytes, float* out, int64_t ldo, dif_stream_t stream) {
     Tail<float> tail = {};
     if (tail_enabled) tail = Tail<float>{x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, 1, relu};
     return spmm_part_entry<float>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, ldx, row_begin, n_rows, F, attn, lda,
                                   attn_scale, gcn_scale, row_order, n_split_rows, tail, part, own_blk_begin, own_blk_end,
-                                  scratch, scratch_bytes, out, ldo, stream);
+                                  max_workgroups, scratch, scratch_bytes, out, ldo, stream);
 }
 
 extern "C" int dif_gcn_spmm_part_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_blocks, const int32_t* src,
@@ -810,13 +831,13 @@ extern "C" int dif_gcn_spmm_part_bf16(const int32_t* rowptr, const int32_t* blkp
                                       float attn_scale, float gcn_scale, const int32_t* row_order, int64_t n_split_rows,
                                       int tail_enabled, const void* x0, int64_t ldx0, const void* prev, int64_t ldp,
                                       float alpha, const void* ln_weight, const void* ln_bias, float ln_eps, int relu,
-                                      int part, int own_blk_begin, int own_blk_end, float* scratch, size_t scratch_bytes,
-                                      void* out, int64_t ldo, dif_stream_t stream) {
+                                      int part, int own_blk_begin, int own_blk_end, int max_workgroups, float* scratch,
+                                      size_t scratch_bytes, void* out, int64_t ldo, dif_stream_t stream) {
     using B = dif::bf16;
     auto c = [](const void* p) { return static_cast<const B*>(p); };
     Tail<B> tail = {};
     if (tail_enabled) tail = Tail<B>{c(x0), ldx0, c(prev), ldp, alpha, c(ln_weight), c(ln_bias), ln_eps, 1, relu};
     return spmm_part_entry<B>(rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, c(x), ldx, row_begin, n_rows, F, c(attn), lda,
                               attn_scale, gcn_scale, row_order, n_split_rows, tail, part, own_blk_begin, own_blk_end,
-                              scratch, scratch_bytes, static_cast<B*>(out), ldo, stream);
+                              max_workgroups, scratch, scratch_bytes, static_cast<B*>(out), ldo, stream);
 }

@@ -165,7 +165,9 @@ int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int3
  *           be a pointer such that x + s*ldx is valid only for the rank's own source rows s (local rows minus
  *           row offset): no other row is read.
  *   part 1: sweeps all other blocks on top of `scratch` and finishes with the combine / tail epilogue.
- * Same launch geometry in both parts (same n_rows, row_order, n_split_rows).  Blocked kernel only: n_blocks > 1,
+ * max_workgroups (0 = one per CU) caps the persistent grid: a workgroup of this kernel fills a CU, so part 0 is launched
+ * on fewer workgroups than CUs to leave room for the collective's own kernel.  `scratch` holds one fp32 row per shard
+ * row, so the two parts may differ in geometry.  Blocked kernel only: n_blocks > 1,
  * F % 4 == 0, F <= 256, 16-byte aligned rows (DIF_E_SHAPE otherwise).  tail_enabled = 0 ignores the tail arguments. */
 size_t dif_gcn_spmm_part_scratch_bytes(int64_t n_rows, int64_t n_split_rows, int F);
 int dif_gcn_spmm_part_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
@@ -175,8 +177,9 @@ int dif_gcn_spmm_part_f32(const int32_t* rowptr, const int32_t* blkptr, int n_bl
                           const int32_t* row_order, int64_t n_split_rows, int tail_enabled,
                           const float* x0, int64_t ldx0, const float* prev, int64_t ldp, float alpha,
                           const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
-                          int part, int own_blk_begin, int own_blk_end, float* scratch,
-                          size_t scratch_bytes, float* out, int64_t ldo, dif_stream_t stream);
+                          int part, int own_blk_begin, int own_blk_end, int max_workgroups,
+                          float* scratch, size_t scratch_bytes, float* out, int64_t ldo,
+                          dif_stream_t stream);
 int dif_gcn_spmm_part_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
                            const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
                            const void* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
@@ -184,8 +187,9 @@ int dif_gcn_spmm_part_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_b
                            const int32_t* row_order, int64_t n_split_rows, int tail_enabled,
                            const void* x0, int64_t ldx0, const void* prev, int64_t ldp, float alpha,
                            const void* ln_weight, const void* ln_bias, float ln_eps, int relu,
-                           int part, int own_blk_begin, int own_blk_end, float* scratch,
-                           size_t scratch_bytes, void* out, int64_t ldo, dif_stream_t stream);
+                           int part, int own_blk_begin, int own_blk_end, int max_workgroups,
+                           float* scratch, size_t scratch_bytes, void* out, int64_t ldo,
+                           dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * f2  induced subgraph of a node subset with relabelling -- the per-batch graph step of the mini-batch path,
