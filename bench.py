@@ -140,11 +140,11 @@ def main():
     with torch.no_grad():
         if use_graph:  # cold: CSR build (degree, values, stable sort), once per graph
             esz = 2 if store == torch.bfloat16 else 4
-            ops.csr_cache.get(edge_index, None, n, hidden * esz)   # first build also pays hipMalloc for the workspace
+            ops.csr_cache.get(edge_index, None, n, hidden * esz, shard)   # first build also pays hipMalloc for the workspace
             ops.csr_cache.clear()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ops.csr_cache.get(edge_index, None, n, hidden * esz)   # timed: what every new graph / mini-batch costs
+            ops.csr_cache.get(edge_index, None, n, hidden * esz, shard)   # timed: what every new graph / mini-batch costs
             torch.cuda.synchronize()
             cold_ms = (time.perf_counter() - t0) * 1e3
         for _ in range(args.warmup):
