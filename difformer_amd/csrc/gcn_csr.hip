@@ -77,12 +77,14 @@ Plan make_plan(int64_t E, int64_t N, int64_t NB, int64_t block_rows = 0) {
     return p;
 }
 
-// ---- degree count + sort keys (destination) / values (edge id) ------------------------------
+// ---- sort keys (row it is filed under x source block) and payloads --------------------------------
+// Payload: the edge id when the graph is weighted (the weight is fetched after the sort), otherwise directly the node
+// id the entry will gather -- the sorted payload then IS the CSR `src` array and the fill pass needs no random access
+// into edge_index.  No per-key counting here: the pointer table is read off the sorted keys (csr_bounds_kernel).
 __global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ edge_index, int64_t E,
                                                         int64_t N, int64_t NB, int64_t block_rows, int transpose,
-                                                        uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals, int32_t* __restrict__ deg,
-                                                        int32_t* __restrict__ degc,
+                                                        int weighted, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals, int32_t* __restrict__ degc,
                                                         int32_t* __restrict__ status) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < E; e += stride) {
@@ -96,9 +98,20 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restric
         // grouped by source (row), blocked by destination
         const int64_t key = transpose ? r * NB + c / block_rows : c * NB + r / block_rows;
         keys[e] = static_cast<uint32_t>(key);
-        vals[e] = static_cast<uint32_t>(e);
-        atomicAdd(&deg[key], 1);               // forward: summed over a row's blocks = in-degree over `col` (:66)
-        if (transpose) atomicAdd(&degc[c], 1); // the normalisation always uses the in-degree over `col`
+        vals[e] = weighted ? static_cast<uint32_t>(e) : static_cast<uint32_t>(transpose ? c : r);
+        if (transpose) atomicAdd(&degc[c], 1); // the normalisation always uses the in-degree over `col` (:66)
+    }
+}
+
+// kptr[j] = first position of the sorted keys holding a key >= j, for j in [0, n_keys]  (kptr[n_keys] = E): thread k
+// owns the gap between key[k-1] and key[k].  Replaces E atomic increments + a scan over the n_keys counters.
+__global__ __launch_bounds__(256) void csr_bounds_kernel(const uint32_t* __restrict__ key_sorted, int64_t E,
+                                                         int64_t n_keys, int32_t* __restrict__ kptr) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k <= E; k += stride) {
+        const int64_t lo = (k == 0) ? 0 : static_cast<int64_t>(key_sorted[k - 1]) + 1;
+        const int64_t hi = (k == E) ? n_keys : static_cast<int64_t>(key_sorted[k]);
+        for (int64_t j = lo; j <= hi; ++j) kptr[j] = static_cast<int32_t>(k);
     }
 }
 
@@ -305,10 +318,13 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict
                                                        float* __restrict__ val) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < E; k += stride) {
-        const uint32_t e = eid_sorted[k];
+        const uint32_t e = eid_sorted[k];                 // weighted: edge id; unweighted: already the node to gather
         const uint32_t grp = key_sorted[k] / NB;          // the row this entry is filed under
-        int64_t other = edge_index[transpose ? E + e : e];
-        if (other < 0 || other >= N) other = 0;           // flagged in status by csr_count_kernel
+        int64_t other = e;
+        if (edge_weight) {
+            other = edge_index[transpose ? E + e : e];
+            if (other < 0 || other >= N) other = 0;       // flagged in status by csr_count_kernel
+        }
         const int64_t r = transpose ? grp : other;        // source      (difformer.py:65 `row`)
         const int64_t c = transpose ? other : grp;        // destination (`col`)
         const float dn_in = dinv[c];
@@ -402,25 +418,25 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     int32_t* table = reinterpret_cast<int32_t*>(ws + p.off_table);
     int32_t* bsum = reinterpret_cast<int32_t*>(ws + p.off_bsum);
 
-    hipError_t he = hipMemsetAsync(kcnt, 0, static_cast<size_t>(p.n_keys + 1) * 4, st);
-    if (he == hipSuccess) he = hipMemsetAsync(status, 0, 4, st);
+    hipError_t he = hipMemsetAsync(status, 0, 4, st);
     if (he == hipSuccess && transpose) he = hipMemsetAsync(degc, 0, static_cast<size_t>(N + 1) * 4, st);
     if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_csr_build: memset: %s", hipGetErrorString(he));
 
     const int64_t cap = 8 * dif::kCUs;
-    if (E > 0) {
+    if (E == 0) {           // no entries: every pointer is 0
+        he = hipMemsetAsync(kcnt, 0, static_cast<size_t>(p.n_keys + 1) * 4, st);
+        if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_csr_build: memset: %s", hipGetErrorString(he));
+        hipLaunchKernelGGL(csr_ptrs_kernel, dim3(static_cast<unsigned>((N + 256) / 256)), dim3(256), 0, st, kcnt, N, p.NB,
+                           rowptr, n_blocks > 1 ? blkptr : nullptr, degc, dinv);
+        return dif::launch_status("csr_ptrs_kernel");
+    }
+    {
         int64_t g = (E + 255) / 256;
         if (g > cap) g = cap;
         hipLaunchKernelGGL(csr_count_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N, p.NB,
-                           p.block_rows, transpose, keys_a, vals_a, kcnt, degc, status);
+                           p.block_rows, transpose, edge_weight != nullptr, keys_a, vals_a, degc, status);
         if (int rc = dif::launch_status("csr_count_kernel")) return rc;
     }
-    // kptr[0..N*NB] = exclusive scan of the per-key counts (kcnt[N*NB] == 0, so kptr[N*NB] = E)
-    if (int rc = exclusive_scan(kcnt, p.n_keys + 1, kcnt, nullptr, bsum, st)) return rc;
-    hipLaunchKernelGGL(csr_ptrs_kernel, dim3(static_cast<unsigned>((N + 256) / 256)), dim3(256), 0, st, kcnt, N, p.NB,
-                       rowptr, n_blocks > 1 ? blkptr : nullptr, degc, dinv);
-    if (int rc = dif::launch_status("csr_ptrs_kernel")) return rc;
-    if (E == 0) return 0;
 
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     const unsigned sort_grid = static_cast<unsigned>((p.n_chunks + kSortWaves - 1) / kSortWaves);
@@ -436,8 +452,14 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
         uint32_t* t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
-    int64_t g = (E + 255) / 256;
+    int64_t g = (E + 1 + 255) / 256;
     if (g > cap) g = cap;
+    // key pointers kptr[0 .. N*NB] from the sorted keys, then rowptr / blkptr / dinv
+    hipLaunchKernelGGL(csr_bounds_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, kin, E, p.n_keys, kcnt);
+    if (int rc = dif::launch_status("csr_bounds_kernel")) return rc;
+    hipLaunchKernelGGL(csr_ptrs_kernel, dim3(static_cast<unsigned>((N + 256) / 256)), dim3(256), 0, st, kcnt, N, p.NB,
+                       rowptr, n_blocks > 1 ? blkptr : nullptr, degc, dinv);
+    if (int rc = dif::launch_status("csr_ptrs_kernel")) return rc;
     hipLaunchKernelGGL(csr_fill_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N,
                        static_cast<uint32_t>(p.NB), transpose, edge_weight, kin, vin, dinv, src, val);
     return dif::launch_status("csr_fill_kernel");
