@@ -375,24 +375,30 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict
 // node classification/main-batch.py:131  subgraph(idx_i, edge_index, num_nodes=n, relabel_nodes=True)  (torch_geometric
 // 1.7.2, un-vendored: node_mask[subset] = True; keep edges whose two ends are in the subset, in their original order;
 // new id of subset[i] is i).  The reference runs it on the CPU over the whole edge list for every batch.
+// `member` is a bitmap of the subset (N bits: 200 KB for Pokec, L2-resident), the membership test of the flag pass;
+// `newid` (N x int32) is only consulted for the few edges that survive it.
 __global__ __launch_bounds__(256) void subgraph_mark_kernel(const int64_t* __restrict__ subset, int64_t B, int64_t N,
-                                                            int32_t* __restrict__ newid, int32_t* __restrict__ status) {
+                                                            int32_t* __restrict__ newid, uint32_t* __restrict__ member,
+                                                            int32_t* __restrict__ status) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= B) return;
     const int64_t v = subset[i];
     if (v < 0 || v >= N) { atomicOr(status, 1); return; }
     newid[v] = static_cast<int32_t>(i) + 1;          // 0 = not in the subset
+    atomicOr(&member[v >> 5], 1u << (v & 31));
 }
 
 __global__ __launch_bounds__(256) void subgraph_flag_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
-                                                            const int32_t* __restrict__ newid,
+                                                            const uint32_t* __restrict__ member,
                                                             int32_t* __restrict__ keep, int32_t* __restrict__ status) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e <= E; e += stride) {
         if (e == E) { keep[e] = 0; continue; }        // sentinel so the scan's last entry is the kept count
         const int64_t r = edge_index[e], c = edge_index[E + e];
         if (r < 0 || r >= N || c < 0 || c >= N) { atomicOr(status, 1); keep[e] = 0; continue; }
-        keep[e] = (newid[r] != 0 && newid[c] != 0) ? 1 : 0;
+        int k = 0;
+        if ((member[r >> 5] >> (r & 31)) & 1u) k = (member[c >> 5] >> (c & 31)) & 1u;   // second test only for ~B/N of the edges
+        keep[e] = k;
     }
 }
 
@@ -569,7 +575,8 @@ extern "C" int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n
 extern "C" size_t dif_subgraph_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N <= 0) return 0;
     return align256(static_cast<size_t>(N) * 4) + align256(static_cast<size_t>(E + 1) * 4) +
-           align256(static_cast<size_t>((E + 1 + kScanTile - 1) / kScanTile + 1) * 4);
+           align256(static_cast<size_t>((E + 1 + kScanTile - 1) / kScanTile + 1) * 4) +
+           align256(static_cast<size_t>((N + 31) / 32) * 4);
 }
 
 extern "C" int dif_subgraph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* subset, int64_t B,
@@ -590,18 +597,21 @@ extern "C" int dif_subgraph(const int64_t* edge_index, int64_t E, int64_t N, con
     int32_t* newid = reinterpret_cast<int32_t*>(ws);
     int32_t* keep = reinterpret_cast<int32_t*>(ws + align256(static_cast<size_t>(N) * 4));
     int32_t* bsum = reinterpret_cast<int32_t*>(ws + align256(static_cast<size_t>(N) * 4) + align256(static_cast<size_t>(E + 1) * 4));
+    uint32_t* member = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(bsum) +
+                                                   align256(static_cast<size_t>((E + 1 + kScanTile - 1) / kScanTile + 1) * 4));
     hipError_t he = hipMemsetAsync(newid, 0, static_cast<size_t>(N) * 4, st);
+    if (he == hipSuccess) he = hipMemsetAsync(member, 0, static_cast<size_t>((N + 31) / 32) * 4, st);
     if (he == hipSuccess) he = hipMemsetAsync(status, 0, 4, st);
     if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_subgraph: memset: %s", hipGetErrorString(he));
     if (B > 0) {
         hipLaunchKernelGGL(subgraph_mark_kernel, dim3(static_cast<unsigned>((B + 255) / 256)), dim3(256), 0, st, subset, B,
-                           N, newid, status);
+                           N, newid, member, status);
         if (int rc = dif::launch_status("subgraph_mark_kernel")) return rc;
     }
     const int64_t cap = 8 * dif::kCUs;
     int64_t g = (E + 1 + 255) / 256;
     if (g > cap) g = cap;
-    hipLaunchKernelGGL(subgraph_flag_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N, newid,
+    hipLaunchKernelGGL(subgraph_flag_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N, member,
                        keep, status);
     if (int rc = dif::launch_status("subgraph_flag_kernel")) return rc;
     if (int rc = exclusive_scan(keep, E + 1, keep, nullptr, bsum, st)) return rc;
