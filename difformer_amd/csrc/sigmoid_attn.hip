@@ -237,15 +237,26 @@ __global__ __launch_bounds__(256) void sigmoid_combine_kernel(const float* __res
     }
 }
 
+// Key splits S: every (query group, head, column tile) is cut into S workgroups over disjoint key ranges (+ a combine
+// pass).  Two workgroups fit a CU, so the launch runs in ceil(groups * S / 512) rounds of workgroups that each sweep
+// n_ktiles / (8 S) key tiles per wave plus a fixed cost worth ~4 tiles (LDS fold of the 8 waves, partial stores).
+// S minimises rounds x per-workgroup time: it fills the chip when there are few query groups (Cora: 85 groups -> S = 6)
+// and trims the half-empty last round when there are many (N = 20,000: 625 groups, S = 1 runs 2 rounds for 1.22
+// rounds of work; S = 4 runs 5 quarter-rounds).
 int key_splits(int64_t N, int64_t L, int H, int D) {
     const int64_t groups = ((N + kQGroup - 1) / kQGroup) * H * ((D + kDTile - 1) / kDTile);
     const int64_t n_ktiles = (L + 15) / 16;
-    int64_t s = (dif::kCUs + groups - 1) / groups;              // aim at one 8-wave workgroup per CU
-    const int64_t smax = (n_ktiles + kWaves - 1) / kWaves;        // keep >= one key tile per wave
-    if (s > smax) s = smax;
-    if (s > 16) s = 16;
-    if (s < 1) s = 1;
-    return static_cast<int>(s);
+    const int64_t slots = 2 * dif::kCUs;
+    int64_t smax = (n_ktiles + kWaves - 1) / kWaves;              // keep >= one key tile per wave
+    if (smax > 16) smax = 16;
+    int best = 1;
+    double best_cost = -1.0;
+    for (int64_t s = 1; s <= smax; ++s) {
+        const int64_t rounds = (groups * s + slots - 1) / slots;
+        const double cost = static_cast<double>(rounds) * (static_cast<double>(n_ktiles) / (kWaves * s) + 4.0);
+        if (best_cost < 0 || cost < best_cost * 0.98) { best_cost = cost; best = static_cast<int>(s); }   // ties -> fewer splits
+    }
+    return best;
 }
 
 }  // namespace
