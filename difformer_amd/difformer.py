@@ -129,6 +129,8 @@ class DIFFormerConv(nn.Module):
             if self.use_graph and not v.is_contiguous():
                 v = v.contiguous()   # the SpMM gathers whole rows: 4*H*D-byte contiguous rows are ~8 % faster
         if not self.use_graph:
+            if isinstance(attn, ops.LazyAttention):
+                attn = attn.materialize()
             return ag.layer_tail(attn, x0, prev, alpha, ln_weight, ln_bias, eps), q, k
         if edge_index is None:
             raise ValueError("use_graph=True needs an edge_index")

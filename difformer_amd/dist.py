@@ -94,6 +94,13 @@ class RowShard:
                             group=self.side_group if self.side_group is not None else self.group)
         return buf
 
+    def all_reduce_sum_async(self, buf: torch.Tensor):
+        """Start the in-place sum of the record and return the work handle (None when there is nothing to wait for)."""
+        if self.world <= 1:
+            return None
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM,
+                               group=self.side_group if self.side_group is not None else self.group, async_op=True)
+
     def all_gather_rows_async(self, local: torch.Tensor):
         """Start the all-gather of the value rows and return a handle; `handle.wait()` gives the gathered tensor.
         Lets the record all-reduce + the apply kernel run while the 4*N*H*D bytes move over xGMI."""

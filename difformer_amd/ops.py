@@ -55,13 +55,35 @@ def project_simple_attention(x, Wq, bq, Wk, bk, Wv, bv, H, D, shard: Optional[Ro
     q, v, reduced = be.project_reduce(x, Wq, bq, Wk, bk, Wv, bv, H, D)
     n_global = x.shape[0]
     if shard is not None and shard.world > 1:
-        if gather_values:
-            # start moving the value rows now: the record all-reduce (second communicator) and the apply kernel
-            # run while they are in flight; gcn_aggregate picks the handle up
-            v = GatheredRows(v, shard.all_gather_rows_async(v.reshape(v.shape[0], H * D)))
-        shard.all_reduce_sum(reduced)
         n_global = shard.n_global
+        if gather_values:
+            # start moving the value rows now, and the record all-reduce on the second communicator; the part of the
+            # SpMM that needs only this rank's own rows runs under both (gcn_aggregate), then `apply`, then the rest
+            v = GatheredRows(v, shard.all_gather_rows_async(v.reshape(v.shape[0], H * D)))
+            work = shard.all_reduce_sum_async(reduced)
+
+            def finish():
+                if work is not None:
+                    work.wait()
+                return be.simple_apply(q, reduced, n_global, D)
+            return LazyAttention(finish, q.shape[0], H, D), v
+        shard.all_reduce_sum(reduced)
     return be.simple_apply(q, reduced, n_global, D), v
+
+
+class LazyAttention:
+    """The `simple` attention of a row-sharded layer whose record all-reduce is still in flight: materialize() waits
+    for it and runs the apply kernel.  gcn_aggregate calls it after part 0 of the SpMM, which needs neither."""
+
+    def __init__(self, finish, n, H, D):
+        self._finish, self._value = finish, None
+        self.shape = (n, H, D)
+
+    def materialize(self):
+        if self._value is None:
+            self._value = self._finish()
+            self._finish = None
+        return self._value
 
 
 class GatheredRows:
@@ -232,10 +254,11 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
     destination rows.  `tail` (H == 1 only) = dict(x0, prev, alpha, ln_weight, ln_bias, eps) fuses the
     layer tail of :139-140 / :200-203 into the SpMM epilogue; the result is then [n, 1, D]."""
     n, H, D = x.shape
-    a2 = None if attn is None else attn.reshape(n, H * D)
     be = get_backend()
     args = (csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz)
+    flat = lambda a: None if a is None else (a.materialize() if isinstance(a, LazyAttention) else a).reshape(n, H * D)
     if shard is None or shard.world <= 1:
+        a2 = flat(attn)
         x2 = x.reshape(n, H * D)
         out = be.spmm(*args, x2, 0, n, a2, attn_scale, gcn_scale, tail, csr.row_order(0, n))
         return out.reshape(n, H, D)
@@ -258,10 +281,12 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
         local = local if local.is_contiguous() else local.contiguous()
         scratch = be.spmm(*args, local, row_begin, n_rows, None, attn_scale, gcn_scale, None, order,
                           (0, own_lo, own_hi, None, row_begin))
+        a2 = flat(attn)                        # waits for the record all-reduce, runs `apply` -- after part 0 is queued
         x2 = handle.wait()
         out = be.spmm(*args, x2, row_begin, n_rows, a2, attn_scale, gcn_scale, tail, order,
                       (1, own_lo, own_hi, scratch, 0))
     else:
+        a2 = flat(attn)
         x2 = handle.wait()
         out = be.spmm(*args, x2, row_begin, n_rows, a2, attn_scale, gcn_scale, tail, order)
     return out.reshape(n_rows, H, D)
