@@ -231,11 +231,11 @@ def norm_relu(x, ln_weight, ln_bias, eps):
 
 
 def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
-    """nn.Linear (-> LayerNorm) (-> ReLU).  Narrow inputs (C_in <= 64) run the fused HIP kernel when no gradient is
+    """nn.Linear (-> LayerNorm) (-> ReLU).  Narrow inputs (C_in <= 128) run the fused HIP kernel when no gradient is
     needed; wide ones use the vendor GEMM (rocBLAS via F.linear) followed by the fused LayerNorm/ReLU kernel."""
     fn = torch.nn.functional
     grad = _needs_grad(x, weight, bias, ln_weight, ln_bias)
-    if not grad and x.dim() == 2 and x.shape[1] <= 64 and (ln_weight is None or weight.shape[0] <= 64):
+    if not grad and x.dim() == 2 and x.shape[1] <= 128 and (ln_weight is None or weight.shape[0] <= 64):
         return ops.linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
     y = fn.linear(x, weight, bias)
     if ln_weight is not None:

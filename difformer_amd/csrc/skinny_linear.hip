@@ -19,11 +19,14 @@ namespace {
 using dif::f32x4;
 using dif::Elem;
 
-constexpr int kLinStride = 68;          // floats per LDS weight row (64 + 4: b128 reads of 16 rows hit all banks)
-constexpr int kLinMaxBlocks = 4;        // 64-feature blocks per workgroup
+// LDS weight rows hold 64 input channels (+4 floats: b128 reads of 16 rows hit all banks) for C_in <= 64, 128 (+4) for
+// C_in <= 128 (Pokec's 65 features); a workgroup keeps 4 resp. 2 blocks of 64 output features.
+constexpr int lin_stride(int kq) { return kq <= 4 ? 68 : 132; }
+constexpr int lin_channels(int kq) { return kq <= 4 ? 64 : 128; }
+constexpr int lin_max_blocks(int kq) { return kq <= 4 ? 4 : 2; }
 
 // grid (row chunks, ceil(C_out/256)); 256 threads; dynamic LDS = blocks * 64 * (kLinStride + 1) floats.
-// KQ = number of 16-channel groups of C_in actually used (1..4).
+// KQ = number of 16-channel groups of C_in actually used (1..8).
 template <int KQ, typename T>
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict__ x, int64_t ldx, int64_t n_rows,
                                                             int C_in, const T* __restrict__ W,
@@ -36,6 +39,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
     const int wave = threadIdx.x >> 6;
     const int l15 = lane & 15;
     const int lg = lane >> 4;
+    constexpr int kLinStride = lin_stride(KQ), kCW = lin_channels(KQ), kLinMaxBlocks = lin_max_blocks(KQ);
     const int f0 = blockIdx.y * 64 * kLinMaxBlocks;
     int nblk = (C_out - f0 + 63) / 64;
     if (nblk > kLinMaxBlocks) nblk = kLinMaxBlocks;
@@ -43,18 +47,18 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
     float* sm_b = sm + nblk * 64 * kLinStride;              // [nblk*64] bias in feature order
 
     // 8 loads in flight per thread before their LDS stores (a plain load -> store loop is 16 round trips per block)
-    for (int base = threadIdx.x; base < nblk * 64 * 64; base += 256 * 8) {
+    for (int base = threadIdx.x; base < nblk * 64 * kCW; base += 256 * 8) {
         float wv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = base + 256 * u;                      // nblk * 4096 is a multiple of 2048: e stays in range
-            const int f = e >> 6, c = e & 63;
+            const int e = base + 256 * u;                      // nblk * 64 * kCW is a multiple of 2048: e stays in range
+            const int f = e / kCW, c = e % kCW;
             wv[u] = (f0 + f < C_out && c < C_in) ? Elem<T>::ld(W + static_cast<int64_t>(f0 + f) * C_in + c) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = base + 256 * u;
-            const int f = e >> 6, c = e & 63;
+            const int f = e / kCW, c = e % kCW;
             sm_w[((f & ~63) + 16 * (f & 3) + ((f & 63) >> 2)) * kLinStride + c] = wv[u];
         }
     }
@@ -166,11 +170,13 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
                  const T* ln_weight, const T* ln_bias, float ln_eps, int relu, T* out, int64_t ldo, dif_stream_t stream) {
     DIF_REQUIRE(n_rows > 0 && C_in > 0 && C_out > 0, DIF_E_BADARG, "dif_linear: n_rows, C_in, C_out must be positive");
     DIF_REQUIRE(x && W && bias && out, DIF_E_BADARG, "dif_linear: null pointer");
-    DIF_REQUIRE(C_in <= 64, DIF_E_SHAPE, "dif_linear: covers C_in <= 64 (got %d); use the vendor GEMM", C_in);
+    DIF_REQUIRE(C_in <= 128, DIF_E_SHAPE, "dif_linear: covers C_in <= 128 (got %d); use the vendor GEMM", C_in);
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
                 "dif_linear: ln_weight and ln_bias must be given together");
     DIF_REQUIRE(!ln_weight || C_out <= 64, DIF_E_SHAPE, "dif_linear: fused LayerNorm needs C_out <= 64");
     DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear: leading dimension smaller than a row");
+    const int kq = (C_in + 15) / 16;
+    const int kLinMaxBlocks = lin_max_blocks(kq), kLinStride = lin_stride(kq);
     const int gy = (C_out + 64 * kLinMaxBlocks - 1) / (64 * kLinMaxBlocks);
     DIF_REQUIRE(gy <= 65535, DIF_E_RANGE, "dif_linear: C_out too large");
     const int nblk = (C_out >= 64 * kLinMaxBlocks) ? kLinMaxBlocks : (C_out + 63) / 64;
@@ -184,14 +190,17 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
     if (gx < 1) gx = 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(static_cast<unsigned>(gx), gy), block(256);
-    const int kq = (C_in + 15) / 16;
 #define DIF_LIN(KQ) \
     hipLaunchKernelGGL((skinny_linear_kernel<KQ, T>), grid, block, lds, st, x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, \
                        ln_bias, ln_eps, relu, out, ldo, vec, ovec)
     if (kq == 1) DIF_LIN(1);
     else if (kq == 2) DIF_LIN(2);
     else if (kq == 3) DIF_LIN(3);
-    else DIF_LIN(4);
+    else if (kq == 4) DIF_LIN(4);
+    else if (kq == 5) DIF_LIN(5);
+    else if (kq == 6) DIF_LIN(6);
+    else if (kq == 7) DIF_LIN(7);
+    else DIF_LIN(8);
 #undef DIF_LIN
     return dif::launch_status("skinny_linear_kernel");
 }

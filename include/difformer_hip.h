@@ -232,7 +232,7 @@ int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_bl
 /* ---------------------------------------------------------------------------------------
  * a5 ends  input MLP  difformer.py:188-191 (Linear -> LayerNorm -> ReLU)  and output Linear :208 for the
  * narrow shapes of this model:  out = x W^T + b  [-> LayerNorm(ln_weight, ln_bias, eps)] [-> ReLU].
- * x [n_rows, C_in], W [C_out, C_in] (nn.Linear layout), b [C_out].  Covers C_in <= 64 (and C_out <= 64
+ * x [n_rows, C_in], W [C_out, C_in] (nn.Linear layout), b [C_out].  Covers C_in <= 128 (and C_out <= 64
  * when LayerNorm is fused); DIF_E_SHAPE otherwise -- the host then uses the vendor GEMM.
  * ------------------------------------------------------------------------------------- */
 int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const float* W,

@@ -337,7 +337,10 @@ def test_spmm_with_fused_tail_matches_unfused(n, e, d, n_blocks, dev):
 
 @pytest.mark.parametrize("n,ci,co,ln,relu", [(132534, 8, 64, True, True), (5000, 64, 112, False, False),
                                               (777, 33, 7, False, False), (1000, 64, 64, True, False),
-                                              (100, 10, 10, True, True), (17, 1, 200, False, True)])
+                                              (100, 10, 10, True, True), (17, 1, 200, False, True),
+                                              (3000, 64, 256, False, False), (3000, 64, 700, False, True),
+                                              (100000, 65, 64, True, True), (2000, 100, 130, False, False),
+                                              (2000, 128, 64, True, False), (333, 127, 300, False, True)])
 def test_skinny_linear_vs_numpy(n, ci, co, ln, relu, dev):
     from difformer_amd import ops
     g = torch.Generator().manual_seed(ci * 100 + co)
