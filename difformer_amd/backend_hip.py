@@ -410,6 +410,70 @@ class HipBackend:
         _lib.check(rc, name)
         return out
 
+    # ---- a3, dense unweighted graphs: feature-sliced product with LDS-staged sources (csrc/gcn_sliced.hip) ----------
+    def sliced_plan(self, n_src, n_rows, F):
+        """int32[8] geometry (ctypes array) or None when the shape is not covered."""
+        plan = (ctypes.c_int32 * 8)()
+        rc = self.lib.dif_sliced_plan(int(n_src), int(n_rows), int(F), plan)
+        return plan if rc == 0 else None
+
+    def sliced_build(self, rowptr, blkptr, src, n_src, nnz, row_begin, n_rows, F, plan):
+        """-> (entries uint16 [512 * n_blocks], table int32) or None when a (row, tile) group exceeds the byte counters.
+        Two host syncs (status, block count): cold path, once per (graph, shard, F)."""
+        dev = _require_device(rowptr, blkptr, src)
+        slices, panels, P, S, W, R, T, NT = (int(v) for v in plan)
+        i32 = dict(dtype=torch.int32, device=dev)
+        srt = torch.empty(max(int(nnz), 1), dtype=torch.int16, device=dev)
+        counts = torch.empty(int(n_rows) * NT * 16, dtype=torch.uint8, device=dev)
+        lengths = torch.empty(panels * NT * S * 4, **i32)
+        table = torch.empty(2 * panels * NT * W + 1, **i32)
+        status = torch.empty(1, **i32)
+        with _Timed(self, "dif_sliced_measure", dev):
+            rc = self.lib.dif_sliced_measure(_ptr(rowptr), _ptr(blkptr), _ptr(src), int(n_src), int(nnz), int(row_begin),
+                                             int(n_rows), int(F), plan, _ptr(srt), _ptr(counts), _ptr(lengths), _ptr(table),
+                                             _ptr(status), _stream(dev))
+        _lib.check(rc, "dif_sliced_measure")
+        bad, n_blocks = (int(v) for v in torch.stack([status[0], table[-1]]).tolist())
+        if bad:
+            return None
+        entries = torch.empty(512 * max(n_blocks, 1), dtype=torch.int16, device=dev)
+        with _Timed(self, "dif_sliced_emit", dev):
+            rc = self.lib.dif_sliced_emit(_ptr(rowptr), _ptr(blkptr), int(n_src), int(row_begin), int(n_rows), int(F), plan,
+                                          _ptr(srt), _ptr(counts), _ptr(table), max(n_blocks, 1), _ptr(entries), _stream(dev))
+        _lib.check(rc, "dif_sliced_emit")
+        return entries, table
+
+    def sliced_prescale(self, x, rowptr, n_src, plan):
+        """x [n_src, F] fp32 -> ys [F/4, T*NT, 4]: rows scaled by deg^-1/2, slice-major."""
+        dev = _require_device(x, rowptr)
+        _f32(x, "x")
+        F = x.shape[1]
+        x, ldx = _row_major(x, F)
+        if ldx % 4 or x.data_ptr() % 16:
+            x, ldx = x.contiguous(), F
+        ys = torch.empty((F // 4, int(plan[6]) * int(plan[7]), 4), dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_sliced_prescale_f32", dev):
+            rc = self.lib.dif_sliced_prescale_f32(_ptr(x), ldx, _ptr(rowptr), int(n_src), F, plan, _ptr(ys), _stream(dev))
+        _lib.check(rc, "dif_sliced_prescale_f32")
+        return ys
+
+    def sliced_spmm(self, entries, table, plan, ys, rowptr, n_src, row_begin, n_rows, F, attn=None, attn_scale=1.0,
+                    gcn_scale=1.0):
+        dev = _require_device(entries, table, ys, rowptr, attn)
+        lda = 0
+        if attn is not None:
+            _f32(attn, "attn")
+            attn, lda = _row_major(attn, F)
+            if lda % 4 or attn.data_ptr() % 16:
+                attn, lda = attn.contiguous(), F
+        out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_sliced_spmm_f32", dev):
+            rc = self.lib.dif_sliced_spmm_f32(_ptr(entries), _ptr(table), plan, _ptr(ys), _ptr(rowptr), int(n_src),
+                                              int(row_begin), int(n_rows), int(F), _ptr(attn), lda, float(attn_scale),
+                                              float(gcn_scale), _ptr(out), F, _stream(dev))
+        _lib.check(rc, "dif_sliced_spmm_f32")
+        return out
+
     def row_order(self, rowptr, row_begin, n_rows):
         """Rows [row_begin, row_begin + n_rows) by descending degree (indices inside the shard) ->
         (order int32 [n_rows], stats int32 [2] = {rows with degree > 4x mean, max degree}), both on the device."""

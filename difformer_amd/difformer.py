@@ -49,7 +49,8 @@ def full_attention_conv(qs, ks, vs, kernel, output_attn=False):
 def gcn_conv(x, edge_index, edge_weight):
     """x [N,H,D], edge_index [2,E] int64, edge_weight [E] or None -> [N,H,D]
     (reference: difformer.py:63-79).  The normalised CSR is built on first use and cached."""
-    csr = ops.csr_cache.get(edge_index, edge_weight, x.shape[0], x.shape[1] * x.shape[2] * x.element_size())
+    csr = ops.csr_cache.get(edge_index, edge_weight, x.shape[0], x.shape[1] * x.shape[2] * x.element_size(),
+                            elem_size=x.element_size())
     return ag.gcn_aggregate(csr, x)
 
 
@@ -136,7 +137,7 @@ class DIFFormerConv(nn.Module):
             raise ValueError("use_graph=True needs an edge_index")
         n_global = shard.n_global if shard is not None else v.shape[0]
         esize = (v.local if isinstance(v, ops.GatheredRows) else v).element_size()
-        csr = ops.csr_cache.get(edge_index, edge_weight, n_global, v.shape[1] * v.shape[2] * esize, shard)
+        csr = ops.csr_cache.get(edge_index, edge_weight, n_global, v.shape[1] * v.shape[2] * esize, shard, esize)
         if self.graph_weight > 0:                              # difformer.py:130-132
             a_s, g_s = 1.0 - self.graph_weight, float(self.graph_weight)
         else:                                                  # difformer.py:134

@@ -99,7 +99,7 @@ class TransConv(nn.Module):
             return ag.layer_tail(attn, None, prev, alpha, ln_weight, ln_bias, eps, relu)
         if edge_index is None:
             raise ValueError("use_graph=True needs an edge_index")
-        csr = ops.csr_cache.get(edge_index, edge_weight, v.shape[0], H * D * v.element_size())
+        csr = ops.csr_cache.get(edge_index, edge_weight, v.shape[0], H * D * v.element_size(), elem_size=v.element_size())
         if self.graph_weight > 0:                                                        # :151-152
             a_s, g_s = 1.0 - self.graph_weight, float(self.graph_weight)
         else:                                                                            # :154

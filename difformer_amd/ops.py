@@ -144,6 +144,29 @@ def choose_shard_blocks(num_nodes, row_bytes, nnz, shard):
     return None
 
 
+SLICED_MIN_DEGREE = 48      # entries per row from which the LDS-staged product beats the gather kernels
+SLICED_MIN_ROWS = 8192
+
+
+def sliced_tiling(num_nodes, F, nnz, edge_weight, shard, elem_size):
+    """(n_tiles, tile_rows) the feature-sliced product would use for this graph, or None when it is not a candidate
+    (edge weights, sharded run, non-fp32 rows, sparse or small graph).  csr_cache builds the CSR with that blocking."""
+    if edge_weight is not None or elem_size != 4 or (shard is not None and shard.world > 1):
+        return None
+    if F % 4 or F > 256 or num_nodes < SLICED_MIN_ROWS or nnz < SLICED_MIN_DEGREE * num_nodes:
+        return None
+    be = get_backend()
+    plan = be.sliced_plan(num_nodes, num_nodes, F) if hasattr(be, "sliced_plan") else None
+    return None if plan is None else (int(plan[7]), int(plan[6]))
+
+
+class SlicedAdjacency:
+    """Entry blocks + table + geometry of the feature-sliced product (include/difformer_hip.h, dif_sliced_*)."""
+
+    def __init__(self, plan, entries, table):
+        self.plan, self.entries, self.table = plan, entries, table
+
+
 class GraphCSR:
     """Normalised adjacency in CSR over destination rows (built once per graph, on device)."""
 
@@ -154,6 +177,8 @@ class GraphCSR:
         self._edges = None          # weak references to (edge_index, edge_weight) for the lazily built adjoint
         self._adjoint = None
         self._orders = {}           # (row_begin, n_rows) -> rows by descending degree (blocked SpMM load balance)
+        self.weighted = self.transposed = False
+        self._sliced = {}           # (row_begin, n_rows, F) -> SlicedAdjacency | None
 
     def row_order(self, row_begin, n_rows):
         """(order, n_split) for the blocked SpMM over a shard: its rows by descending degree, the first n_split of them
@@ -176,9 +201,41 @@ class GraphCSR:
         rowptr, blkptr, src, val = get_backend().csr_build(edge_index, edge_weight, int(num_nodes), int(n_blocks),
                                                            transpose, int(block_rows))
         csr = cls(rowptr, blkptr, n_blocks, src, val, num_nodes, edge_index.shape[1], block_rows)
+        csr.weighted, csr.transposed = edge_weight is not None, bool(transpose)
         if not transpose:
             csr._edges = (weakref.ref(edge_index), None if edge_weight is None else weakref.ref(edge_weight))
         return csr
+
+    def sliced(self, row_begin, n_rows, F):
+        """The feature-sliced LDS format of rows [row_begin, row_begin + n_rows) for F fp32 feature columns
+        (csrc/gcn_sliced.hip), built on first use -- or None when this graph keeps the gather kernels: edge weights,
+        an adjoint CSR, a blocking that is not the format's tiling, skewed degrees (lock-step lanes pay the longest row
+        of a 64-row slot) or a (row, tile) group beyond the byte counters."""
+        key = (int(row_begin), int(n_rows), int(F))
+        if key not in self._sliced:
+            self._sliced[key] = self._build_sliced(*key)
+        return self._sliced[key]
+
+    def _build_sliced(self, row_begin, n_rows, F):
+        if self.weighted or self.transposed or self.nnz == 0:
+            return None
+        be = get_backend()
+        if self.num_nodes < SLICED_MIN_ROWS or self.nnz < SLICED_MIN_DEGREE * self.num_nodes or not hasattr(be, "sliced_plan"):
+            return None
+        plan = be.sliced_plan(self.num_nodes, n_rows, F)
+        if plan is None:
+            return None
+        T, NT = int(plan[6]), int(plan[7])
+        if NT != self.n_blocks or (NT > 1 and T != self.block_rows):
+            return None
+        deg = self.rowptr[row_begin + 1: row_begin + n_rows + 1] - self.rowptr[row_begin: row_begin + n_rows]
+        max_deg, total = (int(v) for v in torch.stack([deg.max(), deg.sum()]).tolist())       # one sync, cold path
+        if max_deg * n_rows > 2 * total:
+            return None
+        built = be.sliced_build(self.rowptr, self.blkptr, self.src, self.num_nodes, self.nnz, row_begin, n_rows, F, plan)
+        if built is None:
+            return None
+        return SlicedAdjacency(plan, built[0], built[1])
 
     def hold_edges(self):
         """Strong references to the tensors this CSR was built from (None if already freed).  The autograd node of the
@@ -219,11 +276,16 @@ class _CSRCache:
             k += (id(edge_weight), edge_weight.data_ptr(), edge_weight._version)
         return k
 
-    def get(self, edge_index, edge_weight, num_nodes, row_bytes=256, shard=None):
-        """`row_bytes` = bytes of one feature row the SpMM will gather (H*D*4); picks the blocking -- aligned with the
-        rank boundaries of `shard` when the run is row-sharded."""
+    def get(self, edge_index, edge_weight, num_nodes, row_bytes=256, shard=None, elem_size=4):
+        """`row_bytes` = bytes of one feature row the SpMM will gather (H*D*elem_size); picks the blocking -- the
+        tiling of the feature-sliced product for dense unweighted fp32 graphs, else ~2.5 MiB source blocks, aligned
+        with the rank boundaries of `shard` when the run is row-sharded."""
+        tiling = sliced_tiling(num_nodes, row_bytes // elem_size, edge_index.shape[1], edge_weight, shard, elem_size)
         aligned = choose_shard_blocks(num_nodes, row_bytes, edge_index.shape[1], shard)
-        n_blocks, block_rows = aligned if aligned else (choose_source_blocks(num_nodes, row_bytes, edge_index.shape[1]), 0)
+        if tiling is not None:
+            n_blocks, block_rows = tiling if tiling[0] > 1 else (1, 0)
+        else:
+            n_blocks, block_rows = aligned if aligned else (choose_source_blocks(num_nodes, row_bytes, edge_index.shape[1]), 0)
         key = self._key(edge_index, edge_weight, num_nodes, n_blocks, block_rows)
         hit = self.entries.get(key)
         if hit is not None:
@@ -260,6 +322,19 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
     if shard is None or shard.world <= 1:
         a2 = flat(attn)
         x2 = x.reshape(n, H * D)
+        sl = csr.sliced(0, n, H * D) if (x.dtype == torch.float32 and n == csr.num_nodes) else None
+        if sl is not None:
+            # dense unweighted graph: sources pre-scaled and staged slice by slice in LDS (csrc/gcn_sliced.hip); the
+            # LayerNorm of the tail needs whole rows, which the slice workgroups do not have: it runs as its own pass
+            ys = be.sliced_prescale(x2, csr.rowptr, csr.num_nodes, sl.plan)
+            out = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, 0, n, H * D, a2,
+                                 attn_scale, gcn_scale)
+            if tail is not None:
+                out = be.layer_tail(out.reshape(n, H, D), tail.get("x0"), tail.get("prev"), tail.get("alpha", 0.5),
+                                    tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5),
+                                    tail.get("relu", False))
+                return out.reshape(n, 1, D)
+            return out.reshape(n, H, D)
         out = be.spmm(*args, x2, 0, n, a2, attn_scale, gcn_scale, tail, csr.row_order(0, n))
         return out.reshape(n, H, D)
     # row-sharded: the one exchange step of this operator is the all-gather of the value rows (N*H*D elements)

@@ -159,6 +159,46 @@ size_t dif_row_order_workspace_bytes(int64_t n_rows);
 int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int32_t* order, int32_t* stats,
                   void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * a3, dense graphs without edge weights: feature-sliced product with the source rows staged in LDS
+ *     (same function of node classification/difformer.py:63-79 as dif_gcn_spmm_f32 for edge_weight = None:
+ *      value_e = deg[col]^-1/2 * deg[row]^-1/2 factors into a pre-scaled source row and a per-destination scale, so
+ *      an entry is only a source index; results agree with dif_gcn_spmm_f32 to fp32 rounding, not bit for bit)
+ *
+ * A workgroup owns a panel of destination rows and a 16-byte slice of the feature row; source rows are swept in tiles
+ * of plan[6] rows held in LDS; an entry is a 16-bit tile-local row number read with one ds_read_b128 (csrc/gcn_sliced.hip).
+ *   dif_sliced_plan     plan int32[8] = {slices = F/4, panels, rows per panel, 64-row slots per panel, waves, rounds,
+ *                       tile rows T (multiple of 16, <= 10,208), tiles NT}.  Host-only, deterministic in its arguments.
+ *                       DIF_E_SHAPE when F % 4 != 0 or F > 1024.
+ *   dif_sliced_measure  needs the CSR built by dif_csr_build(n_blocks = NT, block_rows = T) (blkptr may be NULL when
+ *                       NT == 1).  Re-orders every (row, tile) group by LDS bank (-> `sorted` uint16[nnz], `counts`
+ *                       16 bytes per (local row, tile)), schedules the entries (-> `lengths` int32[panels*NT*slots*4]) and
+ *                       writes `table` int32[2*panels*NT*waves + 1] = {first block, blocks per round} per (panel, tile,
+ *                       wave) and the total number of 1-KiB blocks in its last element.  status[0] != 0: a (row, tile)
+ *                       group holds more than 255 entries -- use dif_gcn_spmm_f32 for this graph.
+ *   dif_sliced_emit     writes the blocks: `entries` uint16[512 * n_blocks] with n_blocks = table[2*panels*NT*waves]
+ *                       (read back by the caller: the size is data dependent).  sorted / counts / lengths may be freed
+ *                       afterwards; entries + table + plan are the format.
+ *   dif_sliced_prescale_f32  ys float[F/4][T*NT][4] = deg^-1/2 (0 for a node without incoming entries, :74) times x,
+ *                       slice-major; x holds all n_src rows.
+ *   dif_sliced_spmm_f32 out[r,:] = gcn_scale * deg[r]^-1/2 * sum_e ys[src_e] (+ attn_scale * attn[r,:]) for the n_rows
+ *                       rows the format was built for (out / attn hold only those rows).  Deterministic.
+ * ------------------------------------------------------------------------------------- */
+int dif_sliced_plan(int64_t n_src, int64_t n_rows, int F, int32_t* plan);
+int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, const int32_t* src, int64_t n_src,
+                       int64_t nnz, int64_t row_begin, int64_t n_rows, int F, const int32_t* plan,
+                       uint16_t* sorted, void* counts, int32_t* lengths, int32_t* table, int32_t* status,
+                       dif_stream_t stream);
+int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int64_t n_src, int64_t row_begin,
+                    int64_t n_rows, int F, const int32_t* plan, const uint16_t* sorted, const void* counts,
+                    const int32_t* table, int64_t n_blocks, uint16_t* entries, dif_stream_t stream);
+int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_t* rowptr, int64_t n_src, int F,
+                            const int32_t* plan, float* ys, dif_stream_t stream);
+int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table, const int32_t* plan, const float* ys,
+                        const int32_t* rowptr, int64_t n_src, int64_t row_begin, int64_t n_rows, int F,
+                        const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out,
+                        int64_t ldo, dif_stream_t stream);
+
 /* Split product for row-sharded runs (one process per GPU): a rank owns the source rows of the blocks
  * [own_blk_begin, own_blk_end) before the all-gather of the value rows has delivered the others.
  *   part 0: sweeps only those blocks and parks the fp32 accumulators in `scratch` (no epilogue, `out` untouched).  `x` may

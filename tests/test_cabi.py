@@ -25,7 +25,7 @@ def lib():
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and len(names) == 35
+    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and "dif_sliced_spmm_f32" in names and len(names) == 40
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -50,6 +50,23 @@ def test_version_and_size_helpers(lib):
     assert lib.dif_sigmoid_workspace_bytes(16384, 16384, 1, 64, 64) == 0         # 512 query groups = one full round: no key split
     assert lib.dif_sigmoid_workspace_bytes(20000, 20000, 1, 64, 64) > 0          # 625 groups: split to trim the last round
     assert lib.dif_sigmoid_workspace_bytes(2708, 2708, 1, 64, 64) > 0            # Cora: keys split over workgroups
+
+
+def test_sliced_plan_is_host_side_arithmetic(lib):
+    """dif_sliced_plan: geometry of the feature-sliced product (no device call)."""
+    plan = (ctypes.c_int32 * 8)()
+    assert lib.dif_sliced_plan(132534, 132534, 64, plan) == 0
+    slices, panels, P, S, W, R, T, NT = list(plan)
+    assert (slices, panels) == (16, 16) and P * panels >= 132534 and S == -(-P // 64) and W * R >= S and W <= 16
+    assert T % 16 == 0 and T <= 10208 and T * NT >= 132534 and NT == 13
+    assert lib.dif_sliced_plan(2000000, 2000000, 64, plan) == 0 and plan[1] * plan[0] > 256     # more panels than CUs
+    assert plan[5] <= 10
+    assert lib.dif_sliced_plan(1000, 1000, 30, plan) == -2 and b"F % 4" in lib.dif_last_error()
+    assert lib.dif_sliced_plan(5000, 5000, 64, plan) == 0 and plan[7] == 1                     # one tile: plain CSR
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    assert rc == -1 and b"null pointer" in lib.dif_last_error()
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, 6000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    assert rc == -1 and b"plan does not match" in lib.dif_last_error()
 
 
 def test_argument_checks_reject_before_touching_the_device(lib):
