@@ -16,8 +16,9 @@ all-gather of the value rows per layer over RCCL.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the gcn_conv SpMM): algorithmic
 bytes per launch = 8*nnz + 4*(N+1) + 2*n_rows*H*D*4 over its mean duration from
-HIP events recorded on the launching stream inside the timed region.  `cpu_baseline` times the oracle
-port (numpy + OpenMP C) of the same forward on the host cores (rank 0, N=1 only).
+HIP events recorded on the launching stream in a short pass right after the timed region (the timed
+region holds nothing but the K steps).  `cpu_baseline` times the whole forward of the oracle port
+(numpy + OpenMP C) on the host cores, 1 warm-up + 3 runs, median (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -67,29 +68,25 @@ def make_graph(n, pairs, dev, zipf=False):
     return torch.stack([torch.cat([a, b, loops]), torch.cat([b, a, loops])]).contiguous()
 
 
-def cpu_baseline(model, x, edge_index, cfg, n_layers):
-    """Oracle port timed on the host: input MLP + ONE propagation layer + output MLP on the full graph;
-    the propagation-layer time is multiplied by the layer count (every layer does identical work)."""
+def cpu_baseline(model, x, edge_index, cfg, repeats=3):
+    """The oracle port (numpy + OpenMP C restatement of the reference, oracle/) timed on the host cores: the WHOLE
+    forward on the full graph, one warm-up + `repeats` timed runs, median."""
     from oracle import difformer_oracle as orc
     p = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     xh = x.cpu().numpy()
     ei = None if edge_index is None else edge_index.cpu().numpy()
     cores = os.cpu_count() or 1
     os.environ["ORACLE_THREADS"] = str(cores)
-    t0 = time.perf_counter()
-    h = orc.linear(xh, p["fcs.0.weight"], p["fcs.0.bias"])
-    h = np.maximum(orc.layer_norm(h, p["bns.0.weight"], p["bns.0.bias"]), np.float32(0))
-    t1 = time.perf_counter()
-    c = orc.difformer_conv(p, "convs.0.", h, h, ei, None, h, cfg)
-    c = np.float32(0.5) * c + np.float32(0.5) * h
-    c = orc.layer_norm(c, p["bns.1.weight"], p["bns.1.bias"])
-    t2 = time.perf_counter()
-    orc.linear(c, p["fcs.1.weight"], p["fcs.1.bias"])
-    t3 = time.perf_counter()
-    total = (t1 - t0) + n_layers * (t2 - t1) + (t3 - t2)
-    return {"value": x.shape[0] / total, "unit": "nodes/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (numpy + OpenMP C gcn_conv) on the full graph: input MLP + 1 of {n_layers} propagation "
-                      f"layers ({t2 - t1:.2f} s, x{n_layers}) + output MLP; forward = {total:.2f} s"}
+    orc.difformer_forward(p, xh, ei, None, cfg)
+    times = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        orc.difformer_forward(p, xh, ei, None, cfg)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": x.shape[0] / med, "unit": "nodes/s", "cores": cores, "kind": "port",
+            "sample": f"whole {cfg['num_layers']}-layer forward of the oracle port (numpy + OpenMP C gcn_conv) on the full "
+                      f"graph, 1 warm-up + {repeats} timed runs: median {med:.2f} s (min {min(times):.2f}, max {max(times):.2f})"}
 
 
 def main():
@@ -142,11 +139,15 @@ def main():
     with torch.no_grad():
         if use_graph:  # cold: CSR build (degree, values, stable sort), once per graph
             esz = 2 if store == torch.bfloat16 else 4
-            ops.csr_cache.get(edge_index, None, n, hidden * esz, shard)   # first build also pays hipMalloc for the workspace
+            def cold_build():      # CSR + (dense unweighted fp32 graphs, one GPU) the feature-sliced LDS format
+                csr = ops.csr_cache.get(edge_index, None, n, hidden * esz, shard, esz)
+                if shard is None and esz == 4:
+                    csr.sliced(0, n, hidden)
+            cold_build()           # first build also pays hipMalloc for the workspaces
             ops.csr_cache.clear()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ops.csr_cache.get(edge_index, None, n, hidden * esz, shard)   # timed: what every new graph / mini-batch costs
+            cold_build()           # timed: what every new graph / mini-batch costs
             torch.cuda.synchronize()
             cold_ms = (time.perf_counter() - t0) * 1e3
         for _ in range(args.warmup):
@@ -157,7 +158,6 @@ def main():
         if use_graph_replay:
             for _ in range(2):
                 step()
-        be.kernel_events = {}
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -168,12 +168,21 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if use_graph_replay:
-            # per-kernel HIP events cannot be recorded inside a replayed graph: time the dominant kernel with the
-            # same events on the same stream in a short eager pass right after the timed region
-            for _ in range(min(args.steps, 5)):
-                model(x, edge_index)
-            torch.cuda.synchronize()
+        # Separate short pass right after the timed region (nothing but the K steps sits inside it): per-forward HIP
+        # events on the launching stream -> median / spread, and per-entry-point events -> the dominant kernel's mean
+        # launch duration for the roofline.
+        fwd_events = []
+        for _ in range(min(args.steps, 10)):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(torch.cuda.current_stream(dev))
+            step()
+            b.record(torch.cuda.current_stream(dev))
+            fwd_events.append((a, b))
+        be.kernel_events = {}
+        for _ in range(min(args.steps, 5)):
+            model(x, edge_index)
+        torch.cuda.synchronize()
+        fwd_ms = sorted(a.elapsed_time(b) for a, b in fwd_events)
     ktimes = be.kernel_times_ms()
     be.kernel_events = None
     if world > 1:
@@ -187,28 +196,34 @@ def main():
     # roofline of the dominant kernel on this rank
     if use_graph:
         esz = 2 if store == torch.bfloat16 else 4
-        dom, alg_bytes = "dif_gcn_spmm_f32", 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * esz
-        dom_name = "spmm_blocked_kernel (gcn_conv)"
+        alg_bytes = 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * esz
+        if ktimes.get("dif_sliced_spmm_f32"):
+            dom, dom_name, dom_key = "dif_sliced_spmm_f32", "sliced_spmm_kernel (gcn_conv)", "sliced_spmm_kernel"
+        else:
+            dom, dom_name, dom_key = "dif_gcn_spmm_f32", "spmm_blocked_kernel (gcn_conv)", "spmm_blocked_kernel"
     elif kernel == "simple":
-        dom, alg_bytes = "dif_project_reduce_f32", 3.0 * n_local * hidden * 4
+        dom, alg_bytes, dom_key = "dif_project_reduce_f32", 3.0 * n_local * hidden * 4, "project_reduce_kernel"
         dom_name = "project_reduce_kernel (+finalize)"
     else:
-        dom, alg_bytes = "dif_sigmoid_attn_f32", 4.0 * n_local * hidden * 4
+        dom, alg_bytes, dom_key = "dif_sigmoid_attn_f32", 4.0 * n_local * hidden * 4, "sigmoid_attn_kernel"
         dom_name = "sigmoid_attn_kernel"
     dom_ms = float(np.mean(ktimes[dom])) if ktimes.get(dom) else None
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
     # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE, calibrated; scripts/pmc_traffic.sh) stored under profiles/ -- a counter run cannot
     # share a process with this timed run.  Only valid for the single-GPU workload it was collected on.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_c4.json")
-    if world == 1 and use_graph and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("workload") == args.workload:
-            traffic = tj["kernels"].get("spmm_blocked_kernel", {}).get("hbm_bytes_per_launch")
+    traffic = tsrc = None
+    for tfile in ("r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
+        tpath = os.path.join(ROOT, "profiles", tfile)
+        if world == 1 and use_graph and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and dom_key in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom_key].get("hbm_bytes_per_launch")
+                tsrc = f"profiles/{tfile} (rocprofv3 PMC, separate passes)"
+                break
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic_c4.json (rocprofv3 PMC, separate passes)" if traffic else None,
+                "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms}
 
     if args.per_kernel and rank == 0:
@@ -220,12 +235,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and store == torch.float32:
         cfg = dict(hidden_channels=hidden, num_layers=layers, num_heads=1, kernel=kernel, alpha=0.5, use_bn=True,
                    use_residual=True, use_weight=True, use_graph=use_graph, graph_weight=-1, use_source=False)
-        cpu = cpu_baseline(model, x_full, edge_index, cfg, layers)
+        cpu = cpu_baseline(model, x_full, edge_index, cfg)
 
     if rank == 0:
         print(json.dumps({
             "metric": "DIFFormer-layer forward nodes/sec", "value": value, "unit": "nodes/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_step_events": {"median": fwd_ms[len(fwd_ms) // 2], "min": fwd_ms[0], "max": fwd_ms[-1], "n": len(fwd_ms)},
+            "higher_is_better": True,
             "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": "bf16" if store == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "nodes": n, "csr_entries": nnz, "in_channels": f_in,
                        "hidden": hidden, "heads": 1, "layers": layers, "kernel": kernel, "use_graph": use_graph,
