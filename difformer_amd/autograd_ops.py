@@ -65,6 +65,10 @@ class _SimpleAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v):
+        if q.shape[0] != v.shape[0] or k.shape[0] != v.shape[0]:
+            # the kernels take the row count from q: L < N would read past the end of k / v (difformer.py:29 raises too)
+            raise RuntimeError(f"simple kernel needs as many queries as sources (N={q.shape[0]}, L={v.shape[0]}; "
+                               "difformer.py:29)")
         be = ops.get_backend()
         reduced = be.simple_reduce(q, k, v)
         out = be.simple_apply(q, reduced, q.shape[0], v.shape[2])

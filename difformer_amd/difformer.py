@@ -73,6 +73,7 @@ class DIFFormerConv(nn.Module):
         self.graph_weight = graph_weight
         self.use_source = use_source
         self.row_shard = None  # set through DIFFormer.set_row_shard for multi-GPU runs
+        self._fused_wb = None  # (key, weight, bias) of the concatenated projections (inference only)
 
     def reset_parameters(self):
         self.Wk.reset_parameters()
@@ -85,9 +86,22 @@ class DIFFormerConv(nn.Module):
         H, D = self.num_heads, self.out_channels
         if query_input is source_input:
             mods = [self.Wq, self.Wk] + ([self.Wv] if self.use_weight else [])
-            w = torch.cat([m.weight for m in mods], dim=0)
-            b = torch.cat([m.bias for m in mods], dim=0)
-            qkv = F.linear(source_input, w, b)               # [n, (2|3)*H*D]; q/k/v are column slices
+            params = [t for m in mods for t in (m.weight, m.bias)]
+            if ag._needs_grad(*params):
+                w = torch.cat([m.weight for m in mods], dim=0)
+                b = torch.cat([m.bias for m in mods], dim=0)
+            else:
+                # inference: the concatenation is rebuilt only when a parameter changes (in-place optimiser steps and
+                # load_state_dict bump _version; .to() replaces the tensors) -- two concat kernels per layer otherwise
+                key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in params)
+                if self._fused_wb is None or self._fused_wb[0] != key:
+                    with torch.no_grad():
+                        self._fused_wb = (key, torch.cat([m.weight for m in mods], dim=0),
+                                          torch.cat([m.bias for m in mods], dim=0))
+                w, b = self._fused_wb[1], self._fused_wb[2]
+            # [n, (2|3)*H*D]; q/k/v are column slices.  Narrow inputs take the hand-written Linear kernel (one launch,
+            # x read once), wide ones the vendor GEMM (autograd_ops.linear decides).
+            qkv = ag.linear(source_input, w, b) if w.shape[0] <= 256 else F.linear(source_input, w, b)
             q = qkv[:, : H * D].reshape(-1, H, D)
             k = qkv[:, H * D: 2 * H * D].reshape(-1, H, D)
             v = qkv[:, 2 * H * D:].reshape(-1, H, D) if self.use_weight else None
@@ -127,8 +141,9 @@ class DIFFormerConv(nn.Module):
                 attn = ag.sigmoid_attention(q, k, v_att, shard)
             else:
                 raise ValueError(f"unknown attention kernel {self.kernel!r}")
-            if self.use_graph and not v.is_contiguous():
-                v = v.contiguous()   # the SpMM gathers whole rows: 4*H*D-byte contiguous rows are ~8 % faster
+            if self.use_graph and not v.is_contiguous() and v.shape[0] >= 65536:
+                v = v.contiguous()   # the blocked SpMM gathers whole rows: contiguous rows are ~8 % faster on big graphs;
+                                     # small graphs take the strided view as it is (every kernel has a leading dimension)
         if not self.use_graph:
             if isinstance(attn, ops.LazyAttention):
                 attn = attn.materialize()

@@ -15,6 +15,7 @@ regime), the all-gather moves N*H*D*4 bytes per layer in one call.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -57,6 +58,10 @@ class RowShard:
             self.counts = split_rows(self.n_global, self.world)
         if sum(self.counts) != self.n_global or len(self.counts) != self.world:
             raise ValueError("RowShard: counts must have one entry per rank and sum to n_global")
+        if self.world > 1 and min(self.counts) <= 0:
+            # a rank without rows would fail its kernels' argument checks while the others block in the collectives
+            raise ValueError(f"RowShard: every rank needs at least one row (n_global={self.n_global}, world={self.world} "
+                             f"gives blocks {self.counts}); use fewer ranks or pass explicit counts")
         self.offsets = [0]
         for c in self.counts:
             self.offsets.append(self.offsets[-1] + c)
@@ -67,12 +72,13 @@ class RowShard:
             return cls(n_global)
         world = dist.get_world_size(group)
         side = None
-        if world > 1:
-            try:
-                ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
-                side = dist.new_group(ranks=ranks)      # collective: every rank of `group` must get here
-            except Exception:                           # no second communicator: both collectives share `group`
-                side = None
+        # Two communicators in flight at once (the record all-reduce on its own one while the all-gather of the value
+        # rows runs) is an optimisation torch.distributed documents as unsafe unless the user orders the collectives;
+        # it has not been validated on multi-GPU hardware here, so it is opt-in.  The default shares `group`: the
+        # two collectives are then issued in the same order on every rank and serialise.
+        if world > 1 and os.environ.get("DIFFORMER_OVERLAP_COLLECTIVES", "0") == "1":
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+            side = dist.new_group(ranks=ranks)          # collective: every rank of `group` gets here; errors propagate
         return cls(n_global, dist.get_rank(group), world, group, side_group=side)
 
     @property

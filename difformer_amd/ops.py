@@ -280,6 +280,12 @@ class _CSRCache:
         """`row_bytes` = bytes of one feature row the SpMM will gather (H*D*elem_size); picks the blocking -- the
         tiling of the feature-sliced product for dense unweighted fp32 graphs, else ~2.5 MiB source blocks, aligned
         with the rank boundaries of `shard` when the run is row-sharded."""
+        if edge_weight is not None and edge_weight.requires_grad and torch.is_grad_enabled():
+            # the reference's gcn_conv is differentiable in edge_weight (value = w * d_in * d_out through
+            # torch_sparse.matmul); the CSR values here are built outside autograd
+            raise NotImplementedError("difformer_amd: gradients with respect to edge_weight are not implemented; "
+                                      "detach() it or keep it a constant of the graph")
+        self._purge()
         tiling = sliced_tiling(num_nodes, row_bytes // elem_size, edge_index.shape[1], edge_weight, shard, elem_size)
         aligned = choose_shard_blocks(num_nodes, row_bytes, edge_index.shape[1], shard)
         if tiling is not None:
@@ -300,6 +306,15 @@ class _CSRCache:
         while len(self.entries) > self.capacity:
             self.entries.popitem(last=False)
         return csr
+
+    def _purge(self):
+        """Drop entries whose edge tensors have been freed: a mini-batch loop (main-batch.py:126-131) makes a new
+        edge_index per batch, and a dead entry would otherwise pin its CSR (and sliced format) in HBM until eight
+        newer graphs push it out."""
+        dead = [k for k, (ei_ref, ew_ref, _) in self.entries.items()
+                if ei_ref() is None or (ew_ref is not None and ew_ref() is None)]
+        for k in dead:
+            del self.entries[k]
 
     def clear(self):
         self.entries.clear()

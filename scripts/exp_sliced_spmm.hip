@@ -316,11 +316,119 @@ __global__ __launch_bounds__(1024) void sliced_kernel4(const uint4* __restrict__
     else sweep4<R - 1>(tile, ell, offw, ysl, out, N, T, NT, P, W, R, slices, panel, slice, w, lane);
 }
 
+// ---- v5: v2 layout with options: BSTEP = steps per block (8: uint4 per lane, 4: uint2 per lane), DMA = tile loaded by
+// global_load_lds (no VGPR round trip), EXTRA = dummy packed FMAs per 4 steps (VALU headroom probe).
+template <int NR, int BSTEP, bool DMA, int EXTRA>
+__device__ __forceinline__ void sweep5(f32x4* tile, const uint32_t* __restrict__ ell, const int2* __restrict__ tabw,
+                                       const f32x4* __restrict__ ysl, f32x4* __restrict__ out, int N, int T, int NT, int P,
+                                       int W, int slices, int panel, int slice, int w, int lane) {
+    constexpr int DW = BSTEP / 2;            // dwords per lane per block
+    const uint32_t four = 4;
+    f32x4 acc[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dummy = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto half = [&](uint32_t w0, uint32_t w1, f32x4& a) {
+        const uint32_t wds[2] = {w0, w1};
+        f32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint32_t lo, hi;
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                : "=v"(lo) : "v"(four), "v"(wds[q]));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                : "=v"(hi) : "v"(four), "v"(wds[q]));
+            v[2 * q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + lo);
+            v[2 * q + 1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + hi);
+        }
+        const f32x4 s = (v[0] + v[1]) + (v[2] + v[3]);
+        a += s;
+#pragma unroll
+        for (int x = 0; x < EXTRA; ++x) dummy = dummy * s + s;       // 2 v_pk_fma_f32 each
+    };
+    for (int t = 0; t < NT; ++t) {
+        const int2 tb = tabw[static_cast<size_t>(t) * W];
+        const int start = __builtin_amdgcn_readfirstlane(tb.x), nb = __builtin_amdgcn_readfirstlane(tb.y);
+        const uint32_t* base = ell + (static_cast<size_t>(start) * 64 + lane) * DW;
+        uint32_t e[NR][DW];
+        auto load = [&](uint32_t (&d)[DW], const uint32_t* p) {
+            if constexpr (DW == 4) { const uint4 r = *reinterpret_cast<const uint4*>(p); d[0] = r.x; d[1] = r.y; d[2] = r.z; d[3] = r.w; }
+            else { const uint2 r = *reinterpret_cast<const uint2*>(p); d[0] = r.x; d[1] = r.y; }
+        };
+#pragma unroll
+        for (int j = 0; j < NR; ++j) load(e[j], base + static_cast<size_t>(j) * 64 * DW);
+        __syncthreads();
+        {
+            const f32x4* src = ysl + static_cast<size_t>(t) * T;
+            if (DMA) {
+                for (int b0 = w * 64; b0 < T; b0 += W * 64) {
+                    const int i = b0 + lane;
+                    __builtin_amdgcn_global_load_lds(src + (i < T ? i : T - 1), tile + b0, 16, 0, 0);
+                }
+            } else {
+                const int nth = blockDim.x;
+                for (int b0 = threadIdx.x; b0 < T; b0 += 5 * nth) {
+                    f32x4 r[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { const int i = b0 + u * nth; r[u] = i < T ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { const int i = b0 + u * nth; if (i < T) tile[i] = r[u]; }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k + 1 < nb; ++k) {
+            const uint32_t* nx = base + static_cast<size_t>(k + 1) * NR * 64 * DW;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                half(e[j][0], e[j][1], acc[j]);
+                if constexpr (DW == 4) half(e[j][2], e[j][3], acc[j]);
+                load(e[j], nx + static_cast<size_t>(j) * 64 * DW);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            half(e[j][0], e[j][1], acc[j]);
+            if constexpr (DW == 4) half(e[j][2], e[j][3], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int lrow = (j * W + w) * 64 + lane;
+        const int64_t row = static_cast<int64_t>(panel) * P + lrow;
+        if (EXTRA > 0) acc[j] += dummy * 1e-30f;
+        if (lrow < P && row < N) out[row * slices + slice] = acc[j];
+    }
+}
+
+template <int R, int BSTEP, bool DMA, int EXTRA>
+__global__ __launch_bounds__(1024) void sliced_kernel5(const uint32_t* __restrict__ ell, const int2* __restrict__ tab,
+                                                       const f32x4* __restrict__ ys, f32x4* __restrict__ out, int N,
+                                                       int Npad, int T, int NT, int P, int S, int W, int slices) {
+    __shared__ f32x4 tile[10224];
+    const int b = blockIdx.x;
+    const int xcd = b & 7, k = b >> 3;
+    const int per = gridDim.x >> 3;
+    const int panel = xcd * (per / slices) + k / slices;
+    const int slice = k % slices;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < 16) tile[T + threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4* ysl = ys + static_cast<size_t>(slice) * Npad;
+    const int2* tabw = tab + static_cast<size_t>(panel) * NT * W + w;
+    const int nr = (S - w + W - 1) / W;
+    if (nr == R) sweep5<R, BSTEP, DMA, EXTRA>(tile, ell, tabw, ysl, out, N, T, NT, P, W, slices, panel, slice, w, lane);
+    else sweep5<R - 1, BSTEP, DMA, EXTRA>(tile, ell, tabw, ysl, out, N, T, NT, P, W, slices, panel, slice, w, lane);
+}
+
 struct Fmt {
     int N, F, slices, panels, P, S, W, R, T, NT, Npad;
     std::vector<uint16_t> ell;      // blocks of 64 lanes x 8 entries
     std::vector<int32_t> off;       // v1: [panels][NT][W][R+1], block units; v2: [panels][NT][W] {start, nb}
     int v2 = 0;
+    int bstep = 8;      // steps per block
     int64_t nnz = 0, steps = 0;
 };
 
@@ -422,26 +530,28 @@ static void build(Fmt& f, int N, int F, double deg, int W, int R, int order, uin
             for (int i = 0; i < 16; ++i) sched[kGroupLanes[g][i]] = gs[i];
             len = std::max<int>(len, gs[0].size());
         }
-        const int nb = (len + 7) / 8;
+        const int BS = f.bstep;
+        const int nb = (len + BS - 1) / BS;
         nblk[c] = nb;
-        steps += nb * 8;
+        steps += nb * BS;
         std::vector<uint16_t>& out = chunks[c];
-        out.resize(static_cast<size_t>(nb) * 512);
+        out.resize(static_cast<size_t>(nb) * 64 * BS);
         for (int g = 0; g < 4; ++g)
             for (int i = 0; i < 16; ++i) {
                 const int l = kGroupLanes[g][i];
-                for (int k2 = 0; k2 < nb * 8; ++k2) {
+                for (int k2 = 0; k2 < nb * BS; ++k2) {
                     const uint16_t v = k2 < static_cast<int>(sched[l].size()) ? sched[l][k2] : static_cast<uint16_t>(f.T + i);
-                    out[(static_cast<size_t>(k2 / 8) * 64 + l) * 8 + (k2 % 8)] = v;
+                    out[(static_cast<size_t>(k2 / BS) * 64 + l) * BS + (k2 % BS)] = v;
                 }
             }
     }
     f.nnz = nnz; f.steps = steps;
     // bubble block: lane l reads zero row T + (its position inside its hardware lane group)
     uint16_t bub[512];
+    const int BSZ = 64 * f.bstep;        // entries per block
     for (int g = 0; g < 4; ++g)
         for (int i = 0; i < 16; ++i)
-            for (int k2 = 0; k2 < 8; ++k2) bub[kGroupLanes[g][i] * 8 + k2] = static_cast<uint16_t>(f.T + i);
+            for (int k2 = 0; k2 < f.bstep; ++k2) bub[kGroupLanes[g][i] * f.bstep + k2] = static_cast<uint16_t>(f.T + i);
     if (f.v2) {
         // [p][t][w] -> {start, nb}; blocks in [k][j] order, every round of the wave padded to nb blocks
         f.off.assign(static_cast<size_t>(f.panels) * f.NT * W * 2, 0);
@@ -458,10 +568,10 @@ static void build(Fmt& f, int N, int F, double deg, int W, int R, int order, uin
                     if (nb < 1) nb = 1;
                     o[1] = nb;
                     tot += static_cast<int64_t>(nb) * nr;
-                    steps += static_cast<int64_t>(nb) * nr * 8;
+                    steps += static_cast<int64_t>(nb) * nr * f.bstep;
                 }
         f.steps = steps;
-        f.ell.resize(static_cast<size_t>(tot) * 512);
+        f.ell.resize(static_cast<size_t>(tot) * BSZ);
 #pragma omp parallel for schedule(dynamic, 16)
         for (int c = 0; c < f.panels * f.NT * W; ++c) {
             const int w = c % W;
@@ -471,9 +581,9 @@ static void build(Fmt& f, int N, int F, double deg, int W, int R, int order, uin
                 const std::vector<uint16_t>& ch = chunks[c * R + j];
                 const int have = nblk[c * R + j];
                 for (int k2 = 0; k2 < nb; ++k2) {
-                    uint16_t* dst = &f.ell[(static_cast<size_t>(start) + static_cast<size_t>(k2) * nr + j) * 512];
-                    if (k2 < have) memcpy(dst, &ch[static_cast<size_t>(k2) * 512], 1024);
-                    else memcpy(dst, bub, 1024);
+                    uint16_t* dst = &f.ell[(static_cast<size_t>(start) + static_cast<size_t>(k2) * nr + j) * BSZ];
+                    if (k2 < have) memcpy(dst, &ch[static_cast<size_t>(k2) * BSZ], BSZ * 2);
+                    else memcpy(dst, bub, BSZ * 2);
                 }
             }
         }
@@ -567,32 +677,66 @@ static float run4(const Fmt& f, const uint16_t* d_ell, const int32_t* d_off, con
     return ms / iters;
 }
 
+template <int R, int BSTEP, bool DMA, int EXTRA>
+static float run5(const Fmt& f, const uint16_t* d_ell, const int32_t* d_off, const float* d_ys, float* d_out, int iters) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto go = [&]() {
+        hipLaunchKernelGGL((sliced_kernel5<R, BSTEP, DMA, EXTRA>), dim3(256), dim3(f.W * 64), 0, 0,
+                           reinterpret_cast<const uint32_t*>(d_ell), reinterpret_cast<const int2*>(d_off),
+                           reinterpret_cast<const f32x4*>(d_ys), reinterpret_cast<f32x4*>(d_out), f.N, f.Npad, f.T, f.NT, f.P,
+                           f.S, f.W, f.slices);
+    };
+    for (int i = 0; i < 3; ++i) go();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) go();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 132534;
     const double deg = argc > 2 ? atof(argv[2]) : 598.0;
     const int only = argc > 3 ? atoi(argv[3]) : -1;     // run a single configuration (for profiling)
     const int F = 64;
-    struct Cfg { int W, R, order, v2; } cfgs[] = {{16, 9, 1, 0}, {16, 9, 1, 1}, {13, 10, 1, 1}, {16, 9, 1, 2}, {13, 10, 1, 2}};   // v2: 0 = v1 kernel, 1 = v2/v3 kernel, 2 = v4 kernel on the v1 layout
+    // v5 variants on the equalised [k][j] layout, W = 15 waves x 9 rounds (the product's geometry at C4)
+    struct Cfg { int bstep, dma, extra; const char* what; } cfgs[] = {
+        {8, 0, 0, "8-step blocks, register-staged tile (the product kernel)"},
+        {8, 1, 0, "8-step blocks, tile by global_load_lds"},
+        {4, 0, 0, "4-step blocks, register-staged tile"},
+        {4, 1, 0, "4-step blocks, tile by global_load_lds"},
+        {8, 0, 1, "8-step, +2 dummy v_pk_fma per 4 steps"},
+        {8, 0, 2, "8-step, +4 dummy v_pk_fma per 4 steps"},
+        {8, 0, 4, "8-step, +8 dummy v_pk_fma per 4 steps"},
+    };
     std::vector<float> ys;
     int ci = -1;
+    Fmt f8, f4;
     for (const Cfg& c : cfgs) {
         ++ci;
         if (only >= 0 && ci != only) continue;
-        Fmt f;
-        f.v2 = c.v2 == 1;
-        double t0 = omp_get_wtime();
-        build(f, N, F, deg, c.W, c.R, c.order, 7);
-        double t1 = omp_get_wtime();
-        printf("[%d] v%d W=%d R=%d order=%d: T=%d NT=%d P=%d S=%d nnz=%lld padded steps x64=%lld (x%.3f) blocks=%zu (%.1f MB) host build %.1fs\n",
-               ci, c.v2 + 1, c.W, c.R, c.order, f.T, f.NT, f.P, f.S, (long long)f.nnz, (long long)f.steps * 64, f.steps * 64.0 / f.nnz,
-               f.ell.size() / 512, f.ell.size() * 2 / 1e6, t1 - t0);
+        Fmt& f = c.bstep == 8 ? f8 : f4;
+        if (f.ell.empty()) {
+            f.v2 = 1;
+            f.bstep = c.bstep;
+            double t0 = omp_get_wtime();
+            build(f, N, F, deg, 15, 9, 1, 7);
+            printf("format bstep=%d: T=%d NT=%d P=%d S=%d nnz=%lld padded steps x64=%lld (x%.3f) %.1f MB, host build %.1fs\n", c.bstep,
+                   f.T, f.NT, f.P, f.S, (long long)f.nnz, (long long)f.steps * 64, f.steps * 64.0 / f.nnz, f.ell.size() * 2 / 1e6,
+                   omp_get_wtime() - t0);
+        }
         ys.resize(static_cast<size_t>(f.slices) * f.Npad * 4);
         std::mt19937 rng(3);
         std::uniform_real_distribution<float> u(-1.f, 1.f);
-        for (size_t i = 0; i < ys.size(); ++i) ys[i] = u(rng);
-        for (int s = 0; s < f.slices; ++s)
+        for (size_t i2 = 0; i2 < ys.size(); ++i2) ys[i2] = u(rng);
+        for (int s2 = 0; s2 < f.slices; ++s2)
             for (int r = N; r < f.Npad; ++r)
-                for (int q = 0; q < 4; ++q) ys[(static_cast<size_t>(s) * f.Npad + r) * 4 + q] = 0.f;
+                for (int q = 0; q < 4; ++q) ys[(static_cast<size_t>(s2) * f.Npad + r) * 4 + q] = 0.f;
         uint16_t* d_ell; int32_t* d_off; float *d_ys, *d_out;
         CK(hipMalloc(&d_ell, f.ell.size() * 2));
         CK(hipMalloc(&d_off, f.off.size() * 4));
@@ -602,51 +746,41 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(d_off, f.off.data(), f.off.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_ys, ys.data(), ys.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemset(d_out, 0, static_cast<size_t>(N) * F * 4));
-        float ms = 0, ms1 = 0, ms2 = 0;
-        if (c.v2 == 2) {
-            if (c.R == 10) ms = run4<10>(f, d_ell, d_off, d_ys, d_out, 20);
-            else ms = run4<9>(f, d_ell, d_off, d_ys, d_out, 20);
-        } else if (!c.v2) {
-            if (c.R == 10) ms = run<10>(f, d_ell, d_off, d_ys, d_out, 20);
-            else ms = run<9>(f, d_ell, d_off, d_ys, d_out, 20);
-        } else if (c.R == 10) {
-            if (only < 0) { ms1 = run2<10, 1>(f, d_ell, d_off, d_ys, d_out, 20); ms2 = run2<10, 2>(f, d_ell, d_off, d_ys, d_out, 20); }
-            ms = run2<10, 0>(f, d_ell, d_off, d_ys, d_out, 20);
-        } else {
-            if (only < 0) { ms1 = run2<9, 1>(f, d_ell, d_off, d_ys, d_out, 20); ms2 = run2<9, 2>(f, d_ell, d_off, d_ys, d_out, 20); }
-            ms = run2<9, 0>(f, d_ell, d_off, d_ys, d_out, 20);
-        }
-        printf("   kernel %.4f ms  (%.1f G entries/s, algorithmic 702 MB -> %.0f GB/s)   [no tile reload %.4f ms, tile loads only %.4f ms]\n",
-               ms, f.nnz / ms / 1e6, 702.4e6 / ms / 1e6, ms1, ms2);
+        float ms = 0;
+        const int it = 30;
+        if (c.bstep == 8 && !c.dma && c.extra == 0) ms = run5<9, 8, false, 0>(f, d_ell, d_off, d_ys, d_out, it);
+        else if (c.bstep == 8 && c.dma) ms = run5<9, 8, true, 0>(f, d_ell, d_off, d_ys, d_out, it);
+        else if (c.bstep == 4 && !c.dma) ms = run5<9, 4, false, 0>(f, d_ell, d_off, d_ys, d_out, it);
+        else if (c.bstep == 4 && c.dma) ms = run5<9, 4, true, 0>(f, d_ell, d_off, d_ys, d_out, it);
+        else if (c.extra == 1) ms = run5<9, 8, false, 1>(f, d_ell, d_off, d_ys, d_out, it);
+        else if (c.extra == 2) ms = run5<9, 8, false, 2>(f, d_ell, d_off, d_ys, d_out, it);
+        else ms = run5<9, 8, false, 4>(f, d_ell, d_off, d_ys, d_out, it);
+        printf("[%d] %-62s %.4f ms  (702 MB -> %.0f GB/s)\n", ci, c.what, ms, 702.4e6 / ms / 1e6);
         std::vector<float> out(static_cast<size_t>(N) * F);
         CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
         double maxerr = 0;
+        const int BS = f.bstep;
         for (int trial = 0; trial < 40; ++trial) {
-            const int p = trial % f.panels, s = (trial * 7) % f.S, l = (trial * 13) % 64, sl = (trial * 5) % f.slices;
-            const int j = s / f.W, w = s % f.W;
+            const int p = trial % f.panels, s2 = (trial * 7) % f.S, l = (trial * 13) % 64, sl = (trial * 5) % f.slices;
+            const int j = s2 / f.W, w = s2 % f.W;
             const int nr = (f.S - w + f.W - 1) / f.W;
-            const int64_t row = static_cast<int64_t>(p) * f.P + s * 64 + l;
-            if (s * 64 + l >= f.P || row >= N) continue;
+            const int64_t row = static_cast<int64_t>(p) * f.P + s2 * 64 + l;
+            if (s2 * 64 + l >= f.P || row >= N) continue;
             double ref[4] = {0, 0, 0, 0};
             for (int t = 0; t < f.NT; ++t) {
-                auto add_block = [&](int64_t b) {
-                    for (int k2 = 0; k2 < 8; ++k2) {
-                        const int v = f.ell[(static_cast<size_t>(b) * 64 + l) * 8 + k2];
+                const int32_t* o = &f.off[((static_cast<size_t>(p) * f.NT + t) * f.W + w) * 2];
+                for (int k2 = 0; k2 < o[1]; ++k2) {
+                    const int64_t b = static_cast<int64_t>(o[0]) + static_cast<int64_t>(k2) * nr + j;
+                    for (int k3 = 0; k3 < BS; ++k3) {
+                        const int v = f.ell[(static_cast<size_t>(b) * 64 + l) * BS + k3];
                         if (v >= f.T) continue;
                         for (int q = 0; q < 4; ++q) ref[q] += ys[(static_cast<size_t>(sl) * f.Npad + t * f.T + v) * 4 + q];
                     }
-                };
-                if (c.v2 == 1) {
-                    const int32_t* o = &f.off[((static_cast<size_t>(p) * f.NT + t) * f.W + w) * 2];
-                    for (int k2 = 0; k2 < o[1]; ++k2) add_block(static_cast<int64_t>(o[0]) + static_cast<int64_t>(k2) * nr + j);
-                } else {
-                    const int32_t* o = &f.off[((static_cast<size_t>(p) * f.NT + t) * f.W + w) * (f.R + 1)];
-                    for (int b = o[j]; b < o[j + 1]; ++b) add_block(b);
                 }
             }
             for (int q = 0; q < 4; ++q) maxerr = std::max(maxerr, std::abs(ref[q] - out[row * F + sl * 4 + q]));
         }
-        printf("   max abs err on sampled rows %.3e\n", maxerr);
+        printf("      max abs err on sampled rows %.3e\n", maxerr);
         CK(hipFree(d_ell)); CK(hipFree(d_off)); CK(hipFree(d_ys)); CK(hipFree(d_out));
     }
     return 0;

@@ -39,6 +39,72 @@ def test_full_attention_conv_golden(name, dev):
     assert rel_err(out.cpu().numpy(), c["out_f64"]) < TOL
 
 
+# ------------------------------------------------------------------ a6: dense attention maps (difformer.py:42-43, :58-59, :211-226)
+ATTNW = load_golden("attnw")
+
+
+@pytest.mark.parametrize("name", sorted(ATTNW))
+def test_full_attention_conv_output_attn_golden(name, dev):
+    """output_attn=True returns (out, [N, L, H] weights); fixtures are outputs of the reference itself."""
+    from difformer_amd import full_attention_conv
+    c = ATTNW[name]
+    out, attn = full_attention_conv(t(c["q"], dev), t(c["k"], dev), t(c["v"], dev), str(c["kernel"]), output_attn=True)
+    assert attn.shape == c["attn_f64"].shape and attn.dtype == torch.float32
+    assert rel_err(out.cpu().numpy(), c["out_f64"]) < TOL
+    assert rel_err(attn.cpu().numpy(), c["attn_f64"]) < TOL
+
+
+@pytest.mark.parametrize("kernel,n,h,d", [("simple", 300, 1, 64), ("sigmoid", 300, 1, 64), ("sigmoid", 150, 3, 16),
+                                          ("simple", 2708, 1, 64)])
+def test_output_attn_vs_oracle_weights(kernel, n, h, d, dev):
+    from difformer_amd import full_attention_conv
+    g = torch.Generator().manual_seed(n + d)
+    q, k, v = (torch.randn(n, h, d, generator=g) for _ in range(3))
+    out, attn = full_attention_conv(q.to(dev), k.to(dev), v.to(dev), kernel, output_attn=True)
+    q64, k64, v64 = (a.double().numpy() for a in (q, k, v))
+    if kernel == "simple":
+        ref_w = orc.simple_attention_weights(q64, k64)
+        ref_o = orc.simple_attention(q64, k64, v64)
+    else:
+        ref_o, ref_w = orc.sigmoid_attention(q64, k64, v64, return_weights=True)
+    assert rel_err(attn.cpu().numpy(), ref_w) < TOL and rel_err(out.cpu().numpy(), ref_o) < TOL
+    if kernel == "sigmoid":      # rows of the sigmoid map are a convex combination
+        assert torch.allclose(attn.sum(dim=1), torch.ones(n, h, device=dev), atol=1e-5)
+
+
+def test_simple_output_attn_with_several_heads_fails_like_the_reference(dev):
+    """difformer.py:43 divides a [N,L,H] tensor by a [N,H,1] one: only H == 1 broadcasts."""
+    from difformer_amd import full_attention_conv
+    q, k, v = (torch.randn(40, 2, 8, device=dev) for _ in range(3))
+    with pytest.raises(RuntimeError):
+        full_attention_conv(q, k, v, "simple", output_attn=True)
+
+
+@pytest.mark.parametrize("kernel", ["simple", "sigmoid"])
+def test_get_attentions_and_conv_output_attn_on_device(kernel, dev):
+    """DIFFormer.get_attentions (:211-226; no graph term) and DIFFormerConv(..., output_attn=True) (:142-143) against
+    the oracle's weights of the same projected q, k."""
+    from difformer_amd import DIFFormer
+    torch.manual_seed(5)
+    n, f_in, hidden = 200, 24, 64
+    model = DIFFormer(f_in, hidden, 5, num_layers=2, kernel=kernel, use_graph=False).to(dev).eval()
+    x = torch.randn(n, f_in, device=dev)
+    with torch.no_grad():
+        att = model.get_attentions(x)
+        assert att.shape == (2, n, n, 1)
+        p = {k_: v_.detach().cpu().double().numpy() for k_, v_ in model.state_dict().items()}
+        h = orc.linear(x.cpu().double().numpy(), p["fcs.0.weight"], p["fcs.0.bias"])
+        h = np.maximum(orc.layer_norm(h, p["bns.0.weight"], p["bns.0.bias"]), 0.0)
+        qs = orc.linear(h, p["convs.0.Wq.weight"], p["convs.0.Wq.bias"]).reshape(n, 1, hidden)
+        ks = orc.linear(h, p["convs.0.Wk.weight"], p["convs.0.Wk.bias"]).reshape(n, 1, hidden)
+        ref = orc.simple_attention_weights(qs, ks) if kernel == "simple" else \
+            orc.sigmoid_attention(qs, ks, qs, return_weights=True)[1]
+        assert rel_err(att[0].cpu().numpy(), ref) < TOL
+        hx = torch.from_numpy(h).float().to(dev)
+        out, w = model.convs[0](hx, hx, None, None, hx, output_attn=True)
+        assert out.shape == (n, hidden) and rel_err(w.cpu().numpy(), ref) < TOL
+
+
 # ------------------------------------------------------------------ a1 seeded sizes + properties
 @pytest.mark.parametrize("n,h,d", [(1, 1, 64), (15, 1, 64), (17, 2, 32), (2708, 1, 64), (50000, 1, 64),
                                    (4099, 1, 128), (1000, 1, 300), (777, 3, 20), (333, 1, 7), (132534, 1, 64)])

@@ -102,6 +102,10 @@ def test_split_rows_and_row_shard():
     assert split_rows(132534, 8) == [16568] * 7 + [16558]       # ceil(N / world) rounded up to a multiple of 8
     assert split_rows(1000, 8) == [125] * 8                     # small graphs: plain ceil(N / world)
     assert split_rows(5, 8) == [1, 1, 1, 1, 1, 0, 0, 0]
+    with pytest.raises(ValueError, match="at least one row"):       # a rank without rows would hang the collectives
+        RowShard(5, rank=0, world=8)
+    with pytest.raises(ValueError, match="at least one row"):
+        RowShard(9, rank=3, world=4)                                 # [3, 3, 3, 0]
     assert split_rows(64, 2) == [32, 32]
     s = RowShard(10, rank=2, world=3)
     assert s.counts == [4, 4, 2] and s.offsets == [0, 4, 8, 10] and (s.row_begin, s.n_local) == (8, 2)
@@ -134,6 +138,26 @@ def test_csr_cache_identity_version_and_eviction(fake_backend):
     for _ in range(20):
         ops.csr_cache.get(torch.randint(0, 50, (2, 10)), None, 50)
     assert len(ops.csr_cache.entries) <= ops.csr_cache.capacity
+    # entries whose edge tensors are gone are dropped at the next lookup (a mini-batch loop makes one graph per batch)
+    ops.csr_cache.clear()
+    keep = torch.randint(0, 50, (2, 40))
+    ops.csr_cache.get(keep, None, 50)
+    for _ in range(3):
+        ops.csr_cache.get(torch.randint(0, 50, (2, 10)), None, 50)     # temporaries: freed right after the call
+    ops.csr_cache.get(keep, None, 50)
+    assert len(ops.csr_cache.entries) == 1
+    wg = torch.rand(40, requires_grad=True)
+    with pytest.raises(NotImplementedError, match="edge_weight"):     # the reference differentiates through the values
+        ops.csr_cache.get(keep, wg, 50)
+    with torch.no_grad():
+        ops.csr_cache.get(keep, wg, 50)
+
+
+def test_simple_attention_under_grad_checks_the_lengths(fake_backend):
+    from difformer_amd import full_attention_conv
+    q = torch.randn(6, 1, 4, requires_grad=True)
+    with pytest.raises(RuntimeError, match="as many queries as sources"):
+        full_attention_conv(q, torch.randn(5, 1, 4), torch.randn(5, 1, 4), "simple")
 
 
 def test_row_major_layout_helper():
