@@ -410,6 +410,63 @@ class HipBackend:
         _lib.check(rc, name)
         return out
 
+    # ---- a1 + a4 + tail in closed form (csrc/simple_layer.hip) ---------------------------------------------------------
+    def gram(self, x, rowptr=None, plan=None):
+        """x [n, C] fp32 -> (record [C*C + C + 2] = {X^T X, column sums}, ys | None).  With rowptr + plan the pass also
+        writes the slice-major copy of x scaled by deg^-1/2 that sliced_spmm reads."""
+        dev = _require_device(x, rowptr)
+        _f32(x, "x")
+        n, C = x.shape
+        x, ldx = _row_major(x, C)
+        if ldx % 4 or x.data_ptr() % 16:
+            x, ldx = x.contiguous(), C
+        record = torch.empty(C * C + C + 2, dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.dif_gram_workspace_bytes(n, C)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        ys = None
+        if plan is not None:
+            ys = torch.empty((C // 4, int(plan[6]) * int(plan[7]), 4), dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_gram_f32", dev):
+            rc = self.lib.dif_gram_f32(_ptr(x), ldx, n, C, _ptr(rowptr) if plan is not None else None, plan, _ptr(ys),
+                                       _ptr(record), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_gram_f32")
+        return record, ys
+
+    def simple_coeffs(self, record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale):
+        dev = _require_device(record, Wq, bq, Wk, bk, Wv, bv)
+        ws_ = [None if t is None else _f32(t, "weight").contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
+        coef = torch.empty(self.lib.dif_simple_coeffs_len(C, D), dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_simple_coeffs_f32", dev):
+            rc = self.lib.dif_simple_coeffs_f32(_ptr(record), int(n_global), C, D, *[_ptr(t) for t in ws_], float(attn_scale),
+                                                _ptr(coef), _stream(dev))
+        _lib.check(rc, "dif_simple_coeffs_f32")
+        return coef
+
+    def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
+                     alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
+        dev = _require_device(x, coef, ax, Wv, bv, row_sums, x0, ln_weight, ln_bias)
+        n, C = x.shape
+        x, ldx = _row_major(x, C)
+        if ldx % 4 or x.data_ptr() % 16:
+            x, ldx = x.contiguous(), C
+        ldax = ldx0 = 0
+        if ax is not None:
+            ax, ldax = _row_major(ax, C)
+        if x0 is not None:
+            x0, ldx0 = _row_major(x0, D)
+        if Wv is not None:
+            Wv, bv = Wv.contiguous(), bv.contiguous()
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_simple_layer_f32", dev):
+            rc = self.lib.dif_simple_layer_f32(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
+                                               _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
+                                               float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps), int(bool(relu)),
+                                               _ptr(out), D, _stream(dev))
+        _lib.check(rc, "dif_simple_layer_f32")
+        return out
+
     # ---- a3, dense unweighted graphs: feature-sliced product with LDS-staged sources (csrc/gcn_sliced.hip) ----------
     def sliced_plan(self, n_src, n_rows, F):
         """int32[8] geometry (ctypes array) or None when the shape is not covered."""

@@ -1,0 +1,538 @@
+// a1 + a4 + a5 tail in closed form for the `simple` kernel with query_input == source_input == x
+// (node classification/difformer.py:18-39, :115-140, :200-203), H == 1, C_in <= 64, D <= 64, eval mode.
+//
+// With q = x Wq^T + bq, k = x Wk^T + bk, v = x Wv^T + bv every quantity stage 1 of the simple kernel needs is a
+// function of the GRAM matrix G = X^T X, the column sums sx = sum_rows x and the weights:
+//     K^T V  = Wk G Wv^T + (Wk sx) bv^T + bk (Wv sx)^T + N bk bv^T       sum k = Wk sx + N bk      sum v = Wv sx + N bv
+//     |Q|^2  = tr(Wq G Wq^T) + 2 bq.(Wq sx) + N |bq|^2                    (|K|^2 alike)
+// and stage 2 is linear in x:   num_i = x_i Mn + cn,  den_i = x_i.u + cd   with
+//     Mn = s Wq^T KtV,  cn = s bq KtV + sum v,  u = s Wq^T (sum k),  cd = s bq.(sum k) + N,  s = 1/(|Q| |K|).
+// gcn_conv is linear as well:  A_hat (x Wv^T + 1 bv^T) = (A_hat x) Wv^T + (A_hat 1) bv^T, so the SpMM runs on x itself.
+// A layer is then
+//     dif_gram_f32           one pass over x: G, sx (+ the pre-scaled slice-major copy of x the sliced SpMM reads)
+//     dif_simple_coeffs_f32  one workgroup: Mn, cn, u, cd from the 4,160-float record (the only thing that would cross GPUs)
+//     SpMM on x              ax = g_s A_hat x                                       (gcn_sliced.hip / gcn_spmm.hip)
+//     dif_simple_layer_f32   out = LN(alpha (a_s num/den + ax Wv^T + g_s rs bv [+ x0]) + (1-alpha) x)
+// q, k, v and the attention output never reach HBM: per layer the non-SpMM traffic is x read twice, ax read once,
+// out (and the slice-major copy) written once, against q, v, attn, conv written and re-read before.
+#include <type_traits>
+
+#include "dif_common.h"
+
+namespace {
+
+using dif::f32x4;
+
+constexpr int kWaves = 4;
+constexpr int kWStride = 68;     // padded LDS row (floats): 16 lanes x b128 land on 64 distinct banks
+constexpr int kGramMaxChunks = 512;
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+__device__ __forceinline__ float dinv_of(const int32_t* __restrict__ rowptr, int64_t row) {
+    const int32_t d = rowptr[row + 1] - rowptr[row];
+    return d > 0 ? sqrtf(1.0f / static_cast<float>(d)) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Gram record.  A wave reads four whole rows per instruction (lane = 16*lg + l15: row base + lg, columns 4*l15..+3), which
+// is at once the coalesced stream, the A / B operand of v_mfma_f32_16x16x4_f32 contracting over ROWS
+//   D[i][j] += sum_k A[i][k] B[k][j],  A[i][k] = X[row k][4i + ta],  B[k][j] = X[row k][4j + tb]
+//   -> lane holds G[4*(4lg + reg) + ta][4*l15 + tb]  in acc[ta][tb][reg]
+// and one 16-byte slice of the row for the slice-major copy (ys[l15][row] = dinv[row] * x[row][4*l15..]).
+// ------------------------------------------------------------------------------------------------------------
+template <bool WRITE_YS>
+__global__ __launch_bounds__(64 * kWaves, 2) void gram_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C,
+                                                              const int32_t* __restrict__ rowptr, f32x4* __restrict__ ys,
+                                                              int64_t npad, float* __restrict__ ws, int64_t ws_stride) {
+    __shared__ __attribute__((aligned(16))) float sm_g[kWaves][64 * 64];
+    __shared__ float sm_s[kWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const bool col_ok = 4 * l15 < C;
+    // G is symmetric: only the products with ta <= tb are formed (10 of 16), the fold mirrors them
+    f32x4 acc[10];
+#pragma unroll
+    for (int a = 0; a < 10; ++a) acc[a] = zero4();
+    f32x4 sx = zero4();
+    const int64_t n16 = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kWaves + wave, stride = static_cast<int64_t>(gridDim.x) * kWaves;
+    auto load16 = [&](f32x4 (&xv)[4], int64_t tile) {      // 16 consecutive rows: four loads in flight
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = tile * 16 + 4 * u + lg;
+            xv[u] = (row < n_rows && col_ok) ? *reinterpret_cast<const f32x4*>(x + row * ldx + 4 * l15) : zero4();
+        }
+    };
+    f32x4 nxt[4];
+    if (first < n16) load16(nxt, first);
+    for (int64_t tile = first; tile < n16; tile += stride) {
+        f32x4 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = nxt[u];
+        if (tile + stride < n16) load16(nxt, tile + stride);          // next tile's rows arrive under this tile's MFMAs
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (WRITE_YS) {
+                const int64_t row = tile * 16 + 4 * u + lg;
+                if (row < n_rows && col_ok) ys[static_cast<int64_t>(l15) * npad + row] = xv[u] * dinv_of(rowptr, row);
+            }
+            sx += xv[u];
+            int a = 0;
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = ta; tb < 4; ++tb, ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][ta], xv[u][tb], acc[a], 0, 0, 0);
+        }
+    }
+    if (WRITE_YS) {          // rows n_rows .. npad-1 of the copy are read by the last tile of the sweep: zero them
+        const int64_t pad = npad - n_rows;
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pad * 16;
+             i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+            const int64_t sl = i / pad, r = n_rows + i % pad;
+            if (4 * sl < C) ys[sl * npad + r] = zero4();
+        }
+    }
+    // fold: every wave parks its 64 x 64 partial (both triangles), then the workgroup adds the four copies in a fixed order
+    {
+        int a = 0;
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = ta; tb < 4; ++tb, ++a)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = 4 * (4 * lg + reg) + ta, j = 4 * l15 + tb;
+                    sm_g[wave][i * 64 + j] = acc[a][reg];
+                    if (ta != tb) sm_g[wave][j * 64 + i] = acc[a][reg];
+                }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float a = sx[t];
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        if (lg == 0) sm_s[wave][4 * l15 + t] = a;
+    }
+    __syncthreads();
+    float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
+    for (int e = threadIdx.x; e < 64 * 64; e += 64 * kWaves) {
+        const int a = e >> 6, b = e & 63;
+        if (a < C && b < C) rec[a * C + b] = ((sm_g[0][e] + sm_g[1][e]) + sm_g[2][e]) + sm_g[3][e];
+    }
+    if (threadIdx.x < C) rec[C * C + threadIdx.x] = ((sm_s[0][threadIdx.x] + sm_s[1][threadIdx.x]) + sm_s[2][threadIdx.x]) + sm_s[3][threadIdx.x];
+}
+
+int gram_chunks(int64_t n_rows) {
+    const int64_t tiles = (n_rows + 15) / 16;
+    int64_t p = (tiles + kWaves - 1) / kWaves;
+    if (p > 2 * dif::kCUs) p = 2 * dif::kCUs;
+    if (p > kGramMaxChunks) p = kGramMaxChunks;
+    if (p < 1) p = 1;
+    return static_cast<int>(p);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Coefficients: one workgroup of 1024 threads, four 64^3 products through LDS.
+//   coef = [MnT: D x C (feature-major, a_s folded in)][cn: D][u: C][cd][s][|Q|^2][|K|^2]
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kLd = 68;
+
+// one 16 x 16 tile of a 64 x 64 x 64 product on the fp32 MFMA: A(i, k), B(k, j) are LDS accessors;
+// lane holds D[16ti + 4lg + reg][16tj + l15]
+template <typename FA, typename FB>
+__device__ __forceinline__ f32x4 tile_product(FA A, FB B, int ti, int tj, int l15, int lg) {
+    f32x4 d = zero4();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(A(16 * ti + l15, 4 * ks + lg), B(4 * ks + lg, 16 * tj + l15), d, 0, 0, 0);
+    return d;
+}
+
+__global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ rec, float n_global, int C, int D,
+                                                      const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                      const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                      const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                      float attn_scale, float* __restrict__ coef) {
+    __shared__ float sG[64 * kLd], sWq[64 * kLd], sWk[64 * kLd], sWv[64 * kLd], sT[64 * kLd], sKtV[64 * kLd];
+    __shared__ float s_sx[64], s_bq[64], s_bk[64], s_bv[64], s_wk[64], s_wq[64], s_wv[64], s_ks[64], s_vs[64];
+    __shared__ float s_red[2][16];
+    __shared__ float s_scal[4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int ti = wave >> 2, tj = wave & 3;       // this wave's 16 x 16 tile of every 64 x 64 product
+    const bool has_wv = Wv != nullptr;            // use_weight = False: v = x (needs C == D), Wv = I, bv = 0
+    for (int e = tid; e < 64 * 64; e += 1024) {
+        const int a = e >> 6, b = e & 63;
+        sG[a * kLd + b] = (a < C && b < C) ? rec[a * C + b] : 0.f;
+        sWq[a * kLd + b] = (a < D && b < C) ? Wq[a * C + b] : 0.f;
+        sWk[a * kLd + b] = (a < D && b < C) ? Wk[a * C + b] : 0.f;
+        sWv[a * kLd + b] = has_wv ? ((a < D && b < C) ? Wv[a * C + b] : 0.f) : (a == b && a < D ? 1.f : 0.f);
+    }
+    if (tid < 64) {
+        s_sx[tid] = tid < C ? rec[C * C + tid] : 0.f;
+        s_bq[tid] = tid < D ? bq[tid] : 0.f;
+        s_bk[tid] = tid < D ? bk[tid] : 0.f;
+        s_bv[tid] = (has_wv && tid < D) ? bv[tid] : 0.f;
+    }
+    __syncthreads();
+    // W sx for the three projections: 192 dot products, 12 per wave, one column per lane
+    for (int r = wave * 12; r < wave * 12 + 12; ++r) {
+        const int m = r & 63, which = r >> 6;
+        const float* W = which == 0 ? sWk : which == 1 ? sWq : sWv;
+        const float a = dif::wave_sum(W[m * kLd + lane] * s_sx[lane]);
+        if (lane == 0) (which == 0 ? s_wk : which == 1 ? s_wq : s_wv)[m] = a;
+    }
+    // T = Wk G (kept), Wq G (only its trace against Wq): |K|^2, |Q|^2 main terms
+    {
+        const f32x4 tk = tile_product([&](int i, int k) { return sWk[i * kLd + k]; }, [&](int k, int j) { return sG[k * kLd + j]; },
+                                      ti, tj, l15, lg);
+        const f32x4 tq = tile_product([&](int i, int k) { return sWq[i * kLd + k]; }, [&](int k, int j) { return sG[k * kLd + j]; },
+                                      ti, tj, l15, lg);
+        float pk = 0.f, pq = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = 16 * ti + 4 * lg + reg, c = 16 * tj + l15;
+            sT[m * kLd + c] = tk[reg];
+            pk += tk[reg] * sWk[m * kLd + c];
+            pq += tq[reg] * sWq[m * kLd + c];
+        }
+        pq = dif::wave_sum(pq);
+        pk = dif::wave_sum(pk);
+        if (lane == 0) { s_red[0][wave] = pq; s_red[1][wave] = pk; }
+    }
+    __syncthreads();
+    // KtV = T Wv^T + rank-one terms; sum k, sum v; the scale
+    {
+        const f32x4 kv = tile_product([&](int i, int k) { return sT[i * kLd + k]; }, [&](int k, int j) { return sWv[j * kLd + k]; },
+                                      ti, tj, l15, lg);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = 16 * ti + 4 * lg + reg, d = 16 * tj + l15;
+            sKtV[m * kLd + d] = kv[reg] + s_wk[m] * s_bv[d] + s_bk[m] * s_wv[d] + n_global * s_bk[m] * s_bv[d];
+        }
+    }
+    if (tid < 64) {
+        s_ks[tid] = s_wk[tid] + n_global * s_bk[tid];
+        s_vs[tid] = s_wv[tid] + n_global * s_bv[tid];
+    }
+    if (wave == 15) {
+        float q2 = lane < 16 ? s_red[0][lane] : 0.f, k2 = lane < 16 ? s_red[1][lane] : 0.f;
+        q2 += 2.f * s_bq[lane] * s_wq[lane] + n_global * s_bq[lane] * s_bq[lane];
+        k2 += 2.f * s_bk[lane] * s_wk[lane] + n_global * s_bk[lane] * s_bk[lane];
+        q2 = dif::wave_sum(q2);
+        k2 = dif::wave_sum(k2);
+        if (lane == 0) {
+            s_scal[0] = 1.0f / (sqrtf(q2) * sqrtf(k2));          // difformer.py:20-21: zero norms give inf / nan as there
+            s_scal[1] = q2;
+            s_scal[2] = k2;
+        }
+    }
+    __syncthreads();
+    const float s = s_scal[0];
+    float* MnT = coef;
+    float* cn = coef + D * C;
+    float* u = cn + D;
+    {   // MnT[d][c] = a_s s sum_m KtV[m][d] Wq[m][c]
+        const f32x4 mn = tile_product([&](int i, int k) { return sKtV[k * kLd + i]; }, [&](int k, int j) { return sWq[k * kLd + j]; },
+                                      ti, tj, l15, lg);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int d = 16 * ti + 4 * lg + reg, c = 16 * tj + l15;
+            if (d < D && c < C) MnT[d * C + c] = attn_scale * s * mn[reg];
+        }
+    }
+    if (wave == 0) {                     // cn[d] = a_s (s bq KtV + sum v), one column per lane
+        float a = 0.f;
+        for (int m = 0; m < 64; ++m) a += s_bq[m] * sKtV[m * kLd + lane];
+        if (lane < D) cn[lane] = attn_scale * (s * a + s_vs[lane]);
+    } else if (wave == 1) {              // u[c] = s Wq^T (sum k)
+        float a = 0.f;
+        for (int m = 0; m < 64; ++m) a += sWq[m * kLd + lane] * s_ks[m];
+        if (lane < C) u[lane] = s * a;
+    } else if (wave == 2) {
+        const float a = dif::wave_sum(s_bq[lane] * s_ks[lane]);
+        if (lane == 0) {
+            u[C] = s * a + n_global;
+            u[C + 1] = s;
+            u[C + 2] = s_scal[1];
+            u[C + 3] = s_scal[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The layer: per 16-row tile and wave, two 64 x 64 MFMA products (x Mn, ax Wv^T), computed TRANSPOSED
+//   D[i = feature][j = row] = sum_c W[feature][c] X[row][c]
+//   A[i = lane%16][k = lane/16] = W[16ft + lane%16][16cq + 4*(lane/16) + t]    (ds_read_b128, LDS row stride 68)
+//   B[k = lane/16][j = lane%16] = X[r0 + lane%16][16cq + 4*(lane/16) + t]      (one dwordx4 per cq: the coalesced stream)
+//   -> lane (lg, l15) holds Y[row r0 + l15][features 16ft + 4lg .. +3]: four consecutive features of ONE row,
+// i.e. the very layout of the loaded x fragment.  So the residual operand is already in registers, the denominator of
+// the row is in the lane, LayerNorm folds over the four lane groups with two shuffles and rows leave as 16-byte stores.
+// ------------------------------------------------------------------------------------------------------------
+struct LayerArgs {
+    const float* x; int64_t ldx;          // layer input [n, C]
+    const float* ax; int64_t ldax;        // g_s * A_hat x [n, C] or null (use_graph = False)
+    const float* coef;                    // dif_simple_coeffs_f32 output
+    const float* Wv; const float* bv;     // [D, C], [D] or null (use_weight = False: the graph term is ax itself)
+    const float* rs; float gcn_scale;     // row sums of A_hat (for the bias of the value projection) or null
+    const float* x0; int64_t ldx0;        // use_source
+    int residual; float alpha;            // alpha * z + (1 - alpha) * x
+    const float* ln_w; const float* ln_b; float eps; int relu;
+    float* out; int64_t ldo;
+    int64_t n_rows; int C, D;
+};
+
+template <bool GUARD>
+__device__ __forceinline__ void load_rows(f32x4 (&xa)[4], const float* __restrict__ x, int64_t ldx, int64_t r, int64_t n, int lg,
+                                          int C) {
+    if (!GUARD) {
+        const float* p = x + r * ldx + 4 * lg;
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) xa[cq] = *reinterpret_cast<const f32x4*>(p + 16 * cq);
+    } else {
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+            const int c = 16 * cq + 4 * lg;
+            xa[cq] = (r < n && c < C) ? *reinterpret_cast<const f32x4*>(x + r * ldx + c) : zero4();
+        }
+    }
+}
+
+// y[ft] (+)= W_tile x^T for the four feature tiles; W in LDS [64 x kWStride]
+__device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], const float* __restrict__ w, int l15, int lg) {
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) {
+        f32x4 wf[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) wf[ft] = *reinterpret_cast<const f32x4*>(&w[(16 * ft + l15) * kWStride + 16 * cq + 4 * lg]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)      // four independent accumulator chains back to back
+                y[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ft][t], xa[cq][t], y[ft], 0, 0, 0);
+    }
+}
+
+template <bool EXACT, bool GRAPH_W>
+__global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs a) {
+    __shared__ __attribute__((aligned(16))) float sm_w[2][64 * kWStride];   // MnT, Wv (zero padded)
+    __shared__ __attribute__((aligned(16))) float sm_cn[64], sm_u[64], sm_bv[64], sm_lw[64], sm_lb[64];
+    __shared__ float sm_cd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int C = a.C, D = a.D;
+    for (int e = threadIdx.x; e < 64 * 64; e += 64 * kWaves) {
+        const int f = e >> 6, c = e & 63;
+        sm_w[0][f * kWStride + c] = (f < D && c < C) ? a.coef[f * C + c] : 0.f;
+        if (GRAPH_W) sm_w[1][f * kWStride + c] = (f < D && c < C) ? a.Wv[f * C + c] : 0.f;
+    }
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        sm_cn[i] = i < D ? a.coef[D * C + i] : 0.f;
+        sm_u[i] = i < C ? a.coef[D * C + D + i] : 0.f;
+        sm_bv[i] = (GRAPH_W && a.rs && i < D) ? a.bv[i] * a.gcn_scale : 0.f;
+        sm_lw[i] = (a.ln_w && i < D) ? a.ln_w[i] : 1.f;
+        sm_lb[i] = (a.ln_b && i < D) ? a.ln_b[i] : 0.f;
+    }
+    if (threadIdx.x == 0) sm_cd = a.coef[D * C + D + C];
+    __syncthreads();
+    const float cd = sm_cd;
+    const float inv_d = 1.0f / static_cast<float>(D);
+    // per-lane constants: this lane's 16 channels of u and its 16 features (16ft + 4lg + reg) of the vectors
+    f32x4 uu[4];
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) uu[cq] = *reinterpret_cast<const f32x4*>(&sm_u[16 * cq + 4 * lg]);
+
+    const int64_t n_tiles = (a.n_rows + 15) / 16;
+    const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kWaves + wave, stride = static_cast<int64_t>(gridDim.x) * kWaves;
+
+    auto body = [&](int64_t tile, auto guard_tag) {
+        constexpr bool G = decltype(guard_tag)::value;
+        const int64_t row = tile * 16 + l15;
+        const bool row_ok = !G || row < a.n_rows;
+        f32x4 xa[4];
+        load_rows<G>(xa, a.x, a.ldx, row, a.n_rows, lg, C);
+        f32x4 ga[4];
+        if (a.ax) load_rows<G>(ga, a.ax, a.ldax, row, a.n_rows, lg, C);
+        // denominator of this lane's row: x.u + cd, folded over the four lane groups
+        float den = 0.f;
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) den += xa[cq][t] * uu[cq][t];
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        const float rden = 1.0f / (den + cd);
+        f32x4 y[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] = *reinterpret_cast<const f32x4*>(&sm_cn[16 * ft + 4 * lg]);
+        project_t(y, xa, sm_w[0], l15, lg);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] *= rden;
+        if (a.ax) {
+            if (GRAPH_W) {
+                const float rsv = (a.rs && row_ok) ? a.rs[row] : 0.f;
+                f32x4 z[4];
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) z[ft] = *reinterpret_cast<const f32x4*>(&sm_bv[16 * ft + 4 * lg]) * rsv;
+                project_t(z, ga, sm_w[1], l15, lg);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) y[ft] += z[ft];
+            } else {          // use_weight = False: the aggregated rows are the graph term (C == D), same layout
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) y[ft] += ga[ft];
+            }
+        }
+        if (a.x0) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const int f = 16 * ft + 4 * lg;
+                if (row_ok && (EXACT || f < D)) {
+                    if (EXACT || ((a.ldx0 & 3) == 0 && f + 3 < D)) y[ft] += *reinterpret_cast<const f32x4*>(a.x0 + row * a.ldx0 + f);
+                    else
+                        for (int r = 0; r < 4; ++r) if (f + r < D) y[ft][r] += a.x0[row * a.ldx0 + f + r];
+                }
+            }
+        }
+        if (a.residual) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) y[ft] = a.alpha * y[ft] + (1.0f - a.alpha) * xa[ft];
+        }
+        if (a.ln_w) {
+            float mu = 0.f;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mu += (EXACT || 16 * ft + 4 * lg + r < D) ? y[ft][r] : 0.f;
+            mu += __shfl_xor(mu, 16, 64);
+            mu += __shfl_xor(mu, 32, 64);
+            mu *= inv_d;
+            float var = 0.f;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dz = (EXACT || 16 * ft + 4 * lg + r < D) ? y[ft][r] - mu : 0.f;
+                    y[ft][r] = dz;
+                    var += dz * dz;
+                }
+            var += __shfl_xor(var, 16, 64);
+            var += __shfl_xor(var, 32, 64);
+            const float rstd = 1.0f / sqrtf(var * inv_d + a.eps);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+                y[ft] = y[ft] * rstd * *reinterpret_cast<const f32x4*>(&sm_lw[16 * ft + 4 * lg]) +
+                        *reinterpret_cast<const f32x4*>(&sm_lb[16 * ft + 4 * lg]);
+        }
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f = 16 * ft + 4 * lg;
+            f32x4 v = y[ft];
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (row_ok && (EXACT || f < D)) {
+                if (EXACT || ((a.ldo & 3) == 0 && f + 3 < D)) *reinterpret_cast<f32x4*>(a.out + row * a.ldo + f) = v;
+                else
+                    for (int r = 0; r < 4; ++r) if (f + r < D) a.out[row * a.ldo + f + r] = v[r];
+            }
+        }
+    };
+    int64_t tile = first;
+    if (EXACT) {
+        for (; tile < n_fast; tile += stride) {
+            asm volatile("" ::: "memory");
+            body(tile, std::false_type{});
+        }
+    }
+    for (; tile < n_tiles; tile += stride) {
+        asm volatile("" ::: "memory");
+        body(tile, std::true_type{});
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dif_gram_workspace_bytes(int64_t n_rows, int C) {
+    if (n_rows <= 0 || C <= 0 || C > 64) return 0;
+    const size_t rec = (static_cast<size_t>(C) * C + C + 3) & ~size_t(3);
+    return rec * sizeof(float) * static_cast<size_t>(gram_chunks(n_rows));
+}
+
+// record = [G: C x C][sx: C][2 unused floats]; ys / rowptr / plan may be null (no slice-major copy).
+extern "C" int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, const int32_t* rowptr, const int32_t* plan,
+                            float* ys, float* record, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(x && record && workspace && n_rows > 0, DIF_E_BADARG, "dif_gram: null pointer or no rows");
+    DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0, DIF_E_SHAPE, "dif_gram: covers C <= 64, C %% 4 == 0 (got %d)", C);
+    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned16(x), DIF_E_BADARG, "dif_gram: rows of x must be 16-byte aligned");
+    DIF_REQUIRE(workspace_bytes >= dif_gram_workspace_bytes(n_rows, C), DIF_E_WORKSPACE, "dif_gram: workspace too small");
+    DIF_REQUIRE((ys == nullptr) || (rowptr && plan && dif::aligned16(ys)), DIF_E_BADARG,
+                "dif_gram: the slice-major copy needs rowptr, the plan and a 16-byte aligned buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int P = gram_chunks(n_rows);
+    const int64_t rec = (static_cast<int64_t>(C) * C + C + 3) & ~int64_t(3);
+    float* ws = static_cast<float*>(workspace);
+    if (ys) {
+        const int64_t npad = static_cast<int64_t>(plan[6]) * plan[7];
+        DIF_REQUIRE(plan[0] == C / 4 && npad >= n_rows, DIF_E_BADARG, "dif_gram: plan does not match C / n_rows");
+        hipLaunchKernelGGL((gram_kernel<true>), dim3(P), dim3(64 * kWaves), 0, st, x, ldx, n_rows, C, rowptr,
+                           reinterpret_cast<f32x4*>(ys), npad, ws, rec);
+    } else {
+        hipLaunchKernelGGL((gram_kernel<false>), dim3(P), dim3(64 * kWaves), 0, st, x, ldx, n_rows, C, nullptr, nullptr,
+                           int64_t(0), ws, rec);
+    }
+    if (int rc = dif::launch_status("gram_kernel")) return rc;
+    return dif::launch_record_finalize(ws, P, rec, C * C + C, 0, record, st);
+}
+
+extern "C" size_t dif_simple_coeffs_len(int C, int D) {
+    if (C <= 0 || D <= 0) return 0;
+    return static_cast<size_t>(D) * C + D + C + 4;
+}
+
+extern "C" int dif_simple_coeffs_f32(const float* record, int64_t n_global, int C, int D, const float* Wq, const float* bq,
+                                     const float* Wk, const float* bk, const float* Wv, const float* bv, float attn_scale,
+                                     float* coef, dif_stream_t stream) {
+    DIF_REQUIRE(record && Wq && bq && Wk && bk && coef && n_global > 0, DIF_E_BADARG, "dif_simple_coeffs: null pointer");
+    DIF_REQUIRE(C > 0 && C <= 64 && D > 0 && D <= 64, DIF_E_SHAPE, "dif_simple_coeffs: covers C, D <= 64 (got %d, %d)", C, D);
+    DIF_REQUIRE((Wv == nullptr) == (bv == nullptr), DIF_E_BADARG, "dif_simple_coeffs: Wv and bv go together");
+    DIF_REQUIRE(Wv != nullptr || C == D, DIF_E_SHAPE, "dif_simple_coeffs: without a value projection C must equal D (difformer.py:120)");
+    hipLaunchKernelGGL(coeffs_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), record,
+                       static_cast<float>(n_global), C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale, coef);
+    return dif::launch_status("coeffs_kernel");
+}
+
+extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                    const float* ax, int64_t ldax, const float* Wv, const float* bv, const float* row_sums,
+                                    float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,
+                                    const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out,
+                                    int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(x && coef && out && n_rows > 0, DIF_E_BADARG, "dif_simple_layer: null pointer or no rows");
+    DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0 && D > 0 && D <= 64, DIF_E_SHAPE,
+                "dif_simple_layer: covers C <= 64 (C %% 4 == 0) and D <= 64 (got %d, %d)", C, D);
+    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned16(x) && ldo >= D, DIF_E_BADARG,
+                "dif_simple_layer: rows of x must be 16-byte aligned, ldo >= D");
+    DIF_REQUIRE(dif::aligned16(out) && (!x0 || dif::aligned16(x0)), DIF_E_BADARG, "dif_simple_layer: out / x0 must be 16-byte aligned");
+    DIF_REQUIRE(!ax || (ldax >= C && ldax % 4 == 0 && dif::aligned16(ax)), DIF_E_BADARG,
+                "dif_simple_layer: rows of ax must be 16-byte aligned");
+    DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG, "dif_simple_layer: ln_weight and ln_bias go together");
+    DIF_REQUIRE((Wv == nullptr) == (bv == nullptr), DIF_E_BADARG, "dif_simple_layer: Wv and bv go together");
+    DIF_REQUIRE(Wv != nullptr || !ax || C == D, DIF_E_SHAPE, "dif_simple_layer: without a value projection C must equal D");
+    DIF_REQUIRE(!residual || C == D, DIF_E_SHAPE, "dif_simple_layer: the residual needs C == D");
+    DIF_REQUIRE(!x0 || ldx0 >= D, DIF_E_BADARG, "dif_simple_layer: ldx0 smaller than a row");
+    LayerArgs a = {x, ldx, ax, ldax, coef, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha, ln_weight, ln_bias, ln_eps,
+                   relu, out, ldo, n_rows, C, D};
+    const int P = gram_chunks(n_rows);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
+    const bool gw = ax != nullptr && Wv != nullptr;
+#define DIF_LAYER(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G>), dim3(P), dim3(64 * kWaves), 0, st, a)
+    if (exact) { if (gw) DIF_LAYER(true, true); else DIF_LAYER(true, false); }
+    else { if (gw) DIF_LAYER(false, true); else DIF_LAYER(false, false); }
+#undef DIF_LAYER
+    return dif::launch_status("simple_layer_kernel");
+}

@@ -122,12 +122,47 @@ class DIFFormerConv(nn.Module):
         params = (self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, self.Wv.weight, self.Wv.bias)
         return not ag._needs_grad(source_input, *params)
 
+    def _closed_form(self, query_input, source_input, prev, want_qk):
+        """The whole layer through the Gram-record formulation (csrc/simple_layer.hip): `simple` kernel, one head,
+        query == source, narrow fp32 rows, one GPU, inference; the residual must mix with the layer input itself."""
+        x = source_input
+        if not (self.kernel == 'simple' and query_input is source_input and self.num_heads == 1 and not want_qk):
+            return False
+        if x.dim() != 2 or x.dtype != torch.float32 or x.shape[1] > 64 or x.shape[1] % 4 or self.out_channels > 64:
+            return False
+        if not self.use_weight and x.shape[1] != self.out_channels:
+            return False
+        if prev is not None and (prev is not x or x.shape[1] != self.out_channels):
+            return False
+        if self.row_shard is not None and self.row_shard.world > 1:
+            return False
+        if not hasattr(ops.get_backend(), "gram"):
+            return False
+        params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias]
+        if self.use_weight:
+            params += [self.Wv.weight, self.Wv.bias]
+        return not ag._needs_grad(x, *params)
+
     def _layer(self, query_input, source_input, edge_index, edge_weight, x0=None, prev=None, alpha=0.5,
                ln_weight=None, ln_bias=None, eps=1e-5, want_qk=False):
         """Propagation (:115-136) followed by the tail (:137-140 and, when given, :200-203) -> ([n,D], q, k)."""
         H = self.num_heads
         shard = self.row_shard
         q = k = None
+        if self._closed_form(query_input, source_input, prev, want_qk):
+            if self.use_graph and edge_index is None:
+                raise ValueError("use_graph=True needs an edge_index")
+            x = source_input
+            csr = None
+            if self.use_graph:
+                csr = ops.csr_cache.get(edge_index, edge_weight, x.shape[0], x.shape[1] * 4, None, 4)
+            a_s, g_s = (1.0 - self.graph_weight, float(self.graph_weight)) if self.graph_weight > 0 else (1.0, 1.0)
+            if not self.use_graph:
+                a_s = 1.0                                       # difformer.py:130-136: the mix only exists with a graph
+            Wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
+            out = ops.simple_layer_closed_form(x, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv, csr,
+                                               a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps)
+            return out, None, None
         if not want_qk and self._fusable_projection(query_input, source_input):
             attn, v = ops.project_simple_attention(source_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,
                                                    self.Wk.bias, self.Wv.weight, self.Wv.bias, H,

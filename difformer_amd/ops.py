@@ -179,6 +179,7 @@ class GraphCSR:
         self._orders = {}           # (row_begin, n_rows) -> rows by descending degree (blocked SpMM load balance)
         self.weighted = self.transposed = False
         self._sliced = {}           # (row_begin, n_rows, F) -> SlicedAdjacency | None
+        self._row_sums = None
 
     def row_order(self, row_begin, n_rows):
         """(order, n_split) for the blocked SpMM over a shard: its rows by descending degree, the first n_split of them
@@ -236,6 +237,17 @@ class GraphCSR:
         if built is None:
             return None
         return SlicedAdjacency(plan, built[0], built[1])
+
+    def row_sums(self):
+        """A_hat 1 (float32 [N]): what the bias of the value projection turns into under the aggregation,
+        A_hat (x Wv^T + 1 bv^T) = (A_hat x) Wv^T + (A_hat 1) bv^T.  One small product per graph, cached."""
+        if self._row_sums is None:
+            ones = torch.ones((self.num_nodes, 4), dtype=torch.float32, device=self.rowptr.device)
+            be = get_backend()
+            out = be.spmm(self.rowptr, self.blkptr, self.n_blocks, self.src, self.val, self.num_nodes, self.nnz, ones, 0,
+                          self.num_nodes, None, 1.0, 1.0, None, self.row_order(0, self.num_nodes))
+            self._row_sums = out[:, 0].contiguous()
+        return self._row_sums
 
     def hold_edges(self):
         """Strong references to the tensors this CSR was built from (None if already freed).  The autograd node of the
@@ -380,6 +392,29 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
         x2 = handle.wait()
         out = be.spmm(*args, x2, row_begin, n_rows, a2, attn_scale, gcn_scale, tail, order)
     return out.reshape(n_rows, H, D)
+
+
+def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
+                             ln_bias, eps, relu=False):
+    """One DIFFormer layer with the `simple` kernel on a single GPU, query == source == x [n, C], one head
+    (csrc/simple_layer.hip): Gram record -> coefficients -> SpMM on x -> the layer kernel.  q, k, v and the attention
+    output never reach memory.  csr = None: use_graph = False.  Wv = None: use_weight = False."""
+    be = get_backend()
+    n, C = x.shape
+    D = Wq.shape[0]
+    sl = csr.sliced(0, n, C) if (csr is not None and n == csr.num_nodes) else None
+    record, ys = be.gram(x, csr.rowptr if sl is not None else None, sl.plan if sl is not None else None)
+    coef = be.simple_coeffs(record, n, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
+    ax = rs = None
+    if csr is not None:
+        if sl is not None:
+            ax = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, 0, n, C, None, 1.0, gcn_scale)
+        else:
+            ax = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x, 0, n, None, 1.0,
+                         gcn_scale, None, csr.row_order(0, n))
+        if Wv is not None:
+            rs = csr.row_sums()
+    return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu)
 
 
 # ------------------------------------------------------------------------------------------

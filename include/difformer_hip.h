@@ -160,6 +160,36 @@ int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int3
                   void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a1 + a4 + a5 tail in closed form (csrc/simple_layer.hip): the `simple` kernel with query_input == source_input == x,
+ * one head, C_in <= 64 (C_in % 4 == 0), D <= 64, inference.   node classification/difformer.py:18-39, :115-140, :200-203
+ *
+ * Stage 1 of the simple kernel only needs G = X^T X and sx = sum_rows x (K^T V = Wk G Wv^T + ..., |Q|^2 = tr(Wq G Wq^T)
+ * + ...), stage 2 is linear in x (num = x Mn + cn, den = x.u + cd) and gcn_conv is linear too (A_hat (x Wv^T + 1 bv^T)
+ * = (A_hat x) Wv^T + (A_hat 1) bv^T), so q, k, v and the attention output never reach memory:
+ *   dif_gram_f32           record float[C*C + C + 2] = {G, sx}; with ys != NULL also the slice-major copy of x scaled by
+ *                          deg^-1/2 that dif_sliced_spmm_f32 reads (plan from dif_sliced_plan(n_rows, n_rows, C)).  The
+ *                          record is the only thing a row-sharded run has to all-reduce.
+ *   dif_simple_coeffs_f32  coef float[dif_simple_coeffs_len(C, D)] = {MnT [D x C], cn [D], u [C], cd, s, |Q|^2, |K|^2} with
+ *                          attn_scale (1 - graph_weight, or 1) folded into MnT / cn; n_global = number of rows of the
+ *                          whole graph (the +N of :22,:38).  Wv = bv = NULL: use_weight = False (v = x, C == D, :120).
+ *   dif_simple_layer_f32   out = LN(alpha * (num/den + ax Wv^T + gcn_scale * row_sums * bv [+ x0]) + (1 - alpha) * x) with
+ *                          ax = gcn_scale * A_hat x from the SpMM run on x (NULL: use_graph = False), row_sums = A_hat 1
+ *                          (NULL when bv is not needed); residual = 0 skips the alpha mix, ln_weight = NULL the LayerNorm.
+ * ------------------------------------------------------------------------------------- */
+size_t dif_gram_workspace_bytes(int64_t n_rows, int C);
+int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, const int32_t* rowptr, const int32_t* plan,
+                 float* ys, float* record, void* workspace, size_t workspace_bytes, dif_stream_t stream);
+size_t dif_simple_coeffs_len(int C, int D);
+int dif_simple_coeffs_f32(const float* record, int64_t n_global, int C, int D, const float* Wq, const float* bq,
+                          const float* Wk, const float* bk, const float* Wv, const float* bv, float attn_scale,
+                          float* coef, dif_stream_t stream);
+int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                         const float* ax, int64_t ldax, const float* Wv, const float* bv, const float* row_sums,
+                         float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,
+                         const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out,
+                         int64_t ldo, dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a3, dense graphs without edge weights: feature-sliced product with the source rows staged in LDS
  *     (same function of node classification/difformer.py:63-79 as dif_gcn_spmm_f32 for edge_weight = None:
  *      value_e = deg[col]^-1/2 * deg[row]^-1/2 factors into a pre-scaled source row and a per-destination scale, so

@@ -1,0 +1,133 @@
+"""Closed-form `simple` layer (csrc/simple_layer.hip) through the C ABI: Gram record, coefficients and the layer kernel
+against the float64 oracle (oracle.* <- node classification/difformer.py:18-39, :63-79, :113-145, :200-203).
+Tolerance 1e-4 (north_star) on max|y - y64| / max|y64|; measured errors are ~1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import difformer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("n,c", [(1, 64), (15, 64), (16, 64), (1000, 64), (132534, 64), (5000, 32), (777, 8), (4099, 48)])
+def test_gram_record_vs_numpy(n, c, dev):
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g) + 0.3
+    rec, ys = ops.get_backend().gram(x.to(dev))
+    assert ys is None
+    rec = rec.cpu().numpy().astype(np.float64)
+    x64 = x.double().numpy()
+    G, sx = x64.T @ x64, x64.sum(0)
+    assert rel_err(rec[: c * c].reshape(c, c), G) < 1e-5 and rel_err(rec[c * c: c * c + c], sx) < 1e-5
+
+
+def test_gram_writes_the_scaled_slice_major_copy(dev):
+    from difformer_amd import ops
+    n, c = 12000, 64
+    g = torch.Generator().manual_seed(2)
+    ei = torch.stack([torch.randint(0, n, (n * 64,), generator=g), torch.randint(n // 20, n, (n * 64,), generator=g)]).to(dev)
+    x = torch.randn(n, c, generator=g).to(dev)
+    csr = ops.csr_cache.get(ei, None, n, c * 4)
+    sl = csr.sliced(0, n, c)
+    assert sl is not None
+    be = ops.get_backend()
+    rec, ys = be.gram(x, csr.rowptr, sl.plan)
+    ref = be.sliced_prescale(x, csr.rowptr, n, sl.plan)          # the stand-alone pass of gcn_sliced.hip
+    assert torch.equal(ys, ref)                                   # same float ops -> same bits, zero padding included
+    deg = (csr.rowptr[1:] - csr.rowptr[:-1]).float()
+    assert (deg[: n // 20] == 0).all() and (ys[:, : n // 20] == 0).all()     # no incoming entries -> contributes nothing
+
+
+def _params(c, d, g, use_weight=True):
+    mk = lambda *s: torch.randn(*s, generator=g) * 0.3
+    return dict(Wq=mk(d, c), bq=mk(d), Wk=mk(d, c), bk=mk(d), Wv=mk(d, c) if use_weight else None,
+                bv=mk(d) if use_weight else None)
+
+
+@pytest.mark.parametrize("n,c,d,use_weight", [(500, 64, 64, True), (132534, 64, 64, True), (3000, 32, 64, True),
+                                              (2000, 64, 16, True), (1500, 48, 48, False)])
+def test_closed_form_attention_matches_the_simple_kernel(n, c, d, use_weight, dev):
+    """coefficients + layer kernel with no graph, residual or norm == full_attention_conv(q, k, v, 'simple')[:, 0, :]."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + c + d)
+    x = torch.randn(n, c, generator=g)
+    p = _params(c, d, g, use_weight)
+    be = ops.get_backend()
+    td = lambda a: None if a is None else a.to(dev)
+    rec, _ = be.gram(x.to(dev))
+    coef = be.simple_coeffs(rec, n, c, d, td(p["Wq"]), td(p["bq"]), td(p["Wk"]), td(p["bk"]), td(p["Wv"]), td(p["bv"]), 1.0)
+    out = be.simple_layer(x.to(dev), coef, d).cpu().numpy()
+    x64 = x.double().numpy()
+    lin = lambda W, b: x64 @ W.double().numpy().T + b.double().numpy()
+    q, k = lin(p["Wq"], p["bq"]), lin(p["Wk"], p["bk"])
+    v = lin(p["Wv"], p["bv"]) if use_weight else x64
+    ref = orc.simple_attention(q[:, None, :], k[:, None, :], v[:, None, :])[:, 0, :]
+    assert rel_err(out, ref) < TOL
+    # the output is ~ mean(v) + O(1/N), which hides the query-dependent part: check the coefficients themselves
+    # (num = x Mn + cn, den = x.u + cd) against their float64 definitions
+    Wq, bq = p["Wq"].double().numpy(), p["bq"].double().numpy()
+    sc = 1.0 / (np.sqrt((q * q).sum()) * np.sqrt((k * k).sum()))
+    ktv, ksum, vsum = k.T @ v, k.sum(0), v.sum(0)
+    cf = coef.cpu().numpy().astype(np.float64)
+    MnT, cn, u, cd = cf[: d * c].reshape(d, c), cf[d * c: d * c + d], cf[d * c + d: d * c + d + c], cf[d * c + d + c]
+    assert rel_err(MnT, (sc * Wq.T @ ktv).T) < 1e-4 and rel_err(cn, sc * bq @ ktv + vsum) < 1e-5
+    assert rel_err(u, sc * Wq.T @ ksum) < 1e-4 and abs(cd - (sc * bq @ ksum + n)) < 1e-5 * n
+    s_, q2, k2 = cf[-3:]
+    assert abs(q2 - (q * q).sum()) <= 1e-5 * (q * q).sum() and abs(k2 - (k * k).sum()) <= 1e-5 * (k * k).sum()
+    assert abs(s_ - sc) <= 1e-5 * sc
+
+
+@pytest.mark.parametrize("n,deg,c,use_weight,graph_weight,use_source,ln,residual",
+                         [(20000, 60, 64, True, -1, False, True, True),          # sliced SpMM on x
+                          (3000, 8, 64, True, 0.3, True, True, True),            # lane-group SpMM, convex mix, + x0
+                          (9000, 70, 64, False, -1, False, True, True),          # use_weight = False
+                          (4000, 10, 32, True, -1, False, False, False),         # narrow, no tail
+                          (2500, 6, 64, True, -1, True, False, True)])
+def test_closed_form_layer_vs_oracle(n, deg, c, use_weight, graph_weight, use_source, ln, residual, dev):
+    from difformer_amd import DIFFormerConv
+    torch.manual_seed(n)
+    g = torch.Generator().manual_seed(n + 1)
+    conv = DIFFormerConv(c, c, 1, kernel="simple", use_graph=True, use_weight=use_weight, graph_weight=graph_weight,
+                         use_source=use_source).to(dev).eval()
+    x = torch.randn(n, c, generator=g)
+    x0 = torch.randn(n, c, generator=g)
+    ei = torch.cat([torch.randint(0, n, (2, n * deg), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+    lw, lb = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    xd = x.to(dev)
+    with torch.no_grad():
+        out, _, _ = conv._layer(xd, xd, ei.to(dev), None, x0.to(dev) if use_source else None, xd if residual else None, 0.4,
+                                lw.to(dev) if ln else None, lb.to(dev) if ln else None, 1e-5)
+    p = {"c." + k: v.detach().cpu().double().numpy() for k, v in conv.state_dict().items()}
+    cfg = dict(num_heads=1, kernel="simple", use_graph=True, use_weight=use_weight, graph_weight=graph_weight,
+               use_source=use_source, hidden_channels=c)
+    x64 = x.double().numpy()
+    z = orc.difformer_conv(p, "c.", x64, x64, ei.numpy(), None, x0.double().numpy(), cfg)
+    if residual:
+        z = 0.4 * z + 0.6 * x64
+    if ln:
+        z = orc.layer_norm(z, lw.double().numpy(), lb.double().numpy())
+    assert rel_err(out.cpu().numpy(), z) < TOL
+
+
+def test_closed_form_layer_without_graph_matches_the_operator_path(dev):
+    """use_graph = False (BASELINE config C3): closed form vs the q/k/v path of round 1 (want_qk forces it)."""
+    from difformer_amd import DIFFormerConv
+    torch.manual_seed(3)
+    conv = DIFFormerConv(64, 64, 1, kernel="simple", use_graph=False).to(dev).eval()
+    x = torch.randn(50000, 64, device=dev)
+    lw, lb = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev)
+    with torch.no_grad():
+        new, _, _ = conv._layer(x, x, None, None, None, x, 0.5, lw, lb, 1e-5)
+        old, q, k = conv._layer(x, x, None, None, None, x, 0.5, lw, lb, 1e-5, want_qk=True)
+    assert q is not None and rel_err(new.cpu().numpy(), old.cpu().numpy()) < 1e-5
