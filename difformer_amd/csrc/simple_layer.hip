@@ -177,12 +177,17 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
         s_bv[tid] = (has_wv && tid < D) ? bv[tid] : 0.f;
     }
     __syncthreads();
-    // W sx for the three projections: 192 dot products, 12 per wave, one column per lane
-    for (int r = wave * 12; r < wave * 12 + 12; ++r) {
+    // W sx for the three projections: 192 dot products, four lanes per row (16 columns each), folded by two shuffles
+    if (tid < 768) {
+        const int r = tid >> 2, part = tid & 3;
         const int m = r & 63, which = r >> 6;
-        const float* W = which == 0 ? sWk : which == 1 ? sWq : sWv;
-        const float a = dif::wave_sum(W[m * kLd + lane] * s_sx[lane]);
-        if (lane == 0) (which == 0 ? s_wk : which == 1 ? s_wq : s_wv)[m] = a;
+        const float* W = (which == 0 ? sWk : which == 1 ? sWq : sWv) + m * kLd + 16 * part;
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a += W[c] * s_sx[16 * part + c];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (part == 0) (which == 0 ? s_wk : which == 1 ? s_wq : s_wv)[m] = a;
     }
     // T = Wk G (kept), Wq G (only its trace against Wq): |K|^2, |Q|^2 main terms
     {
@@ -243,15 +248,23 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
             if (d < D && c < C) MnT[d * C + c] = attn_scale * s * mn[reg];
         }
     }
-    if (wave == 0) {                     // cn[d] = a_s (s bq KtV + sum v), one column per lane
+    if (tid < 256) {                     // cn[d] = a_s (s bq KtV + sum v): four lanes per column
+        const int d = tid >> 2, part = tid & 3;
         float a = 0.f;
-        for (int m = 0; m < 64; ++m) a += s_bq[m] * sKtV[m * kLd + lane];
-        if (lane < D) cn[lane] = attn_scale * (s * a + s_vs[lane]);
-    } else if (wave == 1) {              // u[c] = s Wq^T (sum k)
+#pragma unroll
+        for (int m = 16 * part; m < 16 * part + 16; ++m) a += s_bq[m] * sKtV[m * kLd + d];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (part == 0 && d < D) cn[d] = attn_scale * (s * a + s_vs[d]);
+    } else if (tid < 512) {              // u[c] = s Wq^T (sum k)
+        const int c = (tid - 256) >> 2, part = tid & 3;
         float a = 0.f;
-        for (int m = 0; m < 64; ++m) a += sWq[m * kLd + lane] * s_ks[m];
-        if (lane < C) u[lane] = s * a;
-    } else if (wave == 2) {
+#pragma unroll
+        for (int m = 16 * part; m < 16 * part + 16; ++m) a += sWq[m * kLd + c] * s_ks[m];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (part == 0 && c < C) u[c] = s * a;
+    } else if (wave == 8) {
         const float a = dif::wave_sum(s_bq[lane] * s_ks[lane]);
         if (lane == 0) {
             u[C] = s * a + n_global;
@@ -282,6 +295,8 @@ struct LayerArgs {
     const float* ln_w; const float* ln_b; float eps; int relu;
     float* out; int64_t ldo;
     int64_t n_rows; int C, D;
+    // NEXT: the Gram record of `out` (the next layer's input) and its slice-major pre-scaled copy, from the same pass
+    const int32_t* rowptr; f32x4* ys_next; int64_t npad; float* ws; int64_t ws_stride;
 };
 
 template <bool GUARD>
@@ -315,10 +330,12 @@ __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], c
     }
 }
 
-template <bool EXACT, bool GRAPH_W>
+template <bool EXACT, bool GRAPH_W, bool NEXT>
 __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs a) {
     __shared__ __attribute__((aligned(16))) float sm_w[2][64 * kWStride];   // MnT, Wv (zero padded)
     __shared__ __attribute__((aligned(16))) float sm_cn[64], sm_u[64], sm_bv[64], sm_lw[64], sm_lb[64];
+    __shared__ __attribute__((aligned(16))) float sm_t[NEXT ? kWaves : 1][16 * kWStride];   // NEXT: a wave's finished tile
+    __shared__ float sm_s[kWaves][64];
     __shared__ float sm_cd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -348,6 +365,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
     const int64_t n_tiles = (a.n_rows + 15) / 16;
     const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * kWaves + wave, stride = static_cast<int64_t>(gridDim.x) * kWaves;
+    f32x4 gacc[NEXT ? 10 : 1];          // NEXT: upper half of out^T out (see gram_kernel)
+    f32x4 gsx = zero4();
+#pragma unroll
+    for (int i = 0; i < (NEXT ? 10 : 1); ++i) gacc[i] = zero4();
 
     auto body = [&](int64_t tile, auto guard_tag) {
         constexpr bool G = decltype(guard_tag)::value;
@@ -440,6 +461,29 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
                 else
                     for (int r = 0; r < 4; ++r) if (f + r < D) a.out[row * a.ldo + f + r] = v[r];
             }
+            if (NEXT) {         // park the finished row piece (zero outside the matrix) for the row-contracting re-read
+                if (!(row_ok && (EXACT || f < D))) v = zero4();
+                else if (!EXACT)
+                    for (int r = 0; r < 4; ++r) if (f + r >= D) v[r] = 0.f;
+                *reinterpret_cast<f32x4*>(&sm_t[wave][l15 * kWStride + f]) = v;
+            }
+        }
+        if (NEXT) {
+            // the tile again, four whole rows per read (row 4u + lg, columns 4*l15..+3): operand of the Gram product
+            // contracting over rows, and one 16-byte slice of the row for the slice-major copy
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(&sm_t[wave][(4 * u + lg) * kWStride + 4 * l15]);
+                const int64_t r2 = tile * 16 + 4 * u + lg;
+                if (a.ys_next && (!G || r2 < a.n_rows) && 4 * l15 < D) a.ys_next[static_cast<int64_t>(l15) * a.npad + r2] = xv * dinv_of(a.rowptr, r2);
+                gsx += xv;
+                int i = 0;
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                    for (int tb = ta; tb < 4; ++tb, ++i)
+                        gacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[ta], xv[tb], gacc[i], 0, 0, 0);
+            }
         }
     };
     int64_t tile = first;
@@ -452,6 +496,63 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
     for (; tile < n_tiles; tile += stride) {
         asm volatile("" ::: "memory");
         body(tile, std::true_type{});
+    }
+    if (NEXT) {
+        const int64_t pad = a.ys_next ? a.npad - a.n_rows : 0;   // rows of the copy past the matrix are read by the last source tile
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pad * 16;
+             i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+            const int64_t sl = i / pad, r = a.n_rows + i % pad;
+            if (4 * sl < D) a.ys_next[sl * a.npad + r] = zero4();
+        }
+        // fold the four waves' Gram partials through the weight region (no longer needed): (w0 + w2) + (w1 + w3)
+        __syncthreads();
+        float* buf = &sm_w[0][0];                       // 2 x 40 x 64 floats needed, 2 x 64 x 68 there
+        if (wave >= 2) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) buf[((wave - 2) * 40 + i * 4 + reg) * 64 + lane] = gacc[i][reg];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = gsx[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lg == 0) sm_s[wave][4 * l15 + t] = v;
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) gacc[i][reg] += buf[(wave * 40 + i * 4 + reg) * 64 + lane];
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) buf[(i * 4 + reg) * 64 + lane] = gacc[i][reg];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float* rec = a.ws + static_cast<int64_t>(blockIdx.x) * a.ws_stride;
+            int i = 0;
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = ta; tb < 4; ++tb, ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float v = gacc[i][reg] + buf[(i * 4 + reg) * 64 + lane];
+                        const int gi = 4 * (4 * lg + reg) + ta, gj = 4 * l15 + tb;
+                        if (gi < D && gj < D) {
+                            rec[gi * D + gj] = v;
+                            if (ta != tb) rec[gj * D + gi] = v;
+                        }
+                    }
+            if (lane < D) rec[D * D + lane] = ((sm_s[0][lane] + sm_s[1][lane]) + sm_s[2][lane]) + sm_s[3][lane];
+        }
     }
 }
 
@@ -510,7 +611,8 @@ extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows,
                                     const float* ax, int64_t ldax, const float* Wv, const float* bv, const float* row_sums,
                                     float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,
                                     const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out,
-                                    int64_t ldo, dif_stream_t stream) {
+                                    int64_t ldo, float* next_record, const int32_t* rowptr, const int32_t* plan,
+                                    float* next_ys, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
     DIF_REQUIRE(x && coef && out && n_rows > 0, DIF_E_BADARG, "dif_simple_layer: null pointer or no rows");
     DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0 && D > 0 && D <= 64, DIF_E_SHAPE,
                 "dif_simple_layer: covers C <= 64 (C %% 4 == 0) and D <= 64 (got %d, %d)", C, D);
@@ -524,15 +626,33 @@ extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows,
     DIF_REQUIRE(Wv != nullptr || !ax || C == D, DIF_E_SHAPE, "dif_simple_layer: without a value projection C must equal D");
     DIF_REQUIRE(!residual || C == D, DIF_E_SHAPE, "dif_simple_layer: the residual needs C == D");
     DIF_REQUIRE(!x0 || ldx0 >= D, DIF_E_BADARG, "dif_simple_layer: ldx0 smaller than a row");
-    LayerArgs a = {x, ldx, ax, ldax, coef, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha, ln_weight, ln_bias, ln_eps,
-                   relu, out, ldo, n_rows, C, D};
+    const bool next = next_record != nullptr;
     const int P = gram_chunks(n_rows);
+    const int64_t rec = (static_cast<int64_t>(D) * D + D + 3) & ~int64_t(3);
+    int64_t npad = 0;
+    if (next) {
+        DIF_REQUIRE(D % 4 == 0, DIF_E_SHAPE, "dif_simple_layer: the Gram record of the output needs D %% 4 == 0");
+        DIF_REQUIRE(workspace && workspace_bytes >= dif_gram_workspace_bytes(n_rows, D), DIF_E_WORKSPACE,
+                    "dif_simple_layer: workspace too small for the next record (dif_gram_workspace_bytes(n_rows, D))");
+        DIF_REQUIRE((next_ys == nullptr) || (rowptr && plan && dif::aligned16(next_ys)), DIF_E_BADARG,
+                    "dif_simple_layer: the slice-major copy needs rowptr, the plan and a 16-byte aligned buffer");
+        if (next_ys) {
+            npad = static_cast<int64_t>(plan[6]) * plan[7];
+            DIF_REQUIRE(plan[0] == D / 4 && npad >= n_rows, DIF_E_BADARG, "dif_simple_layer: plan does not match D / n_rows");
+        }
+    }
+    LayerArgs a = {x, ldx, ax, ldax, coef, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha, ln_weight, ln_bias, ln_eps,
+                   relu, out, ldo, n_rows, C, D, rowptr, reinterpret_cast<f32x4*>(next_ys), npad, static_cast<float*>(workspace), rec};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
     const bool gw = ax != nullptr && Wv != nullptr;
-#define DIF_LAYER(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G>), dim3(P), dim3(64 * kWaves), 0, st, a)
-    if (exact) { if (gw) DIF_LAYER(true, true); else DIF_LAYER(true, false); }
-    else { if (gw) DIF_LAYER(false, true); else DIF_LAYER(false, false); }
+#define DIF_LAYER(E, G, N) hipLaunchKernelGGL((simple_layer_kernel<E, G, N>), dim3(P), dim3(64 * kWaves), 0, st, a)
+#define DIF_LAYER2(E, G) do { if (next) DIF_LAYER(E, G, true); else DIF_LAYER(E, G, false); } while (0)
+    if (exact) { if (gw) DIF_LAYER2(true, true); else DIF_LAYER2(true, false); }
+    else { if (gw) DIF_LAYER2(false, true); else DIF_LAYER2(false, false); }
+#undef DIF_LAYER2
 #undef DIF_LAYER
-    return dif::launch_status("simple_layer_kernel");
+    if (int rc = dif::launch_status("simple_layer_kernel")) return rc;
+    if (next) return dif::launch_record_finalize(static_cast<float*>(workspace), P, rec, D * D + D, 0, next_record, st);
+    return 0;
 }

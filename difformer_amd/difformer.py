@@ -144,7 +144,7 @@ class DIFFormerConv(nn.Module):
         return not ag._needs_grad(x, *params)
 
     def _layer(self, query_input, source_input, edge_index, edge_weight, x0=None, prev=None, alpha=0.5,
-               ln_weight=None, ln_bias=None, eps=1e-5, want_qk=False):
+               ln_weight=None, ln_bias=None, eps=1e-5, want_qk=False, carry=None):
         """Propagation (:115-136) followed by the tail (:137-140 and, when given, :200-203) -> ([n,D], q, k)."""
         H = self.num_heads
         shard = self.row_shard
@@ -161,7 +161,7 @@ class DIFFormerConv(nn.Module):
                 a_s = 1.0                                       # difformer.py:130-136: the mix only exists with a graph
             Wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
             out = ops.simple_layer_closed_form(x, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv, csr,
-                                               a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps)
+                                               a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps, carry=carry)
             return out, None, None
         if not want_qk and self._fusable_projection(query_input, source_input):
             attn, v = ops.project_simple_attention(source_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,
@@ -258,15 +258,18 @@ class DIFFormer(nn.Module):
         layer_ = []
         x = self._input_layer(x, self.training)                # difformer.py:188-192
         layer_.append(x)
+        carry = {}      # closed-form layers hand the Gram record / slice-major copy of their output to the next one
         for i, conv in enumerate(self.convs):
             bn = self.bns[i + 1] if self.use_bn else None
+            carry["want_next"] = (not self.training) and i + 1 < len(self.convs)
             # head mean, + layer_[0] (use_source), alpha-residual, LayerNorm ride in the last kernel of the
             # layer (:137-140, :200-203)
             x, _, _ = conv._layer(x, x, edge_index, edge_weight, layer_[0] if conv.use_source else None,
                                   layer_[i] if self.residual else None, self.alpha,
                                   bn.weight if bn is not None else None, bn.bias if bn is not None else None,
-                                  bn.eps if bn is not None else 1e-5)
-            x = F.dropout(x, p=self.dropout, training=self.training)
+                                  bn.eps if bn is not None else 1e-5, carry=carry)
+            if self.training:
+                x = F.dropout(x, p=self.dropout, training=True)
             layer_.append(x)
         return ag.linear(x, self.fcs[-1].weight, self.fcs[-1].bias)   # :208
 

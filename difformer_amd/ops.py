@@ -395,15 +395,22 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
 
 
 def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
-                             ln_bias, eps, relu=False):
+                             ln_bias, eps, relu=False, carry=None):
     """One DIFFormer layer with the `simple` kernel on a single GPU, query == source == x [n, C], one head
     (csrc/simple_layer.hip): Gram record -> coefficients -> SpMM on x -> the layer kernel.  q, k, v and the attention
-    output never reach memory.  csr = None: use_graph = False.  Wv = None: use_weight = False."""
+    output never reach memory.  csr = None: use_graph = False.  Wv = None: use_weight = False.
+    `carry` (dict, optional) chains layers: a layer whose output feeds another closed-form layer over the same graph
+    (carry["want_next"]) leaves the Gram record and the slice-major copy of its output there, from the same pass, and
+    the next layer picks them up instead of running dif_gram_f32."""
     be = get_backend()
     n, C = x.shape
     D = Wq.shape[0]
     sl = csr.sliced(0, n, C) if (csr is not None and n == csr.num_nodes) else None
-    record, ys = be.gram(x, csr.rowptr if sl is not None else None, sl.plan if sl is not None else None)
+    have = carry.get("products") if carry is not None else None
+    if have is not None and have["x"] is x and have["sl"] is sl:
+        record, ys = have["record"], have["ys"]
+    else:
+        record, ys = be.gram(x, csr.rowptr if sl is not None else None, sl.plan if sl is not None else None)
     coef = be.simple_coeffs(record, n, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
     ax = rs = None
     if csr is not None:
@@ -414,7 +421,16 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
                          gcn_scale, None, csr.row_order(0, n))
         if Wv is not None:
             rs = csr.row_sums()
-    return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu)
+    want_next = carry is not None and carry.get("want_next", False) and D % 4 == 0 and D == C
+    if carry is not None:
+        carry["products"] = None
+    if not want_next:
+        return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu)
+    out, record2, ys2 = be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps,
+                                        relu, True, csr.rowptr if sl is not None else None,
+                                        sl.plan if sl is not None else None)
+    carry["products"] = dict(x=out, sl=sl, record=record2, ys=ys2)
+    return out
 
 
 # ------------------------------------------------------------------------------------------

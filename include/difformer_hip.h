@@ -175,6 +175,8 @@ int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int3
  *   dif_simple_layer_f32   out = LN(alpha * (num/den + ax Wv^T + gcn_scale * row_sums * bv [+ x0]) + (1 - alpha) * x) with
  *                          ax = gcn_scale * A_hat x from the SpMM run on x (NULL: use_graph = False), row_sums = A_hat 1
  *                          (NULL when bv is not needed); residual = 0 skips the alpha mix, ln_weight = NULL the LayerNorm.
+ *                          next_record != NULL: the same pass also leaves dif_gram_f32's record of `out` (the next layer's
+ *                          input; workspace >= dif_gram_workspace_bytes(n_rows, D)) and, with next_ys, its slice-major copy.
  * ------------------------------------------------------------------------------------- */
 size_t dif_gram_workspace_bytes(int64_t n_rows, int C);
 int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, const int32_t* rowptr, const int32_t* plan,
@@ -187,7 +189,8 @@ int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int
                          const float* ax, int64_t ldax, const float* Wv, const float* bv, const float* row_sums,
                          float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,
                          const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out,
-                         int64_t ldo, dif_stream_t stream);
+                         int64_t ldo, float* next_record, const int32_t* rowptr, const int32_t* plan, float* next_ys,
+                         void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a3, dense graphs without edge weights: feature-sliced product with the source rows staged in LDS

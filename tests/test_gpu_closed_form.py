@@ -131,3 +131,37 @@ def test_closed_form_layer_without_graph_matches_the_operator_path(dev):
         new, _, _ = conv._layer(x, x, None, None, None, x, 0.5, lw, lb, 1e-5)
         old, q, k = conv._layer(x, x, None, None, None, x, 0.5, lw, lb, 1e-5, want_qk=True)
     assert q is not None and rel_err(new.cpu().numpy(), old.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("n,deg,c", [(20000, 60, 64), (3000, 8, 32), (12345, 0, 64)])
+def test_layer_kernel_leaves_the_next_layers_products(n, deg, c, dev):
+    """want_next: the Gram record and the slice-major copy of the OUTPUT come out of the same pass and equal what
+    dif_gram_f32 computes from that output (copy bit for bit, record to fp32 rounding)."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, c, generator=g).to(dev)
+    p = {k: (None if v is None else v.to(dev)) for k, v in _params(c, c, g).items()}
+    lw, lb = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+    be = ops.get_backend()
+    csr = sl = None
+    if deg:
+        ei = torch.cat([torch.randint(0, n, (2, n * deg), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+        csr = ops.csr_cache.get(ei, None, n, c * 4)
+        sl = csr.sliced(0, n, c)
+    carry = {"want_next": True}
+    out = ops.simple_layer_closed_form(x, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
+                                       lw, lb, 1e-5, carry=carry)
+    prod = carry["products"]
+    assert prod is not None and prod["x"] is out and prod["sl"] is sl
+    rec, ys = be.gram(out, csr.rowptr if sl is not None else None, sl.plan if sl is not None else None)
+    assert rel_err(prod["record"].cpu().numpy()[: c * c + c], rec.cpu().numpy()[: c * c + c]) < 1e-5
+    if sl is not None:
+        assert torch.equal(prod["ys"], ys)
+    else:
+        assert prod["ys"] is None
+    # and the next layer uses them: same result as a fresh call without the carry
+    a = ops.simple_layer_closed_form(out, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
+                                     lw, lb, 1e-5, carry=carry)
+    b = ops.simple_layer_closed_form(out, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
+                                     lw, lb, 1e-5)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
