@@ -443,9 +443,10 @@ class HipBackend:
         return coef
 
     def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
-                     alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, want_next=False, next_rowptr=None,
-                     next_plan=None):
-        """-> out [n, D]; with want_next also (record, ys | None) of `out` for the next layer (see gram())."""
+                     alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, next_rowptr=None, next_plan=None,
+                     next_record=False):
+        """-> out [n, D]; with next_plan -> (out, ys, record | None): also the slice-major scaled copy of `out` for the
+        next layer's SpMM (see gram()), and with next_record its Gram record from the same pass."""
         dev = _require_device(x, coef, ax, Wv, bv, row_sums, x0, ln_weight, ln_bias)
         n, C = x.shape
         x, ldx = _row_major(x, C)
@@ -463,12 +464,12 @@ class HipBackend:
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
         record = ys = ws = None
         ws_bytes = 0
-        if want_next:
+        if next_plan is not None:
+            ys = torch.empty((D // 4, int(next_plan[6]) * int(next_plan[7]), 4), dtype=torch.float32, device=dev)
+        if next_record:
             record = torch.empty(D * D + D + 2, dtype=torch.float32, device=dev)
             ws_bytes = self.lib.dif_gram_workspace_bytes(n, D)
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-            if next_plan is not None:
-                ys = torch.empty((D // 4, int(next_plan[6]) * int(next_plan[7]), 4), dtype=torch.float32, device=dev)
         with _Timed(self, "dif_simple_layer_f32", dev):
             rc = self.lib.dif_simple_layer_f32(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
                                                _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
@@ -477,7 +478,9 @@ class HipBackend:
                                                next_plan if ys is not None else None, _ptr(ys), _ptr(ws), ws_bytes,
                                                _stream(dev))
         _lib.check(rc, "dif_simple_layer_f32")
-        return (out, record, ys) if want_next else out
+        if next_plan is None and not next_record:
+            return out
+        return out, ys, record
 
     # ---- a3, dense unweighted graphs: feature-sliced product with LDS-staged sources (csrc/gcn_sliced.hip) ----------
     def sliced_plan(self, n_src, n_rows, F):

@@ -25,7 +25,7 @@ using dif::f32x4;
 
 constexpr int kWaves = 4;
 constexpr int kWStride = 68;     // padded LDS row (floats): 16 lanes x b128 land on 64 distinct banks
-constexpr int kGramMaxChunks = 512;
+constexpr int kRecordChunksPerCU = 3;   // most workgroups per CU of any kernel that writes partial Gram records
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -41,22 +41,25 @@ __device__ __forceinline__ float dinv_of(const int32_t* __restrict__ rowptr, int
 //   -> lane holds G[4*(4lg + reg) + ta][4*l15 + tb]  in acc[ta][tb][reg]
 // and one 16-byte slice of the row for the slice-major copy (ys[l15][row] = dinv[row] * x[row][4*l15..]).
 // ------------------------------------------------------------------------------------------------------------
+constexpr int kGramWaves = 8;
+
 template <bool WRITE_YS>
-__global__ __launch_bounds__(64 * kWaves, 2) void gram_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C,
-                                                              const int32_t* __restrict__ rowptr, f32x4* __restrict__ ys,
-                                                              int64_t npad, float* __restrict__ ws, int64_t ws_stride) {
-    __shared__ __attribute__((aligned(16))) float sm_g[kWaves][64 * 64];
-    __shared__ float sm_s[kWaves][64];
+__global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C,
+                                                                  const int32_t* __restrict__ rowptr, f32x4* __restrict__ ys,
+                                                                  int64_t npad, float* __restrict__ ws, int64_t ws_stride) {
+    __shared__ float sm_f[4 * 40 * 64];          // fold buffer: 40 accumulator registers x 64 lanes for up to 4 waves
+    __shared__ float sm_s[kGramWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const bool col_ok = 4 * l15 < C;
-    // G is symmetric: only the products with ta <= tb are formed (10 of 16), the fold mirrors them
+    // G is symmetric: only the products with ta <= tb are formed (10 of 16), the record write mirrors them
     f32x4 acc[10];
 #pragma unroll
     for (int a = 0; a < 10; ++a) acc[a] = zero4();
     f32x4 sx = zero4();
     const int64_t n16 = (n_rows + 15) / 16;
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * kWaves + wave, stride = static_cast<int64_t>(gridDim.x) * kWaves;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kGramWaves + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kGramWaves;
     auto load16 = [&](f32x4 (&xv)[4], int64_t tile) {      // 16 consecutive rows: four loads in flight
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -94,20 +97,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void gram_kernel(const float* __res
             if (4 * sl < C) ys[sl * npad + r] = zero4();
         }
     }
-    // fold: every wave parks its 64 x 64 partial (both triangles), then the workgroup adds the four copies in a fixed order
-    {
-        int a = 0;
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-            for (int tb = ta; tb < 4; ++tb, ++a)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int i = 4 * (4 * lg + reg) + ta, j = 4 * l15 + tb;
-                    sm_g[wave][i * 64 + j] = acc[a][reg];
-                    if (ta != tb) sm_g[wave][j * 64 + i] = acc[a][reg];
-                }
-    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         float a = sx[t];
@@ -115,20 +104,62 @@ __global__ __launch_bounds__(64 * kWaves, 2) void gram_kernel(const float* __res
         a += __shfl_xor(a, 32, 64);
         if (lg == 0) sm_s[wave][4 * l15 + t] = a;
     }
-    __syncthreads();
-    float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
-    for (int e = threadIdx.x; e < 64 * 64; e += 64 * kWaves) {
-        const int a = e >> 6, b = e & 63;
-        if (a < C && b < C) rec[a * C + b] = ((sm_g[0][e] + sm_g[1][e]) + sm_g[2][e]) + sm_g[3][e];
+    // fold the eight waves in registers, halving the live set three times through LDS (fixed order):
+    // ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
+#pragma unroll
+    for (int half = kGramWaves / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) sm_f[((wave - half) * 40 + i * 4 + reg) * 64 + lane] = acc[i][reg];
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[i][reg] += sm_f[(wave * 40 + i * 4 + reg) * 64 + lane];
+        }
+        __syncthreads();
     }
-    if (threadIdx.x < C) rec[C * C + threadIdx.x] = ((sm_s[0][threadIdx.x] + sm_s[1][threadIdx.x]) + sm_s[2][threadIdx.x]) + sm_s[3][threadIdx.x];
+    float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
+    if (wave == 0) {
+        int i = 0;
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = ta; tb < 4; ++tb, ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int gi = 4 * (4 * lg + reg) + ta, gj = 4 * l15 + tb;
+                    if (gi < C && gj < C) {
+                        rec[gi * C + gj] = acc[i][reg];
+                        if (ta != tb) rec[gj * C + gi] = acc[i][reg];
+                    }
+                }
+    } else if (wave == 1 && lane < C) {
+        float a = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < kGramWaves; ++w2) a += sm_s[w2][lane];
+        rec[C * C + lane] = a;
+    }
 }
 
-int gram_chunks(int64_t n_rows) {
+// workgroups of kWaves waves; `per_cu` = how many of them fit a CU (registers / LDS of the kernel in question)
+int row_chunks(int64_t n_rows, int per_cu) {
     const int64_t tiles = (n_rows + 15) / 16;
     int64_t p = (tiles + kWaves - 1) / kWaves;
-    if (p > 2 * dif::kCUs) p = 2 * dif::kCUs;
-    if (p > kGramMaxChunks) p = kGramMaxChunks;
+    if (p > static_cast<int64_t>(per_cu) * dif::kCUs) p = static_cast<int64_t>(per_cu) * dif::kCUs;
+    if (p < 1) p = 1;
+    return static_cast<int>(p);
+}
+// the Gram kernel: eight waves per workgroup, at least four tiles per wave, one workgroup per CU at most (every
+// workgroup pays a fold and a 16.6-KB partial record)
+int gram_chunks(int64_t n_rows) {
+    const int64_t tiles = (n_rows + 15) / 16;
+    int64_t p = (tiles + 4 * kGramWaves - 1) / (4 * kGramWaves);
+    if (p > dif::kCUs) p = dif::kCUs;
     if (p < 1) p = 1;
     return static_cast<int>(p);
 }
@@ -155,7 +186,7 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
                                                       const float* __restrict__ Wk, const float* __restrict__ bk,
                                                       const float* __restrict__ Wv, const float* __restrict__ bv,
                                                       float attn_scale, float* __restrict__ coef) {
-    __shared__ float sG[64 * kLd], sWq[64 * kLd], sWk[64 * kLd], sWv[64 * kLd], sT[64 * kLd], sKtV[64 * kLd];
+    __shared__ __attribute__((aligned(16))) float sG[64 * kLd], sWq[64 * kLd], sWk[64 * kLd], sWv[64 * kLd], sT[64 * kLd], sKtV[64 * kLd];
     __shared__ float s_sx[64], s_bq[64], s_bk[64], s_bv[64], s_wk[64], s_wq[64], s_wv[64], s_ks[64], s_vs[64];
     __shared__ float s_red[2][16];
     __shared__ float s_scal[4];
@@ -163,12 +194,28 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     const int ti = wave >> 2, tj = wave & 3;       // this wave's 16 x 16 tile of every 64 x 64 product
     const bool has_wv = Wv != nullptr;            // use_weight = False: v = x (needs C == D), Wv = I, bv = 0
-    for (int e = tid; e < 64 * 64; e += 1024) {
-        const int a = e >> 6, b = e & 63;
-        sG[a * kLd + b] = (a < C && b < C) ? rec[a * C + b] : 0.f;
-        sWq[a * kLd + b] = (a < D && b < C) ? Wq[a * C + b] : 0.f;
-        sWk[a * kLd + b] = (a < D && b < C) ? Wk[a * C + b] : 0.f;
-        sWv[a * kLd + b] = has_wv ? ((a < D && b < C) ? Wv[a * C + b] : 0.f) : (a == b && a < D ? 1.f : 0.f);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (C == 64 && D == 64 && al16(rec) && al16(Wq) && al16(Wk) && (!has_wv || al16(Wv))) {
+        // dense 64 x 64 blocks: one 16-byte load per matrix and thread, all in flight together
+        const int e = 4 * tid, a = e >> 6, b = e & 63;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(rec + e), q4 = *reinterpret_cast<const f32x4*>(Wq + e),
+                    k4 = *reinterpret_cast<const f32x4*>(Wk + e);
+        f32x4 v4 = zero4();
+        if (has_wv) v4 = *reinterpret_cast<const f32x4*>(Wv + e);
+        else
+            for (int r = 0; r < 4; ++r) v4[r] = (a == b + r) ? 1.f : 0.f;
+        *reinterpret_cast<f32x4*>(&sG[a * kLd + b]) = g4;
+        *reinterpret_cast<f32x4*>(&sWq[a * kLd + b]) = q4;
+        *reinterpret_cast<f32x4*>(&sWk[a * kLd + b]) = k4;
+        *reinterpret_cast<f32x4*>(&sWv[a * kLd + b]) = v4;
+    } else {
+        for (int e = tid; e < 64 * 64; e += 1024) {
+            const int a = e >> 6, b = e & 63;
+            sG[a * kLd + b] = (a < C && b < C) ? rec[a * C + b] : 0.f;
+            sWq[a * kLd + b] = (a < D && b < C) ? Wq[a * C + b] : 0.f;
+            sWk[a * kLd + b] = (a < D && b < C) ? Wk[a * C + b] : 0.f;
+            sWv[a * kLd + b] = has_wv ? ((a < D && b < C) ? Wv[a * C + b] : 0.f) : (a == b && a < D ? 1.f : 0.f);
+        }
     }
     if (tid < 64) {
         s_sx[tid] = tid < C ? rec[C * C + tid] : 0.f;
@@ -331,7 +378,7 @@ __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], c
 }
 
 template <bool EXACT, bool GRAPH_W, bool NEXT>
-__global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs a) {
+__global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel(LayerArgs a) {
     __shared__ __attribute__((aligned(16))) float sm_w[2][64 * kWStride];   // MnT, Wv (zero padded)
     __shared__ __attribute__((aligned(16))) float sm_cn[64], sm_u[64], sm_bv[64], sm_lw[64], sm_lb[64];
     __shared__ __attribute__((aligned(16))) float sm_t[NEXT ? kWaves : 1][16 * kWStride];   // NEXT: a wave's finished tile
@@ -340,10 +387,27 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int C = a.C, D = a.D;
-    for (int e = threadIdx.x; e < 64 * 64; e += 64 * kWaves) {
-        const int f = e >> 6, c = e & 63;
-        sm_w[0][f * kWStride + c] = (f < D && c < C) ? a.coef[f * C + c] : 0.f;
-        if (GRAPH_W) sm_w[1][f * kWStride + c] = (f < D && c < C) ? a.Wv[f * C + c] : 0.f;
+    if (EXACT && (reinterpret_cast<uintptr_t>(a.coef) & 15u) == 0 && (!GRAPH_W || (reinterpret_cast<uintptr_t>(a.Wv) & 15u) == 0)) {
+        // dense 64 x 64 blocks: all eight 16-byte loads of a thread are in flight before the first LDS store (an
+        // element-wise loop runs 32 load -> store round trips back to back: ~30 us of prologue per workgroup)
+        f32x4 wreg[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wreg[0][i] = *reinterpret_cast<const f32x4*>(a.coef + 4 * (threadIdx.x + 256 * i));
+            if (GRAPH_W) wreg[1][i] = *reinterpret_cast<const f32x4*>(a.Wv + 4 * (threadIdx.x + 256 * i));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * (threadIdx.x + 256 * i);
+            *reinterpret_cast<f32x4*>(&sm_w[0][(e >> 6) * kWStride + (e & 63)]) = wreg[0][i];
+            if (GRAPH_W) *reinterpret_cast<f32x4*>(&sm_w[1][(e >> 6) * kWStride + (e & 63)]) = wreg[1][i];
+        }
+    } else {
+        for (int e = threadIdx.x; e < 64 * 64; e += 64 * kWaves) {
+            const int f = e >> 6, c = e & 63;
+            sm_w[0][f * kWStride + c] = (f < D && c < C) ? a.coef[f * C + c] : 0.f;
+            if (GRAPH_W) sm_w[1][f * kWStride + c] = (f < D && c < C) ? a.Wv[f * C + c] : 0.f;
+        }
     }
     if (threadIdx.x < 64) {
         const int i = threadIdx.x;
@@ -357,10 +421,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
     __syncthreads();
     const float cd = sm_cd;
     const float inv_d = 1.0f / static_cast<float>(D);
-    // per-lane constants: this lane's 16 channels of u and its 16 features (16ft + 4lg + reg) of the vectors
-    f32x4 uu[4];
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq) uu[cq] = *reinterpret_cast<const f32x4*>(&sm_u[16 * cq + 4 * lg]);
 
     const int64_t n_tiles = (a.n_rows + 15) / 16;
     const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
@@ -376,14 +436,14 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
         const bool row_ok = !G || row < a.n_rows;
         f32x4 xa[4];
         load_rows<G>(xa, a.x, a.ldx, row, a.n_rows, lg, C);
-        f32x4 ga[4];
-        if (a.ax) load_rows<G>(ga, a.ax, a.ldax, row, a.n_rows, lg, C);
         // denominator of this lane's row: x.u + cd, folded over the four lane groups
         float den = 0.f;
 #pragma unroll
-        for (int cq = 0; cq < 4; ++cq)
+        for (int cq = 0; cq < 4; ++cq) {
+            const f32x4 uu = *reinterpret_cast<const f32x4*>(&sm_u[16 * cq + 4 * lg]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) den += xa[cq][t] * uu[cq][t];
+            for (int t = 0; t < 4; ++t) den += xa[cq][t] * uu[t];
+        }
         den += __shfl_xor(den, 16, 64);
         den += __shfl_xor(den, 32, 64);
         const float rden = 1.0f / (den + cd);
@@ -394,14 +454,13 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) y[ft] *= rden;
         if (a.ax) {
-            if (GRAPH_W) {
+            f32x4 ga[4];
+            load_rows<G>(ga, a.ax, a.ldax, row, a.n_rows, lg, C);
+            if (GRAPH_W) {        // the second product accumulates on top of the attention term
                 const float rsv = (a.rs && row_ok) ? a.rs[row] : 0.f;
-                f32x4 z[4];
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft) z[ft] = *reinterpret_cast<const f32x4*>(&sm_bv[16 * ft + 4 * lg]) * rsv;
-                project_t(z, ga, sm_w[1], l15, lg);
-#pragma unroll
-                for (int ft = 0; ft < 4; ++ft) y[ft] += z[ft];
+                for (int ft = 0; ft < 4; ++ft) y[ft] += *reinterpret_cast<const f32x4*>(&sm_bv[16 * ft + 4 * lg]) * rsv;
+                project_t(y, ga, sm_w[1], l15, lg);
             } else {          // use_weight = False: the aggregated rows are the graph term (C == D), same layout
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft) y[ft] += ga[ft];
@@ -448,6 +507,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
                 y[ft] = y[ft] * rstd * *reinterpret_cast<const f32x4*>(&sm_lw[16 * ft + 4 * lg]) +
                         *reinterpret_cast<const f32x4*>(&sm_lb[16 * ft + 4 * lg]);
         }
+        float dscale = 0.f;
+        if (!NEXT && a.ys_next && row_ok) dscale = dinv_of(a.rowptr, row);
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
             const int f = 16 * ft + 4 * lg;
@@ -460,6 +521,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
                 if (EXACT || ((a.ldo & 3) == 0 && f + 3 < D)) *reinterpret_cast<f32x4*>(a.out + row * a.ldo + f) = v;
                 else
                     for (int r = 0; r < 4; ++r) if (f + r < D) a.out[row * a.ldo + f + r] = v[r];
+            }
+            if (!NEXT && a.ys_next) {
+                // slice-major pre-scaled copy for the next layer's SpMM straight from the registers: this lane holds
+                // slice 4ft + lg of its row, the 16 lanes of a group 16 consecutive rows -> 256 contiguous bytes
+                if (row_ok && (EXACT || f < D)) a.ys_next[static_cast<int64_t>(4 * ft + lg) * a.npad + row] = v * dscale;
             }
             if (NEXT) {         // park the finished row piece (zero outside the matrix) for the row-contracting re-read
                 if (!(row_ok && (EXACT || f < D))) v = zero4();
@@ -496,6 +562,14 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
     for (; tile < n_tiles; tile += stride) {
         asm volatile("" ::: "memory");
         body(tile, std::true_type{});
+    }
+    if (!NEXT && a.ys_next) {
+        const int64_t pad = a.npad - a.n_rows;          // rows of the copy past the matrix are read by the last source tile
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pad * 16;
+             i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+            const int64_t sl = i / pad, r = a.n_rows + i % pad;
+            if (4 * sl < D) a.ys_next[sl * a.npad + r] = zero4();
+        }
     }
     if (NEXT) {
         const int64_t pad = a.ys_next ? a.npad - a.n_rows : 0;   // rows of the copy past the matrix are read by the last source tile
@@ -561,7 +635,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void simple_layer_kernel(LayerArgs 
 extern "C" size_t dif_gram_workspace_bytes(int64_t n_rows, int C) {
     if (n_rows <= 0 || C <= 0 || C > 64) return 0;
     const size_t rec = (static_cast<size_t>(C) * C + C + 3) & ~size_t(3);
-    return rec * sizeof(float) * static_cast<size_t>(gram_chunks(n_rows));
+    return rec * sizeof(float) * static_cast<size_t>(row_chunks(n_rows, kRecordChunksPerCU));
 }
 
 // record = [G: C x C][sx: C][2 unused floats]; ys / rowptr / plan may be null (no slice-major copy).
@@ -580,10 +654,10 @@ extern "C" int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, 
     if (ys) {
         const int64_t npad = static_cast<int64_t>(plan[6]) * plan[7];
         DIF_REQUIRE(plan[0] == C / 4 && npad >= n_rows, DIF_E_BADARG, "dif_gram: plan does not match C / n_rows");
-        hipLaunchKernelGGL((gram_kernel<true>), dim3(P), dim3(64 * kWaves), 0, st, x, ldx, n_rows, C, rowptr,
+        hipLaunchKernelGGL((gram_kernel<true>), dim3(P), dim3(64 * kGramWaves), 0, st, x, ldx, n_rows, C, rowptr,
                            reinterpret_cast<f32x4*>(ys), npad, ws, rec);
     } else {
-        hipLaunchKernelGGL((gram_kernel<false>), dim3(P), dim3(64 * kWaves), 0, st, x, ldx, n_rows, C, nullptr, nullptr,
+        hipLaunchKernelGGL((gram_kernel<false>), dim3(P), dim3(64 * kGramWaves), 0, st, x, ldx, n_rows, C, nullptr, nullptr,
                            int64_t(0), ws, rec);
     }
     if (int rc = dif::launch_status("gram_kernel")) return rc;
@@ -626,14 +700,16 @@ extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows,
     DIF_REQUIRE(Wv != nullptr || !ax || C == D, DIF_E_SHAPE, "dif_simple_layer: without a value projection C must equal D");
     DIF_REQUIRE(!residual || C == D, DIF_E_SHAPE, "dif_simple_layer: the residual needs C == D");
     DIF_REQUIRE(!x0 || ldx0 >= D, DIF_E_BADARG, "dif_simple_layer: ldx0 smaller than a row");
-    const bool next = next_record != nullptr;
-    const int P = gram_chunks(n_rows);
+    const bool next = next_record != nullptr;          // Gram record of the output from the same pass (slower)
+    const int P = row_chunks(n_rows, next ? kRecordChunksPerCU : 4);
     const int64_t rec = (static_cast<int64_t>(D) * D + D + 3) & ~int64_t(3);
     int64_t npad = 0;
     if (next) {
-        DIF_REQUIRE(D % 4 == 0, DIF_E_SHAPE, "dif_simple_layer: the Gram record of the output needs D %% 4 == 0");
         DIF_REQUIRE(workspace && workspace_bytes >= dif_gram_workspace_bytes(n_rows, D), DIF_E_WORKSPACE,
                     "dif_simple_layer: workspace too small for the next record (dif_gram_workspace_bytes(n_rows, D))");
+    }
+    if (next || next_ys) {
+        DIF_REQUIRE(D % 4 == 0, DIF_E_SHAPE, "dif_simple_layer: products for the next layer need D %% 4 == 0");
         DIF_REQUIRE((next_ys == nullptr) || (rowptr && plan && dif::aligned16(next_ys)), DIF_E_BADARG,
                     "dif_simple_layer: the slice-major copy needs rowptr, the plan and a 16-byte aligned buffer");
         if (next_ys) {

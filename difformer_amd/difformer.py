@@ -11,6 +11,8 @@ There is no CPU path: tensors must be float32 on the GPU.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -19,6 +21,8 @@ from . import ops
 from . import autograd_ops as ag
 
 __all__ = ["full_attention_conv", "gcn_conv", "DIFFormerConv", "DIFFormer"]
+
+_CHAIN_GRAM = os.environ.get("DIFFORMER_CHAIN_GRAM", "0") == "1"
 
 
 def _dense_attention(qs, ks, kernel):
@@ -258,7 +262,10 @@ class DIFFormer(nn.Module):
         layer_ = []
         x = self._input_layer(x, self.training)                # difformer.py:188-192
         layer_.append(x)
-        carry = {}      # closed-form layers hand the Gram record / slice-major copy of their output to the next one
+        # closed-form layers write the slice-major copy of their output (the next layer's SpMM operand) from their
+        # registers; DIFFORMER_CHAIN_GRAM=1 makes them leave the Gram record of the output too (measured slower than the
+        # stand-alone Gram pass at C4: 65 us against 33 + 23 us; profiles/r02_experiments.md)
+        carry = {"next_record": _CHAIN_GRAM}
         for i, conv in enumerate(self.convs):
             bn = self.bns[i + 1] if self.use_bn else None
             carry["want_next"] = (not self.training) and i + 1 < len(self.convs)

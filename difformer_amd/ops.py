@@ -399,18 +399,22 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     """One DIFFormer layer with the `simple` kernel on a single GPU, query == source == x [n, C], one head
     (csrc/simple_layer.hip): Gram record -> coefficients -> SpMM on x -> the layer kernel.  q, k, v and the attention
     output never reach memory.  csr = None: use_graph = False.  Wv = None: use_weight = False.
-    `carry` (dict, optional) chains layers: a layer whose output feeds another closed-form layer over the same graph
-    (carry["want_next"]) leaves the Gram record and the slice-major copy of its output there, from the same pass, and
-    the next layer picks them up instead of running dif_gram_f32."""
+    `carry` (dict, optional) chains layers over the same graph: with carry["want_next"] the layer kernel also writes the
+    slice-major pre-scaled copy of its output (the next layer's SpMM operand) from its registers, and with
+    carry["next_record"] the Gram record of the output too; the next layer picks up what it finds."""
     be = get_backend()
     n, C = x.shape
     D = Wq.shape[0]
     sl = csr.sliced(0, n, C) if (csr is not None and n == csr.num_nodes) else None
     have = carry.get("products") if carry is not None else None
-    if have is not None and have["x"] is x and have["sl"] is sl:
-        record, ys = have["record"], have["ys"]
-    else:
-        record, ys = be.gram(x, csr.rowptr if sl is not None else None, sl.plan if sl is not None else None)
+    if have is not None and not (have["x"] is x and have["sl"] is sl):
+        have = None
+    record = have["record"] if have is not None else None
+    ys = have["ys"] if have is not None else None
+    if record is None:
+        need_ys = sl is not None and ys is None
+        record, ys2 = be.gram(x, csr.rowptr if need_ys else None, sl.plan if need_ys else None)
+        ys = ys2 if need_ys else ys
     coef = be.simple_coeffs(record, n, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
     ax = rs = None
     if csr is not None:
@@ -422,13 +426,14 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
         if Wv is not None:
             rs = csr.row_sums()
     want_next = carry is not None and carry.get("want_next", False) and D % 4 == 0 and D == C
+    want_rec = want_next and carry.get("next_record", False)
     if carry is not None:
         carry["products"] = None
-    if not want_next:
+    if not (want_next and (sl is not None or want_rec)):
         return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu)
-    out, record2, ys2 = be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps,
-                                        relu, True, csr.rowptr if sl is not None else None,
-                                        sl.plan if sl is not None else None)
+    out, ys2, record2 = be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps,
+                                        relu, csr.rowptr if sl is not None else None, sl.plan if sl is not None else None,
+                                        want_rec)
     carry["products"] = dict(x=out, sl=sl, record=record2, ys=ys2)
     return out
 

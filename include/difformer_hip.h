@@ -175,8 +175,10 @@ int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int3
  *   dif_simple_layer_f32   out = LN(alpha * (num/den + ax Wv^T + gcn_scale * row_sums * bv [+ x0]) + (1 - alpha) * x) with
  *                          ax = gcn_scale * A_hat x from the SpMM run on x (NULL: use_graph = False), row_sums = A_hat 1
  *                          (NULL when bv is not needed); residual = 0 skips the alpha mix, ln_weight = NULL the LayerNorm.
- *                          next_record != NULL: the same pass also leaves dif_gram_f32's record of `out` (the next layer's
- *                          input; workspace >= dif_gram_workspace_bytes(n_rows, D)) and, with next_ys, its slice-major copy.
+ *                          next_ys != NULL: the pass also writes the slice-major copy of `out` scaled by deg^-1/2 (what
+ *                          dif_gram_f32 would write for the next layer), 256 contiguous bytes per lane group.
+ *                          next_record != NULL: it leaves dif_gram_f32's record of `out` as well (workspace >=
+ *                          dif_gram_workspace_bytes(n_rows, D)); measured slower than a separate dif_gram_f32 at C4.
  * ------------------------------------------------------------------------------------- */
 size_t dif_gram_workspace_bytes(int64_t n_rows, int C);
 int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, const int32_t* rowptr, const int32_t* plan,

@@ -148,7 +148,7 @@ def test_layer_kernel_leaves_the_next_layers_products(n, deg, c, dev):
         ei = torch.cat([torch.randint(0, n, (2, n * deg), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
         csr = ops.csr_cache.get(ei, None, n, c * 4)
         sl = csr.sliced(0, n, c)
-    carry = {"want_next": True}
+    carry = {"want_next": True, "next_record": True}
     out = ops.simple_layer_closed_form(x, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
                                        lw, lb, 1e-5, carry=carry)
     prod = carry["products"]
@@ -159,6 +159,15 @@ def test_layer_kernel_leaves_the_next_layers_products(n, deg, c, dev):
         assert torch.equal(prod["ys"], ys)
     else:
         assert prod["ys"] is None
+    # the cheaper default: only the copy comes out of the layer kernel (from its registers), the record is computed fresh
+    carry2 = {"want_next": True}
+    out2 = ops.simple_layer_closed_form(x, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
+                                        lw, lb, 1e-5, carry=carry2)
+    assert torch.equal(out2, out)
+    if sl is not None:
+        assert carry2["products"]["record"] is None and torch.equal(carry2["products"]["ys"], ys)
+    else:
+        assert carry2["products"] is None
     # and the next layer uses them: same result as a fresh call without the carry
     a = ops.simple_layer_closed_form(out, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
                                      lw, lb, 1e-5, carry=carry)
