@@ -128,7 +128,7 @@ class DIFFormerConv(nn.Module):
 
     def _closed_form(self, query_input, source_input, prev, want_qk):
         """The whole layer through the Gram-record formulation (csrc/simple_layer.hip): `simple` kernel, one head,
-        query == source, narrow fp32 rows, one GPU, inference; the residual must mix with the layer input itself."""
+        query == source, narrow fp32 rows, inference; the residual must mix with the layer input itself."""
         x = source_input
         if not (self.kernel == 'simple' and query_input is source_input and self.num_heads == 1 and not want_qk):
             return False
@@ -137,8 +137,6 @@ class DIFFormerConv(nn.Module):
         if not self.use_weight and x.shape[1] != self.out_channels:
             return False
         if prev is not None and (prev is not x or x.shape[1] != self.out_channels):
-            return False
-        if self.row_shard is not None and self.row_shard.world > 1:
             return False
         if not hasattr(ops.get_backend(), "gram"):
             return False
@@ -159,13 +157,15 @@ class DIFFormerConv(nn.Module):
             x = source_input
             csr = None
             if self.use_graph:
-                csr = ops.csr_cache.get(edge_index, edge_weight, x.shape[0], x.shape[1] * 4, None, 4)
+                n_global = shard.n_global if shard is not None else x.shape[0]
+                csr = ops.csr_cache.get(edge_index, edge_weight, n_global, x.shape[1] * 4, shard, 4)
             a_s, g_s = (1.0 - self.graph_weight, float(self.graph_weight)) if self.graph_weight > 0 else (1.0, 1.0)
             if not self.use_graph:
                 a_s = 1.0                                       # difformer.py:130-136: the mix only exists with a graph
             Wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
             out = ops.simple_layer_closed_form(x, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv, csr,
-                                               a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps, carry=carry)
+                                               a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps, carry=carry,
+                                               shard=shard)
             return out, None, None
         if not want_qk and self._fusable_projection(query_input, source_input):
             attn, v = ops.project_simple_attention(source_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,

@@ -150,8 +150,9 @@ SLICED_MIN_ROWS = 8192
 
 def sliced_tiling(num_nodes, F, nnz, edge_weight, shard, elem_size):
     """(n_tiles, tile_rows) the feature-sliced product would use for this graph, or None when it is not a candidate
-    (edge weights, sharded run, non-fp32 rows, sparse or small graph).  csr_cache builds the CSR with that blocking."""
-    if edge_weight is not None or elem_size != 4 or (shard is not None and shard.world > 1):
+    (edge weights, non-fp32 rows, sparse or small graph).  csr_cache builds the CSR with that blocking; the tiling
+    depends on the number of SOURCE rows only, so row shards share it."""
+    if edge_weight is not None or elem_size != 4:
         return None
     if F % 4 or F > 256 or num_nodes < SLICED_MIN_ROWS or nnz < SLICED_MIN_DEGREE * num_nodes:
         return None
@@ -395,37 +396,53 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
 
 
 def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
-                             ln_bias, eps, relu=False, carry=None):
-    """One DIFFormer layer with the `simple` kernel on a single GPU, query == source == x [n, C], one head
+                             ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None):
+    """One DIFFormer layer with the `simple` kernel, query == source == x [n, C] (this rank's rows), one head
     (csrc/simple_layer.hip): Gram record -> coefficients -> SpMM on x -> the layer kernel.  q, k, v and the attention
     output never reach memory.  csr = None: use_graph = False.  Wv = None: use_weight = False.
-    `carry` (dict, optional) chains layers over the same graph: with carry["want_next"] the layer kernel also writes the
-    slice-major pre-scaled copy of its output (the next layer's SpMM operand) from its registers, and with
+    Row-sharded: the two exchange steps of SURVEY 8e keep their place -- ONE all-reduce of the 4,160-float Gram record
+    (instead of the KtV record) and ONE all-gather of the source rows (x instead of v), started first so that the
+    Gram pass and the coefficients run under it.
+    `carry` (dict, optional; single GPU) chains layers over the same graph: with carry["want_next"] the layer kernel also
+    writes the slice-major pre-scaled copy of its output (the next layer's SpMM operand) from its registers, and with
     carry["next_record"] the Gram record of the output too; the next layer picks up what it finds."""
     be = get_backend()
     n, C = x.shape
     D = Wq.shape[0]
-    sl = csr.sliced(0, n, C) if (csr is not None and n == csr.num_nodes) else None
-    have = carry.get("products") if carry is not None else None
+    sharded = shard is not None and shard.world > 1
+    n_global, row_begin = (shard.n_global, shard.row_begin) if sharded else (n, 0)
+    sl = None
+    if csr is not None and (sharded or n == csr.num_nodes):
+        sl = csr.sliced(row_begin, n, C)
+    handle = shard.all_gather_rows_async(x) if (sharded and csr is not None) else None
+    have = carry.get("products") if (carry is not None and not sharded) else None
     if have is not None and not (have["x"] is x and have["sl"] is sl):
         have = None
     record = have["record"] if have is not None else None
     ys = have["ys"] if have is not None else None
     if record is None:
-        need_ys = sl is not None and ys is None
+        need_ys = sl is not None and ys is None and not sharded
         record, ys2 = be.gram(x, csr.rowptr if need_ys else None, sl.plan if need_ys else None)
         ys = ys2 if need_ys else ys
-    coef = be.simple_coeffs(record, n, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
+    if sharded:
+        shard.all_reduce_sum(record)
+    coef = be.simple_coeffs(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
     ax = rs = None
     if csr is not None:
+        x_src = handle.wait() if sharded else x
         if sl is not None:
-            ax = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, 0, n, C, None, 1.0, gcn_scale)
+            if ys is None:
+                ys = be.sliced_prescale(x_src, csr.rowptr, csr.num_nodes, sl.plan)
+            ax = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, row_begin, n, C, None, 1.0,
+                                gcn_scale)
         else:
-            ax = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x, 0, n, None, 1.0,
-                         gcn_scale, None, csr.row_order(0, n))
+            ax = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x_src, row_begin, n,
+                         None, 1.0, gcn_scale, None, csr.row_order(row_begin, n))
         if Wv is not None:
             rs = csr.row_sums()
-    want_next = carry is not None and carry.get("want_next", False) and D % 4 == 0 and D == C
+            if sharded:
+                rs = rs[row_begin: row_begin + n]
+    want_next = (carry is not None and not sharded and carry.get("want_next", False) and D % 4 == 0 and D == C)
     want_rec = want_next and carry.get("next_record", False)
     if carry is not None:
         carry["products"] = None

@@ -113,6 +113,54 @@ class OracleBackend:
                                   tail.get("relu", False))
         return out
 
+    # ---- closed-form `simple` layer (csrc/simple_layer.hip), restated with numpy in float64 --------------------------
+    def gram(self, x, rowptr=None, plan=None):
+        xx = _np(x).astype(np.float64)
+        rec = np.concatenate([(xx.T @ xx).ravel(), xx.sum(0), [0.0, 0.0]])
+        return torch.from_numpy(rec.astype(np.float32)), None
+
+    def simple_coeffs(self, record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale):
+        r = _np(record).astype(np.float64)
+        G, sx, N = r[: C * C].reshape(C, C), r[C * C: C * C + C], float(n_global)
+        Wq, bq, Wk, bk = (_np(t).astype(np.float64) for t in (Wq, bq, Wk, bk))
+        Wv = np.eye(D, C) if Wv is None else _np(Wv).astype(np.float64)
+        bv = np.zeros(D) if bv is None else _np(bv).astype(np.float64)
+        ktv = Wk @ G @ Wv.T + np.outer(Wk @ sx, bv) + np.outer(bk, Wv @ sx) + N * np.outer(bk, bv)
+        ksum, vsum = Wk @ sx + N * bk, Wv @ sx + N * bv
+        q2 = np.trace(Wq @ G @ Wq.T) + 2 * bq @ (Wq @ sx) + N * bq @ bq
+        k2 = np.trace(Wk @ G @ Wk.T) + 2 * bk @ (Wk @ sx) + N * bk @ bk
+        s = 1.0 / (np.sqrt(q2) * np.sqrt(k2))
+        coef = np.concatenate([(attn_scale * s * (Wq.T @ ktv)).T.ravel(), attn_scale * (s * bq @ ktv + vsum),
+                               s * (Wq.T @ ksum), [s * bq @ ksum + N, s, q2, k2]])
+        return torch.from_numpy(coef.astype(np.float32))
+
+    def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
+                     alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, next_rowptr=None, next_plan=None,
+                     next_record=False):
+        self.closed_form_calls = getattr(self, "closed_form_calls", 0) + 1
+        xx, cf = _np(x).astype(np.float64), _np(coef).astype(np.float64)
+        C = xx.shape[1]
+        MnT, cn, u, cd = cf[: D * C].reshape(D, C), cf[D * C: D * C + D], cf[D * C + D: D * C + D + C], cf[D * C + D + C]
+        z = (xx @ MnT.T + cn) / (xx @ u + cd)[:, None]
+        if ax is not None:
+            a = _np(ax).astype(np.float64)
+            if Wv is not None:
+                z = z + a @ _np(Wv).astype(np.float64).T
+                if row_sums is not None:
+                    z = z + gcn_scale * np.outer(_np(row_sums).astype(np.float64), _np(bv).astype(np.float64))
+            else:
+                z = z + a
+        if x0 is not None:
+            z = z + _np(x0)
+        if residual:
+            z = alpha * z + (1.0 - alpha) * xx
+        if ln_weight is not None:
+            z = orc.layer_norm(z, _np(ln_weight).astype(np.float64), _np(ln_bias).astype(np.float64), eps)
+        if relu:
+            z = np.maximum(z, 0.0)
+        out = torch.from_numpy(z.astype(np.float32))
+        return out if (next_plan is None and not next_record) else (out, None, None)
+
     def row_order(self, rowptr, row_begin, n_rows):
         deg = np.diff(_np(rowptr).astype(np.int64))[row_begin: row_begin + n_rows]
         stats = np.array([(deg * n_rows > 4 * deg.sum()).sum(), deg.max()], dtype=np.int32)

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, kernel, n, out_q):
+def _worker(rank, world, port, kernel, n, out_q, heads=2):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, kernel, n, out_q):
             ops.choose_source_blocks = lambda num_nodes, row_bytes, nnz: 4
             ops.L2_SLICE_BYTES = (-(-n // world) + 7) // 8 * 8 // 2 * 128 / 1.1
         torch.manual_seed(7)
-        model = DIFFormer(12, 16, 5, num_layers=2, num_heads=2, kernel=kernel, use_source=True).eval()
+        model = DIFFormer(12, 16, 5, num_layers=2, num_heads=heads, kernel=kernel, use_source=True).eval()
         g = torch.Generator().manual_seed(3)
         x = torch.randn(n, 12, generator=g)
         ei = torch.cat([torch.randint(0, n, (2, 6 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
@@ -58,21 +58,25 @@ def _worker(rank, world, port, kernel, n, out_q):
             from difformer_amd.dist import RowShard as RS
             odd = RS(n, rank, world, None, counts=[n - 30, 7, 23])
             ok = ok and bool(torch.equal(odd.all_gather_rows(odd.local_rows(x).contiguous()), x))
-        if n >= 64 * world * world:
+        if n >= 64 * world * world and heads > 1:
             csr = list(ops.csr_cache.entries.values())[-1][2]
             ok = ok and csr.n_blocks == 2 * world and ops._BACKEND.part_calls == {0: 2, 1: 2}     # 2 layers x 2 parts
+        if heads == 1 and kernel == "simple":
+            # one head: the layers ran in closed form (Gram record all-reduced, source rows all-gathered)
+            ok = ok and getattr(ops._BACKEND, "closed_form_calls", 0) == 4                          # 2 layers x 2 forwards
         out_q.put((rank, err, tuple(local.shape), ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kernel,world,n", [("simple", 2, 64), ("simple", 3, 50), ("sigmoid", 2, 41), ("simple", 2, 300),
-                                            ("simple", 3, 620)])
-def test_row_sharded_forward_matches_single_process(kernel, world, n):
+@pytest.mark.parametrize("kernel,world,n,heads", [("simple", 2, 64, 2), ("simple", 3, 50, 2), ("sigmoid", 2, 41, 2),
+                                                  ("simple", 2, 300, 2), ("simple", 3, 620, 2), ("simple", 2, 300, 1),
+                                                  ("simple", 3, 50, 1)])
+def test_row_sharded_forward_matches_single_process(kernel, world, n, heads):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kernel, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kernel, n, q, heads)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]

@@ -174,3 +174,60 @@ def test_layer_kernel_leaves_the_next_layers_products(n, deg, c, dev):
     b = ops.simple_layer_closed_form(out, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
                                      lw, lb, 1e-5)
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+class _EmulatedShard:
+    """One rank of a row-sharded run, emulated inside one process: the all-reduce hands back the record of the whole
+    matrix, the all-gather all source rows (what the collectives of dist.RowShard would deliver)."""
+
+    def __init__(self, x_full, rec_full, counts, rank):
+        self.world, self.rank, self.n_global, self.counts = len(counts), rank, x_full.shape[0], counts
+        self.offsets = [0] + list(np.cumsum(counts))
+        self._x, self._rec = x_full, rec_full
+        self.calls = []
+
+    row_begin = property(lambda s: int(s.offsets[s.rank]))
+    n_local = property(lambda s: int(s.counts[s.rank]))
+
+    def all_reduce_sum(self, buf):
+        self.calls.append("all_reduce")
+        buf.copy_(self._rec)
+        return buf
+
+    def all_gather_rows_async(self, local):
+        assert torch.equal(local, self._x[self.row_begin: self.row_begin + self.n_local])
+        self.calls.append("all_gather")
+        x = self._x
+
+        class H:
+            def wait(self_inner):
+                return x
+        return H()
+
+
+@pytest.mark.parametrize("world,n,deg", [(2, 20000, 60), (4, 20000, 60), (3, 3000, 8)])
+def test_closed_form_layer_row_sharded_rank_by_rank(world, n, deg, dev):
+    """Every rank's closed-form layer (Gram record of its rows -> all-reduce -> coefficients -> all-gather of x -> the
+    product over its destination rows -> layer kernel) reproduces its rows of the unsharded layer."""
+    from difformer_amd import ops
+    from difformer_amd.dist import split_rows
+    c = 64
+    g = torch.Generator().manual_seed(world)
+    x = torch.randn(n, c, generator=g).to(dev)
+    p = {k: v.to(dev) for k, v in _params(c, c, g).items()}
+    lw, lb = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+    ei = torch.cat([torch.randint(0, n, (2, n * deg), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    csr = ops.csr_cache.get(ei, None, n, c * 4)
+    args = (p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5, lw, lb, 1e-5)
+    full = ops.simple_layer_closed_form(x, *args)
+    rec_full, _ = ops.get_backend().gram(x)
+    counts = split_rows(n, world)
+    lo = 0
+    for r in range(world):
+        sh = _EmulatedShard(x, rec_full, counts, r)
+        out = ops.simple_layer_closed_form(x[lo: lo + counts[r]].contiguous(), *args, shard=sh)
+        assert sh.calls == ["all_gather", "all_reduce"]            # the gather is started first, the reduce follows the Gram pass
+        if deg >= 48:
+            assert csr.sliced(lo, counts[r], c) is not None        # the shard has its own sliced format
+        assert rel_err(out.cpu().numpy(), full[lo: lo + counts[r]].cpu().numpy()) < 1e-5, (world, r)
+        lo += counts[r]
