@@ -346,6 +346,39 @@ class HipBackend:
         out = torch.stack([out_ei[0, :kept], out_ei[1, :kept]])
         return out, (None if out_w is None else out_w[:kept].clone())
 
+    def subgraph_batches(self, perm, batch_size, edge_index, edge_weight, num_nodes):
+        """All induced subgraphs of an epoch (main-batch.py:121-131) from one pass over the edge list ->
+        (edge_index [2, kept] grouped by batch, edge_weight [kept] | None, batch_ptr: python list of n_batches + 1 ints)."""
+        dev = _require_device(perm, edge_index, edge_weight)
+        if edge_index.dtype != torch.int64 or perm.dtype != torch.int64:
+            raise TypeError("difformer_amd: perm and edge_index must be int64")
+        ei, pm = edge_index.contiguous(), perm.contiguous()
+        E, M = int(ei.shape[1]), int(pm.numel())
+        nb = -(-M // int(batch_size))
+        ew = None if edge_weight is None else _f32(edge_weight, "edge_weight").contiguous()
+        bptr = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        ws_bytes = self.lib.dif_subgraph_batches_workspace_bytes(E, num_nodes, nb)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_subgraph_batches", dev):
+            rc = self.lib.dif_subgraph_batches_group(_ptr(ei), E, num_nodes, _ptr(pm), M, int(batch_size), _ptr(bptr),
+                                                     _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_subgraph_batches_group")
+        ptr = bptr.tolist()                                   # one sync per epoch: the result size is data dependent
+        bad = int(status.item())
+        if bad & 1:
+            raise IndexError(f"difformer_amd: perm / edge_index hold node ids outside [0, {num_nodes})")
+        if bad & 2:
+            raise ValueError("difformer_amd: perm repeats a node id")
+        kept = ptr[-1]
+        out_ei = torch.empty((2, max(kept, 1)), dtype=torch.int64, device=dev)
+        out_w = None if ew is None else torch.empty(max(kept, 1), dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_subgraph_batches", dev):
+            rc = self.lib.dif_subgraph_batches_emit(_ptr(ei), E, num_nodes, M, int(batch_size), _ptr(ew), _ptr(bptr), kept,
+                                                    _ptr(out_ei), _ptr(out_w), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_subgraph_batches_emit")
+        return out_ei[:, :kept], (None if out_w is None else out_w[:kept]), ptr
+
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
              gcn_scale=1.0, tail=None, order=None, part=None):
         """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps[, relu]): fuse the layer tail (H == 1).

@@ -420,6 +420,99 @@ __global__ __launch_bounds__(256) void subgraph_emit_kernel(const int64_t* __res
     if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = pos[E];
 }
 
+
+// ---- all mini-batches of an epoch in one pass (f2; node classification/main-batch.py:121-131) ------------------------
+// The reference draws a permutation of the training nodes once per epoch and then, for every batch of `batch_size`
+// consecutive entries, filters the WHOLE edge list (subgraph(..., relabel_nodes=True), on the CPU).  Here the edge list
+// is streamed once for all batches: info[v] = 1 + position of v in the permutation; an edge survives iff both ends sit
+// in the same batch (position / batch_size), its key is that batch (255 = dropped), and one stable radix pass on the key
+// groups the surviving edge ids batch by batch in their original order.
+__global__ __launch_bounds__(256) void batches_mark_kernel(const int64_t* __restrict__ perm, int64_t M, int64_t N,
+                                                           int32_t* __restrict__ info, int32_t* __restrict__ status) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int64_t v = perm[i];
+    if (v < 0 || v >= N) { atomicOr(status, 1); return; }
+    if (atomicExch(&info[v], static_cast<int32_t>(i) + 1) != 0) atomicOr(status, 2);      // repeated id
+}
+
+__global__ __launch_bounds__(256) void batches_key_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
+                                                          const int32_t* __restrict__ info, int32_t batch_size, int shift_hi,
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                          int32_t* __restrict__ status) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < E; e += stride) {
+        const int64_t r = edge_index[e], c = edge_index[E + e];
+        uint32_t key = 0xffffu;                                   // dropped: sorts behind every batch
+        if (r < 0 || r >= N || c < 0 || c >= N) atomicOr(status, 1);
+        else {
+            const int32_t pr = info[r];
+            if (pr) {
+                const int32_t pc = info[c];
+                if (pc) {
+                    const int32_t br = (pr - 1) / batch_size;
+                    if (br == (pc - 1) / batch_size) key = static_cast<uint32_t>(br);
+                }
+            }
+        }
+        keys[e] = shift_hi ? key : (key & 0xffu);                 // one 8-bit pass when there are < 255 batches
+        vals[e] = static_cast<uint32_t>(e);
+    }
+}
+
+// batch_ptr[b] = first sorted position holding a key >= b (b = 0 .. n_batches); the kept count is batch_ptr[n_batches]
+__global__ __launch_bounds__(256) void batches_ptr_kernel(const uint32_t* __restrict__ keys_sorted, int64_t E, int n_batches,
+                                                          int64_t* __restrict__ batch_ptr) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k <= E; k += stride) {
+        const int64_t lo = (k == 0) ? 0 : static_cast<int64_t>(keys_sorted[k - 1]) + 1;
+        int64_t hi = (k == E) ? n_batches : static_cast<int64_t>(keys_sorted[k]);
+        if (hi > n_batches) hi = n_batches;
+        for (int64_t j = lo; j <= hi; ++j) batch_ptr[j] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void batches_emit_kernel(const int64_t* __restrict__ edge_index, int64_t E,
+                                                           const float* __restrict__ edge_weight,
+                                                           const int32_t* __restrict__ info, int32_t batch_size,
+                                                           const uint32_t* __restrict__ vals_sorted,
+                                                           const int64_t* __restrict__ batch_ptr, int n_batches, int64_t cap,
+                                                           int64_t* __restrict__ out_ei, float* __restrict__ out_w) {
+    const int64_t kept = batch_ptr[n_batches];
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < kept && i < cap; i += stride) {
+        const int64_t e = vals_sorted[i];
+        out_ei[i] = (info[edge_index[e]] - 1) % batch_size;               // subset[j] becomes node j of its batch
+        out_ei[cap + i] = (info[edge_index[E + e]] - 1) % batch_size;
+        if (out_w) out_w[i] = edge_weight[e];
+    }
+}
+
+struct BatchPlan { int rounds; int64_t n_chunks, table_len; int passes; size_t off_info, off_ka, off_kb, off_va, off_vb, off_table, off_bsum, total; };
+BatchPlan make_batch_plan(int64_t E, int64_t N, int n_batches) {
+    BatchPlan p;
+    int64_t rounds = (E + 64 * 4096 - 1) / (64 * 4096);
+    if (rounds < kSortRoundsMin) rounds = kSortRoundsMin;
+    if (rounds > kSortRoundsMax) rounds = kSortRoundsMax;
+    p.rounds = static_cast<int>(rounds);
+    const int64_t chunk = 64 * rounds;
+    p.n_chunks = (E + chunk - 1) / chunk;
+    if (p.n_chunks < 1) p.n_chunks = 1;
+    p.table_len = p.n_chunks * kRadix;
+    p.passes = n_batches < 255 ? 1 : 2;
+    const size_t e = static_cast<size_t>(E > 0 ? E : 1);
+    size_t o = 0;
+    p.off_info = o;  o += align256(static_cast<size_t>(N) * 4);
+    p.off_ka = o;    o += align256(e * 4);
+    p.off_kb = o;    o += align256(e * 4);
+    p.off_va = o;    o += align256(e * 4);
+    p.off_vb = o;    o += align256(e * 4);
+    p.off_table = o; o += align256(static_cast<size_t>(p.table_len) * 4);
+    p.off_bsum = o;  o += align256(static_cast<size_t>((p.table_len + kScanTile - 1) / kScanTile + 1) * 4);
+    p.total = o;
+    return p;
+}
+
 }  // namespace
 
 extern "C" size_t dif_csr_workspace_bytes(int64_t E, int64_t N, int n_blocks) {
@@ -618,4 +711,91 @@ extern "C" int dif_subgraph(const int64_t* edge_index, int64_t E, int64_t N, con
     hipLaunchKernelGGL(subgraph_emit_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, edge_weight,
                        newid, keep, E, out_edge_index, out_weight, out_count);
     return dif::launch_status("subgraph_emit_kernel");
+}
+
+extern "C" size_t dif_subgraph_batches_workspace_bytes(int64_t E, int64_t N, int n_batches) {
+    if (E < 0 || N <= 0 || n_batches <= 0) return 0;
+    return make_batch_plan(E, N, n_batches).total;
+}
+
+// Phase 1: batch_ptr int64[n_batches + 1] (device) <- offsets of every batch's edges in the grouped order; the kept
+// count is its last element.  The workspace keeps the grouped edge ids for phase 2.
+extern "C" int dif_subgraph_batches_group(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* perm, int64_t M,
+                                          int64_t batch_size, int64_t* batch_ptr, int32_t* status, void* workspace,
+                                          size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && E >= 0 && M > 0 && batch_size > 0, DIF_E_BADARG, "dif_subgraph_batches: need N, M, batch_size > 0, E >= 0");
+    DIF_REQUIRE(E < (int64_t(1) << 31) - 4096 && N < (int64_t(1) << 31) - 1 && M <= N && batch_size < (int64_t(1) << 31),
+                DIF_E_RANGE, "dif_subgraph_batches: sizes must fit int32 and M <= N");
+    const int64_t nb64 = (M + batch_size - 1) / batch_size;
+    DIF_REQUIRE(nb64 < 65535, DIF_E_RANGE, "dif_subgraph_batches: at most 65,534 batches");
+    const int n_batches = static_cast<int>(nb64);
+    DIF_REQUIRE(batch_ptr && status && workspace && perm && (E == 0 || edge_index), DIF_E_BADARG, "dif_subgraph_batches: null pointer");
+    const BatchPlan p = make_batch_plan(E, N, n_batches);
+    DIF_REQUIRE(workspace_bytes >= p.total, DIF_E_WORKSPACE, "dif_subgraph_batches: workspace too small");
+    DIF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DIF_E_BADARG, "dif_subgraph_batches: workspace must be 256-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    int32_t* info = reinterpret_cast<int32_t*>(ws + p.off_info);
+    uint32_t *ka = reinterpret_cast<uint32_t*>(ws + p.off_ka), *kb = reinterpret_cast<uint32_t*>(ws + p.off_kb);
+    uint32_t *va = reinterpret_cast<uint32_t*>(ws + p.off_va), *vb = reinterpret_cast<uint32_t*>(ws + p.off_vb);
+    int32_t* table = reinterpret_cast<int32_t*>(ws + p.off_table);
+    int32_t* bsum = reinterpret_cast<int32_t*>(ws + p.off_bsum);
+    hipError_t he = hipMemsetAsync(info, 0, static_cast<size_t>(N) * 4, st);
+    if (he == hipSuccess) he = hipMemsetAsync(status, 0, 4, st);
+    if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_subgraph_batches: memset: %s", hipGetErrorString(he));
+    hipLaunchKernelGGL(batches_mark_kernel, dim3(static_cast<unsigned>((M + 255) / 256)), dim3(256), 0, st, perm, M, N, info, status);
+    if (int rc = dif::launch_status("batches_mark_kernel")) return rc;
+    const int64_t cap = 8 * dif::kCUs;
+    int64_t g = (E + 1 + 255) / 256;
+    if (g > cap) g = cap;
+    if (E > 0) {
+        hipLaunchKernelGGL(batches_key_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N, info,
+                           static_cast<int32_t>(batch_size), p.passes > 1 ? 1 : 0, ka, va, status);
+        if (int rc = dif::launch_status("batches_key_kernel")) return rc;
+        const unsigned sort_grid = static_cast<unsigned>((p.n_chunks + kSortWaves - 1) / kSortWaves);
+        uint32_t *kin = ka, *kout = kb, *vin = va, *vout = vb;
+        for (int pass = 0; pass < p.passes; ++pass) {
+            const int shift = pass * kRadixBits;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, E, shift, p.n_chunks, p.rounds, table);
+            if (int rc = dif::launch_status("radix_hist_kernel")) return rc;
+            if (int rc = exclusive_scan(table, p.table_len, table, nullptr, bsum, st)) return rc;
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, vin, E, shift, p.n_chunks,
+                               p.rounds, table, kout, vout);
+            if (int rc = dif::launch_status("radix_scatter_kernel")) return rc;
+            uint32_t* t = kin; kin = kout; kout = t;
+            t = vin; vin = vout; vout = t;
+        }
+        // sorted keys / ids now sit in (kin, vin): after one pass that is (kb, vb), after two (ka, va)
+        hipLaunchKernelGGL(batches_ptr_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, kin, E, n_batches, batch_ptr);
+        return dif::launch_status("batches_ptr_kernel");
+    }
+    he = hipMemsetAsync(batch_ptr, 0, static_cast<size_t>(n_batches + 1) * 8, st);
+    return he == hipSuccess ? 0 : dif::fail(static_cast<int>(he), "dif_subgraph_batches: memset: %s", hipGetErrorString(he));
+}
+
+// Phase 2: out_edge_index int64 [2, capacity] (row r at offset r * capacity), capacity >= batch_ptr[n_batches]:
+// the surviving edges batch by batch, in their original order, ends renumbered inside their batch.
+extern "C" int dif_subgraph_batches_emit(const int64_t* edge_index, int64_t E, int64_t N, int64_t M, int64_t batch_size,
+                                         const float* edge_weight, const int64_t* batch_ptr, int64_t capacity,
+                                         int64_t* out_edge_index, float* out_weight, const void* workspace,
+                                         size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && E >= 0 && M > 0 && batch_size > 0 && capacity >= 0, DIF_E_BADARG, "dif_subgraph_batches_emit: bad sizes");
+    const int64_t nb64 = (M + batch_size - 1) / batch_size;
+    DIF_REQUIRE(nb64 < 65535, DIF_E_RANGE, "dif_subgraph_batches: at most 65,534 batches");
+    const int n_batches = static_cast<int>(nb64);
+    DIF_REQUIRE(batch_ptr && workspace && (capacity == 0 || (edge_index && out_edge_index)), DIF_E_BADARG, "dif_subgraph_batches_emit: null pointer");
+    DIF_REQUIRE((edge_weight == nullptr) == (out_weight == nullptr), DIF_E_BADARG,
+                "dif_subgraph_batches_emit: edge_weight and out_weight must be given together");
+    const BatchPlan p = make_batch_plan(E, N, n_batches);
+    DIF_REQUIRE(workspace_bytes >= p.total, DIF_E_WORKSPACE, "dif_subgraph_batches_emit: workspace too small");
+    if (capacity == 0 || E == 0) return 0;
+    const char* ws = static_cast<const char*>(workspace);
+    const int32_t* info = reinterpret_cast<const int32_t*>(ws + p.off_info);
+    const uint32_t* vals = reinterpret_cast<const uint32_t*>(ws + (p.passes == 1 ? p.off_vb : p.off_va));
+    int64_t g = (capacity + 255) / 256;
+    if (g > 8 * dif::kCUs) g = 8 * dif::kCUs;
+    hipLaunchKernelGGL(batches_emit_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), edge_index,
+                       E, edge_weight, info, static_cast<int32_t>(batch_size), vals, batch_ptr, n_batches, capacity,
+                       out_edge_index, out_weight);
+    return dif::launch_status("batches_emit_kernel");
 }

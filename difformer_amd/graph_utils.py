@@ -3,6 +3,7 @@
 scripts import, so a driver can switch by changing one import; all of them keep the graph on the GPU.
 
     subgraph          node classification/main-batch.py:131   (HIP kernels: mark, flag, scan, emit)
+    subgraph_batches  main-batch.py:121-131, all batches of an epoch in one pass (HIP: mark, key, stable radix pass, emit)
     add_self_loops    main.py:76, main-batch.py:98            (tensor plumbing)
     remove_self_loops main.py:75, main-batch.py:97            (tensor plumbing)
     to_undirected     main.py:73                              (tensor plumbing: both directions, duplicates coalesced)
@@ -24,6 +25,19 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes=
     if not relabel_nodes:
         ei = subset[ei]
     return ei, ew
+
+
+def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=None):
+    """Every mini-batch subgraph of an epoch from ONE pass over the edge list (csrc/gcn_csr.hip, dif_subgraph_batches_*).
+
+    main-batch.py:121-131 cuts a permutation of the training nodes into batches and calls
+    `subgraph(idx_i, edge_index, num_nodes=n, relabel_nodes=True)` once per batch; with
+        batches = subgraph_batches(train_idx[perm], batch_size, edge_index, num_nodes=n)
+    before the loop, `edge_index_i, _ = batches[i]` returns the identical tensors (same edges, same order, same
+    relabelling) without touching the edge list again.  Returns a list of (edge_index_b [2, E_b], edge_attr_b | None)."""
+    n = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
+    ei, ew, ptr = ops.get_backend().subgraph_batches(perm, batch_size, edge_index, edge_attr, n)
+    return [(ei[:, ptr[b]: ptr[b + 1]], None if ew is None else ew[ptr[b]: ptr[b + 1]]) for b in range(len(ptr) - 1)]
 
 
 def add_self_loops(edge_index, edge_weight=None, fill_value=1.0, num_nodes=None):

@@ -278,6 +278,25 @@ int dif_subgraph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t*
                  const float* edge_weight, int64_t* out_edge_index, float* out_weight, int64_t* out_count,
                  int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
+/* All mini-batches of an epoch in ONE pass over the edge list (main-batch.py:121-131: a permutation of the training
+ * nodes is cut into batches of `batch_size` consecutive entries and subgraph(idx_i, edge_index, relabel_nodes=True) is
+ * called per batch, each call filtering the whole edge list).  perm int64[M] (no repeats); batch b = perm[b*batch_size ..].
+ *   dif_subgraph_batches_group  streams the edge list once: an edge survives iff both ends lie in the same batch; a
+ *       stable radix pass groups the surviving edge ids by batch.  batch_ptr int64[n_batches + 1] (device) <- offsets,
+ *       its last element = number of surviving edges (read it back to size the output).  status[0]: 1 = id outside
+ *       [0, N), 2 = repeated id in perm.  n_batches = ceil(M / batch_size) < 65,535.
+ *   dif_subgraph_batches_emit   out_edge_index int64 [2, capacity]: batch b owns columns [batch_ptr[b], batch_ptr[b+1]),
+ *       edges in their original order, ends renumbered inside the batch (perm[b*batch_size + j] -> j): exactly what the
+ *       per-batch call returns.  Same workspace as the group call (it holds the grouped edge ids). */
+size_t dif_subgraph_batches_workspace_bytes(int64_t E, int64_t N, int n_batches);
+int dif_subgraph_batches_group(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* perm, int64_t M,
+                               int64_t batch_size, int64_t* batch_ptr, int32_t* status, void* workspace,
+                               size_t workspace_bytes, dif_stream_t stream);
+int dif_subgraph_batches_emit(const int64_t* edge_index, int64_t E, int64_t N, int64_t M, int64_t batch_size,
+                              const float* edge_weight, const int64_t* batch_ptr, int64_t capacity,
+                              int64_t* out_edge_index, float* out_weight, const void* workspace,
+                              size_t workspace_bytes, dif_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * a4/a5  tail of DIFFormerConv.forward + the per-layer tail of DIFFormer.forward
  *        node classification/difformer.py:137 (mean over heads), :139-140 (+= x_0),

@@ -46,3 +46,21 @@ for store in (torch.float32, torch.bfloat16):
     print(f"{str(store):16s} {nb} batches of {BATCH}: {tot * 1e3:7.1f} ms per pass over {N} nodes "
           f"({N / tot / 1e6:.1f} M nodes/s)  per batch: subgraph {t['subgraph'] / nb * 1e3:.2f} ms, "
           f"CSR build {t['csr'] / nb * 1e3:.2f} ms, forward {t['forward'] / nb * 1e3:.2f} ms", flush=True)
+
+    # round 2: every batch's subgraph from ONE pass over the edge list (dif_subgraph_batches_*)
+    def epoch_batched():
+        perm = torch.randperm(N, device=dev, generator=g)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        batches = gu.subgraph_batches(perm, BATCH, edge_index, None, num_nodes=N)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        outs = []
+        with torch.no_grad():
+            for i, (ei, _) in enumerate(batches):
+                outs.append(model(xs[perm[i * BATCH:(i + 1) * BATCH]], ei))
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, len(outs)
+
+    epoch_batched()
+    tg, tf, nb = epoch_batched()
+    print(f"{str(store):16s} batched: all {nb} subgraphs {tg * 1e3:.2f} ms + CSR builds and forwards {tf * 1e3:.2f} ms = "
+          f"{(tg + tf) * 1e3:.1f} ms per pass ({N / (tg + tf) / 1e6:.1f} M nodes/s)", flush=True)

@@ -781,6 +781,35 @@ def test_subgraph_relabel_matches_numpy(dev):
     assert u.tolist() == [[0, 1, 1, 2], [1, 0, 2, 1]]
 
 
+@pytest.mark.parametrize("n,e,m,bsz,weighted", [(50000, 1200000, 50000, 10000, True), (50000, 1200000, 31234, 7000, False),
+                                                 (3000, 40000, 3000, 10, False), (1000, 5000, 1000, 1000, True)])
+def test_subgraph_batches_equal_the_per_batch_calls(n, e, m, bsz, weighted, dev):
+    """All mini-batch subgraphs of an epoch from ONE pass over the edge list (main-batch.py:121-131): every batch must be
+    exactly what subgraph(idx_i, edge_index, relabel_nodes=True) returns for it -- integer work, compared exactly
+    against the oracle's restatement of torch_geometric.utils.subgraph (the last batch is ragged, 300 batches need two
+    radix passes, one batch = the whole permutation)."""
+    from difformer_amd import graph_utils as gu
+    g = torch.Generator().manual_seed(n + bsz)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei = torch.cat([ei, torch.arange(n).repeat(2, 1)], dim=1)           # self loops survive in their node's batch
+    w = torch.rand(ei.shape[1], generator=g) if weighted else None
+    perm = torch.randperm(n, generator=g)[:m]
+    batches = gu.subgraph_batches(perm.to(dev), bsz, ei.to(dev), None if w is None else w.to(dev), num_nodes=n)
+    assert len(batches) == -(-m // bsz)
+    for b, (eb, wb) in enumerate(batches):
+        idx = perm[b * bsz: (b + 1) * bsz]
+        ref, ref_w = orc.subgraph(idx.numpy(), ei.numpy(), None if w is None else w.numpy(), relabel_nodes=True, num_nodes=n)
+        assert np.array_equal(eb.cpu().numpy(), ref), b
+        if weighted:
+            assert np.array_equal(wb.cpu().numpy(), ref_w), b
+        else:
+            assert wb is None
+    with pytest.raises(ValueError):
+        gu.subgraph_batches(torch.tensor([1, 2, 1], device=dev), 2, ei.to(dev), None, num_nodes=n)
+    with pytest.raises(IndexError):
+        gu.subgraph_batches(torch.tensor([1, n + 3], device=dev), 2, ei.to(dev), None, num_nodes=n)
+
+
 def _random_cfgs(count, seed):
     rng = np.random.default_rng(seed)
     cfgs = []
