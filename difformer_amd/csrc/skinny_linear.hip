@@ -1,5 +1,5 @@
 // a5 ends: the input MLP (node classification/difformer.py:188-191  Linear -> LayerNorm -> ReLU) and the
-// output Linear (:208) for the narrow shapes DIFFormer uses (C_in <= 64: ogbn-proteins 8->64, hidden->classes
+// output Linear (:208) for the narrow shapes DIFFormer uses (C_in <= 128: ogbn-proteins 8->64, hidden->classes
 // 64->112).  One pass: x read once, y written once, LayerNorm/ReLU applied in registers.  Vendor GEMMs are
 // tuned for large K and spend ~100 us on these (K = 8: 4 MB in, 34 MB out).
 //

@@ -548,5 +548,5 @@ def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None
 
 
 def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
-    """x W^T + b (-> LayerNorm) (-> ReLU) for C_in <= 64 (difformer.py:188-191, :208)."""
+    """x W^T + b (-> LayerNorm) (-> ReLU) for C_in <= 128 (difformer.py:188-191, :208; csrc/skinny_linear.hip)."""
     return get_backend().linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
