@@ -51,6 +51,9 @@ SIGNATURES = {
     "dif_subgraph_batches_workspace_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "dif_subgraph_batches_group": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_subgraph_batches_emit": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dif_subgraph_batches_csr_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "dif_subgraph_batches_csr": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp,
+                                         c_sz, c_vp]),
     "dif_gcn_spmm_f32": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int,
                                  c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dif_gram_workspace_bytes": (c_sz, [c_i64, c_int]),

@@ -346,9 +346,11 @@ class HipBackend:
         out = torch.stack([out_ei[0, :kept], out_ei[1, :kept]])
         return out, (None if out_w is None else out_w[:kept].clone())
 
-    def subgraph_batches(self, perm, batch_size, edge_index, edge_weight, num_nodes):
+    def subgraph_batches(self, perm, batch_size, edge_index, edge_weight, num_nodes, build_csr=False):
         """All induced subgraphs of an epoch (main-batch.py:121-131) from one pass over the edge list ->
-        (edge_index [2, kept] grouped by batch, edge_weight [kept] | None, batch_ptr: python list of n_batches + 1 ints)."""
+        (edge_index [2, kept] grouped by batch, edge_weight [kept] | None, batch_ptr: python list of n_batches + 1 ints,
+        csr | None) with csr = (rowptr int32 [M + 1], src int32 [kept], val float32 [kept]) over all batches when
+        build_csr (one sort instead of one dif_csr_build per batch)."""
         dev = _require_device(perm, edge_index, edge_weight)
         if edge_index.dtype != torch.int64 or perm.dtype != torch.int64:
             raise TypeError("difformer_amd: perm and edge_index must be int64")
@@ -377,7 +379,20 @@ class HipBackend:
             rc = self.lib.dif_subgraph_batches_emit(_ptr(ei), E, num_nodes, M, int(batch_size), _ptr(ew), _ptr(bptr), kept,
                                                     _ptr(out_ei), _ptr(out_w), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_subgraph_batches_emit")
-        return out_ei[:, :kept], (None if out_w is None else out_w[:kept]), ptr
+        csr = None
+        if build_csr:
+            rowptr = torch.empty(M + 1, dtype=torch.int32, device=dev)
+            src = torch.empty(max(kept, 1), dtype=torch.int32, device=dev)
+            val = torch.empty(max(kept, 1), dtype=torch.float32, device=dev)
+            ws2_bytes = self.lib.dif_subgraph_batches_csr_workspace_bytes(kept, M)
+            ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
+            with _Timed(self, "dif_subgraph_batches", dev):
+                rc = self.lib.dif_subgraph_batches_csr(_ptr(ei), E, num_nodes, M, int(batch_size), _ptr(ew), kept, _ptr(ws),
+                                                       ws_bytes, _ptr(rowptr), _ptr(src), _ptr(val), _ptr(ws2), ws2_bytes,
+                                                       _stream(dev))
+            _lib.check(rc, "dif_subgraph_batches_csr")
+            csr = (rowptr, src, val)
+        return out_ei[:, :kept], (None if out_w is None else out_w[:kept]), ptr, csr
 
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
              gcn_scale=1.0, tail=None, order=None, part=None):

@@ -488,6 +488,75 @@ __global__ __launch_bounds__(256) void batches_emit_kernel(const int64_t* __rest
     }
 }
 
+// Batched CSR of the surviving edges: one sort on key = batch * batch_size + local destination (payload = edge id),
+// so every batch's CSR (its own degrees, its own normalisation: difformer.py:63-75 on the subgraph) is a slice of one
+// set of arrays -- instead of one dif_csr_build per batch.
+__global__ __launch_bounds__(256) void batches_csr_key_kernel(const int64_t* __restrict__ edge_index, int64_t E,
+                                                              const int32_t* __restrict__ info,
+                                                              const uint32_t* __restrict__ eid_grouped, int64_t kept,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < kept; i += stride) {
+        const uint32_t e = eid_grouped[i];
+        keys[i] = static_cast<uint32_t>(info[edge_index[E + e]] - 1);     // position of the destination in the permutation
+        vals[i] = e;                                                      //   = batch * batch_size + local id
+    }
+}
+
+__global__ __launch_bounds__(256) void batches_csr_dinv_kernel(const int32_t* __restrict__ rowptr, int64_t M,
+                                                               float* __restrict__ dinv) {
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g < M) dinv[g] = sqrtf(1.0f / static_cast<float>(rowptr[g + 1] - rowptr[g]));
+}
+
+__global__ __launch_bounds__(256) void batches_csr_fill_kernel(const int64_t* __restrict__ edge_index, int64_t E,
+                                                               const float* __restrict__ edge_weight,
+                                                               const int32_t* __restrict__ info, int32_t batch_size,
+                                                               const uint32_t* __restrict__ key_sorted,
+                                                               const uint32_t* __restrict__ eid_sorted, int64_t kept,
+                                                               const float* __restrict__ dinv, int32_t* __restrict__ src,
+                                                               float* __restrict__ val) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < kept; k += stride) {
+        const uint32_t e = eid_sorted[k];
+        const int64_t gc = key_sorted[k];                                 // destination (`col`), global position
+        const int64_t gr = info[edge_index[e]] - 1;                       // source (`row`): same batch by construction
+        const float dn_in = dinv[gc], dn_out = dinv[gr];
+        float v = edge_weight ? __fmul_rn(__fmul_rn(edge_weight[e], dn_in), dn_out) : __fmul_rn(dn_in, dn_out);
+        if (!isfinite(v)) v = 0.f;
+        src[k] = static_cast<int32_t>(gr % batch_size);
+        val[k] = v;
+    }
+}
+
+struct BatchCsrPlan { int rounds; int64_t n_chunks, table_len; int passes; size_t off_ka, off_kb, off_va, off_vb, off_dinv, off_table, off_bsum, total; };
+BatchCsrPlan make_batch_csr_plan(int64_t kept, int64_t M) {
+    BatchCsrPlan p;
+    int64_t rounds = (kept + 64 * 4096 - 1) / (64 * 4096);
+    if (rounds < kSortRoundsMin) rounds = kSortRoundsMin;
+    if (rounds > kSortRoundsMax) rounds = kSortRoundsMax;
+    p.rounds = static_cast<int>(rounds);
+    const int64_t chunk = 64 * rounds;
+    p.n_chunks = (kept + chunk - 1) / chunk;
+    if (p.n_chunks < 1) p.n_chunks = 1;
+    p.table_len = p.n_chunks * kRadix;
+    int bits = 1;
+    while ((int64_t(1) << bits) < M) ++bits;
+    p.passes = (bits + kRadixBits - 1) / kRadixBits;
+    const size_t e = static_cast<size_t>(kept > 0 ? kept : 1);
+    const int64_t scan_n = p.table_len > M + 1 ? p.table_len : M + 1;
+    size_t o = 0;
+    p.off_ka = o;    o += align256(e * 4);
+    p.off_kb = o;    o += align256(e * 4);
+    p.off_va = o;    o += align256(e * 4);
+    p.off_vb = o;    o += align256(e * 4);
+    p.off_dinv = o;  o += align256(static_cast<size_t>(M + 1) * 4);
+    p.off_table = o; o += align256(static_cast<size_t>(p.table_len) * 4);
+    p.off_bsum = o;  o += align256(static_cast<size_t>((scan_n + kScanTile - 1) / kScanTile + 1) * 4);
+    p.total = o;
+    return p;
+}
+
 struct BatchPlan { int rounds; int64_t n_chunks, table_len; int passes; size_t off_info, off_ka, off_kb, off_va, off_vb, off_table, off_bsum, total; };
 BatchPlan make_batch_plan(int64_t E, int64_t N, int n_batches) {
     BatchPlan p;
@@ -798,4 +867,70 @@ extern "C" int dif_subgraph_batches_emit(const int64_t* edge_index, int64_t E, i
                        E, edge_weight, info, static_cast<int32_t>(batch_size), vals, batch_ptr, n_batches, capacity,
                        out_edge_index, out_weight);
     return dif::launch_status("batches_emit_kernel");
+}
+
+extern "C" size_t dif_subgraph_batches_csr_workspace_bytes(int64_t kept, int64_t M) {
+    if (kept < 0 || M <= 0) return 0;
+    return make_batch_csr_plan(kept, M).total;
+}
+
+// Phase 2b (optional): the CSR of EVERY batch from one sort.  rowptr int32[M + 1] over the positions of the permutation
+// (row b*batch_size + j = node j of batch b), src int32[kept] (batch-local source ids), val float32[kept]: the slice
+// [rowptr[b*batch_size], rowptr[min((b+1)*batch_size, M)]) = [batch_ptr[b], batch_ptr[b+1]) is exactly what dif_csr_build
+// returns for that batch's edge list (entries in original edge order, degrees and normalisation of the subgraph), with
+// rowptr shifted by batch_ptr[b].  kept = batch_ptr[n_batches] as read back by the caller; group_workspace is the
+// workspace of dif_subgraph_batches_group.
+extern "C" int dif_subgraph_batches_csr(const int64_t* edge_index, int64_t E, int64_t N, int64_t M, int64_t batch_size,
+                                        const float* edge_weight, int64_t kept, const void* group_workspace,
+                                        size_t group_workspace_bytes, int32_t* rowptr, int32_t* src, float* val,
+                                        void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && E >= 0 && M > 0 && batch_size > 0 && kept >= 0 && kept <= E, DIF_E_BADARG, "dif_subgraph_batches_csr: bad sizes");
+    const int64_t nb64 = (M + batch_size - 1) / batch_size;
+    DIF_REQUIRE(nb64 < 65535, DIF_E_RANGE, "dif_subgraph_batches: at most 65,534 batches");
+    DIF_REQUIRE(rowptr && group_workspace && workspace && (kept == 0 || (edge_index && src && val)), DIF_E_BADARG,
+                "dif_subgraph_batches_csr: null pointer");
+    const BatchPlan gp = make_batch_plan(E, N, static_cast<int>(nb64));
+    DIF_REQUIRE(group_workspace_bytes >= gp.total, DIF_E_WORKSPACE, "dif_subgraph_batches_csr: group workspace too small");
+    const BatchCsrPlan p = make_batch_csr_plan(kept, M);
+    DIF_REQUIRE(workspace_bytes >= p.total, DIF_E_WORKSPACE, "dif_subgraph_batches_csr: workspace too small");
+    DIF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DIF_E_BADARG, "dif_subgraph_batches_csr: workspace must be 256-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char* gws = static_cast<const char*>(group_workspace);
+    const int32_t* info = reinterpret_cast<const int32_t*>(gws + gp.off_info);
+    const uint32_t* grouped = reinterpret_cast<const uint32_t*>(gws + (gp.passes == 1 ? gp.off_vb : gp.off_va));
+    char* ws = static_cast<char*>(workspace);
+    uint32_t *ka = reinterpret_cast<uint32_t*>(ws + p.off_ka), *kb = reinterpret_cast<uint32_t*>(ws + p.off_kb);
+    uint32_t *va = reinterpret_cast<uint32_t*>(ws + p.off_va), *vb = reinterpret_cast<uint32_t*>(ws + p.off_vb);
+    float* dinv = reinterpret_cast<float*>(ws + p.off_dinv);
+    int32_t* table = reinterpret_cast<int32_t*>(ws + p.off_table);
+    int32_t* bsum = reinterpret_cast<int32_t*>(ws + p.off_bsum);
+    if (kept == 0) {
+        hipError_t he = hipMemsetAsync(rowptr, 0, static_cast<size_t>(M + 1) * 4, st);
+        return he == hipSuccess ? 0 : dif::fail(static_cast<int>(he), "dif_subgraph_batches_csr: memset: %s", hipGetErrorString(he));
+    }
+    const int64_t cap = 8 * dif::kCUs;
+    int64_t g = (kept + 1 + 255) / 256;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(batches_csr_key_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, info, grouped, kept, ka, va);
+    if (int rc = dif::launch_status("batches_csr_key_kernel")) return rc;
+    const unsigned sort_grid = static_cast<unsigned>((p.n_chunks + kSortWaves - 1) / kSortWaves);
+    uint32_t *kin = ka, *kout = kb, *vin = va, *vout = vb;
+    for (int pass = 0; pass < p.passes; ++pass) {
+        const int shift = pass * kRadixBits;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, kept, shift, p.n_chunks, p.rounds, table);
+        if (int rc = dif::launch_status("radix_hist_kernel")) return rc;
+        if (int rc = exclusive_scan(table, p.table_len, table, nullptr, bsum, st)) return rc;
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, vin, kept, shift, p.n_chunks,
+                           p.rounds, table, kout, vout);
+        if (int rc = dif::launch_status("radix_scatter_kernel")) return rc;
+        uint32_t* t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    hipLaunchKernelGGL(csr_bounds_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, kin, kept, M, rowptr);
+    if (int rc = dif::launch_status("csr_bounds_kernel")) return rc;
+    hipLaunchKernelGGL(batches_csr_dinv_kernel, dim3(static_cast<unsigned>((M + 255) / 256)), dim3(256), 0, st, rowptr, M, dinv);
+    if (int rc = dif::launch_status("batches_csr_dinv_kernel")) return rc;
+    hipLaunchKernelGGL(batches_csr_fill_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, edge_weight, info,
+                       static_cast<int32_t>(batch_size), kin, vin, kept, dinv, src, val);
+    return dif::launch_status("batches_csr_fill_kernel");
 }

@@ -10,6 +10,8 @@ scripts import, so a driver can switch by changing one import; all of them keep 
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
@@ -27,17 +29,34 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes=
     return ei, ew
 
 
-def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=None):
+def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=None, build_csr=True):
     """Every mini-batch subgraph of an epoch from ONE pass over the edge list (csrc/gcn_csr.hip, dif_subgraph_batches_*).
 
     main-batch.py:121-131 cuts a permutation of the training nodes into batches and calls
     `subgraph(idx_i, edge_index, num_nodes=n, relabel_nodes=True)` once per batch; with
         batches = subgraph_batches(train_idx[perm], batch_size, edge_index, num_nodes=n)
     before the loop, `edge_index_i, _ = batches[i]` returns the identical tensors (same edges, same order, same
-    relabelling) without touching the edge list again.  Returns a list of (edge_index_b [2, E_b], edge_attr_b | None)."""
+    relabelling) without touching the edge list again.  Returns a list of (edge_index_b [2, E_b], edge_attr_b | None).
+    build_csr: the normalised CSR of every batch comes out of one more sort of the surviving edges and is registered in
+    the CSR cache under its batch's edge_index, so `model(x_i, edge_index_i)` builds nothing (keep the returned list
+    alive for the epoch: the registration follows the tensors' lifetime)."""
     n = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
-    ei, ew, ptr = ops.get_backend().subgraph_batches(perm, batch_size, edge_index, edge_attr, n)
-    return [(ei[:, ptr[b]: ptr[b + 1]], None if ew is None else ew[ptr[b]: ptr[b + 1]]) for b in range(len(ptr) - 1)]
+    ei, ew, ptr, csr = ops.get_backend().subgraph_batches(perm, batch_size, edge_index, edge_attr, n, build_csr)
+    nb = len(ptr) - 1
+    out = [(ei[:, ptr[b]: ptr[b + 1]], None if ew is None else ew[ptr[b]: ptr[b + 1]]) for b in range(nb)]
+    if csr is not None:
+        rowptr, src, val = csr
+        m, bs = int(perm.numel()), int(batch_size)
+        ops.csr_cache.reserve(nb + ops.csr_cache.capacity)
+        for b, (eb, wb) in enumerate(out):
+            lo, hi = b * bs, min((b + 1) * bs, m)
+            rp = (rowptr[lo: hi + 1] - ptr[b]).contiguous()
+            e0, e1 = ptr[b], ptr[b + 1]
+            g = ops.GraphCSR(rp, None, 1, src[e0: max(e1, e0 + 1)], val[e0: max(e1, e0 + 1)], hi - lo, e1 - e0)
+            g.weighted = wb is not None
+            g._edges = (weakref.ref(eb), None if wb is None else weakref.ref(wb))
+            ops.csr_cache.put(eb, wb, hi - lo, g)
+    return out
 
 
 def add_self_loops(edge_index, edge_weight=None, fill_value=1.0, num_nodes=None):

@@ -316,9 +316,22 @@ class _CSRCache:
         csr = GraphCSR.build(edge_index, edge_weight, num_nodes, n_blocks, block_rows=block_rows)
         self.entries[key] = (weakref.ref(edge_index), weakref.ref(edge_weight) if edge_weight is not None else None,
                              csr)
-        while len(self.entries) > self.capacity:
+        while len(self.entries) > max(self.capacity, getattr(self, "_floor", 0)):
             self.entries.popitem(last=False)
         return csr
+
+    def put(self, edge_index, edge_weight, num_nodes, csr):
+        """Register a CSR built elsewhere (graph_utils.subgraph_batches: all batches of an epoch from one sort) under the
+        key `get` would use for these tensors, so that `model(x_i, edge_index_i)` finds it without building anything."""
+        key = self._key(edge_index, edge_weight, num_nodes, csr.n_blocks, 0)
+        self.entries[key] = (weakref.ref(edge_index), weakref.ref(edge_weight) if edge_weight is not None else None, csr)
+        self.entries.move_to_end(key)
+        while len(self.entries) > max(self.capacity, getattr(self, "_floor", 0)):
+            self.entries.popitem(last=False)
+
+    def reserve(self, n):
+        """Keep room for at least n entries (an epoch's worth of registered batches must not evict one another)."""
+        self._floor = max(int(n), 0)
 
     def _purge(self):
         """Drop entries whose edge tensors have been freed: a mini-batch loop (main-batch.py:126-131) makes a new

@@ -296,6 +296,16 @@ int dif_subgraph_batches_emit(const int64_t* edge_index, int64_t E, int64_t N, i
                               const float* edge_weight, const int64_t* batch_ptr, int64_t capacity,
                               int64_t* out_edge_index, float* out_weight, const void* workspace,
                               size_t workspace_bytes, dif_stream_t stream);
+/*   dif_subgraph_batches_csr    (optional) the CSR of EVERY batch from one more sort of the surviving edges (key =
+ *       position of the destination in the permutation): rowptr int32[M + 1], src int32[kept] (batch-local ids), val
+ *       float32[kept]; the slice of batch b is what dif_csr_build returns for that batch's edge list (same entry order,
+ *       degrees and normalisation of the subgraph; rowptr shifted by batch_ptr[b]) -- "direct CSR emission": no per-batch
+ *       dif_csr_build.  kept = batch_ptr[n_batches]; group_workspace = the workspace of dif_subgraph_batches_group. */
+size_t dif_subgraph_batches_csr_workspace_bytes(int64_t kept, int64_t M);
+int dif_subgraph_batches_csr(const int64_t* edge_index, int64_t E, int64_t N, int64_t M, int64_t batch_size,
+                             const float* edge_weight, int64_t kept, const void* group_workspace,
+                             size_t group_workspace_bytes, int32_t* rowptr, int32_t* src, float* val,
+                             void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a4/a5  tail of DIFFormerConv.forward + the per-layer tail of DIFFormer.forward

@@ -821,6 +821,17 @@ def test_subgraph_batches_equal_the_per_batch_calls(n, e, m, bsz, weighted, dev)
             assert np.array_equal(wb.cpu().numpy(), ref_w), b
         else:
             assert wb is None
+    # direct CSR emission: every batch's registered CSR is, bit for bit, what dif_csr_build makes of its edge list
+    from difformer_amd import ops
+    for b, (eb, wb) in enumerate(batches):
+        nb_rows = min(bsz, m - b * bsz)
+        got = ops.csr_cache.get(eb, wb, nb_rows, 256)
+        assert got.n_blocks == 1 and got.nnz == eb.shape[1]
+        want = ops.GraphCSR.build(eb.contiguous(), wb, nb_rows, 1)
+        assert torch.equal(got.rowptr, want.rowptr), b
+        assert torch.equal(got.src[: got.nnz], want.src[: got.nnz]) and torch.equal(got.val[: got.nnz], want.val[: got.nnz]), b
+        if b >= 3:
+            break
     with pytest.raises(ValueError):
         gu.subgraph_batches(torch.tensor([1, 2, 1], device=dev), 2, ei.to(dev), None, num_nodes=n)
     with pytest.raises(IndexError):
