@@ -51,6 +51,8 @@ SIGNATURES = {
     "dif_subgraph_batches_workspace_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "dif_subgraph_batches_group": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_subgraph_batches_emit": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dif_graph_prepare_workspace_bytes": (c_sz, [c_i64, c_i64, c_int]),
+    "dif_graph_prepare": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_subgraph_batches_csr_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "dif_subgraph_batches_csr": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp,
                                          c_sz, c_vp]),

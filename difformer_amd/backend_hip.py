@@ -346,6 +346,29 @@ class HipBackend:
         out = torch.stack([out_ei[0, :kept], out_ei[1, :kept]])
         return out, (None if out_w is None else out_w[:kept].clone())
 
+    def graph_prepare(self, edge_index, num_nodes, undirected=False, remove_loops=False, add_loops=False):
+        """to_undirected -> remove_self_loops -> add_self_loops (any subset, in that order) on the device -> [2, E']."""
+        dev = _require_device(edge_index)
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise TypeError("difformer_amd: edge_index must be an int64 tensor of shape [2, E]")
+        ei = edge_index.contiguous()
+        E = int(ei.shape[1])
+        cap = (2 * E if undirected else E) + (num_nodes if add_loops else 0)
+        out = torch.empty((2, max(cap, 1)), dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        ws_bytes = self.lib.dif_graph_prepare_workspace_bytes(E, num_nodes, int(bool(undirected)))
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_graph_prepare", dev):
+            rc = self.lib.dif_graph_prepare(_ptr(ei), E, num_nodes, int(bool(undirected)), int(bool(remove_loops)),
+                                            int(bool(add_loops)), max(cap, 1), _ptr(out), _ptr(count), _ptr(status), _ptr(ws),
+                                            ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_graph_prepare")
+        kept, bad = int(count.item()), int(status.item())       # one sync: the result size is data dependent
+        if bad:
+            raise IndexError(f"difformer_amd: edge_index holds node ids outside [0, {num_nodes})")
+        return torch.stack([out[0, :kept], out[1, :kept]])
+
     def subgraph_batches(self, perm, batch_size, edge_index, edge_weight, num_nodes, build_csr=False):
         """All induced subgraphs of an epoch (main-batch.py:121-131) from one pass over the edge list ->
         (edge_index [2, kept] grouped by batch, edge_weight [kept] | None, batch_ptr: python list of n_batches + 1 ints,

@@ -529,6 +529,101 @@ __global__ __launch_bounds__(256) void batches_csr_fill_kernel(const int64_t* __
     }
 }
 
+// ---- graph preparation of the drivers (node classification/main.py:72-76, main-batch.py:96-98), on device -----------
+//   to_undirected (both directions, duplicates coalesced, sorted by (row, col)) -> remove_self_loops -> add_self_loops
+// Pairs are generated (self loops dropped right there when asked), sorted by col then by row with the stable radix
+// passes above (= lexicographic (row, col)), runs of equal pairs keep their first element, and the N loops are appended.
+__global__ __launch_bounds__(256) void prep_pairs_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
+                                                         int undirected, uint32_t* __restrict__ key_col,
+                                                         uint32_t* __restrict__ val_row, int32_t* __restrict__ status) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < E; e += stride) {
+        int64_t r = edge_index[e], c = edge_index[E + e];
+        if (r < 0 || r >= N || c < 0 || c >= N) { atomicOr(status, 1); r = c = 0; }
+        key_col[e] = static_cast<uint32_t>(c);
+        val_row[e] = static_cast<uint32_t>(r);
+        if (undirected) {
+            key_col[E + e] = static_cast<uint32_t>(r);
+            val_row[E + e] = static_cast<uint32_t>(c);
+        }
+    }
+}
+
+// swap roles between the two sorts: the pairs sorted by col become (key = row, payload = col)
+__global__ __launch_bounds__(256) void prep_swap_kernel(uint32_t* __restrict__ a, uint32_t* __restrict__ b, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t t = a[i];
+        a[i] = b[i];
+        b[i] = t;
+    }
+}
+
+// keep[i] = 1 for the first pair of a run of equal (row, col) (coalesce), 0 for self loops when they are removed
+__global__ __launch_bounds__(256) void prep_flag_kernel(const uint32_t* __restrict__ row, const uint32_t* __restrict__ col,
+                                                        int64_t n, int coalesce, int drop_loops, int32_t* __restrict__ keep) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i <= n; i += stride) {
+        int k = 0;
+        if (i < n) {
+            k = 1;
+            if (coalesce && i > 0 && row[i] == row[i - 1] && col[i] == col[i - 1]) k = 0;
+            if (drop_loops && row[i] == col[i]) k = 0;
+        }
+        keep[i] = k;                                    // keep[n] = 0: the scan's last entry is the kept count
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_emit_kernel(const uint32_t* __restrict__ row, const uint32_t* __restrict__ col,
+                                                        int64_t n, const int32_t* __restrict__ pos, int64_t N, int add_loops,
+                                                        int64_t cap, int64_t* __restrict__ out_ei, int64_t* __restrict__ out_count) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const int64_t kept = pos[n];
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int32_t p = pos[i];
+        if (pos[i + 1] != p) {
+            out_ei[p] = row[i];
+            out_ei[cap + p] = col[i];
+        }
+    }
+    if (add_loops) {
+        for (int64_t v = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; v < N; v += stride) {
+            out_ei[kept + v] = v;
+            out_ei[cap + kept + v] = v;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = kept + (add_loops ? N : 0);
+}
+
+struct PrepPlan { int rounds; int64_t n, n_chunks, table_len; int passes; size_t off_ka, off_kb, off_va, off_vb, off_keep, off_table, off_bsum, total; };
+PrepPlan make_prep_plan(int64_t E, int64_t N, int undirected) {
+    PrepPlan p;
+    p.n = undirected ? 2 * E : E;
+    int64_t rounds = (p.n + 64 * 4096 - 1) / (64 * 4096);
+    if (rounds < kSortRoundsMin) rounds = kSortRoundsMin;
+    if (rounds > kSortRoundsMax) rounds = kSortRoundsMax;
+    p.rounds = static_cast<int>(rounds);
+    const int64_t chunk = 64 * rounds;
+    p.n_chunks = (p.n + chunk - 1) / chunk;
+    if (p.n_chunks < 1) p.n_chunks = 1;
+    p.table_len = p.n_chunks * kRadix;
+    int bits = 1;
+    while ((int64_t(1) << bits) < N) ++bits;
+    p.passes = (bits + kRadixBits - 1) / kRadixBits;
+    const size_t e = static_cast<size_t>(p.n > 0 ? p.n : 1);
+    const int64_t scan_n = p.table_len > p.n + 1 ? p.table_len : p.n + 1;
+    size_t o = 0;
+    p.off_ka = o;    o += align256(e * 4);
+    p.off_kb = o;    o += align256(e * 4);
+    p.off_va = o;    o += align256(e * 4);
+    p.off_vb = o;    o += align256(e * 4);
+    p.off_keep = o;  o += align256((e + 1) * 4);
+    p.off_table = o; o += align256(static_cast<size_t>(p.table_len) * 4);
+    p.off_bsum = o;  o += align256(static_cast<size_t>((scan_n + kScanTile - 1) / kScanTile + 1) * 4);
+    p.total = o;
+    return p;
+}
+
 struct BatchCsrPlan { int rounds; int64_t n_chunks, table_len; int passes; size_t off_ka, off_kb, off_va, off_vb, off_dinv, off_table, off_bsum, total; };
 BatchCsrPlan make_batch_csr_plan(int64_t kept, int64_t M) {
     BatchCsrPlan p;
@@ -933,4 +1028,75 @@ extern "C" int dif_subgraph_batches_csr(const int64_t* edge_index, int64_t E, in
     hipLaunchKernelGGL(batches_csr_fill_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, edge_weight, info,
                        static_cast<int32_t>(batch_size), kin, vin, kept, dinv, src, val);
     return dif::launch_status("batches_csr_fill_kernel");
+}
+
+extern "C" size_t dif_graph_prepare_workspace_bytes(int64_t E, int64_t N, int undirected) {
+    if (E < 0 || N <= 0) return 0;
+    return make_prep_plan(E, N, undirected).total;
+}
+
+// main.py:72-76 / main-batch.py:96-98 in one call: undirected != 0 -> to_undirected (both directions of every edge, equal
+// pairs coalesced, sorted by (row, col)); remove_loops != 0 -> remove_self_loops; add_loops != 0 -> add_self_loops (the N
+// loops appended at the end).  Without `undirected` the surviving edges keep their order.  out_edge_index int64
+// [2, capacity], capacity >= (undirected ? 2E : E) + (add_loops ? N : 0); out_count (device int64) <- edges written.
+extern "C" int dif_graph_prepare(const int64_t* edge_index, int64_t E, int64_t N, int undirected, int remove_loops,
+                                 int add_loops, int64_t capacity, int64_t* out_edge_index, int64_t* out_count,
+                                 int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && E >= 0, DIF_E_BADARG, "dif_graph_prepare: need N > 0, E >= 0");
+    const PrepPlan p = make_prep_plan(E, N, undirected);
+    DIF_REQUIRE(p.n < (int64_t(1) << 31) - 4096 && N < (int64_t(1) << 31) - 1, DIF_E_RANGE, "dif_graph_prepare: sizes must fit int32");
+    DIF_REQUIRE(capacity >= p.n + (add_loops ? N : 0), DIF_E_BADARG, "dif_graph_prepare: capacity too small");
+    DIF_REQUIRE(out_edge_index && out_count && status && workspace && (E == 0 || edge_index), DIF_E_BADARG, "dif_graph_prepare: null pointer");
+    DIF_REQUIRE(workspace_bytes >= p.total, DIF_E_WORKSPACE, "dif_graph_prepare: workspace too small");
+    DIF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DIF_E_BADARG, "dif_graph_prepare: workspace must be 256-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    uint32_t *ka = reinterpret_cast<uint32_t*>(ws + p.off_ka), *kb = reinterpret_cast<uint32_t*>(ws + p.off_kb);
+    uint32_t *va = reinterpret_cast<uint32_t*>(ws + p.off_va), *vb = reinterpret_cast<uint32_t*>(ws + p.off_vb);
+    int32_t* keep = reinterpret_cast<int32_t*>(ws + p.off_keep);
+    int32_t* table = reinterpret_cast<int32_t*>(ws + p.off_table);
+    int32_t* bsum = reinterpret_cast<int32_t*>(ws + p.off_bsum);
+    hipError_t he = hipMemsetAsync(status, 0, 4, st);
+    if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_graph_prepare: memset: %s", hipGetErrorString(he));
+    const int64_t cap = 8 * dif::kCUs;
+    int64_t g = (p.n + 1 + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    uint32_t *row = va, *col = ka;           // after prep_pairs: key = col, payload = row
+    if (E > 0) {
+        hipLaunchKernelGGL(prep_pairs_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N, undirected, ka, va, status);
+        if (int rc = dif::launch_status("prep_pairs_kernel")) return rc;
+    }
+    if (undirected && p.n > 0) {
+        const unsigned sort_grid = static_cast<unsigned>((p.n_chunks + kSortWaves - 1) / kSortWaves);
+        uint32_t *kin = ka, *kout = kb, *vin = va, *vout = vb;
+        for (int phase = 0; phase < 2; ++phase) {          // phase 0: by col, phase 1: by row (stable) -> (row, col) order
+            for (int pass = 0; pass < p.passes; ++pass) {
+                const int shift = pass * kRadixBits;
+                hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, p.n, shift, p.n_chunks, p.rounds, table);
+                if (int rc = dif::launch_status("radix_hist_kernel")) return rc;
+                if (int rc = exclusive_scan(table, p.table_len, table, nullptr, bsum, st)) return rc;
+                hipLaunchKernelGGL(radix_scatter_kernel, dim3(sort_grid), dim3(64 * kSortWaves), 0, st, kin, vin, p.n, shift, p.n_chunks,
+                                   p.rounds, table, kout, vout);
+                if (int rc = dif::launch_status("radix_scatter_kernel")) return rc;
+                uint32_t* t = kin; kin = kout; kout = t;
+                t = vin; vin = vout; vout = t;
+            }
+            if (phase == 0) {                               // keys <- rows, payload <- cols
+                hipLaunchKernelGGL(prep_swap_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, kin, vin, p.n);
+                if (int rc = dif::launch_status("prep_swap_kernel")) return rc;
+            }
+        }
+        row = kin;
+        col = vin;
+    }
+    hipLaunchKernelGGL(prep_flag_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, row, col, p.n, undirected, remove_loops, keep);
+    if (int rc = dif::launch_status("prep_flag_kernel")) return rc;
+    if (int rc = exclusive_scan(keep, p.n + 1, keep, nullptr, bsum, st)) return rc;
+    int64_t g2 = ((p.n > N ? p.n : N) + 255) / 256;
+    if (g2 > cap) g2 = cap;
+    if (g2 < 1) g2 = 1;
+    hipLaunchKernelGGL(prep_emit_kernel, dim3(static_cast<unsigned>(g2)), dim3(256), 0, st, row, col, p.n, keep, N, add_loops, capacity,
+                       out_edge_index, out_count);
+    return dif::launch_status("prep_emit_kernel");
 }

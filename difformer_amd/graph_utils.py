@@ -4,9 +4,10 @@ scripts import, so a driver can switch by changing one import; all of them keep 
 
     subgraph          node classification/main-batch.py:131   (HIP kernels: mark, flag, scan, emit)
     subgraph_batches  main-batch.py:121-131, all batches of an epoch in one pass (HIP: mark, key, stable radix pass, emit)
-    add_self_loops    main.py:76, main-batch.py:98            (tensor plumbing)
-    remove_self_loops main.py:75, main-batch.py:97            (tensor plumbing)
-    to_undirected     main.py:73                              (tensor plumbing: both directions, duplicates coalesced)
+    add_self_loops    main.py:76, main-batch.py:98            (HIP: dif_graph_prepare)
+    remove_self_loops main.py:75, main-batch.py:97            (HIP: dif_graph_prepare; mask when attributes ride along)
+    to_undirected     main.py:73                              (HIP: pairs in both directions, two stable radix sorts, coalesce)
+    prepare_graph     main.py:72-76 in one call
 """
 from __future__ import annotations
 
@@ -59,22 +60,32 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
     return out
 
 
+def _n(edge_index, num_nodes):
+    return int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
+
+
 def add_self_loops(edge_index, edge_weight=None, fill_value=1.0, num_nodes=None):
-    n = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
-    loops = torch.arange(n, device=edge_index.device, dtype=edge_index.dtype).repeat(2, 1)
+    """main.py:76, main-batch.py:98: the N loops appended (HIP: dif_graph_prepare); weights ride along as tensor plumbing."""
+    n = _n(edge_index, num_nodes)
     if edge_weight is not None:
         edge_weight = torch.cat([edge_weight, edge_weight.new_full((n,), fill_value)])
-    return torch.cat([edge_index, loops], dim=1), edge_weight
+    return ops.get_backend().graph_prepare(edge_index, n, add_loops=True), edge_weight
 
 
 def remove_self_loops(edge_index, edge_attr=None):
-    keep = edge_index[0] != edge_index[1]
-    return edge_index[:, keep], (None if edge_attr is None else edge_attr[keep])
+    """main.py:75, main-batch.py:97: edges (v, v) dropped, order kept (HIP: dif_graph_prepare).  With attributes the
+    filter is a mask (the attributes have to follow the same selection)."""
+    if edge_attr is not None:
+        keep = edge_index[0] != edge_index[1]
+        return edge_index[:, keep], edge_attr[keep]
+    return ops.get_backend().graph_prepare(edge_index, _n(edge_index, None), remove_loops=True), None
 
 
 def to_undirected(edge_index, num_nodes=None):
-    """Both directions of every edge, duplicates removed, sorted by (row, col)."""
-    n = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
-    both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
-    key = torch.unique(both[0] * n + both[1])
-    return torch.stack([key // n, key % n])
+    """main.py:73: both directions of every edge, duplicates removed, sorted by (row, col) (HIP: dif_graph_prepare)."""
+    return ops.get_backend().graph_prepare(edge_index, _n(edge_index, num_nodes), undirected=True)
+
+
+def prepare_graph(edge_index, num_nodes=None):
+    """main.py:72-76 in one call: to_undirected -> remove_self_loops -> add_self_loops."""
+    return ops.get_backend().graph_prepare(edge_index, _n(edge_index, num_nodes), True, True, True)

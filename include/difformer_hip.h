@@ -307,6 +307,18 @@ int dif_subgraph_batches_csr(const int64_t* edge_index, int64_t E, int64_t N, in
                              size_t group_workspace_bytes, int32_t* rowptr, int32_t* src, float* val,
                              void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
+/* Graph preparation of the drivers on device (node classification/main.py:72-76, main-batch.py:96-98; torch_geometric.utils
+ * to_undirected / remove_self_loops / add_self_loops, un-vendored), any subset of the three steps in their order:
+ *   undirected   != 0: both directions of every edge, equal pairs coalesced, result sorted by (row, col);
+ *   remove_loops != 0: edges (v, v) dropped;       add_loops != 0: the N loops (v, v) appended at the end.
+ * Without `undirected` the surviving edges keep their order.  out_edge_index int64 [2, capacity] (row r at offset
+ * r * capacity), capacity >= (undirected ? 2E : E) + (add_loops ? N : 0); out_count (device int64) <- edges written;
+ * status[0] != 0: an id outside [0, N). */
+size_t dif_graph_prepare_workspace_bytes(int64_t E, int64_t N, int undirected);
+int dif_graph_prepare(const int64_t* edge_index, int64_t E, int64_t N, int undirected, int remove_loops,
+                      int add_loops, int64_t capacity, int64_t* out_edge_index, int64_t* out_count,
+                      int32_t* status, void* workspace, size_t workspace_bytes, dif_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * a4/a5  tail of DIFFormerConv.forward + the per-layer tail of DIFFormer.forward
  *        node classification/difformer.py:137 (mean over heads), :139-140 (+= x_0),

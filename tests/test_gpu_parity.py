@@ -838,6 +838,33 @@ def test_subgraph_batches_equal_the_per_batch_calls(n, e, m, bsz, weighted, dev)
         gu.subgraph_batches(torch.tensor([1, n + 3], device=dev), 2, ei.to(dev), None, num_nodes=n)
 
 
+@pytest.mark.parametrize("n,e", [(5000, 40000), (132534, 3000000), (70, 2000), (300000, 100)])
+def test_graph_prepare_matches_numpy(n, e, dev):
+    """dif_graph_prepare: to_undirected / remove_self_loops / add_self_loops of main.py:72-76 (torch_geometric semantics:
+    coalesced and sorted by (row, col); loops dropped; N loops appended) -- integer work, exact."""
+    from difformer_amd import graph_utils as gu
+    g = torch.Generator().manual_seed(n)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[:, : e // 10] = ei[:, e // 10: 2 * (e // 10)]               # duplicates
+    ei[1, : e // 20] = ei[0, : e // 20]                             # self loops
+    a = ei.numpy()
+    key = np.unique(np.concatenate([a[0] * n + a[1], a[1] * n + a[0]]))
+    und = np.stack([key // n, key % n])
+    assert np.array_equal(gu.to_undirected(ei.to(dev), num_nodes=n).cpu().numpy(), und)
+    nol = a[:, a[0] != a[1]]
+    out, _ = gu.remove_self_loops(ei.to(dev))
+    assert np.array_equal(out.cpu().numpy(), nol)
+    out, _ = gu.add_self_loops(ei.to(dev), num_nodes=n)
+    assert np.array_equal(out.cpu().numpy(), np.concatenate([a, np.arange(n)[None].repeat(2, 0)], axis=1))
+    full = np.concatenate([und[:, und[0] != und[1]], np.arange(n)[None].repeat(2, 0)], axis=1)
+    assert np.array_equal(gu.prepare_graph(ei.to(dev), num_nodes=n).cpu().numpy(), full)
+    w = torch.rand(e, generator=g).to(dev)
+    o2, w2 = gu.remove_self_loops(ei.to(dev), w)
+    assert np.array_equal(o2.cpu().numpy(), nol) and w2.shape[0] == nol.shape[1]
+    with pytest.raises(IndexError):
+        gu.to_undirected(torch.tensor([[0, n + 1], [1, 2]], device=dev), num_nodes=n)
+
+
 def _random_cfgs(count, seed):
     rng = np.random.default_rng(seed)
     cfgs = []
