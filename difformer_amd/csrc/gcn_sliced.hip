@@ -7,19 +7,24 @@
 // (profiles/r02_pmc_spmm_blocked.json: 174 M requests per launch at C4, 154 G/s, 1.13 ms).  LDS serves random 16-byte
 // reads an order of magnitude faster, so:
 //   * a workgroup (one per CU) owns a PANEL of destination rows and one 16-byte SLICE (4 floats) of the feature row;
-//     16 slices x 16 panels fill the chip at F = 64.  A lane owns whole destination rows: round j of wave w holds rows
-//     (j*W + w)*64 + lane of the panel in a float4 register accumulator -- static registers, no LDS read-modify-write;
+//     16 slices x 16 panels fill the chip at F = 64.  A lane owns whole destination rows: round j of wave w holds one
+//     row per lane in a float4 register accumulator -- static registers, no LDS read-modify-write;
 //   * the sources are swept tile by tile: the slice of T <= 10,208 pre-scaled source rows sits in LDS (all 160 KiB);
 //     an entry is a 16-bit tile-local row number -> ONE ds_read_b128 + one float4 add per entry and lane;
+//   * rows are grouped 64 at a time into SLOTS (in descending-degree order when the degrees are skewed, so that the
+//     lock-step lanes of a slot carry lists of similar length).  Slot g = stratum j x pair index, dealt over the
+//     (panel, wave) pairs in snake order: every wave gets one slot of every degree stratum and the totals balance;
 //   * the lists are stored per (panel, tile, wave) as 1-KiB blocks of 8 entries x 64 lanes, rounds interleaved block
-//     by block and padded to a common length (lock-step lanes), so the body is branch-free and every entry register
-//     is reloaded right after its last use, a whole super-step ahead of its next one;
+//     by block.  Round lengths are padded to a NON-INCREASING sequence (round 0 the longest): the rounds still active
+//     at block row k are then a prefix {0 .. m(k)-1}, and the sweep runs one branch-free, statically unrolled phase per
+//     prefix length.  Every entry register is reloaded right after its last use, a whole block row ahead of its next
+//     one (no register rotation -> counted vmcnt waits);
 //   * inside a (tile, round) the entries of the 16 lanes that share an LDS cycle of ds_read_b128 are scheduled at build
 //     time (greedy edge colouring) so that they hit 16 different bank quads: no bank conflicts (SQ_LDS_BANK_CONFLICT
 //     = 0); idle slots read one of 16 zero rows, also on a free quad.  Random order costs 1.6x.
 // The same adjacency slice is swept by the 16 slice-workgroups of a panel, which sit on one XCD (block b -> XCD b % 8),
 // so the entry stream comes from HBM once.
-// Measured at C4 (79.3 M entries): 0.36 ms per launch against 1.12 ms (profiles/r02_experiments.md).
+// Measured at C4 (79.3 M entries): 0.33 ms per launch against 1.12 ms (profiles/r02_experiments.md).
 #include "dif_common.h"
 
 namespace {
@@ -30,7 +35,7 @@ constexpr int kTileRowsMax = 10208;              // + 16 zero rows = 10,224 rows
 constexpr int kLdsRows = kTileRowsMax + 16;
 constexpr int kMaxRounds = 10;                   // destination rows per lane (float4 accumulator + entry registers each)
 constexpr int kMaxWaves = 16;
-constexpr int kGroupCap = 255;                   // entries of one (row, tile) group (byte counters)
+constexpr int kGroupCap = 65535;                 // entries of one (row, tile) group (16-bit counters)
 
 // lane sets that share one LDS cycle of a ds_read_b128 (MI355X_MICROARCH.md, LDS table): position -> lane
 __device__ const uint8_t kLaneOf[64] = {
@@ -40,33 +45,41 @@ __device__ const uint8_t kLaneOf[64] = {
     36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63};
 
 struct Plan {
-    int slices, panels, P, S, W, R, T, NT;
+    int slices, panels, G, PW, W, R, T, NT;      // G = 64-row slots, PW = panels * W (panel, wave) pairs, R = rounds
 };
+
+// slot of stratum j for pair index pw = wave * panels + panel (snake: odd strata run backwards)
+__host__ __device__ __forceinline__ int64_t slot_of(int j, int pw, int PW) {
+    return static_cast<int64_t>(j) * PW + ((j & 1) ? PW - 1 - pw : pw);
+}
 
 // Geometry for n_rows destination rows (a shard) over n_src source rows at F feature columns.
 int make_plan(int64_t n_src, int64_t n_rows, int F, Plan& p) {
     if (n_src <= 0 || n_rows <= 0 || F <= 0 || F % 4 != 0 || F / 4 > 256) return DIF_E_SHAPE;
     p.slices = F / 4;
-    const int64_t cap = static_cast<int64_t>(kMaxWaves) * kMaxRounds * 64;      // rows one workgroup can own
+    const int64_t G = (n_rows + 63) / 64;
     int64_t panels = dif::kCUs / p.slices;
     if (panels < 1) panels = 1;
-    if (panels * cap < n_rows) panels = (n_rows + cap - 1) / cap;
-    if (panels > n_rows) panels = n_rows;
-    if (panels * p.slices > (int64_t(1) << 20)) return DIF_E_RANGE;
+    const int64_t cap = static_cast<int64_t>(kMaxWaves) * kMaxRounds;            // slots one workgroup can own
+    if (panels * cap < G) panels = (G + cap - 1) / cap;
+    if (panels > G) panels = G;
+    if (panels * p.slices > (int64_t(1) << 20) || G >= (int64_t(1) << 30)) return DIF_E_RANGE;
     p.panels = static_cast<int>(panels);
-    p.P = static_cast<int>((n_rows + panels - 1) / panels);
-    p.S = (p.P + 63) / 64;
+    p.G = static_cast<int>(G);
     // fewest rounds first (they run back to back), then the fewest idle (wave, round) slots
-    int bestW = 0, bestR = 1 << 30, bestWaste = 1 << 30;
+    int bestW = 0, bestR = 1 << 30;
+    int64_t bestWaste = int64_t(1) << 60;
     for (int W = kMaxWaves; W >= 1; --W) {
-        if (W > p.S) continue;
-        const int R = (p.S + W - 1) / W;
-        const int waste = R * W - p.S;
+        const int64_t pw = panels * W;
+        if (pw > G && W > 1) continue;
+        const int R = static_cast<int>((G + pw - 1) / pw);
+        const int64_t waste = static_cast<int64_t>(R) * pw - G;
         if (R < bestR || (R == bestR && waste < bestWaste)) { bestW = W; bestR = R; bestWaste = waste; }
     }
     if (bestR > kMaxRounds) return DIF_E_SHAPE;
     p.W = bestW;
     p.R = bestR;
+    p.PW = p.panels * p.W;
     const int64_t nt = (n_src + kTileRowsMax - 1) / kTileRowsMax;
     if (nt > 32767) return DIF_E_RANGE;
     p.NT = static_cast<int>(nt);
@@ -75,8 +88,8 @@ int make_plan(int64_t n_src, int64_t n_rows, int F, Plan& p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// build, step 1: one thread per (row, tile) group: entries re-ordered by bank quad (source row mod 16) as 16-bit
-// tile-local row numbers, plus the 16 byte counters.
+// build, step 1: one thread per (row position, tile) group: entries re-ordered by bank quad (source row mod 16) as
+// 16-bit tile-local row numbers, plus the 16 16-bit counters (four per 64-bit word).
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void group_bounds(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr,
                                              int64_t n_src, int NT, int64_t row, int t, int32_t& e0, int32_t& e1) {
@@ -84,140 +97,174 @@ __device__ __forceinline__ void group_bounds(const int32_t* __restrict__ rowptr,
     else { e0 = blkptr[static_cast<int64_t>(t) * n_src + row]; e1 = blkptr[static_cast<int64_t>(t + 1) * n_src + row]; }
 }
 
+struct Counts { uint64_t w[4]; };
+
+// exclusive starts of the 16 buckets: lane k of c * 0x0001000100010001 = sum of lanes 0..k (no carries: total <= 65535)
+__device__ __forceinline__ Counts bucket_starts(const Counts& c) {
+    const uint64_t ones = 0x0001000100010001ull;
+    Counts s;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t inc = c.w[k] * ones;
+        s.w[k] = inc - c.w[k] + carry * ones;
+        carry += inc >> 48;
+    }
+    return s;
+}
+
+__device__ __forceinline__ uint32_t lane16(const Counts& c, uint32_t q) {      // 16-bit counter q (dynamic)
+    const uint64_t w = (q < 8u) ? ((q < 4u) ? c.w[0] : c.w[1]) : ((q < 12u) ? c.w[2] : c.w[3]);
+    return static_cast<uint32_t>(w >> ((q & 3u) * 16u)) & 0xffffu;
+}
+
+__device__ __forceinline__ void bump16(Counts& c, uint32_t q) {
+    const uint64_t one = 1ull << ((q & 3u) * 16u);
+    const uint32_t k = q >> 2;
+    c.w[0] += (k == 0u) ? one : 0ull;
+    c.w[1] += (k == 1u) ? one : 0ull;
+    c.w[2] += (k == 2u) ? one : 0ull;
+    c.w[3] += (k == 3u) ? one : 0ull;
+}
+
+__device__ __forceinline__ Counts load_counts(const uint4* __restrict__ cnt, int64_t idx) {
+    const uint4 a = cnt[idx * 2], b = cnt[idx * 2 + 1];
+    Counts c;
+    c.w[0] = static_cast<uint64_t>(a.x) | (static_cast<uint64_t>(a.y) << 32);
+    c.w[1] = static_cast<uint64_t>(a.z) | (static_cast<uint64_t>(a.w) << 32);
+    c.w[2] = static_cast<uint64_t>(b.x) | (static_cast<uint64_t>(b.y) << 32);
+    c.w[3] = static_cast<uint64_t>(b.z) | (static_cast<uint64_t>(b.w) << 32);
+    return c;
+}
+
 __global__ __launch_bounds__(256) void sliced_sort_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr,
                                                           const int32_t* __restrict__ src, int64_t n_src, int NT, int T,
-                                                          int64_t row_begin, int64_t n_rows, uint16_t* __restrict__ srt,
-                                                          uint2* __restrict__ cnt, int32_t* __restrict__ status) {
+                                                          int64_t row_begin, int64_t n_rows, const int32_t* __restrict__ order,
+                                                          uint16_t* __restrict__ srt, uint4* __restrict__ cnt,
+                                                          int32_t* __restrict__ status) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= n_rows * NT) return;
-    const int64_t lrow = idx / NT;
+    const int64_t pos = idx / NT;
     const int t = static_cast<int>(idx % NT);
+    const int64_t lrow = order ? order[pos] : pos;
     int32_t e0, e1;
     group_bounds(rowptr, blkptr, n_src, NT, row_begin + lrow, t, e0, e1);
     const int32_t base = t * T;
-    if (e1 - e0 > kGroupCap) {       // byte counters: such a graph takes the gather kernel
+    Counts c = {{0, 0, 0, 0}};
+    if (e1 - e0 > kGroupCap) {       // 16-bit counters: such a graph takes the gather kernel
         atomicOr(status, 1);
-        cnt[idx * 2] = uint2{0, 0};
-        cnt[idx * 2 + 1] = uint2{0, 0};
-        return;
+        e1 = e0;
     }
-    uint64_t c0 = 0, c1 = 0;          // 16 byte counters
-    for (int32_t e = e0; e < e1; ++e) {
-        const uint32_t q = static_cast<uint32_t>(src[e] - base) & 15u;
-        const uint64_t one = 1ull << ((q & 7u) * 8u);
-        c0 += (q < 8u) ? one : 0ull;
-        c1 += (q < 8u) ? 0ull : one;
-    }
-    cnt[idx * 2] = uint2{static_cast<uint32_t>(c0), static_cast<uint32_t>(c0 >> 32)};
-    cnt[idx * 2 + 1] = uint2{static_cast<uint32_t>(c1), static_cast<uint32_t>(c1 >> 32)};
-    // exclusive starts: byte k of c * 0x0101.. = sum of bytes 0..k (no carries: the total is <= 255)
-    const uint64_t ones = 0x0101010101010101ull;
-    const uint64_t i0 = c0 * ones;
-    uint64_t n0 = i0 - c0;
-    uint64_t n1 = c1 * ones - c1 + (i0 >> 56) * ones;
+    for (int32_t e = e0; e < e1; ++e) bump16(c, static_cast<uint32_t>(src[e] - base) & 15u);
+    cnt[idx * 2] = uint4{static_cast<uint32_t>(c.w[0]), static_cast<uint32_t>(c.w[0] >> 32), static_cast<uint32_t>(c.w[1]),
+                         static_cast<uint32_t>(c.w[1] >> 32)};
+    cnt[idx * 2 + 1] = uint4{static_cast<uint32_t>(c.w[2]), static_cast<uint32_t>(c.w[2] >> 32), static_cast<uint32_t>(c.w[3]),
+                             static_cast<uint32_t>(c.w[3] >> 32)};
+    Counts nx = bucket_starts(c);
     for (int32_t e = e0; e < e1; ++e) {
         const uint32_t loc = static_cast<uint32_t>(src[e] - base);
-        const uint32_t q = loc & 15u, sh = (q & 7u) * 8u;
-        const uint32_t pos = static_cast<uint32_t>(((q < 8u) ? n0 : n1) >> sh) & 0xffu;
-        srt[e0 + pos] = static_cast<uint16_t>(loc);
-        const uint64_t one = 1ull << sh;
-        n0 += (q < 8u) ? one : 0ull;
-        n1 += (q < 8u) ? 0ull : one;
+        const uint32_t q = loc & 15u;
+        srt[e0 + lane16(nx, q)] = static_cast<uint16_t>(loc);
+        bump16(nx, q);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// build, step 2: greedy edge colouring, one THREAD per (panel, tile, slot, hardware lane group).  A step serves the
-// 16 lanes in rotating order; a lane takes the bank quad it still has the most entries on among the quads no earlier
-// lane of the step took (within ~0.2 % of the lower bound max(longest lane, fullest quad)).  EMIT = false only counts
-// the steps; EMIT = true writes the schedule (and zero-row reads on the free quads for idle lanes) into the blocks.
+// build, step 2: greedy edge colouring, one THREAD per (slot, tile, hardware lane group).  A step serves the 16 lanes
+// in rotating order; a lane takes the bank quad it still has the most entries on among the quads no earlier lane of the
+// step took (within ~0.2 % of the lower bound max(longest lane, fullest quad)).  EMIT = false only counts the steps;
+// EMIT = true writes the schedule (and zero-row reads on the free quads for idle lanes) into the blocks.
+// Table row of (panel, tile, wave): {first block, nb_0 >= nb_1 >= ... >= nb_{R-1}} (blocks per round, padded to a
+// non-increasing sequence); block row k holds the rounds j with nb_j > k: block (k, j) = first + sum_j' min(nb_j', k) + j.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kColorThreads = 128;
-constexpr int kColorWords = 64 + 16;         // per thread in LDS: rem[16 lanes][16 quads] bytes + first entry of each lane
+constexpr int kColorWords = 128 + 16;        // per thread in LDS: rem[16 lanes][16 quads] 16-bit + first entry of each lane
 
 template <bool EMIT>
 __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr, int64_t n_src, int64_t row_begin,
-    int64_t n_rows, Plan pl, const uint16_t* __restrict__ srt, const uint2* __restrict__ cnt, int32_t* __restrict__ len,
-    const int32_t* __restrict__ tab, uint16_t* __restrict__ ell) {
+    int64_t n_rows, const int32_t* __restrict__ order, Plan pl, const uint16_t* __restrict__ srt,
+    const uint4* __restrict__ cnt, int32_t* __restrict__ len, const int32_t* __restrict__ tab, uint16_t* __restrict__ ell) {
     __shared__ uint32_t sm[kColorWords * kColorThreads];
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kColorThreads + threadIdx.x;
-    const int64_t n_groups = static_cast<int64_t>(pl.panels) * pl.NT * pl.S * 4;
+    const int64_t n_groups = static_cast<int64_t>(pl.G) * pl.NT * 4;
     if (gid >= n_groups) return;
-    const int g = static_cast<int>(gid & 3);
-    const int64_t c = gid >> 2;
-    const int s = static_cast<int>(c % pl.S);
-    const int t = static_cast<int>((c / pl.S) % pl.NT);
-    const int p = static_cast<int>(c / pl.S / pl.NT);
+    const int grp = static_cast<int>(gid & 3);
+    const int t = static_cast<int>((gid >> 2) % pl.NT);
+    const int64_t g = (gid >> 2) / pl.NT;                     // slot
     uint32_t* my = sm + threadIdx.x;             // word k of this thread: my[k * kColorThreads]
     int remaining = 0;
     for (int i = 0; i < 16; ++i) {
-        const int lane = kLaneOf[g * 16 + i];
-        const int64_t prow = static_cast<int64_t>(s) * 64 + lane;         // row inside the panel
-        const int64_t lrow = static_cast<int64_t>(p) * pl.P + prow;       // row inside the shard
-        uint2 a = uint2{0, 0}, b = uint2{0, 0};
-        int32_t e0 = 0, e1 = 0;
-        if (prow < pl.P && lrow < n_rows) {
-            a = cnt[(lrow * pl.NT + t) * 2];
-            b = cnt[(lrow * pl.NT + t) * 2 + 1];
-            group_bounds(rowptr, blkptr, n_src, pl.NT, row_begin + lrow, t, e0, e1);
-            if (e1 - e0 > kGroupCap) e1 = e0;    // flagged by the sort kernel; keep the walk bounded
+        const int64_t pos = g * 64 + kLaneOf[grp * 16 + i];
+        Counts c = {{0, 0, 0, 0}};
+        int32_t e0 = 0;
+        if (pos < n_rows) {
+            c = load_counts(cnt, pos * pl.NT + t);
+            int32_t e1;
+            group_bounds(rowptr, blkptr, n_src, pl.NT, row_begin + (order ? order[pos] : pos), t, e0, e1);
         }
-        my[(i * 4 + 0) * kColorThreads] = a.x;
-        my[(i * 4 + 1) * kColorThreads] = a.y;
-        my[(i * 4 + 2) * kColorThreads] = b.x;
-        my[(i * 4 + 3) * kColorThreads] = b.y;
-        my[(64 + i) * kColorThreads] = static_cast<uint32_t>(e0);
-        remaining += e1 - e0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            my[(i * 8 + 2 * k) * kColorThreads] = static_cast<uint32_t>(c.w[k]);
+            my[(i * 8 + 2 * k + 1) * kColorThreads] = static_cast<uint32_t>(c.w[k] >> 32);
+            remaining += static_cast<int>((c.w[k] & 0xffffu) + ((c.w[k] >> 16) & 0xffffu) + ((c.w[k] >> 32) & 0xffffu) +
+                                          (c.w[k] >> 48));
+        }
+        my[(128 + i) * kColorThreads] = static_cast<uint32_t>(e0);
     }
     // where this slot's blocks go
-    const int w = s % pl.W, j = s / pl.W;
-    const int nr = (pl.S - w + pl.W - 1) / pl.W;
+    const int j = static_cast<int>(g / pl.PW);
+    const int idxp = static_cast<int>(g % pl.PW);
+    const int pw = (j & 1) ? pl.PW - 1 - idxp : idxp;
+    const int p = pw % pl.panels, w = pw / pl.panels;
+    const int32_t* tb = nullptr;
     int64_t blk0 = 0;
-    int nb = 0;
+    int nbj = 0;
     if (EMIT) {
-        const int32_t* tb = tab + (static_cast<int64_t>(p) * pl.NT + t) * pl.W * 2 + w * 2;
+        tb = tab + ((static_cast<int64_t>(p) * pl.NT + t) * pl.W + w) * (pl.R + 1);
         blk0 = tb[0];
-        nb = tb[1];
+        nbj = tb[1 + j];
     }
+    int64_t rowbase = 0;            // blocks before block row k = step >> 3 of this (panel, tile, wave)
     auto slot_addr = [&](int step, int lane) -> int64_t {
-        return ((blk0 + static_cast<int64_t>(step >> 3) * nr + j) * 64 + lane) * 8 + (step & 7);
+        return ((blk0 + rowbase + j) * 64 + lane) * 8 + (step & 7);
+    };
+    auto new_row = [&](int step) {
+        if (EMIT && (step & 7) == 0) {
+            const int k = step >> 3;
+            rowbase = 0;
+            for (int j2 = 0; j2 < pl.R; ++j2) { const int v = tb[1 + j2]; rowbase += v < k ? v : k; }
+        }
     };
     int step = 0;
     while (remaining > 0) {
+        new_row(step);
         uint32_t used = 0, picked = 0;
         for (int ii = 0; ii < 16; ++ii) {
             const int i = (ii + step) & 15;
             int best = -1;
             uint32_t bestv = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t wd = my[(i * 4 + k) * kColorThreads];
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t wd = my[(i * 8 + k) * kColorThreads];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const uint32_t v = (wd >> (8 * b)) & 0xffu;
-                    const int q = k * 4 + b;
+                for (int b = 0; b < 2; ++b) {
+                    const uint32_t v = (wd >> (16 * b)) & 0xffffu;
+                    const int q = k * 2 + b;
                     if (v > bestv && !((used >> q) & 1u)) { bestv = v; best = q; }
                 }
             }
             if (best < 0) continue;
             used |= 1u << best;
             picked |= 1u << i;
-            my[(i * 4 + (best >> 2)) * kColorThreads] -= 1u << (8 * (best & 3));
+            my[(i * 8 + (best >> 1)) * kColorThreads] -= 1u << (16 * (best & 1));
             --remaining;
             if (EMIT) {
                 // pop from the end of the lane's quad bucket: entry e0 + (entries of lower quads) + (left on this quad)
-                const int lane = kLaneOf[g * 16 + i];
-                const int64_t lrow = static_cast<int64_t>(p) * pl.P + static_cast<int64_t>(s) * 64 + lane;
-                const uint2 a = cnt[(lrow * pl.NT + t) * 2], b2 = cnt[(lrow * pl.NT + t) * 2 + 1];
-                const uint64_t c0 = static_cast<uint64_t>(a.x) | (static_cast<uint64_t>(a.y) << 32);
-                const uint64_t c1 = static_cast<uint64_t>(b2.x) | (static_cast<uint64_t>(b2.y) << 32);
-                const uint64_t ones = 0x0101010101010101ull;
-                const uint64_t i0 = c0 * ones;
-                const uint64_t x0 = i0 - c0, x1 = c1 * ones - c1 + (i0 >> 56) * ones;
-                const uint32_t start = static_cast<uint32_t>(((best < 8) ? x0 : x1) >> ((best & 7) * 8)) & 0xffu;
-                const uint32_t e0 = my[(64 + i) * kColorThreads];
-                ell[slot_addr(step, lane)] = srt[e0 + start + (bestv - 1)];
+                const int lane = kLaneOf[grp * 16 + i];
+                const Counts st = bucket_starts(load_counts(cnt, (g * 64 + lane) * pl.NT + t));
+                const uint32_t e0 = my[(128 + i) * kColorThreads];
+                ell[slot_addr(step, lane)] = srt[e0 + lane16(st, static_cast<uint32_t>(best)) + (bestv - 1)];
             }
         }
         if (EMIT) {             // idle lanes read a zero row on a quad nobody uses in this step
@@ -225,7 +272,7 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
                 if ((picked >> i) & 1u) continue;
                 const int fq = __builtin_ctz(~used & 0xffffu);
                 used |= 1u << fq;
-                ell[slot_addr(step, kLaneOf[g * 16 + i])] = static_cast<uint16_t>(pl.T + fq);
+                ell[slot_addr(step, kLaneOf[grp * 16 + i])] = static_cast<uint16_t>(pl.T + fq);
             }
         }
         ++step;
@@ -233,13 +280,15 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
     if (!EMIT) {
         len[gid] = step;
     } else {
-        for (; step < nb * 8; ++step)
-            for (int i = 0; i < 16; ++i) ell[slot_addr(step, kLaneOf[g * 16 + i])] = static_cast<uint16_t>(pl.T + i);
+        for (; step < nbj * 8; ++step) {
+            new_row(step);
+            for (int i = 0; i < 16; ++i) ell[slot_addr(step, kLaneOf[grp * 16 + i])] = static_cast<uint16_t>(pl.T + i);
+        }
     }
 }
 
-// build, step 3: blocks per (panel, tile, wave) = rounds of the wave x the longest of its rounds (in 8-step blocks,
-// at least one), then an exclusive scan.  tab[(p*NT + t)*W + w] = {first block, blocks per round}; tab[2*n] = total.
+// build, step 3: per (panel, tile, wave) the blocks of every round (8-step blocks, longest of the slot's four lane
+// groups), padded from the right to a non-increasing sequence; exclusive scan of the totals.  tab[n * (R + 1)] = total.
 __global__ __launch_bounds__(1024) void sliced_table_kernel(const int32_t* __restrict__ len, Plan pl, int32_t* __restrict__ tab) {
     __shared__ int32_t sm[1024];
     __shared__ int32_t carry;
@@ -248,19 +297,27 @@ __global__ __launch_bounds__(1024) void sliced_table_kernel(const int32_t* __res
     __syncthreads();
     for (int64_t base = 0; base < n; base += 1024) {
         const int64_t idx = base + threadIdx.x;
-        int32_t blocks = 0, nb = 1;
+        int32_t blocks = 0;
         if (idx < n) {
             const int w = static_cast<int>(idx % pl.W);
-            const int64_t pt = idx / pl.W;
-            const int nr = (pl.S - w + pl.W - 1) / pl.W;
-            for (int j = 0; j < nr; ++j) {
-                const int64_t c = pt * pl.S + (j * pl.W + w);
-                for (int g = 0; g < 4; ++g) {
-                    const int v = (len[c * 4 + g] + 7) >> 3;
-                    nb = v > nb ? v : nb;
+            const int t = static_cast<int>((idx / pl.W) % pl.NT);
+            const int p = static_cast<int>(idx / pl.W / pl.NT);
+            const int pw = w * pl.panels + p;
+            int32_t* row = tab + idx * (pl.R + 1);
+            int32_t env = 0;
+            for (int j = pl.R - 1; j >= 0; --j) {
+                const int64_t g = slot_of(j, pw, pl.PW);
+                int32_t nb = 0;
+                if (g < pl.G) {
+                    for (int q = 0; q < 4; ++q) {
+                        const int32_t v = (len[(g * pl.NT + t) * 4 + q] + 7) >> 3;
+                        nb = v > nb ? v : nb;
+                    }
                 }
+                env = nb > env ? nb : env;
+                row[1 + j] = env;
+                blocks += env;
             }
-            blocks = nb * nr;
         }
         sm[threadIdx.x] = blocks;
         __syncthreads();
@@ -271,15 +328,12 @@ __global__ __launch_bounds__(1024) void sliced_table_kernel(const int32_t* __res
             __syncthreads();
         }
         const int32_t cin = carry;
-        if (idx < n) {
-            tab[idx * 2] = cin + sm[threadIdx.x] - blocks;
-            tab[idx * 2 + 1] = nb;
-        }
+        if (idx < n) tab[idx * (pl.R + 1)] = cin + sm[threadIdx.x] - blocks;
         __syncthreads();
         if (threadIdx.x == 1023) carry = cin + sm[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) tab[n * 2] = carry;
+    if (threadIdx.x == 0) tab[n * (pl.R + 1)] = carry;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -322,6 +376,7 @@ __global__ __launch_bounds__(256) void sliced_prescale_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------------
 struct Epilogue {
     const int32_t* rowptr;
+    const int32_t* order;
     int64_t row_begin, n_rows;
     const float* attn;
     int64_t lda;
@@ -330,41 +385,86 @@ struct Epilogue {
     int64_t ldo;
 };
 
-template <int NR>
-__device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell, const int2* __restrict__ tabw,
-                                      const f32x4* __restrict__ ysl, const Plan pl, const Epilogue ep, int panel,
-                                      int slice, int w, int lane) {
+// four entries (two packed dwords): 16-bit row number -> LDS byte address with one SDWA shift each
+__device__ __forceinline__ void half_block(const f32x4* tile, uint32_t w0, uint32_t w1, f32x4& a) {
     const uint32_t four = 4;
-    const int T = pl.T;
-    f32x4 acc[NR > 0 ? NR : 1];
+    const uint32_t wds[2] = {w0, w1};
+    f32x4 v[4];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // four entries (two packed dwords): 16-bit row number -> LDS byte address with one SDWA shift each
-    auto half = [&](uint32_t w0, uint32_t w1, f32x4& a) {
-        const uint32_t wds[2] = {w0, w1};
-        f32x4 v[4];
+    for (int q = 0; q < 2; ++q) {
+        uint32_t lo, hi;
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+            : "=v"(lo) : "v"(four), "v"(wds[q]));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+            : "=v"(hi) : "v"(four), "v"(wds[q]));
+        v[2 * q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + lo);
+        v[2 * q + 1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + hi);
+    }
+    a += (v[0] + v[1]) + (v[2] + v[3]);
+}
+
+// Phase M: the block rows in which exactly the rounds 0 .. M-1 are active (nb[M] <= k < nb[M-1]).
+template <int M, int NR>
+struct Phases {
+    static __device__ __forceinline__ void run(const f32x4* tile, int& k, const uint4*& cur, uint4 (&e)[NR], f32x4 (&acc)[NR],
+                                               const int (&nb)[NR]) {
+        const int kend = nb[M - 1];
+#pragma unroll 1
+        for (; k + 1 < kend; ++k) {
+            const uint4* nx = cur + M * 64;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            uint32_t lo, hi;
-            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
-                : "=v"(lo) : "v"(four), "v"(wds[q]));
-            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-                : "=v"(hi) : "v"(four), "v"(wds[q]));
-            v[2 * q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + lo);
-            v[2 * q + 1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + hi);
+            for (int j = 0; j < M; ++j) {
+                half_block(tile, e[j].x, e[j].y, acc[j]);
+                half_block(tile, e[j].z, e[j].w, acc[j]);
+                e[j] = nx[j * 64];          // reloaded right after its last use; next use is a whole block row away
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur = nx;
         }
-        a += (v[0] + v[1]) + (v[2] + v[3]);
-    };
-    for (int t = 0; t < pl.NT; ++t) {
-        uint4 e[NR > 0 ? NR : 1];
-        const uint4* base = ell;
-        int nb = 0;
-        if (NR > 0) {
-            const int2 tb = tabw[static_cast<int64_t>(t) * pl.W];
-            nb = __builtin_amdgcn_readfirstlane(tb.y);                       // >= 1
-            base = ell + static_cast<int64_t>(__builtin_amdgcn_readfirstlane(tb.x)) * 64 + lane;
+        if (k < kend) {                     // last row of the phase: the next row keeps only the rounds with nb[j] > k + 1
+            const uint4* nx = cur + M * 64;
 #pragma unroll
-            for (int j = 0; j < NR; ++j) e[j] = base[j * 64];                // in flight across the tile load
+            for (int j = 0; j < M; ++j) {
+                half_block(tile, e[j].x, e[j].y, acc[j]);
+                half_block(tile, e[j].z, e[j].w, acc[j]);
+                e[j] = *((nb[j] > k + 1) ? nx + j * 64 : cur);      // a finished round re-reads a block that exists
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur = nx;
+            ++k;
+            // the registers of the rounds that just ended are re-used by the shorter phases while their last (unused)
+            // load is still in flight; draining here keeps the per-round counted waits inside the next phase's loop
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+        }
+        Phases<M - 1, NR>::run(tile, k, cur, e, acc, nb);
+    }
+};
+template <int NR>
+struct Phases<0, NR> {
+    static __device__ __forceinline__ void run(const f32x4*, int&, const uint4*&, uint4 (&)[NR], f32x4 (&)[NR], const int (&)[NR]) {}
+};
+
+template <int NR>
+__device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell, const int32_t* __restrict__ tabw,
+                                      int64_t tab_stride, const f32x4* __restrict__ ysl, const Plan pl, const Epilogue ep,
+                                      int pw, int slice, int lane) {
+    constexpr int NA = NR > 0 ? NR : 1;
+    const int T = pl.T;
+    f32x4 acc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < pl.NT; ++t) {
+        uint4 e[NA];
+        int nb[NA];
+        const uint4* cur = ell;
+        if (NR > 0) {
+            const int32_t* tr = tabw + static_cast<int64_t>(t) * tab_stride;
+            cur = ell + static_cast<int64_t>(__builtin_amdgcn_readfirstlane(tr[0])) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                nb[j] = __builtin_amdgcn_readfirstlane(tr[1 + j]);
+                e[j] = *((nb[j] > 0) ? cur + j * 64 : ell);                  // in flight across the tile load
+            }
         }
         __syncthreads();                                                      // everyone is done with the previous tile
         {
@@ -384,31 +484,21 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
                 }
             }
         }
+        // The tile loads sit under exec masks, so the compiler's wait-count model would carry them as "possibly
+        // pending" into every phase loop and wait for ALL loads at the top of each block row.  They are complete here
+        // (the LDS stores consumed them, and the entry loads were issued before them): say so.
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
         __syncthreads();
         if (NR > 0) {
-#pragma unroll 1
-            for (int k = 0; k + 1 < nb; ++k) {
-                const uint4* nx = base + static_cast<int64_t>(k + 1) * NR * 64;
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    half(e[j].x, e[j].y, acc[j]);
-                    half(e[j].z, e[j].w, acc[j]);
-                    e[j] = nx[j * 64];          // reloaded right after its last use; next use is a whole super-step away
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                half(e[j].x, e[j].y, acc[j]);
-                half(e[j].z, e[j].w, acc[j]);
-            }
+            int k = 0;
+            Phases<NR, NA>::run(tile, k, cur, e, acc, nb);
         }
     }
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const int64_t prow = static_cast<int64_t>(j * pl.W + w) * 64 + lane;
-        const int64_t lrow = static_cast<int64_t>(panel) * pl.P + prow;
-        if (prow < pl.P && lrow < ep.n_rows) {
+        const int64_t pos = slot_of(j, pw, pl.PW) * 64 + lane;
+        if (pos < ep.n_rows) {
+            const int64_t lrow = ep.order ? ep.order[pos] : pos;
             f32x4 o = acc[j] * (ep.gcn_scale * dinv_of(ep.rowptr, ep.row_begin + lrow));
             if (ep.attn) o += ep.attn_scale * *reinterpret_cast<const f32x4*>(ep.attn + lrow * ep.lda + slice * 4);
             *reinterpret_cast<f32x4*>(ep.out + lrow * ep.ldo + slice * 4) = o;
@@ -417,7 +507,7 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
 }
 
 template <int R>
-__global__ __launch_bounds__(64 * kMaxWaves) void sliced_spmm_kernel(const uint4* __restrict__ ell, const int2* __restrict__ tab,
+__global__ __launch_bounds__(64 * kMaxWaves) void sliced_spmm_kernel(const uint4* __restrict__ ell, const int32_t* __restrict__ tab,
                                                                      const f32x4* __restrict__ ys, int64_t npad, Plan pl,
                                                                      Epilogue ep) {
     __shared__ f32x4 tile[kLdsRows];
@@ -436,14 +526,16 @@ __global__ __launch_bounds__(64 * kMaxWaves) void sliced_spmm_kernel(const uint4
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < 16) tile[pl.T + threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4* ysl = ys + static_cast<int64_t>(slice) * npad;
-    const int2* tabw = tab + static_cast<int64_t>(panel) * pl.NT * pl.W + w;
-    const int nr = (pl.S - w + pl.W - 1) / pl.W;             // rounds of this wave: R or R - 1
-    if (nr == R) sweep<R>(tile, ell, tabw, ysl, pl, ep, panel, slice, w, lane);
-    else sweep<R - 1>(tile, ell, tabw, ysl, pl, ep, panel, slice, w, lane);
+    const int32_t* tabw = tab + (static_cast<int64_t>(panel) * pl.NT * pl.W + w) * (pl.R + 1);
+    const int64_t tab_stride = static_cast<int64_t>(pl.W) * (pl.R + 1);
+    const int pw = w * pl.panels + panel;
+    const bool full = slot_of(R - 1, pw, pl.PW) < pl.G;      // rounds of this wave: R or R - 1
+    if (full) sweep<R>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane);
+    else sweep<R - 1>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane);
 }
 
 template <int R>
-int launch_sweep(hipStream_t st, const uint4* ell, const int2* tab, const f32x4* ys, int64_t npad, const Plan& pl,
+int launch_sweep(hipStream_t st, const uint4* ell, const int32_t* tab, const f32x4* ys, int64_t npad, const Plan& pl,
                  const Epilogue& ep) {
     hipLaunchKernelGGL((sliced_spmm_kernel<R>), dim3(static_cast<unsigned>(pl.panels * pl.slices)), dim3(64 * pl.W), 0, st,
                        ell, tab, ys, npad, pl, ep);
@@ -457,7 +549,7 @@ int check_plan(const int32_t* plan, int64_t n_src, int64_t n_rows, int F, Plan& 
     if (rc) return dif::fail(rc, "dif_sliced: shape not covered (n_src=%lld, n_rows=%lld, F=%d)",
                              static_cast<long long>(n_src), static_cast<long long>(n_rows), F);
     pl = Plan{plan[0], plan[1], plan[2], plan[3], plan[4], plan[5], plan[6], plan[7]};
-    if (pl.slices != want.slices || pl.panels != want.panels || pl.P != want.P || pl.S != want.S || pl.W != want.W ||
+    if (pl.slices != want.slices || pl.panels != want.panels || pl.G != want.G || pl.PW != want.PW || pl.W != want.W ||
         pl.R != want.R || pl.T != want.T || pl.NT != want.NT)
         return dif::fail(DIF_E_BADARG, "dif_sliced: plan does not match dif_sliced_plan(n_src, n_rows, F)");
     return 0;
@@ -471,15 +563,15 @@ extern "C" int dif_sliced_plan(int64_t n_src, int64_t n_rows, int F, int32_t* pl
     const int rc = make_plan(n_src, n_rows, F, p);
     if (rc) return dif::fail(rc, "dif_sliced_plan: shape not covered (n_src=%lld, n_rows=%lld, F=%d): needs F %% 4 == 0, "
                              "F <= 1024", static_cast<long long>(n_src), static_cast<long long>(n_rows), F);
-    const int32_t v[8] = {p.slices, p.panels, p.P, p.S, p.W, p.R, p.T, p.NT};
+    const int32_t v[8] = {p.slices, p.panels, p.G, p.PW, p.W, p.R, p.T, p.NT};
     for (int i = 0; i < 8; ++i) plan[i] = v[i];
     return 0;
 }
 
 extern "C" int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, const int32_t* src, int64_t n_src,
                                   int64_t nnz, int64_t row_begin, int64_t n_rows, int F, const int32_t* plan,
-                                  uint16_t* sorted, void* counts, int32_t* lengths, int32_t* table, int32_t* status,
-                                  dif_stream_t stream) {
+                                  const int32_t* row_order, uint16_t* sorted, void* counts, int32_t* lengths,
+                                  int32_t* table, int32_t* status, dif_stream_t stream) {
     Plan pl;
     if (int rc = check_plan(plan, n_src, n_rows, F, pl)) return rc;
     DIF_REQUIRE(row_begin >= 0 && row_begin + n_rows <= n_src && nnz >= 0, DIF_E_BADARG, "dif_sliced_measure: bad row range");
@@ -487,35 +579,39 @@ extern "C" int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, 
                 "dif_sliced_measure: null pointer");
     DIF_REQUIRE(pl.NT == 1 || blkptr, DIF_E_BADARG,
                 "dif_sliced_measure: more than one tile needs the CSR built with n_blocks = plan[7], block_rows = plan[6]");
+    DIF_REQUIRE(dif::aligned16(counts), DIF_E_BADARG, "dif_sliced_measure: counts must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t he = hipMemsetAsync(status, 0, 4, st);
     if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_sliced_measure: memset: %s", hipGetErrorString(he));
     const int64_t n_groups = n_rows * pl.NT;
     hipLaunchKernelGGL(sliced_sort_kernel, dim3(static_cast<unsigned>((n_groups + 255) / 256)), dim3(256), 0, st, rowptr,
-                       blkptr, src, n_src, pl.NT, pl.T, row_begin, n_rows, sorted, static_cast<uint2*>(counts), status);
+                       blkptr, src, n_src, pl.NT, pl.T, row_begin, n_rows, row_order, sorted, static_cast<uint4*>(counts),
+                       status);
     if (int rc = dif::launch_status("sliced_sort_kernel")) return rc;
-    const int64_t n_hw = static_cast<int64_t>(pl.panels) * pl.NT * pl.S * 4;
+    const int64_t n_hw = static_cast<int64_t>(pl.G) * pl.NT * 4;
     hipLaunchKernelGGL((sliced_color_kernel<false>), dim3(static_cast<unsigned>((n_hw + kColorThreads - 1) / kColorThreads)),
-                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_rows, pl, sorted,
-                       static_cast<const uint2*>(counts), lengths, nullptr, nullptr);
+                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_rows, row_order, pl, sorted,
+                       static_cast<const uint4*>(counts), lengths, nullptr, nullptr);
     if (int rc = dif::launch_status("sliced_color_kernel")) return rc;
     hipLaunchKernelGGL(sliced_table_kernel, dim3(1), dim3(1024), 0, st, lengths, pl, table);
     return dif::launch_status("sliced_table_kernel");
 }
 
 extern "C" int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int64_t n_src, int64_t row_begin,
-                               int64_t n_rows, int F, const int32_t* plan, const uint16_t* sorted, const void* counts,
-                               const int32_t* table, int64_t n_blocks, uint16_t* entries, dif_stream_t stream) {
+                               int64_t n_rows, int F, const int32_t* plan, const int32_t* row_order, const uint16_t* sorted,
+                               const void* counts, const int32_t* table, int64_t n_blocks, uint16_t* entries,
+                               dif_stream_t stream) {
     Plan pl;
     if (int rc = check_plan(plan, n_src, n_rows, F, pl)) return rc;
     DIF_REQUIRE(rowptr && sorted && counts && table && entries && n_blocks >= 1, DIF_E_BADARG, "dif_sliced_emit: null pointer");
     DIF_REQUIRE(pl.NT == 1 || blkptr, DIF_E_BADARG, "dif_sliced_emit: more than one tile needs blkptr");
-    DIF_REQUIRE((reinterpret_cast<uintptr_t>(entries) & 15u) == 0, DIF_E_BADARG, "dif_sliced_emit: entries must be 16-byte aligned");
+    DIF_REQUIRE(dif::aligned16(entries) && dif::aligned16(counts), DIF_E_BADARG,
+                "dif_sliced_emit: entries / counts must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t n_hw = static_cast<int64_t>(pl.panels) * pl.NT * pl.S * 4;
+    const int64_t n_hw = static_cast<int64_t>(pl.G) * pl.NT * 4;
     hipLaunchKernelGGL((sliced_color_kernel<true>), dim3(static_cast<unsigned>((n_hw + kColorThreads - 1) / kColorThreads)),
-                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_rows, pl, sorted,
-                       static_cast<const uint2*>(counts), nullptr, table, entries);
+                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_rows, row_order, pl, sorted,
+                       static_cast<const uint4*>(counts), nullptr, table, entries);
     return dif::launch_status("sliced_color_kernel");
 }
 
@@ -535,9 +631,9 @@ extern "C" int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_
 }
 
 extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table, const int32_t* plan, const float* ys,
-                                   const int32_t* rowptr, int64_t n_src, int64_t row_begin, int64_t n_rows, int F,
-                                   const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out,
-                                   int64_t ldo, dif_stream_t stream) {
+                                   const int32_t* rowptr, const int32_t* row_order, int64_t n_src, int64_t row_begin,
+                                   int64_t n_rows, int F, const float* attn, int64_t lda, float attn_scale, float gcn_scale,
+                                   float* out, int64_t ldo, dif_stream_t stream) {
     Plan pl;
     if (int rc = check_plan(plan, n_src, n_rows, F, pl)) return rc;
     DIF_REQUIRE(entries && table && ys && rowptr && out, DIF_E_BADARG, "dif_sliced_spmm: null pointer");
@@ -547,21 +643,20 @@ extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table
     DIF_REQUIRE(dif::aligned16(entries) && dif::aligned16(ys), DIF_E_BADARG, "dif_sliced_spmm: entries / ys must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t npad = static_cast<int64_t>(pl.T) * pl.NT;
-    const Epilogue ep = {rowptr, row_begin, n_rows, attn, lda, attn_scale, gcn_scale, out, ldo};
+    const Epilogue ep = {rowptr, row_order, row_begin, n_rows, attn, lda, attn_scale, gcn_scale, out, ldo};
     const uint4* e4 = reinterpret_cast<const uint4*>(entries);
-    const int2* tb = reinterpret_cast<const int2*>(table);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(ys);
     switch (pl.R) {
-        case 1: return launch_sweep<1>(st, e4, tb, y4, npad, pl, ep);
-        case 2: return launch_sweep<2>(st, e4, tb, y4, npad, pl, ep);
-        case 3: return launch_sweep<3>(st, e4, tb, y4, npad, pl, ep);
-        case 4: return launch_sweep<4>(st, e4, tb, y4, npad, pl, ep);
-        case 5: return launch_sweep<5>(st, e4, tb, y4, npad, pl, ep);
-        case 6: return launch_sweep<6>(st, e4, tb, y4, npad, pl, ep);
-        case 7: return launch_sweep<7>(st, e4, tb, y4, npad, pl, ep);
-        case 8: return launch_sweep<8>(st, e4, tb, y4, npad, pl, ep);
-        case 9: return launch_sweep<9>(st, e4, tb, y4, npad, pl, ep);
-        case 10: return launch_sweep<10>(st, e4, tb, y4, npad, pl, ep);
+        case 1: return launch_sweep<1>(st, e4, table, y4, npad, pl, ep);
+        case 2: return launch_sweep<2>(st, e4, table, y4, npad, pl, ep);
+        case 3: return launch_sweep<3>(st, e4, table, y4, npad, pl, ep);
+        case 4: return launch_sweep<4>(st, e4, table, y4, npad, pl, ep);
+        case 5: return launch_sweep<5>(st, e4, table, y4, npad, pl, ep);
+        case 6: return launch_sweep<6>(st, e4, table, y4, npad, pl, ep);
+        case 7: return launch_sweep<7>(st, e4, table, y4, npad, pl, ep);
+        case 8: return launch_sweep<8>(st, e4, table, y4, npad, pl, ep);
+        case 9: return launch_sweep<9>(st, e4, table, y4, npad, pl, ep);
+        case 10: return launch_sweep<10>(st, e4, table, y4, npad, pl, ep);
     }
     return dif::fail(DIF_E_SHAPE, "dif_sliced_spmm: %d rounds per wave not covered", pl.R);
 }

@@ -164,8 +164,8 @@ def sliced_tiling(num_nodes, F, nnz, edge_weight, shard, elem_size):
 class SlicedAdjacency:
     """Entry blocks + table + geometry of the feature-sliced product (include/difformer_hip.h, dif_sliced_*)."""
 
-    def __init__(self, plan, entries, table):
-        self.plan, self.entries, self.table = plan, entries, table
+    def __init__(self, plan, entries, table, order=None):
+        self.plan, self.entries, self.table, self.order = plan, entries, table, order     # order: rows by descending degree
 
 
 class GraphCSR:
@@ -211,8 +211,9 @@ class GraphCSR:
     def sliced(self, row_begin, n_rows, F):
         """The feature-sliced LDS format of rows [row_begin, row_begin + n_rows) for F fp32 feature columns
         (csrc/gcn_sliced.hip), built on first use -- or None when this graph keeps the gather kernels: edge weights,
-        an adjoint CSR, a blocking that is not the format's tiling, skewed degrees (lock-step lanes pay the longest row
-        of a 64-row slot) or a (row, tile) group beyond the byte counters."""
+        an adjoint CSR, a blocking that is not the format's tiling, or a (row, tile) group beyond the 16-bit counters.
+        With skewed degrees (max > 2x mean) the 64-row slots are formed in descending-degree order, so that the lock-step
+        lanes of a slot carry lists of similar length."""
         key = (int(row_begin), int(n_rows), int(F))
         if key not in self._sliced:
             self._sliced[key] = self._build_sliced(*key)
@@ -232,12 +233,11 @@ class GraphCSR:
             return None
         deg = self.rowptr[row_begin + 1: row_begin + n_rows + 1] - self.rowptr[row_begin: row_begin + n_rows]
         max_deg, total = (int(v) for v in torch.stack([deg.max(), deg.sum()]).tolist())       # one sync, cold path
-        if max_deg * n_rows > 2 * total:
-            return None
-        built = be.sliced_build(self.rowptr, self.blkptr, self.src, self.num_nodes, self.nnz, row_begin, n_rows, F, plan)
+        order = be.row_order(self.rowptr, row_begin, n_rows)[0] if max_deg * n_rows > 2 * total else None
+        built = be.sliced_build(self.rowptr, self.blkptr, self.src, self.num_nodes, self.nnz, row_begin, n_rows, F, plan, order)
         if built is None:
             return None
-        return SlicedAdjacency(plan, built[0], built[1])
+        return SlicedAdjacency(plan, built[0], built[1], order)
 
     def row_sums(self):
         """A_hat 1 (float32 [N]): what the bias of the value projection turns into under the aggregation,
@@ -369,7 +369,7 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
             # LayerNorm of the tail needs whole rows, which the slice workgroups do not have: it runs as its own pass
             ys = be.sliced_prescale(x2, csr.rowptr, csr.num_nodes, sl.plan)
             out = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, 0, n, H * D, a2,
-                                 attn_scale, gcn_scale)
+                                 attn_scale, gcn_scale, sl.order)
             if tail is not None:
                 out = be.layer_tail(out.reshape(n, H, D), tail.get("x0"), tail.get("prev"), tail.get("alpha", 0.5),
                                     tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5),
@@ -447,7 +447,7 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
             if ys is None:
                 ys = be.sliced_prescale(x_src, csr.rowptr, csr.num_nodes, sl.plan)
             ax = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, row_begin, n, C, None, 1.0,
-                                gcn_scale)
+                                gcn_scale, sl.order)
         else:
             ax = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x_src, row_begin, n,
                          None, 1.0, gcn_scale, None, csr.row_order(row_begin, n))

@@ -202,37 +202,42 @@ int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int
  *
  * A workgroup owns a panel of destination rows and a 16-byte slice of the feature row; source rows are swept in tiles
  * of plan[6] rows held in LDS; an entry is a 16-bit tile-local row number read with one ds_read_b128 (csrc/gcn_sliced.hip).
- *   dif_sliced_plan     plan int32[8] = {slices = F/4, panels, rows per panel, 64-row slots per panel, waves, rounds,
- *                       tile rows T (multiple of 16, <= 10,208), tiles NT}.  Host-only, deterministic in its arguments.
- *                       DIF_E_SHAPE when F % 4 != 0 or F > 1024.
+ *   dif_sliced_plan     plan int32[8] = {slices = F/4, panels, 64-row slots G, (panel, wave) pairs PW = panels * waves,
+ *                       waves, rounds R, tile rows T (multiple of 16, <= 10,208), tiles NT}.  Host-only, deterministic
+ *                       in its arguments.  DIF_E_SHAPE when F % 4 != 0 or F > 1024.  Slot g holds the rows at positions
+ *                       64 g .. 64 g + 63 of row_order (NULL: natural order; pass dif_row_order's descending-degree order
+ *                       when the degrees are skewed, so that the 64 lock-step lanes of a slot carry similar lists);
+ *                       slot j * PW + (j odd ? PW - 1 - pw : pw) is round j of pair pw = wave * panels + panel.
  *   dif_sliced_measure  needs the CSR built by dif_csr_build(n_blocks = NT, block_rows = T) (blkptr may be NULL when
  *                       NT == 1).  Re-orders every (row, tile) group by LDS bank (-> `sorted` uint16[nnz], `counts`
- *                       16 bytes per (local row, tile)), schedules the entries (-> `lengths` int32[panels*NT*slots*4]) and
- *                       writes `table` int32[2*panels*NT*waves + 1] = {first block, blocks per round} per (panel, tile,
- *                       wave) and the total number of 1-KiB blocks in its last element.  status[0] != 0: a (row, tile)
- *                       group holds more than 255 entries -- use dif_gcn_spmm_f32 for this graph.
- *   dif_sliced_emit     writes the blocks: `entries` uint16[512 * n_blocks] with n_blocks = table[2*panels*NT*waves]
+ *                       32 bytes per (row position, tile)), schedules the entries (-> `lengths` int32[G*NT*4]) and
+ *                       writes `table` int32[(R+1)*panels*NT*waves + 1] = {first block, blocks of round 0 >= round 1 >=
+ *                       ... (padded to a non-increasing sequence)} per (panel, tile, wave) and the total number of
+ *                       1-KiB blocks in its last element.  status[0] != 0: a (row, tile) group holds more than 65,535
+ *                       entries -- use dif_gcn_spmm_f32 for this graph.
+ *   dif_sliced_emit     writes the blocks: `entries` uint16[512 * n_blocks] with n_blocks = table[(R+1)*panels*NT*waves]
  *                       (read back by the caller: the size is data dependent).  sorted / counts / lengths may be freed
- *                       afterwards; entries + table + plan are the format.
+ *                       afterwards; entries + table + plan (+ row_order) are the format.
  *   dif_sliced_prescale_f32  ys float[F/4][T*NT][4] = deg^-1/2 (0 for a node without incoming entries, :74) times x,
  *                       slice-major; x holds all n_src rows.
  *   dif_sliced_spmm_f32 out[r,:] = gcn_scale * deg[r]^-1/2 * sum_e ys[src_e] (+ attn_scale * attn[r,:]) for the n_rows
- *                       rows the format was built for (out / attn hold only those rows).  Deterministic.
+ *                       rows the format was built for (out / attn hold only those rows; row_order as at build time).
+ *                       Deterministic.
  * ------------------------------------------------------------------------------------- */
 int dif_sliced_plan(int64_t n_src, int64_t n_rows, int F, int32_t* plan);
 int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, const int32_t* src, int64_t n_src,
                        int64_t nnz, int64_t row_begin, int64_t n_rows, int F, const int32_t* plan,
-                       uint16_t* sorted, void* counts, int32_t* lengths, int32_t* table, int32_t* status,
-                       dif_stream_t stream);
+                       const int32_t* row_order, uint16_t* sorted, void* counts, int32_t* lengths, int32_t* table,
+                       int32_t* status, dif_stream_t stream);
 int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int64_t n_src, int64_t row_begin,
-                    int64_t n_rows, int F, const int32_t* plan, const uint16_t* sorted, const void* counts,
-                    const int32_t* table, int64_t n_blocks, uint16_t* entries, dif_stream_t stream);
+                    int64_t n_rows, int F, const int32_t* plan, const int32_t* row_order, const uint16_t* sorted,
+                    const void* counts, const int32_t* table, int64_t n_blocks, uint16_t* entries, dif_stream_t stream);
 int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_t* rowptr, int64_t n_src, int F,
                             const int32_t* plan, float* ys, dif_stream_t stream);
 int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table, const int32_t* plan, const float* ys,
-                        const int32_t* rowptr, int64_t n_src, int64_t row_begin, int64_t n_rows, int F,
-                        const float* attn, int64_t lda, float attn_scale, float gcn_scale, float* out,
-                        int64_t ldo, dif_stream_t stream);
+                        const int32_t* rowptr, const int32_t* row_order, int64_t n_src, int64_t row_begin,
+                        int64_t n_rows, int F, const float* attn, int64_t lda, float attn_scale, float gcn_scale,
+                        float* out, int64_t ldo, dif_stream_t stream);
 
 /* Split product for row-sharded runs (one process per GPU): a rank owns the source rows of the blocks
  * [own_blk_begin, own_blk_end) before the all-gather of the value rows has delivered the others.

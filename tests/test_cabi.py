@@ -56,16 +56,16 @@ def test_sliced_plan_is_host_side_arithmetic(lib):
     """dif_sliced_plan: geometry of the feature-sliced product (no device call)."""
     plan = (ctypes.c_int32 * 8)()
     assert lib.dif_sliced_plan(132534, 132534, 64, plan) == 0
-    slices, panels, P, S, W, R, T, NT = list(plan)
-    assert (slices, panels) == (16, 16) and P * panels >= 132534 and S == -(-P // 64) and W * R >= S and W <= 16
+    slices, panels, G, PW, W, R, T, NT = list(plan)
+    assert (slices, panels) == (16, 16) and G == -(-132534 // 64) and PW == panels * W and (R - 1) * PW < G <= R * PW and W <= 16
     assert T % 16 == 0 and T <= 10208 and T * NT >= 132534 and NT == 13
     assert lib.dif_sliced_plan(2000000, 2000000, 64, plan) == 0 and plan[1] * plan[0] > 256     # more panels than CUs
     assert plan[5] <= 10
     assert lib.dif_sliced_plan(1000, 1000, 30, plan) == -2 and b"F % 4" in lib.dif_last_error()
     assert lib.dif_sliced_plan(5000, 5000, 64, plan) == 0 and plan[7] == 1                     # one tile: plain CSR
-    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
     assert rc == -1 and b"null pointer" in lib.dif_last_error()
-    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, 6000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, 6000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
     assert rc == -1 and b"plan does not match" in lib.dif_last_error()
 
 

@@ -46,17 +46,24 @@ def _sliced(csr, n, F):
     return sl
 
 
-@pytest.mark.parametrize("n,deg,F", [(20000, 60, 64), (9000, 70, 64), (33000, 50, 128), (12000, 64, 32)])
-def test_sliced_format_holds_the_csr_and_is_bank_conflict_free(n, deg, F, dev):
-    from difformer_amd import ops
-    ei = _dense_graph(n, deg, seed=n + F)
-    eid = ei.to(dev)
-    csr = ops.csr_cache.get(eid, None, n, F * 4)
-    sl = _sliced(csr, n, F)
-    slices, panels, P, S, W, R, T, NT = (int(v) for v in sl.plan)
-    assert slices == F // 4 and NT == csr.n_blocks and T % 16 == 0 and W * R >= S
+def _skewed_graph(n, deg, seed, hubs=40):
+    """Half of the entries land on `hubs` destination rows (max degree ~ n * deg / (2 * hubs) >> mean)."""
+    ei = _dense_graph(n, deg, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    half = ei.shape[1] // 2
+    ei[1, :half] = torch.randint(0, hubs, (half,), generator=g) * (n // hubs)
+    return ei
+
+
+def _check_format(sl, ei, n, csr):
+    slices, panels, G, PW, W, R, T, NT = (int(v) for v in sl.plan)
+    assert NT == csr.n_blocks and T % 16 == 0 and PW == panels * W and G == -(-n // 64) and (R - 1) * PW < G <= R * PW
+    order = np.arange(n) if sl.order is None else sl.order.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(n))
     table = sl.table.cpu().numpy()
+    n_ptw = panels * NT * W
     n_blocks = int(table[-1])
+    rows = table[:-1].reshape(n_ptw, R + 1)
     ent = sl.entries.cpu().numpy().view(np.uint16).reshape(-1, 64, 8)[:n_blocks]
     # every step of every block: the 16 lanes of a hardware group read 16 different bank quads
     quads = (ent & 15).transpose(0, 2, 1)                       # [block, step, lane]
@@ -66,32 +73,61 @@ def test_sliced_format_holds_the_csr_and_is_bank_conflict_free(n, deg, F, dev):
     assert ent.max() < T + 16
     # the real entries of (row, tile) == the CSR group
     src, dst = ei[0].numpy(), ei[1].numpy()
-    order = np.lexsort((src, dst))
-    src_s, dst_s = src[order], dst[order]
+    perm = np.lexsort((src, dst))
+    src_s, dst_s = src[perm], dst[perm]
     rowptr = np.searchsorted(dst_s, np.arange(n + 1))
     assert np.array_equal(rowptr, csr.rowptr.cpu().numpy())
-    total_real = 0
+    if sl.order is not None:
+        deg = np.diff(rowptr)[order]
+        assert np.all(deg[:-1] >= deg[1:]), "slots are formed in descending-degree order"
+    total_real, expect_start, seen_slots = 0, 0, 0
     for p in range(panels):
         for t in range(NT):
             for w in range(W):
-                start, nb = table[2 * ((p * NT + t) * W + w)], table[2 * ((p * NT + t) * W + w) + 1]
-                nr = (S - w + W - 1) // W
-                assert nb >= 1
-                blk = ent[start: start + nb * nr].reshape(nb, nr, 64, 8)
-                for j in range(nr):
-                    lists = blk[:, j].transpose(1, 0, 2).reshape(64, nb * 8)        # [lane, step]
+                start, nb = int(rows[(p * NT + t) * W + w, 0]), rows[(p * NT + t) * W + w, 1:].astype(np.int64)
+                assert start == expect_start and np.all(nb[:-1] >= nb[1:]), "round lengths must not increase"
+                expect_start += int(nb.sum())
+                pw = w * panels + p
+                for j in range(R):
+                    g = j * PW + (PW - 1 - pw if j & 1 else pw)
+                    if g >= G:
+                        assert nb[j] == 0
+                        continue
+                    seen_slots += (t == 0)
+                    blocks = [start + int(np.minimum(nb, k).sum()) + j for k in range(int(nb[j]))]
+                    lists = ent[blocks].transpose(1, 0, 2).reshape(64, -1) if blocks else np.zeros((64, 0), np.uint16)
                     for lane in range(64):
-                        prow = (j * W + w) * 64 + lane
-                        row = p * P + prow
+                        pos = g * 64 + lane
                         got = np.sort(lists[lane][lists[lane] < T].astype(np.int64))
-                        if prow >= P or row >= n:
+                        if pos >= n:
                             assert got.size == 0
                             continue
+                        row = order[pos]
                         seg = src_s[rowptr[row]: rowptr[row + 1]]
                         want = np.sort(seg[(seg >= t * T) & (seg < (t + 1) * T)] - t * T)
                         assert np.array_equal(got, want), (p, t, w, j, lane)
                         total_real += got.size
-    assert total_real == ei.shape[1]
+    assert expect_start == n_blocks and seen_slots == G and total_real == ei.shape[1]
+
+
+@pytest.mark.parametrize("n,deg,F", [(20000, 60, 64), (9000, 70, 64), (33000, 50, 128), (12000, 64, 32)])
+def test_sliced_format_holds_the_csr_and_is_bank_conflict_free(n, deg, F, dev):
+    from difformer_amd import ops
+    ei = _dense_graph(n, deg, seed=n + F)
+    csr = ops.csr_cache.get(ei.to(dev), None, n, F * 4)
+    sl = _sliced(csr, n, F)
+    assert sl.order is None                     # degrees about equal: natural row order
+    _check_format(sl, ei, n, csr)
+
+
+@pytest.mark.parametrize("n,deg,F", [(12000, 64, 64), (25000, 50, 32)])
+def test_sliced_format_on_skewed_degrees_sorts_rows_into_slots(n, deg, F, dev):
+    from difformer_amd import ops
+    ei = _skewed_graph(n, deg, seed=n)
+    csr = ops.csr_cache.get(ei.to(dev), None, n, F * 4)
+    sl = _sliced(csr, n, F)
+    assert sl.order is not None
+    _check_format(sl, ei, n, csr)
 
 
 @pytest.mark.parametrize("n,deg,h,d", [(20000, 60, 1, 64), (9000, 70, 1, 64), (33000, 50, 2, 64), (12000, 64, 1, 32),
@@ -131,7 +167,7 @@ def test_sliced_product_with_attention_combine_and_tail(dev):
     assert rel_err(got.cpu().numpy(), old.cpu().numpy()) < 1e-5
 
 
-def test_sliced_is_declined_for_weights_skew_and_sparse_graphs(dev):
+def test_sliced_is_declined_for_weights_and_sparse_graphs(dev):
     from difformer_amd import ops
     n = 12000
     ei = _dense_graph(n, 64, seed=1).to(dev)
@@ -139,13 +175,25 @@ def test_sliced_is_declined_for_weights_skew_and_sparse_graphs(dev):
     assert ops.csr_cache.get(ei, w, n, 256).sliced(0, n, 64) is None             # edge weights
     sparse = torch.randint(0, n, (2, 5 * n)).to(dev)
     assert ops.csr_cache.get(sparse, None, n, 256).sliced(0, n, 64) is None      # ~5 entries per row
-    skew = ei.clone()
-    skew[1, : ei.shape[1] // 2] = torch.randint(0, 40, (ei.shape[1] // 2,)).to(dev)   # a few hub rows
-    csr = ops.csr_cache.get(skew, None, n, 256)
-    assert csr.sliced(0, n, 64) is None
-    x = torch.randn(n, 1, 64).to(dev)
-    ref = orc.gcn_conv(x.double().cpu().numpy(), skew.cpu().numpy(), None)
-    assert rel_err(ops.gcn_aggregate(csr, x).cpu().numpy(), ref) < 1e-5             # the gather kernels take it
+
+
+@pytest.mark.parametrize("n,deg,hubs", [(12000, 64, 40), (30000, 80, 7), (64000, 50, 2000)])
+def test_sliced_product_on_skewed_degrees(n, deg, hubs, dev):
+    """Hub rows (up to ~170k entries, i.e. beyond 16-bit counters per tile only if a tile held > 65,535 of them) and a
+    long tail of short rows in the same launch: results against the float64 oracle and the gather kernel."""
+    from difformer_amd import gcn_conv, ops
+    ei = _skewed_graph(n, deg, seed=7 * n, hubs=hubs)
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 1, 64, generator=g)
+    eid, xd = ei.to(dev), x.to(dev)
+    csr = ops.csr_cache.get(eid, None, n, 256)
+    sl = csr.sliced(0, n, 64)
+    ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), None)
+    out = gcn_conv(xd, eid, None)
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5
+    if hubs >= 40:
+        assert sl is not None and sl.order is not None
+    assert torch.equal(gcn_conv(xd, eid, None), out)
 
 
 def test_sliced_nodes_without_incoming_entries(dev):
