@@ -588,9 +588,9 @@ class HipBackend:
         _lib.check(rc, "dif_sliced_emit")
         return entries, table
 
-    def sliced_prescale(self, x, rowptr, n_src, plan):
-        """x [n_src, F] fp32 -> ys [F/4, T*NT, 4]: rows scaled by deg^-1/2, slice-major."""
-        dev = _require_device(x, rowptr)
+    def sliced_prescale(self, x, rowptr, n_src, plan, dinv=None):
+        """x [n_src, F] fp32 -> ys [F/4, T*NT, 4]: rows scaled by deg^-1/2 (dinv, or from the row lengths), slice-major."""
+        dev = _require_device(x, rowptr, dinv)
         _f32(x, "x")
         F = x.shape[1]
         x, ldx = _row_major(x, F)
@@ -598,13 +598,14 @@ class HipBackend:
             x, ldx = x.contiguous(), F
         ys = torch.empty((F // 4, int(plan[6]) * int(plan[7]), 4), dtype=torch.float32, device=dev)
         with _Timed(self, "dif_sliced_prescale_f32", dev):
-            rc = self.lib.dif_sliced_prescale_f32(_ptr(x), ldx, _ptr(rowptr), int(n_src), F, plan, _ptr(ys), _stream(dev))
+            rc = self.lib.dif_sliced_prescale_f32(_ptr(x), ldx, _ptr(rowptr), _ptr(dinv), int(n_src), F, plan, _ptr(ys),
+                                                  _stream(dev))
         _lib.check(rc, "dif_sliced_prescale_f32")
         return ys
 
     def sliced_spmm(self, entries, table, plan, ys, rowptr, n_src, row_begin, n_rows, F, attn=None, attn_scale=1.0,
-                    gcn_scale=1.0, order=None):
-        dev = _require_device(entries, table, ys, rowptr, attn, order)
+                    gcn_scale=1.0, order=None, dinv=None):
+        dev = _require_device(entries, table, ys, rowptr, attn, order, dinv)
         lda = 0
         if attn is not None:
             _f32(attn, "attn")
@@ -613,7 +614,7 @@ class HipBackend:
                 attn, lda = attn.contiguous(), F
         out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
         with _Timed(self, "dif_sliced_spmm_f32", dev):
-            rc = self.lib.dif_sliced_spmm_f32(_ptr(entries), _ptr(table), plan, _ptr(ys), _ptr(rowptr), _ptr(order),
+            rc = self.lib.dif_sliced_spmm_f32(_ptr(entries), _ptr(table), plan, _ptr(ys), _ptr(rowptr), _ptr(dinv), _ptr(order),
                                               int(n_src), int(row_begin), int(n_rows), int(F), _ptr(attn), lda,
                                               float(attn_scale), float(gcn_scale), _ptr(out), F, _stream(dev))
         _lib.check(rc, "dif_sliced_spmm_f32")

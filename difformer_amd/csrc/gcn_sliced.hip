@@ -339,7 +339,8 @@ __global__ __launch_bounds__(1024) void sliced_table_kernel(const int32_t* __res
 // ------------------------------------------------------------------------------------------------------------
 // run, step 1: ys[slice][row] = dinv[row] * x[row][4*slice .. 4*slice+3]   (slice-major: a tile of one slice is
 // one contiguous stream), rows >= n_src zero.  dinv = sqrt(1 / in-degree) as difformer.py:66-68; a node without
-// incoming entries contributes nothing (nan_to_num of the infinite value, :74).
+// incoming entries contributes nothing (nan_to_num of the infinite value, :74).  The in-degree is the row length of
+// the CSR; for the ADJOINT product (CSR of the transposed graph, rows = sources) the caller passes the vector.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dinv_of(const int32_t* __restrict__ rowptr, int64_t row) {
     const int32_t d = rowptr[row + 1] - rowptr[row];
@@ -349,7 +350,8 @@ __device__ __forceinline__ float dinv_of(const int32_t* __restrict__ rowptr, int
 constexpr int kPreSlices = 32;      // slices per block of the prescale pass (LDS staging: 32 x 65 float4)
 
 __global__ __launch_bounds__(256) void sliced_prescale_kernel(const float* __restrict__ x, int64_t ldx,
-                                                              const int32_t* __restrict__ rowptr, int64_t n_src,
+                                                              const int32_t* __restrict__ rowptr,
+                                                              const float* __restrict__ dinv, int64_t n_src,
                                                               int64_t npad, int slices, f32x4* __restrict__ ys) {
     __shared__ f32x4 stage[kPreSlices * 65];
     const int64_t row0 = static_cast<int64_t>(blockIdx.x) * 64;
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(256) void sliced_prescale_kernel(const float* __res
         const int r = e / ns, sl = e % ns;
         const int64_t row = row0 + r;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < n_src) v = *reinterpret_cast<const f32x4*>(x + row * ldx + (s0 + sl) * 4) * dinv_of(rowptr, row);
+        if (row < n_src)
+            v = *reinterpret_cast<const f32x4*>(x + row * ldx + (s0 + sl) * 4) * (dinv ? dinv[row] : dinv_of(rowptr, row));
         stage[sl * 65 + r] = v;
     }
     __syncthreads();
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(256) void sliced_prescale_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------------
 struct Epilogue {
     const int32_t* rowptr;
+    const float* dinv;
     const int32_t* order;
     int64_t row_begin, n_rows;
     const float* attn;
@@ -499,7 +503,8 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
         const int64_t pos = slot_of(j, pw, pl.PW) * 64 + lane;
         if (pos < ep.n_rows) {
             const int64_t lrow = ep.order ? ep.order[pos] : pos;
-            f32x4 o = acc[j] * (ep.gcn_scale * dinv_of(ep.rowptr, ep.row_begin + lrow));
+            const int64_t row = ep.row_begin + lrow;
+            f32x4 o = acc[j] * (ep.gcn_scale * (ep.dinv ? ep.dinv[row] : dinv_of(ep.rowptr, row)));
             if (ep.attn) o += ep.attn_scale * *reinterpret_cast<const f32x4*>(ep.attn + lrow * ep.lda + slice * 4);
             *reinterpret_cast<f32x4*>(ep.out + lrow * ep.ldo + slice * 4) = o;
         }
@@ -615,8 +620,8 @@ extern "C" int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int
     return dif::launch_status("sliced_color_kernel");
 }
 
-extern "C" int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_t* rowptr, int64_t n_src, int F,
-                                       const int32_t* plan, float* ys, dif_stream_t stream) {
+extern "C" int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_t* rowptr, const float* dinv, int64_t n_src,
+                                       int F, const int32_t* plan, float* ys, dif_stream_t stream) {
     DIF_REQUIRE(x && rowptr && plan && ys && n_src > 0 && F > 0 && F % 4 == 0 && ldx >= F, DIF_E_BADARG,
                 "dif_sliced_prescale: bad argument");
     DIF_REQUIRE(ldx % 4 == 0 && dif::aligned16(x) && dif::aligned16(ys), DIF_E_BADARG,
@@ -626,14 +631,14 @@ extern "C" int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_
     DIF_REQUIRE(slices == F / 4 && npad >= n_src, DIF_E_BADARG, "dif_sliced_prescale: plan does not match F / n_src");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(sliced_prescale_kernel, dim3(static_cast<unsigned>((npad + 63) / 64), (slices + kPreSlices - 1) / kPreSlices),
-                       dim3(256), 0, st, x, ldx, rowptr, n_src, npad, slices, reinterpret_cast<f32x4*>(ys));
+                       dim3(256), 0, st, x, ldx, rowptr, dinv, n_src, npad, slices, reinterpret_cast<f32x4*>(ys));
     return dif::launch_status("sliced_prescale_kernel");
 }
 
 extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table, const int32_t* plan, const float* ys,
-                                   const int32_t* rowptr, const int32_t* row_order, int64_t n_src, int64_t row_begin,
-                                   int64_t n_rows, int F, const float* attn, int64_t lda, float attn_scale, float gcn_scale,
-                                   float* out, int64_t ldo, dif_stream_t stream) {
+                                   const int32_t* rowptr, const float* dinv, const int32_t* row_order, int64_t n_src,
+                                   int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
+                                   float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream) {
     Plan pl;
     if (int rc = check_plan(plan, n_src, n_rows, F, pl)) return rc;
     DIF_REQUIRE(entries && table && ys && rowptr && out, DIF_E_BADARG, "dif_sliced_spmm: null pointer");
@@ -643,7 +648,7 @@ extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table
     DIF_REQUIRE(dif::aligned16(entries) && dif::aligned16(ys), DIF_E_BADARG, "dif_sliced_spmm: entries / ys must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t npad = static_cast<int64_t>(pl.T) * pl.NT;
-    const Epilogue ep = {rowptr, row_order, row_begin, n_rows, attn, lda, attn_scale, gcn_scale, out, ldo};
+    const Epilogue ep = {rowptr, dinv, row_order, row_begin, n_rows, attn, lda, attn_scale, gcn_scale, out, ldo};
     const uint4* e4 = reinterpret_cast<const uint4*>(entries);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(ys);
     switch (pl.R) {

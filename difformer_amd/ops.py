@@ -179,6 +179,7 @@ class GraphCSR:
         self._adjoint = None
         self._orders = {}           # (row_begin, n_rows) -> rows by descending degree (blocked SpMM load balance)
         self.weighted = self.transposed = False
+        self.dinv = None            # adjoint CSR only: deg^-1/2 of the FORWARD graph (its own row lengths are out-degrees)
         self._sliced = {}           # (row_begin, n_rows, F) -> SlicedAdjacency | None
         self._row_sums = None
 
@@ -220,7 +221,7 @@ class GraphCSR:
         return self._sliced[key]
 
     def _build_sliced(self, row_begin, n_rows, F):
-        if self.weighted or self.transposed or self.nnz == 0:
+        if self.weighted or self.nnz == 0 or (self.transposed and self.dinv is None):
             return None
         be = get_backend()
         if self.num_nodes < SLICED_MIN_ROWS or self.nnz < SLICED_MIN_DEGREE * self.num_nodes or not hasattr(be, "sliced_plan"):
@@ -268,6 +269,11 @@ class GraphCSR:
                                    "until backward()")
             self._adjoint = GraphCSR.build(ei, ew, self.num_nodes, self.n_blocks, transpose=True,
                                            block_rows=self.block_rows)
+            if not self.weighted:
+                # value_e = dinv[col] * dinv[row] with dinv from the in-degree (difformer.py:66-68): the adjoint product
+                # factors the same way, grad_x[s] = dinv[s] * sum_{e: src = s} (dinv * g)[dst_e] -> the sliced kernel
+                deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+                self._adjoint.dinv = torch.where(deg > 0, (1.0 / deg).sqrt(), torch.zeros_like(deg))
         return self._adjoint
 
 
@@ -367,9 +373,9 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
         if sl is not None:
             # dense unweighted graph: sources pre-scaled and staged slice by slice in LDS (csrc/gcn_sliced.hip); the
             # LayerNorm of the tail needs whole rows, which the slice workgroups do not have: it runs as its own pass
-            ys = be.sliced_prescale(x2, csr.rowptr, csr.num_nodes, sl.plan)
+            ys = be.sliced_prescale(x2, csr.rowptr, csr.num_nodes, sl.plan, csr.dinv)
             out = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, 0, n, H * D, a2,
-                                 attn_scale, gcn_scale, sl.order)
+                                 attn_scale, gcn_scale, sl.order, csr.dinv)
             if tail is not None:
                 out = be.layer_tail(out.reshape(n, H, D), tail.get("x0"), tail.get("prev"), tail.get("alpha", 0.5),
                                     tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5),

@@ -206,3 +206,30 @@ def test_sliced_nodes_without_incoming_entries(dev):
     out = gcn_conv(x.to(dev), ei.to(dev), None).cpu().numpy()
     ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), None)
     assert np.isfinite(out).all() and rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("skewed", [False, True])
+def test_sliced_adjoint_product_is_the_gradient(skewed, dev):
+    """backward of difformer.py:75-78: grad_x = A_hat^T g over the CSR of the transposed graph, whose row lengths are
+    OUT-degrees -- the normaliser comes from the forward graph (dinv vector through the C ABI)."""
+    from difformer_amd import gcn_conv, ops
+    n, d = 14000, 64
+    ei = _skewed_graph(n, 60, seed=21) if skewed else _dense_graph(n, 60, seed=20)
+    ei[0, : n] = torch.randint(0, 50, (n,), generator=torch.Generator().manual_seed(3))       # out-degrees != in-degrees
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n, 1, d, generator=g)
+    gout = torch.randn(n, 1, d, generator=g)
+    eid = ei.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = gcn_conv(xd, eid, None)
+    out.backward(gout.to(dev))
+    csr = ops.csr_cache.get(eid, None, n, d * 4)
+    adj = csr.adjoint()
+    assert adj.sliced(0, n, d) is not None and adj.dinv is not None
+    row, col = ei[0].numpy(), ei[1].numpy()                       # difformer.py:63-75 in float64
+    deg = np.bincount(col, minlength=n).astype(np.float64)
+    dinv = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1)), 0.0)
+    val = dinv[col] * dinv[row]
+    want = np.zeros((n, d))
+    np.add.at(want, row, val[:, None] * gout[:, 0, :].double().numpy()[col])
+    assert rel_err(xd.grad[:, 0, :].cpu().numpy(), want) < 1e-5
