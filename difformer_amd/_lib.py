@@ -76,6 +76,9 @@ SIGNATURES = {
     "dif_row_order": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_layer_tail_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,
                                    c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
+    "dif_layer_tail_bwd_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "dif_layer_tail_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp, c_f32,
+                                       c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "dif_linear_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
     "dif_gcn_spmm_tail_f32": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int,
                                       c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp, c_f32,

@@ -1,8 +1,9 @@
 """Autograd glue so the reference's unchanged training scripts (`main.py:130` loss.backward())
-keep working: the FORWARD of every operator is the HIP kernel; the BACKWARD re-derives the
-gradient on the device with differentiable tensor ops (hand-written backward kernels are the
-"next" row of SURVEY.md section 8f).  Under torch.no_grad() / eval these wrappers are
-pass-throughs to ops.py.  Nothing here touches the CPU.
+keep working: the FORWARD of every operator is the HIP kernel; the BACKWARD of the simple attention,
+the aggregation (adjoint product on the same SpMM kernels), the layer tail (LayerNorm / residual / head
+mean) and the weight gradients of the Linear layers are HIP kernels too;
+sigmoid and the batched (v2) attention re-derive their gradient on the device with tensor ops.
+Under torch.no_grad() / eval these wrappers are pass-throughs to ops.py.  Nothing here touches the CPU.
 """
 from __future__ import annotations
 
@@ -111,18 +112,59 @@ class _GcnAggregate(torch.autograd.Function):
 
 
 class _LayerTail(torch.autograd.Function):
+    """Forward and backward are one HIP pass each (csrc/layer_tail.hip, csrc/layer_tail_bwd.hip); shapes the backward
+    kernel does not cover (D % 4 != 0, D > 256, bf16 storage) re-derive the gradient with tensor ops."""
+
     @staticmethod
-    def forward(ctx, conv, x0, prev, alpha, w, b, eps):
+    def forward(ctx, conv, x0, prev, alpha, w, b, eps, relu):
         ctx.save_for_backward(conv, x0, prev, w, b)
-        ctx.alpha, ctx.eps = alpha, eps
-        return ops.layer_tail(conv, x0, prev, alpha, w, b, eps)
+        ctx.alpha, ctx.eps, ctx.relu = alpha, eps, bool(relu)
+        return ops.layer_tail(conv, x0, prev, alpha, w, b, eps, relu)
 
     @staticmethod
     def backward(ctx, g):
         conv, x0, prev, w, b = ctx.saved_tensors
-        grads = _grad_by_recompute(_tail_expr(ctx.alpha, ctx.eps, w is not None), (conv, x0, prev, w, b),
-                                   g.contiguous())
-        return grads[0], grads[1], grads[2], None, grads[3], grads[4], None
+        need = ctx.needs_input_grad
+        got = ops.get_backend().layer_tail_bwd(conv, x0, prev, ctx.alpha, w, b, ctx.eps, ctx.relu, g,
+                                               (need[0], need[1], need[2]))
+        if got is None:
+            expr = _tail_expr(ctx.alpha, ctx.eps, w is not None)
+            fn = (lambda *a: torch.relu(expr(*a))) if ctx.relu else expr
+            got = _grad_by_recompute(fn, (conv, x0, prev, w, b), g.contiguous())
+        return got[0], got[1], got[2], None, got[3], got[4], None, None
+
+
+class _Linear(torch.autograd.Function):
+    """x W^T + b on many rows.  The weight gradient g^T x contracts over the ROWS (K = n, a 64 x 192 result): the
+    vendor GEMM takes ~0.3 ms for it at 132k rows; it is exactly stage 1 of the simple kernel (K^T V and sum K of
+    difformer.py:25-28 with K = g, V = x), one streaming pass that also yields the bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        if bias is not None and x.shape[1] <= 128 and weight.shape[0] <= 64:
+            return ops.linear(x, weight, bias)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = g @ weight
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            n, co = g.shape
+            ci = x.shape[1]
+            g3 = g.reshape(n, 1, co)
+            red = ops.get_backend().simple_reduce(g3, g3, x.detach().reshape(n, 1, ci))
+            gw, gb = red[: co * ci].view(co, ci), red[co * ci: co * ci + co]
+        return gx, gw, gb
+
+
+def _row_linear(x, weight, bias):
+    ok = (x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[0] >= 1024
+          and x.shape[1] <= 256 and weight.shape[0] <= 256)
+    return _Linear.apply(x, weight, bias) if ok else torch.nn.functional.linear(x, weight, bias)
 
 
 # ---- public wrappers -----------------------------------------------------------------------------
@@ -222,15 +264,14 @@ def gcn_aggregate_tail(csr, x, attn, attn_scale, gcn_scale, shard, x0, prev, alp
 
 def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
     if _needs_grad(conv, x0, prev, ln_weight, ln_bias):
-        y = _LayerTail.apply(conv, x0, prev, alpha, ln_weight, ln_bias, eps)
-        return torch.relu(y) if relu else y
+        return _LayerTail.apply(conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu)
     return ops.layer_tail(conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu)
 
 
 def norm_relu(x, ln_weight, ln_bias, eps):
     """LayerNorm -> ReLU of the input layer (difformer.py:189-191) in one kernel when no gradient is needed."""
     if _needs_grad(x, ln_weight, ln_bias):
-        return torch.relu(torch.nn.functional.layer_norm(x, (x.shape[-1],), ln_weight, ln_bias, eps))
+        return _LayerTail.apply(x.unsqueeze(1), None, None, 0.5, ln_weight, ln_bias, eps, True)
     return ops.layer_tail(x.unsqueeze(1), None, None, 0.5, ln_weight, ln_bias, eps, relu=True)
 
 
@@ -241,10 +282,9 @@ def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
     grad = _needs_grad(x, weight, bias, ln_weight, ln_bias)
     if not grad and x.dim() == 2 and x.shape[1] <= 128 and (ln_weight is None or weight.shape[0] <= 64):
         return ops.linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
-    y = fn.linear(x, weight, bias)
+    y = _row_linear(x, weight, bias) if grad else fn.linear(x, weight, bias)
     if ln_weight is not None:
         if grad:
-            y = fn.layer_norm(y, (y.shape[-1],), ln_weight, ln_bias, eps)
-            return torch.relu(y) if relu else y
+            return _LayerTail.apply(y.unsqueeze(1), None, None, 0.5, ln_weight, ln_bias, eps, relu)
         return ops.layer_tail(y.unsqueeze(1), None, None, 0.5, ln_weight, ln_bias, eps, relu=relu)
     return torch.relu(y) if relu else y

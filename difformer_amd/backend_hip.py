@@ -653,6 +653,42 @@ class HipBackend:
         return out
 
     # ---- a4 / a5 tail ----------------------------------------------------------------------
+    def layer_tail_bwd(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu, grad_out, want):
+        """Backward of layer_tail in one pass (csrc/layer_tail_bwd.hip).  want = (conv, x0, prev) booleans.
+        -> (d_conv [n,H,D] | None, d_x0 | None, d_prev | None, d_ln_weight | None, d_ln_bias | None); None when the
+        shape is not covered (D % 4 != 0, D > 256, bf16 storage): the caller re-derives the gradient with tensor ops."""
+        dev = _require_device(conv, x0, prev, ln_weight, ln_bias, grad_out)
+        n, H, D = conv.shape
+        if D % 4 or D > 256 or any(t is not None and t.dtype != torch.float32 for t in (conv, x0, prev, ln_weight, grad_out)):
+            return None
+        conv, ldc = _row_major(conv, H * D)
+        g, ldg = _row_major(grad_out, D)
+        ldx0 = ldp = 0
+        if x0 is not None:
+            x0, ldx0 = _row_major(x0, D)
+        if prev is not None:
+            prev, ldp = _row_major(prev, D)
+        if any(ld % 4 for ld in (ldc, ldg, ldx0, ldp)) or any(t is not None and t.data_ptr() % 16 for t in (conv, g, x0, prev)):
+            return None
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_conv = torch.empty((n, H, D), **f32) if want[0] else None
+        d_x0 = torch.empty((n, D), **f32) if (want[1] and x0 is not None) else None
+        d_prev = torch.empty((n, D), **f32) if (want[2] and prev is not None) else None
+        d_ln = ws = None
+        ws_bytes = 0
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+            d_ln = torch.empty(2 * D + 2, **f32)
+            ws_bytes = self.lib.dif_layer_tail_bwd_workspace_bytes(n, D)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_layer_tail_bwd_f32", dev):
+            rc = self.lib.dif_layer_tail_bwd_f32(_ptr(conv), ldc, n, H, D, _ptr(x0), ldx0, _ptr(prev), ldp, float(alpha),
+                                                 _ptr(ln_weight), _ptr(ln_bias), float(eps), int(bool(relu)), _ptr(g), ldg,
+                                                 _ptr(d_conv), H * D, _ptr(d_x0), D, _ptr(d_prev), D, _ptr(d_ln), _ptr(ws),
+                                                 ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_layer_tail_bwd_f32")
+        return (d_conv, d_x0, d_prev, None if d_ln is None else d_ln[:D], None if d_ln is None else d_ln[D:2 * D])
+
     def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         dev = _require_device(conv, x0, prev, ln_weight, ln_bias)
         n, H, D = conv.shape

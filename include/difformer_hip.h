@@ -354,6 +354,22 @@ int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_bl
                           float* out, int64_t ldo, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f3  backward of dif_layer_tail_f32 (what loss.backward(), main.py:130, asks of difformer.py:137-140, :200-203 and of
+ *     the input layer's LayerNorm -> ReLU, :189-191; the reference leaves it to autograd).  fp32, D % 4 == 0, D <= 256,
+ *     16-byte aligned rows (DIF_E_SHAPE / DIF_E_BADARG otherwise).  The row is re-derived from the forward's inputs
+ *     (conv, x0, prev) and every gradient leaves in one pass:
+ *       d_conv [n,H,D] (each head gets dz / H), d_x0 [n,D], d_prev [n,D]  (each may be NULL: not wanted),
+ *       d_ln float[2 D + 2] = {d ln_weight [D], d ln_bias [D], 0, 0} (NULL iff ln_weight is NULL).
+ *     Deterministic: per-workgroup partial sums in `workspace`, column sums in a fixed order.
+ * ------------------------------------------------------------------------------------- */
+size_t dif_layer_tail_bwd_workspace_bytes(int64_t n_rows, int D);
+int dif_layer_tail_bwd_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, int D, const float* x0,
+                           int64_t ldx0, const float* prev, int64_t ldp, float alpha, const float* ln_weight,
+                           const float* ln_bias, float ln_eps, int relu, const float* grad_out, int64_t ldg,
+                           float* d_conv, int64_t lddc, float* d_x0, int64_t lddx0, float* d_prev, int64_t lddp,
+                           float* d_ln, void* workspace, size_t workspace_bytes, dif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a5 ends  input MLP  difformer.py:188-191 (Linear -> LayerNorm -> ReLU)  and output Linear :208 for the
  * narrow shapes of this model:  out = x W^T + b  [-> LayerNorm(ln_weight, ln_bias, eps)] [-> ReLU].
  * x [n_rows, C_in], W [C_out, C_in] (nn.Linear layout), b [C_out].  Covers C_in <= 128 (and C_out <= 64
