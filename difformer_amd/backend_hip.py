@@ -678,7 +678,7 @@ class HipBackend:
         ws_bytes = 0
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
-            d_ln = torch.empty(2 * D + 2, **f32)
+            d_ln = torch.empty(2 * D, **f32)
             ws_bytes = self.lib.dif_layer_tail_bwd_workspace_bytes(n, D)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _Timed(self, "dif_layer_tail_bwd_f32", dev):

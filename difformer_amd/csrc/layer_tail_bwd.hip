@@ -178,6 +178,6 @@ extern "C" int dif_layer_tail_bwd_f32(const float* conv, int64_t ldc, int64_t n_
 #undef DIF_TAILB
     if (int rc = dif::launch_status("layer_tail_bwd_kernel")) return rc;
     if (!ln_weight) return 0;
-    // d_ln float[2 D + 2] = {d ln_weight, d ln_bias, 0, 0}: column sums of the workgroup records, fixed order
-    return dif::launch_record_finalize(ws, blocks, 2 * D, 2 * D, 0, d_ln, st);
+    // d_ln float[2 D] = {d ln_weight, d ln_bias}: column sums of the workgroup records, fixed order
+    return dif::launch_record_finalize(ws, blocks, 2 * D, 2 * D, -1, d_ln, st);
 }

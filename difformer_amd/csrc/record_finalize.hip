@@ -12,7 +12,7 @@ __global__ __launch_bounds__(1024) void record_finalize_kernel(const float* __re
                                                                int t_main, int tiles, float* __restrict__ reduced) {
     __shared__ float sm[kFinSlices][64];
     const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    if (blockIdx.x + 1 < gridDim.x) {
+    if (static_cast<int>(blockIdx.x) < (t_main + 63) / 64) {
         const int col = blockIdx.x * 64 + c;
         float a = 0.f;
         if (col < t_main) {
@@ -64,7 +64,7 @@ namespace dif {
 
 int launch_record_finalize(const float* ws, int P, int64_t ws_stride, int t_main, int tiles, float* reduced,
                            hipStream_t st) {
-    const int nb = (t_main + 63) / 64 + 1;
+    const int nb = (t_main + 63) / 64 + (tiles >= 0 ? 1 : 0);       // tiles < 0: column sums only, no scalar pair
     hipLaunchKernelGGL(record_finalize_kernel, dim3(nb), dim3(1024), 0, st, ws, P, ws_stride, t_main, tiles, reduced);
     return launch_status("record_finalize_kernel");
 }

@@ -57,16 +57,6 @@ __global__ __launch_bounds__(256) void simple_bwd_prep_kernel(const float* __res
     for (int i = threadIdx.x; i <= H * M; i += 256) part[static_cast<int64_t>(blockIdx.x) * part_stride + i] = sm[i];
 }
 
-// column sums of the prep partials -> sums [H*M + 1]
-__global__ __launch_bounds__(256) void simple_bwd_sum_kernel(const float* __restrict__ part, int P, int part_stride,
-                                                             int len, float* __restrict__ sums) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= len) return;
-    float a = 0.f;
-    for (int p = 0; p < P; ++p) a += part[static_cast<int64_t>(p) * part_stride + c];
-    sums[c] = a;
-}
-
 // ---- row-GEMM: out[n, :C] = A[n, :K] Mat[K x C] + bias[C] + r[n] u[C] + beta Cin[n, :C]   (K, C <= 64, per head) ----
 // Same transposed MFMA formulation as simple_apply_kernel: D[i <-> c][j <-> row] = sum_k Mat[k][c] A[row][k].
 // mat_t != 0: Mat is given transposed in memory (Mat[k][c] = mem[c * ldm + k]).
@@ -175,9 +165,8 @@ extern "C" int dif_simple_bwd_prep_f32(const float* q, int64_t ldq, const float*
     hipLaunchKernelGGL(simple_bwd_prep_kernel, dim3(static_cast<unsigned>(P)), dim3(256), sizeof(float) * (len + 1), st, q,
                        ldq, g, ldg, out, ldo, reduced, n_rows, static_cast<float>(n_global), H, M, D, gn, gd, part, stride);
     if (int rc = dif::launch_status("simple_bwd_prep_kernel")) return rc;
-    hipLaunchKernelGGL(simple_bwd_sum_kernel, dim3((len + 255) / 256), dim3(256), 0, st, part, static_cast<int>(P), stride,
-                       len, sums);
-    return dif::launch_status("simple_bwd_sum_kernel");
+    // column sums of the prep partials -> sums [H*M + 1] (16 slices per column, fixed order)
+    return dif::launch_record_finalize(part, static_cast<int>(P), stride, len, -1, sums, st);
 }
 
 // out[n,h,:C] = A[n,h,:K] Mat_h + bias_h + r[n,h] * u_scale * u_h + (*beta_dev) * Cin[n,h,:C]    (K, C <= 64)

@@ -359,7 +359,7 @@ int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_bl
  *     16-byte aligned rows (DIF_E_SHAPE / DIF_E_BADARG otherwise).  The row is re-derived from the forward's inputs
  *     (conv, x0, prev) and every gradient leaves in one pass:
  *       d_conv [n,H,D] (each head gets dz / H), d_x0 [n,D], d_prev [n,D]  (each may be NULL: not wanted),
- *       d_ln float[2 D + 2] = {d ln_weight [D], d ln_bias [D], 0, 0} (NULL iff ln_weight is NULL).
+ *       d_ln float[2 D] = {d ln_weight [D], d ln_bias [D]} (NULL iff ln_weight is NULL).
  *     Deterministic: per-workgroup partial sums in `workspace`, column sums in a fixed order.
  * ------------------------------------------------------------------------------------- */
 size_t dif_layer_tail_bwd_workspace_bytes(int64_t n_rows, int D);
