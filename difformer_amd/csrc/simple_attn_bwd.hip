@@ -68,17 +68,26 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ Cin, int64_t ldc,
                                                       const float* __restrict__ beta_dev,
                                                       int64_t n_rows, int K, int C, float* __restrict__ out,
-                                                      int64_t ldo) {
+                                                      int64_t ldo, int vec) {
     __shared__ float sm_m[64 * 68];
     const int h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const float* mat = Mat + static_cast<int64_t>(h) * mat_head_stride;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-        const int k = e >> 6, c = e & 63;
-        float v = 0.f;
-        if (k < K && c < C) v = mat_scale * (mat_t ? mat[c * ldm + k] : mat[k * ldm + c]);
-        sm_m[k * 68 + c] = v;
+    {   // all 16 loads of a thread in flight before the first LDS store (a load -> store loop is 16 round trips)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int k = mat_t ? (e & 63) : (e >> 6), c = mat_t ? (e >> 6) : (e & 63);     // coalesced either way
+            v[u] = (k < K && c < C) ? mat_scale * (mat_t ? mat[c * ldm + k] : mat[k * ldm + c]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int k = mat_t ? (e & 63) : (e >> 6), c = mat_t ? (e >> 6) : (e & 63);
+            sm_m[k * 68 + c] = v[u];
+        }
     }
     __syncthreads();
     float afrag[4][4][4];   // [ctile][kq][t] = Mat[16kq + 4lg + t][16 ctile + l15]
@@ -99,10 +108,13 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float* __restrict__ 
         for (int kq = 0; kq < 4; ++kq) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             if (rok) {
+                const int k0 = 16 * kq + 4 * lg;
+                if (vec) {
+                    if (k0 < K) z = *reinterpret_cast<const f32x4*>(A + row * lda + h * a_head_stride + k0);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int kk = 16 * kq + 4 * lg + i;
-                    if (kk < K) z[i] = A[row * lda + h * a_head_stride + kk];
+                    for (int i = 0; i < 4; ++i)
+                        if (k0 + i < K) z[i] = A[row * lda + h * a_head_stride + k0 + i];
                 }
             }
             av[kq] = z;
@@ -119,6 +131,19 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float* __restrict__ 
                     acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ct][kq][t], av[kq][t], acc[ct], 0, 0, 0);
         if (rok) {
             const float rv = r ? r[row * H + h] : 0.f;
+            if (vec) {           // 4 consecutive output columns per lane and tile: 16-byte operands and stores
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int c = 16 * ct + 4 * lg;
+                    if (c >= C) continue;
+                    f32x4 o = acc[ct];
+                    if (bias) o += *reinterpret_cast<const f32x4*>(bias + h * bias_head_stride + c);
+                    if (r) o += (rv * u_scale) * *reinterpret_cast<const f32x4*>(u + h * u_head_stride + c);
+                    if (Cin) o += beta * *reinterpret_cast<const f32x4*>(Cin + row * ldc + h * C + c);
+                    *reinterpret_cast<f32x4*>(out + row * ldo + h * C + c) = o;
+                }
+                continue;
+            }
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -183,8 +208,10 @@ extern "C" int dif_rowgemm_f32(const float* A, int64_t lda, const float* Mat, in
     int64_t gx = (n_steps + 3) / 4;
     if (gx > 3 * dif::kCUs) gx = 3 * dif::kCUs;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    auto ok4 = [](const void* p, int64_t ld) { return !p || (ld % 4 == 0 && dif::aligned16(p)); };
+    const int vec = (K % 4 == 0) && (C % 4 == 0) && ok4(A, lda) && ok4(out, ldo) && ok4(Cin, ldc) && ok4(bias, 4) && ok4(u, 4);
     hipLaunchKernelGGL(rowgemm_kernel, dim3(static_cast<unsigned>(gx), H), dim3(256), 0, st, A, lda, K, Mat, ldm,
                        mat_head_stride, mat_t, mat_scale, bias, C, r, H, u, C, u_scale, Cin, ldc, beta_dev, n_rows, K, C, out,
-                       ldo);
+                       ldo, vec);
     return dif::launch_status("rowgemm_kernel");
 }

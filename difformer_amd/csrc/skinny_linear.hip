@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
                                                             const T* __restrict__ bias, int C_out,
                                                             const T* __restrict__ ln_w,
                                                             const T* __restrict__ ln_b, float eps, int relu,
-                                                            T* __restrict__ out, int64_t ldo, int vec, int ovec) {
+                                                            T* __restrict__ out, int64_t ldo, int vec, int ovec, int wvec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -46,6 +46,29 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
     float* sm_w = sm;                                       // [nblk*64][kLinStride], block-local row 16 (f%4) + (f%64)/4
     float* sm_b = sm + nblk * 64 * kLinStride;              // [nblk*64] bias in feature order
 
+    if (wvec) {
+        // 16-byte loads, eight in flight per thread before their LDS stores: the staging is the fixed cost of a launch
+        // (a 64 -> 192 projection of a Cora-sized graph spent 20 of its 27 us here with 4-byte loads)
+        constexpr int kC4 = kCW / 4;
+        const int units = nblk * 64 * kC4;
+        for (int base = threadIdx.x; base < units; base += 256 * 8) {
+            f32x4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + 256 * u;
+                const int f = e / kC4, c = 4 * (e % kC4);
+                wv[u] = (e < units && f0 + f < C_out && c < C_in) ? Elem<T>::ld4(W + static_cast<int64_t>(f0 + f) * C_in + c)
+                                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + 256 * u;
+                const int f = e / kC4, c = 4 * (e % kC4);
+                if (e < units)
+                    *reinterpret_cast<f32x4*>(&sm_w[((f & ~63) + 16 * (f & 3) + ((f & 63) >> 2)) * kLinStride + c]) = wv[u];
+            }
+        }
+    } else {
     // 8 loads in flight per thread before their LDS stores (a plain load -> store loop is 16 round trips per block)
     for (int base = threadIdx.x; base < nblk * 64 * kCW; base += 256 * 8) {
         float wv[8];
@@ -61,6 +84,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
             const int f = e / kCW, c = e % kCW;
             sm_w[((f & ~63) + 16 * (f & 3) + ((f & 63) >> 2)) * kLinStride + c] = wv[u];
         }
+    }
     }
     for (int f = threadIdx.x; f < nblk * 64; f += 256) sm_b[f] = (f0 + f < C_out) ? Elem<T>::ld(bias + f0 + f) : 0.f;
     __syncthreads();
@@ -183,8 +207,11 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
     const size_t lds = static_cast<size_t>(nblk) * 64 * (kLinStride + 1) * sizeof(float);
     const int vec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned_v4<T>(x);
     const int ovec = (ldo % 4 == 0) && dif::aligned_v4<T>(out);
+    const int wvec = (C_in % 4 == 0) && dif::aligned_v4<T>(W);
     const int64_t n_tiles = (n_rows + 15) / 16;
-    int64_t gx = (n_tiles + 15) / 16;                       // >= 4 row tiles per wave: the weight staging is amortised
+    int64_t gx = (n_tiles + 15) / 16;                       // >= 4 row tiles per wave: the weight staging is amortised ...
+    const int64_t one_each = (n_tiles + 3) / 4;             // ... unless the chip would sit idle: then one tile per wave
+    if (gx < dif::kCUs) gx = one_each < dif::kCUs ? one_each : dif::kCUs;
     const int64_t cap = (nblk <= 2 ? 4 : 2) * dif::kCUs;    // what the LDS footprint lets a CU hold
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
@@ -192,7 +219,7 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
     dim3 grid(static_cast<unsigned>(gx), gy), block(256);
 #define DIF_LIN(KQ) \
     hipLaunchKernelGGL((skinny_linear_kernel<KQ, T>), grid, block, lds, st, x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, \
-                       ln_bias, ln_eps, relu, out, ldo, vec, ovec)
+                       ln_bias, ln_eps, relu, out, ldo, vec, ovec, wvec)
     if (kq == 1) DIF_LIN(1);
     else if (kq == 2) DIF_LIN(2);
     else if (kq == 3) DIF_LIN(3);
