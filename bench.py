@@ -49,6 +49,11 @@ WORKLOADS = {
     # the C4 graph with a skewed (Zipf-like) degree profile, max / mean degree ~13 as in the real
     # ogbn-proteins (7750 / 597), to exercise the SpMM's load balance; not the headline line
     "ogbn-proteins-zipf-s": (132534, 39561252, 8, 112, 64, 4, "simple", True),
+    # the widths the reference's scripts train with (node classification/run.sh:42-44 hidden 128 on Pokec batches;
+    # image and text/run.sh:27 hidden 300): wider than the closed-form / fused-projection kernels (<= 64), so the
+    # projections run on the vendor GEMM and the attention on the stand-alone reduce / apply kernels
+    "pokec-batch-h128": (100000, 115000, 65, 2, 128, 3, "simple", True),
+    "cifar50k-h300": (50000, 0, 512, 10, 300, 4, "simple", False),
 }
 
 

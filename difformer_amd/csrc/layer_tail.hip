@@ -12,8 +12,9 @@ namespace {
 using dif::f32x4;
 using dif::Elem;
 
-// G lanes x 4 elements hold one row (D <= 4G, D % 4 == 0); 256/G rows per block.  T = float | dif::bf16 (storage).
-template <int G, typename T>
+// G lanes x V x 4 elements hold one row (D <= 4 G V, D % 4 == 0; V = 2 only with G = 64: rows of 260..512 elements, the
+// widths of image and text/run.sh); 256/G rows per block.  T = float | dif::bf16 (storage).
+template <int G, int V, typename T>
 __global__ __launch_bounds__(256) void layer_tail_vec_kernel(const T* __restrict__ conv, int64_t ldc,
                                                              int64_t n_rows, int H, int D,
                                                              const T* __restrict__ x0, int64_t ldx0,
@@ -23,41 +24,64 @@ __global__ __launch_bounds__(256) void layer_tail_vec_kernel(const T* __restrict
                                                              T* __restrict__ out, int64_t ldo) {
     constexpr int RPB = 256 / G;
     const int li = threadIdx.x % G;
-    const int col = 4 * li;
-    const bool active = col < D;
     const float inv_h = 1.0f / static_cast<float>(H);
     const float inv_d = 1.0f / static_cast<float>(D);
-    f32x4 w4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-    if (ln_w && active) { w4 = Elem<T>::ld4(ln_w + col); b4 = Elem<T>::ld4(ln_b + col); }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int col[V];
+    bool active[V];
+    f32x4 w4[V], b4[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        col[v] = 4 * (li + v * G);
+        active[v] = col[v] < D;
+        w4[v] = f32x4{1.f, 1.f, 1.f, 1.f};
+        b4[v] = zero;
+        if (ln_w && active[v]) { w4[v] = Elem<T>::ld4(ln_w + col[v]); b4[v] = Elem<T>::ld4(ln_b + col[v]); }
+    }
     const int64_t nrb = (n_rows + RPB - 1) / RPB;
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         const int64_t row = rb * RPB + threadIdx.x / G;
-        const bool ok = active && row < n_rows;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-            const T* c = conv + row * ldc + col;
-            for (int h = 0; h < H; ++h) z += Elem<T>::ld4(c + static_cast<int64_t>(h) * D);
-            if (H > 1) z *= inv_h;                                                  // :137
-            if (x0) z += Elem<T>::ld4(x0 + row * ldx0 + col);                       // :139-140
-            if (prev) z = alpha * z + (1.0f - alpha) * Elem<T>::ld4(prev + row * ldp + col);  // :201
+        f32x4 z[V];
+        bool ok[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            ok[v] = active[v] && row < n_rows;
+            z[v] = zero;
+            if (ok[v]) {
+                const T* c = conv + row * ldc + col[v];
+                for (int h = 0; h < H; ++h) z[v] += Elem<T>::ld4(c + static_cast<int64_t>(h) * D);
+                if (H > 1) z[v] *= inv_h;                                                              // :137
+                if (x0) z[v] += Elem<T>::ld4(x0 + row * ldx0 + col[v]);                                // :139-140
+                if (prev) z[v] = alpha * z[v] + (1.0f - alpha) * Elem<T>::ld4(prev + row * ldp + col[v]);  // :201
+            }
         }
         if (ln_w) {                                                                 // :202-203
-            float s = z[0] + z[1] + z[2] + z[3];
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) s += z[v][0] + z[v][1] + z[v][2] + z[v][3];
 #pragma unroll
             for (int m = 1; m < G; m <<= 1) s += __shfl_xor(s, m, 64);
             const float mu = s * inv_d;
-            f32x4 dz = ok ? (z - mu) : f32x4{0.f, 0.f, 0.f, 0.f};
-            float v = dz[0] * dz[0] + dz[1] * dz[1] + dz[2] * dz[2] + dz[3] * dz[3];
+            float var = 0.f;
 #pragma unroll
-            for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
-            const float rstd = 1.0f / sqrtf(v * inv_d + eps);
-            z = dz * rstd * w4 + b4;
-        }
-        if (relu) {
+            for (int v = 0; v < V; ++v) {
+                z[v] = ok[v] ? (z[v] - mu) : zero;
+                var += z[v][0] * z[v][0] + z[v][1] * z[v][1] + z[v][2] * z[v][2] + z[v][3] * z[v][3];
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) z[i] = fmaxf(z[i], 0.f);
+            for (int m = 1; m < G; m <<= 1) var += __shfl_xor(var, m, 64);
+            const float rstd = 1.0f / sqrtf(var * inv_d + eps);
+#pragma unroll
+            for (int v = 0; v < V; ++v) z[v] = z[v] * rstd * w4[v] + b4[v];
         }
-        if (ok) Elem<T>::st4(out + row * ldo + col, z);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (relu) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[v][i] = fmaxf(z[v][i], 0.f);
+            }
+            if (ok[v]) Elem<T>::st4(out + row * ldo + col[v], z[v]);
+        }
     }
 }
 
@@ -117,31 +141,34 @@ int layer_tail_entry(const T* conv, int64_t ldc, int64_t n_rows, int H, int D, c
                 "dif_layer_tail: leading dimension smaller than a row");
     DIF_REQUIRE(out != conv || H == 1, DIF_E_BADARG, "dif_layer_tail: in-place only for H == 1");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool vec = (D % 4 == 0) && D <= 256 && (ldc % 4 == 0) && (ldo % 4 == 0) && (!x0 || ldx0 % 4 == 0) &&
+    const bool vec = (D % 4 == 0) && D <= 512 && (ldc % 4 == 0) && (ldo % 4 == 0) && (!x0 || ldx0 % 4 == 0) &&
                      (!prev || ldp % 4 == 0) && dif::aligned_v4<T>(conv) && dif::aligned_v4<T>(out) &&
                      (!x0 || dif::aligned_v4<T>(x0)) && (!prev || dif::aligned_v4<T>(prev)) &&
                      (!ln_weight || (dif::aligned_v4<T>(ln_weight) && dif::aligned_v4<T>(ln_bias)));
     // the generic kernel re-reads its inputs after writing `out`: no aliasing there
     DIF_REQUIRE(vec || (out != conv && out != x0 && out != prev), DIF_E_BADARG,
-                "dif_layer_tail: in-place needs D % 4 == 0, D <= 256 and aligned rows");
+                "dif_layer_tail: in-place needs D % 4 == 0, D <= 512 and aligned rows");
     const int64_t cap = 8 * dif::kCUs;
     if (vec) {
         const int q = D / 4;
-#define DIF_TAIL(G)                                                                                            \
+#define DIF_TAIL2(G, V)                                                                                        \
     do {                                                                                                       \
         int64_t gx = (n_rows + (256 / G) - 1) / (256 / G);                                                     \
         if (gx > cap) gx = cap;                                                                                \
-        hipLaunchKernelGGL((layer_tail_vec_kernel<G, T>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, \
+        hipLaunchKernelGGL((layer_tail_vec_kernel<G, V, T>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, \
                            ldc, n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, relu, out, ldo); \
     } while (0)
+#define DIF_TAIL(G) DIF_TAIL2(G, 1)
         if (q <= 1) DIF_TAIL(1);
         else if (q <= 2) DIF_TAIL(2);
         else if (q <= 4) DIF_TAIL(4);
         else if (q <= 8) DIF_TAIL(8);
         else if (q <= 16) DIF_TAIL(16);
         else if (q <= 32) DIF_TAIL(32);
-        else DIF_TAIL(64);
+        else if (q <= 64) DIF_TAIL(64);
+        else DIF_TAIL2(64, 2);
 #undef DIF_TAIL
+#undef DIF_TAIL2
     } else {
         int64_t gx = (n_rows + 3) / 4;
         if (gx > cap) gx = cap;

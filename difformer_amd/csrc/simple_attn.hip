@@ -345,6 +345,105 @@ __global__ __launch_bounds__(256) void simple_apply_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// apply for wide heads (64 < M <= 512, any D): the widths the reference's scripts train with (run.sh: hidden 128, 300,
+// 400).  A workgroup owns 64 output columns (grid.y) and keeps s * KtV[:, those columns] TRANSPOSED in LDS for the whole
+// sweep (row d holds the M contraction values contiguously, +4 floats of padding: the 16 lanes of a ds_read_b128 phase
+// hit 16 different bank quads), so the A operand of every MFMA comes from one 16-byte LDS read per four k-steps and the
+// only global traffic in the loop is q (read once per 64 output columns) and the output tile.
+// ------------------------------------------------------------------------------------------
+constexpr int kWideWaves = 8;
+
+template <bool VEC, typename T>
+__global__ __launch_bounds__(64 * kWideWaves) void simple_apply_wide_kernel(const T* __restrict__ q, int64_t ldq,
+                                                                            const float* __restrict__ reduced,
+                                                                            int64_t n_rows, float n_global, Shape sh,
+                                                                            T* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float sm_dyn[];
+    const int h = blockIdx.z, dt = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int Mp = sh.MT * kTile, ldt = Mp + 4;
+    float* smT = sm_dyn;                       // [64][ldt]: smT[dl][m] = s * KtV[m][64 dt + dl]
+    float* sm_ks = sm_dyn + kTile * ldt;       // [Mp]: s * ksum
+    const float* ktv = reduced + static_cast<int64_t>(h) * sh.M * sh.D;
+    const float* ksum = reduced + sh.H * sh.M * sh.D + h * sh.M;
+    const float* vsum = reduced + sh.H * sh.M * sh.D + sh.H * sh.M + h * sh.D;
+    const float s = 1.0f / (sqrtf(reduced[sh.t_main]) * sqrtf(reduced[sh.t_main + 1]));
+    const int total = Mp * kTile;
+    for (int base = threadIdx.x; base < total; base += 64 * kWideWaves * 8) {      // eight loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + 64 * kWideWaves * u;
+            const int m = e >> 6, d = dt * kTile + (e & 63);
+            v[u] = (e < total && m < sh.M && d < sh.D) ? s * ktv[static_cast<int64_t>(m) * sh.D + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + 64 * kWideWaves * u;
+            if (e < total) smT[(e & 63) * ldt + (e >> 6)] = v[u];
+        }
+    }
+    for (int m = threadIdx.x; m < Mp; m += 64 * kWideWaves) sm_ks[m] = (m < sh.M) ? s * ksum[m] : 0.f;
+    __syncthreads();
+
+    const int64_t n_steps = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kWideWaves + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kWideWaves;
+    auto load_q = [&](f32x4 (&qv)[4], int64_t st, int mt) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            qv[c] = load_row4<VEC>(q, ldq, st * 16 + l15, n_rows, h * sh.M, mt * kTile + 16 * c + 4 * lg, sh.M);
+    };
+    f32x4 qn[4];
+    if (first < n_steps) load_q(qn, first, 0);
+    for (int64_t st = first; st < n_steps; st += stride) {
+        const int64_t r = st * 16 + l15;
+        f32x4 acc[4];
+#pragma unroll
+        for (int dtl = 0; dtl < 4; ++dtl) acc[dtl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float dpart = 0.f;
+        for (int mt = 0; mt < sh.MT; ++mt) {
+            f32x4 qv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qv[c] = qn[c];
+            if (mt + 1 < sh.MT) load_q(qn, st, mt + 1);                 // the next 64 channels arrive under these MFMAs
+            else if (st + stride < n_steps) load_q(qn, st + stride, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int m0 = mt * kTile + 16 * c + 4 * lg;
+#pragma unroll
+                for (int dtl = 0; dtl < 4; ++dtl) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&smT[(16 * dtl + l15) * ldt + m0]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[dtl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[t], qv[c][t], acc[dtl], 0, 0, 0);
+                }
+                const f32x4 k4 = *reinterpret_cast<const f32x4*>(&sm_ks[m0]);
+                dpart += qv[c][0] * k4[0] + qv[c][1] * k4[1] + qv[c][2] * k4[2] + qv[c][3] * k4[3];
+            }
+        }
+        dpart += __shfl_xor(dpart, 16, 64);
+        dpart += __shfl_xor(dpart, 32, 64);
+        const float den = dpart + n_global;                              // difformer.py:37-38
+        if (r < n_rows) {
+#pragma unroll
+            for (int dtl = 0; dtl < 4; ++dtl) {
+                const int d0 = dt * kTile + 16 * dtl + 4 * lg;
+                T* o = out + r * ldo + h * sh.D + d0;
+                if (VEC) {
+                    if (d0 < sh.D) Elem<T>::st4(o, (acc[dtl] + *reinterpret_cast<const f32x4*>(vsum + d0)) / den);   // :29, :39
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (d0 + i < sh.D) Elem<T>::st(o + i, (acc[dtl][i] + vsum[d0 + i]) / den);
+                }
+            }
+        }
+    }
+}
+
 int reduce_chunks(int64_t n_rows) {
     const int64_t n_iters = ((n_rows + 3) / 4 + kRedUnroll - 1) / kRedUnroll;
     int64_t p = (n_iters + kRedWaves - 1) / kRedWaves;
@@ -404,6 +503,30 @@ int simple_apply_entry(const T* q, int64_t ldq, const float* reduced, int64_t n_
                      dif::aligned_v4<T>(out) && dif::aligned16(reduced) && ((H * M * D + H * M) % 4 == 0);
     const bool single = (sh.MT == 1 && sh.DT == 1);
     const int64_t n_steps = (n_rows + 15) / 16;
+    if (!single && sh.MT <= 8) {              // wide heads: 64 output columns per workgroup, s * KtV^T resident in LDS
+        const size_t lds = (static_cast<size_t>(kTile) * (sh.MT * kTile + 4) + sh.MT * kTile) * sizeof(float);
+        int64_t gxw = (n_steps + 2 * kWideWaves - 1) / (2 * kWideWaves);       // >= 2 steps per wave: the staging is amortised
+        const int64_t capw = (lds <= 80 * 1024 ? 2 : 1) * dif::kCUs;
+        if (gxw > capw) gxw = capw;
+        if (gxw < 1) gxw = 1;
+        hipStream_t stw = static_cast<hipStream_t>(stream);
+        dim3 gridw(static_cast<unsigned>(gxw), sh.DT, H), blockw(64 * kWideWaves);
+        const float nfw = static_cast<float>(n_global);
+        // dynamic LDS beyond 64 KiB must be allowed once per kernel (set to the largest case, M = 512)
+        constexpr int kWideLdsMax = (kTile * (8 * kTile + 4) + 8 * kTile) * static_cast<int>(sizeof(float));
+        static const hipError_t allowed[2] = {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_apply_wide_kernel<false, T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kWideLdsMax),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_apply_wide_kernel<true, T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kWideLdsMax)};
+        const hipError_t he = allowed[vec ? 1 : 0];
+        if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_simple_apply: LDS attribute: %s", hipGetErrorString(he));
+        if (vec)
+            hipLaunchKernelGGL((simple_apply_wide_kernel<true, T>), gridw, blockw, lds, stw, q, ldq, reduced, n_rows, nfw, sh, out, ldo);
+        else
+            hipLaunchKernelGGL((simple_apply_wide_kernel<false, T>), gridw, blockw, lds, stw, q, ldq, reduced, n_rows, nfw, sh, out, ldo);
+        return dif::launch_status("simple_apply_wide_kernel");
+    }
     int64_t gx = (n_steps + 3) / 4;
     const int64_t cap = 3 * dif::kCUs;  // persistent: the per-wave fragment prologue is paid once per ~3+ steps
     if (gx > cap) gx = cap;

@@ -1320,3 +1320,27 @@ def test_linear_weight_gradient_through_the_reduce_kernel(n, ci, co):
     assert rel_err(y.detach().cpu().numpy(), y64.detach().numpy()) < 1e-5
     for got, want in ((xd, x64), (wd, w64), (bd, b64)):
         assert rel_err(got.grad.cpu().numpy(), want.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("n,h,m,d,bf16", [(20000, 1, 400, 400, False), (3000, 2, 128, 128, False), (5000, 1, 512, 64, False),
+                                          (4000, 1, 96, 200, False), (2500, 1, 300, 300, True), (9000, 3, 68, 132, False),
+                                          (700, 1, 130, 70, False)])
+def test_simple_apply_wide_heads(n, h, m, d, bf16, dev):
+    """Stage 2 (difformer.py:29-39) for the widths the scripts train with (run.sh: 128 / 300 / 400): the workgroup keeps
+    s * KtV^T for 64 output columns in LDS.  M != D and ragged widths included; checked against the float64 oracle fed
+    with the stage-1 record it implies (so only stage 2 is under test)."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + m + d)
+    q, k = (torch.randn(n, h, m, generator=g) for _ in range(2))
+    v = torch.randn(n, h, d, generator=g)
+    if bf16:
+        q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    be = ops.get_backend()
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    rec = be.simple_reduce(qd, kd, vd)
+    out = be.simple_apply(qd, rec, n, d).float().cpu().numpy()
+    q64, k64, v64 = (t.double().numpy() for t in (q.float(), k.float(), v.float()))
+    s = 1.0 / (np.linalg.norm(q64) * np.linalg.norm(k64))
+    num = s * np.einsum("nhm,hmd->nhd", q64, np.einsum("lhm,lhd->hmd", k64, v64)) + v64.sum(0)
+    den = s * np.einsum("nhm,hm->nh", q64, k64.sum(0)) + n
+    assert rel_err(out, num / den[..., None]) < (2e-2 if bf16 else TOL)
