@@ -94,6 +94,36 @@ def cpu_baseline(model, x, edge_index, cfg, repeats=3):
                       f"graph, 1 warm-up + {repeats} timed runs: median {med:.2f} s (min {min(times):.2f}, max {max(times):.2f})"}
 
 
+def shard_plan(workload, world, rank):
+    """What rank `rank` of `world` processes: C5 mini-batches are independent -> every GPU runs its own batch (replicas,
+    weak scaling, no collective); every other workload is ONE graph whose node rows are split into contiguous blocks
+    (strong scaling; per layer one all-reduce of the 4,226-float record and one all-gather of the rows)."""
+    from difformer_amd.dist import split_rows
+    n = WORKLOADS[workload][0]
+    replicas = world > 1 and workload.startswith("pokec-batch")
+    if world == 1 or replicas:
+        begin, count = 0, n
+    else:
+        counts = split_rows(n, world)
+        begin, count = sum(counts[:rank]), counts[rank]
+    return {"replicas": replicas, "row_begin": begin, "n_local": count, "scaling": "weak" if replicas else "strong",
+            "parallelism": (f"replicas x{world}" if replicas else f"row-shard x{world}") if world > 1 else "single GPU"}
+
+
+def max_over_ranks(seconds, device):
+    """The job is as slow as its slowest rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_value(n, steps, elapsed, world, replicas):
+    """Whole-job nodes per second: replicas each push their own n nodes per step, a sharded graph is one set of n."""
+    return n * steps / elapsed * (world if replicas else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,8 +162,10 @@ def main():
     nnz = 0 if edge_index is None else int(edge_index.shape[1])
 
     # C5: mini-batches are independent -> every GPU runs its own batch, no collective (replicas)
-    replicas = world > 1 and args.workload.startswith("pokec-batch")
+    plan = shard_plan(args.workload, world, rank)
+    replicas = plan["replicas"]
     shard = RowShard.from_process_group(n) if (world > 1 and not replicas) else None
+    assert shard is None or (shard.row_begin, shard.n_local) == (plan["row_begin"], plan["n_local"])
     x = x_full if shard is None else shard.local_rows(x_full).contiguous()
     if shard is not None:
         model.set_row_shard(shard)
@@ -190,13 +222,10 @@ def main():
         fwd_ms = sorted(a.elapsed_time(b) for a, b in fwd_events)
     ktimes = be.kernel_times_ms()
     be.kernel_events = None
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(elapsed, dev)
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = n * args.steps / elapsed * (world if replicas else 1)
+    value = job_value(n, args.steps, elapsed, world, replicas)
 
     # roofline of the dominant kernel on this rank
     if use_graph:
@@ -206,9 +235,15 @@ def main():
             dom, dom_name, dom_key = "dif_sliced_spmm_f32", "sliced_spmm_kernel (gcn_conv)", "sliced_spmm_kernel"
         else:
             dom, dom_name, dom_key = "dif_gcn_spmm_f32", "spmm_blocked_kernel (gcn_conv)", "spmm_blocked_kernel"
+    elif kernel == "simple" and ktimes.get("dif_simple_layer_f32"):
+        # closed-form layer: reads the layer input once, writes the output once (SURVEY 8d counts q, k, v, out: 4 N d s;
+        # q, k, v never exist here)
+        dom, alg_bytes, dom_key = "dif_simple_layer_f32", 2.0 * n_local * hidden * 4, "simple_layer_kernel"
+        dom_name = "simple_layer_kernel (closed-form simple layer)"
     elif kernel == "simple":
-        dom, alg_bytes, dom_key = "dif_project_reduce_f32", 3.0 * n_local * hidden * 4, "project_reduce_kernel"
-        dom_name = "project_reduce_kernel (+finalize)"
+        esz = 2 if store == torch.bfloat16 else 4
+        dom, alg_bytes, dom_key = "dif_simple_apply_f32", 2.0 * n_local * hidden * esz, "simple_apply_kernel"
+        dom_name = "simple_apply_kernel"
     else:
         dom, alg_bytes, dom_key = "dif_sigmoid_attn_f32", 4.0 * n_local * hidden * 4, "sigmoid_attn_kernel"
         dom_name = "sigmoid_attn_kernel"
@@ -248,10 +283,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "ms_per_step_events": {"median": fwd_ms[len(fwd_ms) // 2], "min": fwd_ms[0], "max": fwd_ms[-1], "n": len(fwd_ms)},
             "higher_is_better": True,
-            "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": "bf16" if store == torch.bfloat16 else "f32", "data": "synthetic",
+            "scaling": plan["scaling"], "vs_baseline": None, "dtype": "bf16" if store == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "nodes": n, "csr_entries": nnz, "in_channels": f_in,
                        "hidden": hidden, "heads": 1, "layers": layers, "kernel": kernel, "use_graph": use_graph,
-                       "parallelism": (f"replicas x{world}" if replicas else f"row-shard x{world}") if world > 1 else "single GPU",
+                       "parallelism": plan["parallelism"],
                        "csr": "warm (cached); cold build reported in cold_csr_build_ms",
                        "launch": "hipGraph replay" if use_graph_replay else "eager"},
             "cold_csr_build_ms": cold_ms, "roofline": roofline, "cpu_baseline": cpu,

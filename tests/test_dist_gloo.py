@@ -89,3 +89,58 @@ def test_row_sharded_forward_matches_single_process(kernel, world, n, heads):
         assert shape == (counts[rank], 5)
         assert gathered_ok
         assert err < 1e-5, (rank, err)
+
+
+def _bench_worker(rank, world, port, out_q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from difformer_amd import RowShard
+        res = {}
+        for wl in ("ogbn-proteins-s", "pokec-batch-s-bf16", "cifar50k-s"):
+            plan = bench.shard_plan(wl, world, rank)
+            n = bench.WORKLOADS[wl][0]
+            if not plan["replicas"]:                     # the plan is what RowShard hands the model
+                sh = RowShard.from_process_group(n)
+                assert (sh.row_begin, sh.n_local) == (plan["row_begin"], plan["n_local"])
+            elapsed = bench.max_over_ranks(0.1 * (rank + 1), torch.device("cpu"))       # rank r "took" 0.1 (r + 1) s
+            res[wl] = (plan, elapsed, bench.job_value(n, 10, elapsed, world, plan["replicas"]))
+        out_q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_sharding_arithmetic_dry_run(world):
+    """bench.py --gpus N without GPUs: which rows each rank takes, max-over-ranks timing and the whole-job value."""
+    import bench
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for wl in ("ogbn-proteins-s", "cifar50k-s"):                     # one graph, rows split: strong scaling
+        n = bench.WORKLOADS[wl][0]
+        spans = sorted((got[r][wl][0]["row_begin"], got[r][wl][0]["n_local"]) for r in range(world))
+        assert spans[0][0] == 0 and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert spans[-1][0] + spans[-1][1] == n and min(c for _, c in spans) > 0
+        for r in range(world):
+            plan, elapsed, value = got[r][wl]
+            assert plan["scaling"] == "strong" and plan["parallelism"] == f"row-shard x{world}"
+            assert abs(elapsed - 0.1 * world) < 1e-9 and abs(value - n * 10 / (0.1 * world)) < 1e-3
+    for r in range(world):                                            # independent batches: replicas, weak scaling
+        plan, elapsed, value = got[r]["pokec-batch-s-bf16"]
+        n = bench.WORKLOADS["pokec-batch-s-bf16"][0]
+        assert plan["replicas"] and plan["scaling"] == "weak" and (plan["row_begin"], plan["n_local"]) == (0, n)
+        assert abs(value - world * n * 10 / (0.1 * world)) < 1e-3
+    one = bench.shard_plan("ogbn-proteins-s", 1, 0)
+    assert one["parallelism"] == "single GPU" and one["n_local"] == 132534
