@@ -177,7 +177,7 @@ def test_sliced_is_declined_for_weights_and_sparse_graphs(dev):
     assert ops.csr_cache.get(sparse, None, n, 256).sliced(0, n, 64) is None      # ~5 entries per row
 
 
-@pytest.mark.parametrize("n,deg,hubs", [(12000, 64, 40), (30000, 80, 7), (64000, 50, 2000)])
+@pytest.mark.parametrize("n,deg,hubs", [(12000, 64, 40), (30000, 80, 7), (64000, 50, 2000), (20000, 100, 2)])
 def test_sliced_product_on_skewed_degrees(n, deg, hubs, dev):
     """Hub rows (up to ~170k entries, i.e. beyond 16-bit counters per tile only if a tile held > 65,535 of them) and a
     long tail of short rows in the same launch: results against the float64 oracle and the gather kernel."""
@@ -193,6 +193,8 @@ def test_sliced_product_on_skewed_degrees(n, deg, hubs, dev):
     assert rel_err(out.cpu().numpy(), ref) < 1e-5
     if hubs >= 40:
         assert sl is not None and sl.order is not None
+    if hubs == 2:
+        assert sl is None          # 500,000 entries on one row: a (row, tile) group beyond the 16-bit counters -> gather kernels
     assert torch.equal(gcn_conv(xd, eid, None), out)
 
 
