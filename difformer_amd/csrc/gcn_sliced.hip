@@ -389,21 +389,27 @@ struct Epilogue {
     int64_t ldo;
 };
 
-// four entries (two packed dwords): 16-bit row number -> LDS byte address with one SDWA shift each
-__device__ __forceinline__ void half_block(const f32x4* tile, uint32_t w0, uint32_t w1, f32x4& a) {
+// one block of a round: eight entries (four packed dwords), 16-bit row number -> LDS byte address with one SDWA shift
+// each; the entry register is reloaded (its next block) as soon as the addresses are out, BEFORE the LDS reads, so the
+// load has the whole block in flight even in the phases where few rounds are active
+__device__ __forceinline__ void block8(const f32x4* tile, uint4& e, const uint4* reload, f32x4& a) {
     const uint32_t four = 4;
-    const uint32_t wds[2] = {w0, w1};
+    const uint32_t wds[4] = {e.x, e.y, e.z, e.w};
+    uint32_t ad[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+            : "=v"(ad[2 * q]) : "v"(four), "v"(wds[q]));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+            : "=v"(ad[2 * q + 1]) : "v"(four), "v"(wds[q]));
+    }
+    e = *reload;
     f32x4 v[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        uint32_t lo, hi;
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
-            : "=v"(lo) : "v"(four), "v"(wds[q]));
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-            : "=v"(hi) : "v"(four), "v"(wds[q]));
-        v[2 * q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + lo);
-        v[2 * q + 1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + hi);
-    }
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[q]);
+    a += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[4 + q]);
     a += (v[0] + v[1]) + (v[2] + v[3]);
 }
 
@@ -418,9 +424,7 @@ struct Phases {
             const uint4* nx = cur + M * 64;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                half_block(tile, e[j].x, e[j].y, acc[j]);
-                half_block(tile, e[j].z, e[j].w, acc[j]);
-                e[j] = nx[j * 64];          // reloaded right after its last use; next use is a whole block row away
+                block8(tile, e[j], nx + j * 64, acc[j]);      // reloaded inside; next use is a whole block row away
                 __builtin_amdgcn_sched_barrier(0);
             }
             cur = nx;
@@ -429,9 +433,7 @@ struct Phases {
             const uint4* nx = cur + M * 64;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                half_block(tile, e[j].x, e[j].y, acc[j]);
-                half_block(tile, e[j].z, e[j].w, acc[j]);
-                e[j] = *((nb[j] > k + 1) ? nx + j * 64 : cur);      // a finished round re-reads a block that exists
+                block8(tile, e[j], (nb[j] > k + 1) ? nx + j * 64 : cur, acc[j]);      // a finished round re-reads a block that exists
                 __builtin_amdgcn_sched_barrier(0);
             }
             cur = nx;
@@ -451,13 +453,15 @@ struct Phases<0, NR> {
 template <int NR>
 __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell, const int32_t* __restrict__ tabw,
                                       int64_t tab_stride, const f32x4* __restrict__ ysl, const Plan pl, const Epilogue ep,
-                                      int pw, int slice, int lane) {
+                                      int pw, int slice, int lane, int t0) {
     constexpr int NA = NR > 0 ? NR : 1;
     const int T = pl.T;
     f32x4 acc[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < pl.NT; ++t) {
+    for (int tt = 0; tt < pl.NT; ++tt) {
+        int t = tt + t0;                                                      // XCDs start on different tiles (t0)
+        if (t >= pl.NT) t -= pl.NT;
         uint4 e[NA];
         int nb[NA];
         const uint4* cur = ell;
@@ -470,23 +474,36 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
                 e[j] = *((nb[j] > 0) ? cur + j * 64 : ell);                  // in flight across the tile load
             }
         }
-        __syncthreads();                                                      // everyone is done with the previous tile
         {
+            // The tile's first loads are issued BEFORE the barrier (they land in registers, not in LDS), so their latency
+            // runs under the wait for the slowest wave of the previous tile; the registers written first take the tail
+            // rows.  Wave-uniform bases + one shared lane offset keep the addressing in scalar registers.
+            constexpr int U = NR >= 10 ? 4 : (NR == 9 ? 7 : (NR == 8 ? 9 : 11)), X = 11 - U;
             const f32x4* src = ysl + static_cast<int64_t>(t) * T;
             const int nth = blockDim.x;
-            for (int b0 = threadIdx.x; b0 < T; b0 += 5 * nth) {              // batches of five 16-byte loads per thread
-                f32x4 r[5];
+            const uint32_t tid = threadIdx.x;
+            f32x4 r[U];
 #pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const int i = b0 + u * nth;
-                    r[u] = i < T ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+            for (int u = 0; u < U; ++u) {
+                const f32x4* su = src + u * nth;
+                r[u] = (u * nth + static_cast<int>(tid) < T) ? su[tid] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();                                                  // everyone is done with the previous tile
 #pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const int i = b0 + u * nth;
-                    if (i < T) tile[i] = r[u];
+            for (int u = 0; u < U; ++u) {
+                f32x4* du = tile + u * nth;
+                if (u * nth + static_cast<int>(tid) < T) du[tid] = r[u];
+                if (u < X) {
+                    const f32x4* su = src + (U + u) * nth;
+                    r[u] = ((U + u) * nth + static_cast<int>(tid) < T) ? su[tid] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+#pragma unroll
+            for (int u = 0; u < X; ++u) {
+                f32x4* du = tile + (U + u) * nth;
+                if ((U + u) * nth + static_cast<int>(tid) < T) du[tid] = r[u];
+            }
+            for (int b0 = static_cast<int>(tid) + 11 * nth; b0 < T; b0 += nth) tile[b0] = src[b0];      // fewer than 15 waves
         }
         // The tile loads sit under exec masks, so the compiler's wait-count model would carry them as "possibly
         // pending" into every phase loop and wait for ALL loads at the top of each block row.  They are complete here
@@ -517,12 +534,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void sliced_spmm_kernel(const uint4
                                                                      Epilogue ep) {
     __shared__ f32x4 tile[kLdsRows];
     const int b = blockIdx.x;
-    int panel, slice;
+    int panel, slice, t0 = 0;
     const int per = gridDim.x >> 3;
     if ((gridDim.x & 7) == 0 && per % pl.slices == 0) {      // the slices of a panel share an XCD (block b -> XCD b % 8)
         const int xcd = b & 7, k = b >> 3;
         panel = xcd * (per / pl.slices) + k / pl.slices;
         slice = k % pl.slices;
+        t0 = (xcd * pl.NT) >> 3;                             // XCDs start on different tiles: their tile loads do not coincide
     } else {
         panel = b / pl.slices;
         slice = b % pl.slices;
@@ -535,8 +553,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void sliced_spmm_kernel(const uint4
     const int64_t tab_stride = static_cast<int64_t>(pl.W) * (pl.R + 1);
     const int pw = w * pl.panels + panel;
     const bool full = slot_of(R - 1, pw, pl.PW) < pl.G;      // rounds of this wave: R or R - 1
-    if (full) sweep<R>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane);
-    else sweep<R - 1>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane);
+    if (full) sweep<R>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane, t0);
+    else sweep<R - 1>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane, t0);
 }
 
 template <int R>
