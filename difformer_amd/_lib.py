@@ -67,12 +67,13 @@ SIGNATURES = {
                                      c_i64, c_int, c_f32, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                                      c_vp, c_sz, c_vp]),
     "dif_sliced_plan": (c_int, [c_i64, c_i64, c_int, c_vp]),
-    "dif_sliced_measure": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                   c_vp, c_vp]),
-    "dif_sliced_emit": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "dif_sliced_measure": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                   c_vp, c_vp, c_vp, c_vp]),
+    "dif_sliced_emit": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64,
+                                c_vp, c_vp]),
     "dif_sliced_prescale_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
-    "dif_sliced_spmm_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_i64,
-                                    c_f32, c_f32, c_vp, c_i64, c_vp]),
+    "dif_sliced_spmm_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp,
+                                    c_i64, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "dif_row_order_workspace_bytes": (c_sz, [c_i64]),
     "dif_row_order": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_layer_tail_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,

@@ -560,22 +560,25 @@ class HipBackend:
         rc = self.lib.dif_sliced_plan(int(n_src), int(n_rows), int(F), plan)
         return plan if rc == 0 else None
 
-    def sliced_build(self, rowptr, blkptr, src, n_src, nnz, row_begin, n_rows, F, plan, order=None):
-        """-> (entries uint16 [512 * n_blocks], table int32) or None when a (row, tile) group exceeds the 16-bit
-        counters.  order: the shard's rows by descending degree (row_order) for skewed graphs, None = natural order.
-        Two host syncs (status, block count): cold path, once per (graph, shard, F)."""
-        dev = _require_device(rowptr, blkptr, src, order)
+    def sliced_build(self, rowptr, blkptr, src, n_src, nnz, row_begin, n_rows, F, plan, order=None, parts=None, n_pos=None):
+        """-> (entries uint16 [512 * n_blocks], table int32) or None when a (row position, tile) group exceeds the 16-bit
+        counters.  order: the shard's rows by descending degree (row_order) for skewed graphs, None = natural order;
+        parts (uint16 [n_pos], with order int32 [n_pos]): hub rows split into lock-step parts (include/difformer_hip.h,
+        "row positions"); plan = sliced_plan(n_src, n_pos, F).  Two host syncs (status, block count): cold path, once
+        per (graph, shard, F)."""
+        dev = _require_device(rowptr, blkptr, src, order, parts)
+        n_pos = int(n_rows) if n_pos is None else int(n_pos)
         slices, panels, G, PW, W, R, T, NT = (int(v) for v in plan)
         i32 = dict(dtype=torch.int32, device=dev)
         srt = torch.empty(max(int(nnz), 1), dtype=torch.int16, device=dev)
-        counts = torch.empty(int(n_rows) * NT * 32, dtype=torch.uint8, device=dev)
+        counts = torch.empty(n_pos * NT * 32, dtype=torch.uint8, device=dev)
         lengths = torch.empty(G * NT * 4, **i32)
         table = torch.empty((R + 1) * panels * NT * W + 1, **i32)
         status = torch.empty(1, **i32)
         with _Timed(self, "dif_sliced_measure", dev):
             rc = self.lib.dif_sliced_measure(_ptr(rowptr), _ptr(blkptr), _ptr(src), int(n_src), int(nnz), int(row_begin),
-                                             int(n_rows), int(F), plan, _ptr(order), _ptr(srt), _ptr(counts), _ptr(lengths),
-                                             _ptr(table), _ptr(status), _stream(dev))
+                                             int(n_rows), int(F), plan, _ptr(order), _ptr(parts), n_pos, _ptr(srt),
+                                             _ptr(counts), _ptr(lengths), _ptr(table), _ptr(status), _stream(dev))
         _lib.check(rc, "dif_sliced_measure")
         bad, n_blocks = (int(v) for v in torch.stack([status[0], table[-1]]).tolist())
         if bad:
@@ -583,8 +586,8 @@ class HipBackend:
         entries = torch.empty(512 * max(n_blocks, 1), dtype=torch.int16, device=dev)
         with _Timed(self, "dif_sliced_emit", dev):
             rc = self.lib.dif_sliced_emit(_ptr(rowptr), _ptr(blkptr), int(n_src), int(row_begin), int(n_rows), int(F), plan,
-                                          _ptr(order), _ptr(srt), _ptr(counts), _ptr(table), max(n_blocks, 1), _ptr(entries),
-                                          _stream(dev))
+                                          _ptr(order), _ptr(parts), n_pos, _ptr(srt), _ptr(counts), _ptr(table),
+                                          max(n_blocks, 1), _ptr(entries), _stream(dev))
         _lib.check(rc, "dif_sliced_emit")
         return entries, table
 
@@ -603,9 +606,9 @@ class HipBackend:
         _lib.check(rc, "dif_sliced_prescale_f32")
         return ys
 
-    def sliced_spmm(self, entries, table, plan, ys, rowptr, n_src, row_begin, n_rows, F, attn=None, attn_scale=1.0,
-                    gcn_scale=1.0, order=None, dinv=None):
-        dev = _require_device(entries, table, ys, rowptr, attn, order, dinv)
+    def sliced_spmm(self, sl, ys, rowptr, n_src, row_begin, n_rows, F, attn=None, attn_scale=1.0, gcn_scale=1.0, dinv=None):
+        """sl: the format (ops.SlicedAdjacency: entries, table, plan, order, parts, n_pos) built for these rows."""
+        dev = _require_device(sl.entries, sl.table, ys, rowptr, attn, sl.order, sl.parts, dinv)
         lda = 0
         if attn is not None:
             _f32(attn, "attn")
@@ -613,10 +616,12 @@ class HipBackend:
             if lda % 4 or attn.data_ptr() % 16:
                 attn, lda = attn.contiguous(), F
         out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
+        n_pos = int(n_rows) if sl.n_pos is None else int(sl.n_pos)
         with _Timed(self, "dif_sliced_spmm_f32", dev):
-            rc = self.lib.dif_sliced_spmm_f32(_ptr(entries), _ptr(table), plan, _ptr(ys), _ptr(rowptr), _ptr(dinv), _ptr(order),
-                                              int(n_src), int(row_begin), int(n_rows), int(F), _ptr(attn), lda,
-                                              float(attn_scale), float(gcn_scale), _ptr(out), F, _stream(dev))
+            rc = self.lib.dif_sliced_spmm_f32(_ptr(sl.entries), _ptr(sl.table), sl.plan, _ptr(ys), _ptr(rowptr), _ptr(dinv),
+                                              _ptr(sl.order), _ptr(sl.parts), n_pos, int(n_src), int(row_begin), int(n_rows),
+                                              int(F), _ptr(attn), lda, float(attn_scale), float(gcn_scale), _ptr(out), F,
+                                              _stream(dev))
         _lib.check(rc, "dif_sliced_spmm_f32")
         return out
 

@@ -97,6 +97,24 @@ __device__ __forceinline__ void group_bounds(const int32_t* __restrict__ rowptr,
     else { e0 = blkptr[static_cast<int64_t>(t) * n_src + row]; e1 = blkptr[static_cast<int64_t>(t + 1) * n_src + row]; }
 }
 
+// A row POSITION is a whole destination row, or -- when `parts` is given -- part p of P of one (a hub row split over P
+// consecutive lanes of one slot: in every tile part p takes the p-th of P equal shares of the row's entries), or
+// empty (order[pos] < 0: padding so that the parts of a row never straddle a slot).  parts[pos] = p | P << 8.
+__device__ __forceinline__ void position_bounds(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr,
+                                                int64_t n_src, int NT, int64_t row_begin, const int32_t* __restrict__ order,
+                                                const uint16_t* __restrict__ parts, int64_t pos, int t, int32_t& e0,
+                                                int32_t& e1) {
+    const int64_t lrow = order ? order[pos] : pos;
+    if (lrow < 0) { e0 = e1 = 0; return; }
+    group_bounds(rowptr, blkptr, n_src, NT, row_begin + lrow, t, e0, e1);
+    if (parts) {
+        const uint32_t pp = parts[pos];
+        const int64_t p = pp & 0xffu, P = pp >> 8, c = e1 - e0;
+        e1 = e0 + static_cast<int32_t>(c * (p + 1) / P);
+        e0 = e0 + static_cast<int32_t>(c * p / P);
+    }
+}
+
 struct Counts { uint64_t w[4]; };
 
 // exclusive starts of the 16 buckets: lane k of c * 0x0001000100010001 = sum of lanes 0..k (no carries: total <= 65535)
@@ -139,16 +157,16 @@ __device__ __forceinline__ Counts load_counts(const uint4* __restrict__ cnt, int
 
 __global__ __launch_bounds__(256) void sliced_sort_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr,
                                                           const int32_t* __restrict__ src, int64_t n_src, int NT, int T,
-                                                          int64_t row_begin, int64_t n_rows, const int32_t* __restrict__ order,
+                                                          int64_t row_begin, int64_t n_pos, const int32_t* __restrict__ order,
+                                                          const uint16_t* __restrict__ parts,
                                                           uint16_t* __restrict__ srt, uint4* __restrict__ cnt,
                                                           int32_t* __restrict__ status) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= n_rows * NT) return;
+    if (idx >= n_pos * NT) return;
     const int64_t pos = idx / NT;
     const int t = static_cast<int>(idx % NT);
-    const int64_t lrow = order ? order[pos] : pos;
     int32_t e0, e1;
-    group_bounds(rowptr, blkptr, n_src, NT, row_begin + lrow, t, e0, e1);
+    position_bounds(rowptr, blkptr, n_src, NT, row_begin, order, parts, pos, t, e0, e1);
     const int32_t base = t * T;
     Counts c = {{0, 0, 0, 0}};
     if (e1 - e0 > kGroupCap) {       // 16-bit counters: such a graph takes the gather kernel
@@ -183,8 +201,9 @@ constexpr int kColorWords = 128 + 16;        // per thread in LDS: rem[16 lanes]
 template <bool EMIT>
 __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr, int64_t n_src, int64_t row_begin,
-    int64_t n_rows, const int32_t* __restrict__ order, Plan pl, const uint16_t* __restrict__ srt,
-    const uint4* __restrict__ cnt, int32_t* __restrict__ len, const int32_t* __restrict__ tab, uint16_t* __restrict__ ell) {
+    int64_t n_pos, const int32_t* __restrict__ order, const uint16_t* __restrict__ parts, Plan pl,
+    const uint16_t* __restrict__ srt, const uint4* __restrict__ cnt, int32_t* __restrict__ len,
+    const int32_t* __restrict__ tab, uint16_t* __restrict__ ell) {
     __shared__ uint32_t sm[kColorWords * kColorThreads];
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kColorThreads + threadIdx.x;
     const int64_t n_groups = static_cast<int64_t>(pl.G) * pl.NT * 4;
@@ -198,10 +217,10 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
         const int64_t pos = g * 64 + kLaneOf[grp * 16 + i];
         Counts c = {{0, 0, 0, 0}};
         int32_t e0 = 0;
-        if (pos < n_rows) {
+        if (pos < n_pos) {
             c = load_counts(cnt, pos * pl.NT + t);
             int32_t e1;
-            group_bounds(rowptr, blkptr, n_src, pl.NT, row_begin + (order ? order[pos] : pos), t, e0, e1);
+            position_bounds(rowptr, blkptr, n_src, pl.NT, row_begin, order, parts, pos, t, e0, e1);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -381,7 +400,8 @@ struct Epilogue {
     const int32_t* rowptr;
     const float* dinv;
     const int32_t* order;
-    int64_t row_begin, n_rows;
+    const uint16_t* parts;
+    int64_t row_begin, n_pos;
     const float* attn;
     int64_t lda;
     float attn_scale, gcn_scale;
@@ -478,7 +498,7 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
             // The tile's first loads are issued BEFORE the barrier (they land in registers, not in LDS), so their latency
             // runs under the wait for the slowest wave of the previous tile; the registers written first take the tail
             // rows.  Wave-uniform bases + one shared lane offset keep the addressing in scalar registers.
-            constexpr int U = NR >= 10 ? 4 : (NR == 9 ? 7 : (NR == 8 ? 9 : 11)), X = 11 - U;
+            constexpr int U = NR >= 10 ? 4 : (NR == 9 ? 7 : (NR == 8 ? 9 : 11));
             const f32x4* src = ysl + static_cast<int64_t>(t) * T;
             const int nth = blockDim.x;
             const uint32_t tid = threadIdx.x;
@@ -490,18 +510,18 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
             }
             __syncthreads();                                                  // everyone is done with the previous tile
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                f32x4* du = tile + u * nth;
-                if (u * nth + static_cast<int>(tid) < T) du[tid] = r[u];
-                if (u < X) {
-                    const f32x4* su = src + (U + u) * nth;
-                    r[u] = ((U + u) * nth + static_cast<int>(tid) < T) ? su[tid] : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
+            for (int b = 0; b < 11; b += U) {                                 // batches of U rows per thread, 11 in all
 #pragma unroll
-            for (int u = 0; u < X; ++u) {
-                f32x4* du = tile + (U + u) * nth;
-                if ((U + u) * nth + static_cast<int>(tid) < T) du[tid] = r[u];
+                for (int u = 0; u < U; ++u) {
+                    if (b + u < 11) {
+                        f32x4* du = tile + (b + u) * nth;
+                        if ((b + u) * nth + static_cast<int>(tid) < T) du[tid] = r[u];
+                    }
+                    if (b + U + u < 11) {                                     // the register just written takes its next row
+                        const f32x4* su = src + (b + U + u) * nth;
+                        r[u] = ((b + U + u) * nth + static_cast<int>(tid) < T) ? su[tid] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
             }
             for (int b0 = static_cast<int>(tid) + 11 * nth; b0 < T; b0 += nth) tile[b0] = src[b0];      // fewer than 15 waves
         }
@@ -518,10 +538,26 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int64_t pos = slot_of(j, pw, pl.PW) * 64 + lane;
-        if (pos < ep.n_rows) {
-            const int64_t lrow = ep.order ? ep.order[pos] : pos;
+        int64_t lrow = -1;
+        if (pos < ep.n_pos) lrow = ep.order ? ep.order[pos] : pos;
+        f32x4 sum = acc[j];
+        if (ep.parts) {
+            // the parts of a split row sit in consecutive lanes of this slot: part 0 adds them up in part order
+            const uint32_t pp = (pos < ep.n_pos && lrow >= 0) ? ep.parts[pos] : 0x0100u;
+            const int p = pp & 0xffu, P = pp >> 8;
+            for (int k = 1; __ballot(k < P) != 0ull; ++k) {
+                f32x4 o;
+                o.x = __shfl_down(acc[j].x, k);
+                o.y = __shfl_down(acc[j].y, k);
+                o.z = __shfl_down(acc[j].z, k);
+                o.w = __shfl_down(acc[j].w, k);
+                if (p == 0 && k < P) sum += o;
+            }
+            if (p != 0) lrow = -1;
+        }
+        if (lrow >= 0) {
             const int64_t row = ep.row_begin + lrow;
-            f32x4 o = acc[j] * (ep.gcn_scale * (ep.dinv ? ep.dinv[row] : dinv_of(ep.rowptr, row)));
+            f32x4 o = sum * (ep.gcn_scale * (ep.dinv ? ep.dinv[row] : dinv_of(ep.rowptr, row)));
             if (ep.attn) o += ep.attn_scale * *reinterpret_cast<const f32x4*>(ep.attn + lrow * ep.lda + slice * 4);
             *reinterpret_cast<f32x4*>(ep.out + lrow * ep.ldo + slice * 4) = o;
         }
@@ -565,6 +601,14 @@ int launch_sweep(hipStream_t st, const uint4* ell, const int32_t* tab, const f32
     return dif::launch_status("sliced_spmm_kernel");
 }
 
+// n_pos row positions: the n_rows rows themselves, or (parts != NULL) their parts plus padding
+int check_positions(const int32_t* row_order, const uint16_t* parts, int64_t n_rows, int64_t n_pos, const char* who) {
+    if (parts ? (row_order == nullptr || n_pos < n_rows) : (n_pos != n_rows))
+        return dif::fail(DIF_E_BADARG, "%s: n_pos must equal n_rows without `parts`; with `parts`, row_order and n_pos >= "
+                         "n_rows are required", who);
+    return 0;
+}
+
 int check_plan(const int32_t* plan, int64_t n_src, int64_t n_rows, int F, Plan& pl) {
     if (!plan) return dif::fail(DIF_E_BADARG, "dif_sliced: plan is null");
     Plan want;
@@ -593,10 +637,11 @@ extern "C" int dif_sliced_plan(int64_t n_src, int64_t n_rows, int F, int32_t* pl
 
 extern "C" int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, const int32_t* src, int64_t n_src,
                                   int64_t nnz, int64_t row_begin, int64_t n_rows, int F, const int32_t* plan,
-                                  const int32_t* row_order, uint16_t* sorted, void* counts, int32_t* lengths,
-                                  int32_t* table, int32_t* status, dif_stream_t stream) {
+                                  const int32_t* row_order, const uint16_t* parts, int64_t n_pos, uint16_t* sorted,
+                                  void* counts, int32_t* lengths, int32_t* table, int32_t* status, dif_stream_t stream) {
     Plan pl;
-    if (int rc = check_plan(plan, n_src, n_rows, F, pl)) return rc;
+    if (int rc = check_positions(row_order, parts, n_rows, n_pos, "dif_sliced_measure")) return rc;
+    if (int rc = check_plan(plan, n_src, n_pos, F, pl)) return rc;
     DIF_REQUIRE(row_begin >= 0 && row_begin + n_rows <= n_src && nnz >= 0, DIF_E_BADARG, "dif_sliced_measure: bad row range");
     DIF_REQUIRE(rowptr && (nnz == 0 || src) && sorted && counts && lengths && table && status, DIF_E_BADARG,
                 "dif_sliced_measure: null pointer");
@@ -606,14 +651,14 @@ extern "C" int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t he = hipMemsetAsync(status, 0, 4, st);
     if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_sliced_measure: memset: %s", hipGetErrorString(he));
-    const int64_t n_groups = n_rows * pl.NT;
+    const int64_t n_groups = n_pos * pl.NT;
     hipLaunchKernelGGL(sliced_sort_kernel, dim3(static_cast<unsigned>((n_groups + 255) / 256)), dim3(256), 0, st, rowptr,
-                       blkptr, src, n_src, pl.NT, pl.T, row_begin, n_rows, row_order, sorted, static_cast<uint4*>(counts),
-                       status);
+                       blkptr, src, n_src, pl.NT, pl.T, row_begin, n_pos, row_order, parts, sorted,
+                       static_cast<uint4*>(counts), status);
     if (int rc = dif::launch_status("sliced_sort_kernel")) return rc;
     const int64_t n_hw = static_cast<int64_t>(pl.G) * pl.NT * 4;
     hipLaunchKernelGGL((sliced_color_kernel<false>), dim3(static_cast<unsigned>((n_hw + kColorThreads - 1) / kColorThreads)),
-                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_rows, row_order, pl, sorted,
+                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_pos, row_order, parts, pl, sorted,
                        static_cast<const uint4*>(counts), lengths, nullptr, nullptr);
     if (int rc = dif::launch_status("sliced_color_kernel")) return rc;
     hipLaunchKernelGGL(sliced_table_kernel, dim3(1), dim3(1024), 0, st, lengths, pl, table);
@@ -621,11 +666,12 @@ extern "C" int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, 
 }
 
 extern "C" int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int64_t n_src, int64_t row_begin,
-                               int64_t n_rows, int F, const int32_t* plan, const int32_t* row_order, const uint16_t* sorted,
-                               const void* counts, const int32_t* table, int64_t n_blocks, uint16_t* entries,
-                               dif_stream_t stream) {
+                               int64_t n_rows, int F, const int32_t* plan, const int32_t* row_order, const uint16_t* parts,
+                               int64_t n_pos, const uint16_t* sorted, const void* counts, const int32_t* table,
+                               int64_t n_blocks, uint16_t* entries, dif_stream_t stream) {
     Plan pl;
-    if (int rc = check_plan(plan, n_src, n_rows, F, pl)) return rc;
+    if (int rc = check_positions(row_order, parts, n_rows, n_pos, "dif_sliced_emit")) return rc;
+    if (int rc = check_plan(plan, n_src, n_pos, F, pl)) return rc;
     DIF_REQUIRE(rowptr && sorted && counts && table && entries && n_blocks >= 1, DIF_E_BADARG, "dif_sliced_emit: null pointer");
     DIF_REQUIRE(pl.NT == 1 || blkptr, DIF_E_BADARG, "dif_sliced_emit: more than one tile needs blkptr");
     DIF_REQUIRE(dif::aligned16(entries) && dif::aligned16(counts), DIF_E_BADARG,
@@ -633,7 +679,7 @@ extern "C" int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n_hw = static_cast<int64_t>(pl.G) * pl.NT * 4;
     hipLaunchKernelGGL((sliced_color_kernel<true>), dim3(static_cast<unsigned>((n_hw + kColorThreads - 1) / kColorThreads)),
-                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_rows, row_order, pl, sorted,
+                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_pos, row_order, parts, pl, sorted,
                        static_cast<const uint4*>(counts), nullptr, table, entries);
     return dif::launch_status("sliced_color_kernel");
 }
@@ -654,11 +700,13 @@ extern "C" int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_
 }
 
 extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table, const int32_t* plan, const float* ys,
-                                   const int32_t* rowptr, const float* dinv, const int32_t* row_order, int64_t n_src,
-                                   int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda,
-                                   float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream) {
+                                   const int32_t* rowptr, const float* dinv, const int32_t* row_order, const uint16_t* parts,
+                                   int64_t n_pos, int64_t n_src, int64_t row_begin, int64_t n_rows, int F, const float* attn,
+                                   int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo,
+                                   dif_stream_t stream) {
     Plan pl;
-    if (int rc = check_plan(plan, n_src, n_rows, F, pl)) return rc;
+    if (int rc = check_positions(row_order, parts, n_rows, n_pos, "dif_sliced_spmm")) return rc;
+    if (int rc = check_plan(plan, n_src, n_pos, F, pl)) return rc;
     DIF_REQUIRE(entries && table && ys && rowptr && out, DIF_E_BADARG, "dif_sliced_spmm: null pointer");
     DIF_REQUIRE(row_begin >= 0 && row_begin + n_rows <= n_src, DIF_E_BADARG, "dif_sliced_spmm: row range exceeds n_src");
     DIF_REQUIRE(ldo >= F && ldo % 4 == 0 && dif::aligned16(out) && (!attn || (lda >= F && lda % 4 == 0 && dif::aligned16(attn))),
@@ -666,7 +714,7 @@ extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table
     DIF_REQUIRE(dif::aligned16(entries) && dif::aligned16(ys), DIF_E_BADARG, "dif_sliced_spmm: entries / ys must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t npad = static_cast<int64_t>(pl.T) * pl.NT;
-    const Epilogue ep = {rowptr, dinv, row_order, row_begin, n_rows, attn, lda, attn_scale, gcn_scale, out, ldo};
+    const Epilogue ep = {rowptr, dinv, row_order, parts, row_begin, n_pos, attn, lda, attn_scale, gcn_scale, out, ldo};
     const uint4* e4 = reinterpret_cast<const uint4*>(entries);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(ys);
     switch (pl.R) {

@@ -161,11 +161,52 @@ def sliced_tiling(num_nodes, F, nnz, edge_weight, shard, elem_size):
     return None if plan is None else (int(plan[7]), int(plan[6]))
 
 
-class SlicedAdjacency:
-    """Entry blocks + table + geometry of the feature-sliced product (include/difformer_hip.h, dif_sliced_*)."""
+SLICED_SPLIT_FACTOR = 4.0   # rows beyond this multiple of the mean degree are split into lock-step parts (Zipf C4: 2-6 within 4 %)
+SLICED_MAX_PARTS = 64       # one slot
 
-    def __init__(self, plan, entries, table, order=None):
-        self.plan, self.entries, self.table, self.order = plan, entries, table, order     # order: rows by descending degree
+
+class SlicedAdjacency:
+    """Entry blocks + table + geometry of the feature-sliced product (include/difformer_hip.h, dif_sliced_*).
+    order: rows by descending degree (skewed graphs); parts / n_pos: hub rows split into lock-step parts ("row
+    positions" in the header) -- then order has n_pos entries (-1 = padding) and plan is the geometry of n_pos positions;
+    tile_plan is the geometry the slice-major source copy is written with (tiling only: the same for every shard)."""
+
+    def __init__(self, plan, entries, table, order=None, parts=None, n_pos=None):
+        self.plan, self.entries, self.table, self.order = plan, entries, table, order
+        self.parts, self.n_pos = parts, n_pos
+
+
+def split_positions(deg_sorted, order, cap, max_parts=SLICED_MAX_PARTS):
+    """Row positions for rows sorted by descending degree `deg_sorted` (their ids in `order`): a row of degree d takes
+    P = min(ceil(d / cap), max_parts) consecutive positions of ONE 64-position slot.  Rows with the same P are packed
+    64 // P to a slot (every P-class starts on a fresh slot), the unsplit rows follow in order.
+    -> (order2 int32 [n_pos] with -1 = empty, parts uint16-as-int16 [n_pos] = p | P << 8, n_pos).  Device tensor ops;
+    one host sync for the sizes (cold path)."""
+    dev = deg_sorted.device
+    d = deg_sorted.to(torch.int64)
+    P = torch.clamp((d + cap - 1) // cap, 1, max_parts)
+    n_hub = int((P > 1).sum())                                   # a prefix: the degrees are sorted
+    n = d.numel()
+    Ph = P[:n_hub]
+    vals, counts = torch.unique_consecutive(Ph, return_counts=True)
+    per_slot = 64 // vals
+    class_slots = (counts + per_slot - 1) // per_slot
+    class_base = torch.cumsum(class_slots, 0) - class_slots      # first slot of every class
+    class_first = torch.cumsum(counts, 0) - counts               # first hub row of every class
+    cls = torch.repeat_interleave(torch.arange(vals.numel(), device=dev), counts)
+    k = torch.arange(n_hub, device=dev) - class_first[cls]
+    pos0 = (class_base[cls] + k // per_slot[cls]) * 64 + (k % per_slot[cls]) * Ph
+    hub_slots = int(class_slots.sum())
+    n_pos = hub_slots * 64 + (n - n_hub)
+    order2 = torch.full((n_pos,), -1, dtype=torch.int32, device=dev)
+    parts = torch.full((n_pos,), 0x0100, dtype=torch.int16, device=dev)
+    row_of_part = torch.repeat_interleave(torch.arange(n_hub, device=dev), Ph)
+    p_idx = torch.arange(row_of_part.numel(), device=dev) - (torch.cumsum(Ph, 0) - Ph)[row_of_part]
+    pos = pos0[row_of_part] + p_idx
+    order2[pos] = order[:n_hub][row_of_part].to(torch.int32)
+    parts[pos] = (p_idx + (Ph[row_of_part] << 8)).to(torch.int16)
+    order2[hub_slots * 64:] = order[n_hub:].to(torch.int32)
+    return order2, parts, n_pos
 
 
 class GraphCSR:
@@ -234,11 +275,21 @@ class GraphCSR:
             return None
         deg = self.rowptr[row_begin + 1: row_begin + n_rows + 1] - self.rowptr[row_begin: row_begin + n_rows]
         max_deg, total = (int(v) for v in torch.stack([deg.max(), deg.sum()]).tolist())       # one sync, cold path
-        order = be.row_order(self.rowptr, row_begin, n_rows)[0] if max_deg * n_rows > 2 * total else None
-        built = be.sliced_build(self.rowptr, self.blkptr, self.src, self.num_nodes, self.nnz, row_begin, n_rows, F, plan, order)
+        order = parts = n_pos = None
+        if max_deg * n_rows > 2 * total:
+            order = be.row_order(self.rowptr, row_begin, n_rows)[0]
+            cap = max(int(SLICED_SPLIT_FACTOR * total / n_rows), 64)
+            if max_deg > cap:
+                # hub rows run as several lock-step lanes of one slot instead of one long lane
+                order, parts, n_pos = split_positions(deg[order.long()], order, cap)
+                plan = be.sliced_plan(self.num_nodes, n_pos, F)
+                if plan is None or int(plan[6]) != T or int(plan[7]) != NT:
+                    return None
+        built = be.sliced_build(self.rowptr, self.blkptr, self.src, self.num_nodes, self.nnz, row_begin, n_rows, F, plan, order,
+                                parts, n_pos)
         if built is None:
             return None
-        return SlicedAdjacency(plan, built[0], built[1], order)
+        return SlicedAdjacency(plan, built[0], built[1], order, parts, n_pos)
 
     def row_sums(self):
         """A_hat 1 (float32 [N]): what the bias of the value projection turns into under the aggregation,
@@ -374,8 +425,7 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
             # dense unweighted graph: sources pre-scaled and staged slice by slice in LDS (csrc/gcn_sliced.hip); the
             # LayerNorm of the tail needs whole rows, which the slice workgroups do not have: it runs as its own pass
             ys = be.sliced_prescale(x2, csr.rowptr, csr.num_nodes, sl.plan, csr.dinv)
-            out = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, 0, n, H * D, a2,
-                                 attn_scale, gcn_scale, sl.order, csr.dinv)
+            out = be.sliced_spmm(sl, ys, csr.rowptr, csr.num_nodes, 0, n, H * D, a2, attn_scale, gcn_scale, csr.dinv)
             if tail is not None:
                 out = be.layer_tail(out.reshape(n, H, D), tail.get("x0"), tail.get("prev"), tail.get("alpha", 0.5),
                                     tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5),
@@ -452,8 +502,7 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
         if sl is not None:
             if ys is None:
                 ys = be.sliced_prescale(x_src, csr.rowptr, csr.num_nodes, sl.plan)
-            ax = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, csr.num_nodes, row_begin, n, C, None, 1.0,
-                                gcn_scale, sl.order)
+            ax = be.sliced_spmm(sl, ys, csr.rowptr, csr.num_nodes, row_begin, n, C, None, 1.0, gcn_scale)
         else:
             ax = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x_src, row_begin, n,
                          None, 1.0, gcn_scale, None, csr.row_order(row_begin, n))

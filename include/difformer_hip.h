@@ -223,6 +223,13 @@ int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int
  *   dif_sliced_spmm_f32 out[r,:] = gcn_scale * deg[r]^-1/2 * sum_e ys[src_e] (+ attn_scale * attn[r,:]) for the n_rows
  *                       rows the format was built for (out / attn hold only those rows; row_order as at build time).
  *                       Deterministic.
+ *   row positions       Without `parts` (NULL) the n_pos = n_rows positions are the rows themselves (in row_order).  With
+ *                       `parts` uint16[n_pos] a position is part p of P of row row_order[pos] (parts[pos] = p | P << 8,
+ *                       1 <= P <= 64: in every tile part p takes the p-th of P equal shares of the row's entries) or empty
+ *                       (row_order[pos] < 0); the parts of a row occupy P consecutive positions of ONE slot, part 0 first,
+ *                       and the product adds them up in part order.  Hub rows split this way run as P lock-step lanes
+ *                       instead of one long one, and a (row, tile) group may hold up to P * 65,535 entries.  The plan is
+ *                       dif_sliced_plan(n_src, n_pos, F).
  *   dinv (prescale, spmm): NULL = deg^-1/2 from the row lengths of `rowptr` (the forward product).  For the adjoint
  *                       product (the gradient of :75-78: CSR of the transposed graph, rows = sources) pass the forward
  *                       graph's float[n_src] vector: grad_x[s] = dinv[s] * sum_{e: src = s} (dinv * g)[dst_e].
@@ -230,17 +237,18 @@ int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int
 int dif_sliced_plan(int64_t n_src, int64_t n_rows, int F, int32_t* plan);
 int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, const int32_t* src, int64_t n_src,
                        int64_t nnz, int64_t row_begin, int64_t n_rows, int F, const int32_t* plan,
-                       const int32_t* row_order, uint16_t* sorted, void* counts, int32_t* lengths, int32_t* table,
-                       int32_t* status, dif_stream_t stream);
+                       const int32_t* row_order, const uint16_t* parts, int64_t n_pos, uint16_t* sorted, void* counts,
+                       int32_t* lengths, int32_t* table, int32_t* status, dif_stream_t stream);
 int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int64_t n_src, int64_t row_begin,
-                    int64_t n_rows, int F, const int32_t* plan, const int32_t* row_order, const uint16_t* sorted,
-                    const void* counts, const int32_t* table, int64_t n_blocks, uint16_t* entries, dif_stream_t stream);
+                    int64_t n_rows, int F, const int32_t* plan, const int32_t* row_order, const uint16_t* parts,
+                    int64_t n_pos, const uint16_t* sorted, const void* counts, const int32_t* table, int64_t n_blocks,
+                    uint16_t* entries, dif_stream_t stream);
 int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_t* rowptr, const float* dinv, int64_t n_src,
                             int F, const int32_t* plan, float* ys, dif_stream_t stream);
 int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table, const int32_t* plan, const float* ys,
-                        const int32_t* rowptr, const float* dinv, const int32_t* row_order, int64_t n_src,
-                        int64_t row_begin, int64_t n_rows, int F, const float* attn, int64_t lda, float attn_scale,
-                        float gcn_scale, float* out, int64_t ldo, dif_stream_t stream);
+                        const int32_t* rowptr, const float* dinv, const int32_t* row_order, const uint16_t* parts,
+                        int64_t n_pos, int64_t n_src, int64_t row_begin, int64_t n_rows, int F, const float* attn,
+                        int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream);
 
 /* Split product for row-sharded runs (one process per GPU): a rank owns the source rows of the blocks
  * [own_blk_begin, own_blk_end) before the all-gather of the value rows has delivered the others.

@@ -40,13 +40,12 @@ for world in (1, 2, 4, 8):
         assert sl is not None
         ys = be.sliced_prescale(x, csr.rowptr, n, sl.plan)
         t_pre = timeit(lambda: be.sliced_prescale(x, csr.rowptr, n, sl.plan))
-        t_sp = timeit(lambda: be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, n, lo, cnt, C, None, 1.0, 1.0,
-                                             sl.order))
+        t_sp = timeit(lambda: be.sliced_spmm(sl, ys, csr.rowptr, n, lo, cnt, C, None, 1.0, 1.0))
         xl = x[lo:lo + cnt]
         t_gram = timeit(lambda: be.gram(xl, None, None))
         rec, _ = be.gram(xl, None, None)
         coef = be.simple_coeffs(rec, n, C, C, Wq, bq, Wk, bk, Wv, bv, 1.0)
-        ax = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, n, lo, cnt, C, None, 1.0, 1.0, sl.order)
+        ax = be.sliced_spmm(sl, ys, csr.rowptr, n, lo, cnt, C, None, 1.0, 1.0)
         rs = csr.row_sums()[lo:lo + cnt]
         t_layer = timeit(lambda: be.simple_layer(xl, coef, C, ax, Wv, bv, rs, 1.0, None, True, 0.5, lw, lb, 1e-5, False))
         if base is None:

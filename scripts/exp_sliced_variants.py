@@ -25,7 +25,7 @@ if variant & 4:
     trace = torch.zeros(slices * panels * 2 * NT * 4, dtype=torch.int64, device=dev)
     os.environ["DIF_SLICED_TRACE"] = str(trace.data_ptr())
 ys = be.sliced_prescale(x, csr.rowptr, n, sl.plan)
-f = lambda: be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, n, 0, n, C, None, 1.0, 1.0, sl.order)
+f = lambda: be.sliced_spmm(sl, ys, csr.rowptr, n, 0, n, C, None, 1.0, 1.0)
 out = f()
 # reference: the gather kernel on the same CSR
 ref = ops.gcn_aggregate(csr, x.view(n, 1, C), None, 1.0, 1.0).view(n, C) if False else None

@@ -40,8 +40,8 @@ for it in range(cases):
         ops.csr_cache.clear()
         continue
     ys = be.sliced_prescale(x, csr.rowptr, n, sl.plan)
-    out = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, n, lo, cnt, F, a, 0.7, 1.3, sl.order)
-    out2 = be.sliced_spmm(sl.entries, sl.table, sl.plan, ys, csr.rowptr, n, lo, cnt, F, a, 0.7, 1.3, sl.order)
+    out = be.sliced_spmm(sl, ys, csr.rowptr, n, lo, cnt, F, a, 0.7, 1.3)
+    out2 = be.sliced_spmm(sl, ys, csr.rowptr, n, lo, cnt, F, a, 0.7, 1.3)
     err = float((out - ref).abs().max() / ref.abs().max())
     worst = max(worst, err)
     plan = [int(v) for v in sl.plan]

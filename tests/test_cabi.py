@@ -63,10 +63,13 @@ def test_sliced_plan_is_host_side_arithmetic(lib):
     assert plan[5] <= 10
     assert lib.dif_sliced_plan(1000, 1000, 30, plan) == -2 and b"F % 4" in lib.dif_last_error()
     assert lib.dif_sliced_plan(5000, 5000, 64, plan) == 0 and plan[7] == 1                     # one tile: plain CSR
-    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5000, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
     assert rc == -1 and b"null pointer" in lib.dif_last_error()
-    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, 6000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5000, 6000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
     assert rc == -1 and b"plan does not match" in lib.dif_last_error()
+    # row positions: without `parts` there are exactly n_rows of them; with `parts` the order is required
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5064, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    assert rc == -1 and b"n_pos" in lib.dif_last_error()
 
 
 def test_argument_checks_reject_before_touching_the_device(lib):

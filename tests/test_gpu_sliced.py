@@ -57,9 +57,26 @@ def _skewed_graph(n, deg, seed, hubs=40):
 
 def _check_format(sl, ei, n, csr):
     slices, panels, G, PW, W, R, T, NT = (int(v) for v in sl.plan)
-    assert NT == csr.n_blocks and T % 16 == 0 and PW == panels * W and G == -(-n // 64) and (R - 1) * PW < G <= R * PW
+    n_pos = n if sl.n_pos is None else int(sl.n_pos)
+    assert NT == csr.n_blocks and T % 16 == 0 and PW == panels * W and G == -(-n_pos // 64) and (R - 1) * PW < G <= R * PW
     order = np.arange(n) if sl.order is None else sl.order.cpu().numpy().astype(np.int64)
-    assert np.array_equal(np.sort(order), np.arange(n))
+    assert order.size == n_pos
+    if sl.parts is None:
+        part, nparts = np.zeros(n_pos, np.int64), np.ones(n_pos, np.int64)
+        assert np.array_equal(np.sort(order), np.arange(n))
+    else:
+        pp = sl.parts.cpu().numpy().view(np.uint16).astype(np.int64)
+        part, nparts = pp & 0xFF, pp >> 8
+        live = order >= 0
+        assert np.array_equal(np.sort(order[live & (part == 0)]), np.arange(n)), "every row has exactly one part 0"
+        assert np.all((nparts >= 1) & (nparts <= 64) & (part < nparts))
+        # the parts of a row: consecutive positions of one slot, in part order
+        heads = np.nonzero(live & (part == 0))[0]
+        for h in heads[nparts[heads] > 1]:
+            P = nparts[h]
+            assert h // 64 == (h + P - 1) // 64 and np.all(order[h:h + P] == order[h]) and np.array_equal(part[h:h + P], np.arange(P))
+            assert np.all(nparts[h:h + P] == P)
+        assert int(nparts[heads].sum()) == int(live.sum())
     table = sl.table.cpu().numpy()
     n_ptw = panels * NT * W
     n_blocks = int(table[-1])
@@ -71,15 +88,18 @@ def _check_format(sl, ei, n, csr):
         q = np.sort(quads[:, :, grp], axis=2)
         assert np.array_equal(q, np.broadcast_to(np.arange(16), q.shape)), "bank conflict in the schedule"
     assert ent.max() < T + 16
-    # the real entries of (row, tile) == the CSR group
+    # the real entries of (row position, tile) == its share of the CSR group
     src, dst = ei[0].numpy(), ei[1].numpy()
     perm = np.lexsort((src, dst))
     src_s, dst_s = src[perm], dst[perm]
     rowptr = np.searchsorted(dst_s, np.arange(n + 1))
     assert np.array_equal(rowptr, csr.rowptr.cpu().numpy())
-    if sl.order is not None:
+    if sl.order is not None and sl.parts is None:
         deg = np.diff(rowptr)[order]
         assert np.all(deg[:-1] >= deg[1:]), "slots are formed in descending-degree order"
+    # a part takes its share of the group in CSR order (entries of a (row, tile) group are filed by edge id)
+    csr_src = csr.src.cpu().numpy().astype(np.int64)
+    blkptr = csr.blkptr.cpu().numpy().reshape(NT + 1, n) if NT > 1 else None
     total_real, expect_start, seen_slots = 0, 0, 0
     for p in range(panels):
         for t in range(NT):
@@ -99,12 +119,16 @@ def _check_format(sl, ei, n, csr):
                     for lane in range(64):
                         pos = g * 64 + lane
                         got = np.sort(lists[lane][lists[lane] < T].astype(np.int64))
-                        if pos >= n:
+                        if pos >= n_pos or order[pos] < 0:
                             assert got.size == 0
                             continue
                         row = order[pos]
                         seg = src_s[rowptr[row]: rowptr[row + 1]]
-                        want = np.sort(seg[(seg >= t * T) & (seg < (t + 1) * T)] - t * T)
+                        e0, e1 = (rowptr[row], rowptr[row + 1]) if NT == 1 else (blkptr[t, row], blkptr[t + 1, row])
+                        grp_e = csr_src[e0:e1] - t * T
+                        assert np.array_equal(np.sort(grp_e), seg[(seg >= t * T) & (seg < (t + 1) * T)] - t * T)
+                        c = grp_e.size
+                        want = np.sort(grp_e[c * part[pos] // nparts[pos]: c * (part[pos] + 1) // nparts[pos]])
                         assert np.array_equal(got, want), (p, t, w, j, lane)
                         total_real += got.size
     assert expect_start == n_blocks and seen_slots == G and total_real == ei.shape[1]
@@ -126,12 +150,30 @@ def test_sliced_format_on_skewed_degrees_sorts_rows_into_slots(n, deg, F, dev):
     ei = _skewed_graph(n, deg, seed=n)
     csr = ops.csr_cache.get(ei.to(dev), None, n, F * 4)
     sl = _sliced(csr, n, F)
+    assert sl.order is not None and sl.parts is not None       # 40 hub rows far beyond twice the mean degree: split
+    _check_format(sl, ei, n, csr)
+
+
+@pytest.mark.parametrize("frac,parts", [(4, 1), (16, 3)])
+def test_sliced_format_on_mild_skew(frac, parts, dev):
+    """1/frac of the rows carry half of the entries (mean 60).  frac = 4: ~150 entries, beyond twice the mean (rows are
+    sorted into slots) but below the split threshold of 4x mean; frac = 16: ~510 entries -> three lanes each."""
+    from difformer_amd import ops
+    n, F = 12000, 64
+    g = torch.Generator().manual_seed(2)
+    light = torch.stack([torch.randint(0, n, (n * 30,), generator=g), torch.randint(0, n, (n * 30,), generator=g)])
+    heavy = torch.stack([torch.randint(0, n, (n * 30,), generator=g), torch.randint(0, n // frac, (n * 30,), generator=g)])
+    ei = torch.cat([light, heavy], dim=1)
+    csr = ops.csr_cache.get(ei.to(dev), None, n, F * 4)
+    sl = _sliced(csr, n, F)
     assert sl.order is not None
+    got = 1 if sl.parts is None else int((sl.parts.cpu().numpy().view(np.uint16) >> 8).max())
+    assert got == parts
     _check_format(sl, ei, n, csr)
 
 
 @pytest.mark.parametrize("n,deg,h,d", [(20000, 60, 1, 64), (9000, 70, 1, 64), (33000, 50, 2, 64), (12000, 64, 1, 32),
-                                       (50000, 100, 1, 64)])
+                                       (50000, 100, 1, 64), (150000, 50, 1, 64)])
 def test_sliced_product_vs_oracle_and_gather_kernel(n, deg, h, d, dev):
     from difformer_amd import gcn_conv, ops
     ei = _dense_graph(n, deg, seed=3 * n + d)
@@ -179,8 +221,8 @@ def test_sliced_is_declined_for_weights_and_sparse_graphs(dev):
 
 @pytest.mark.parametrize("n,deg,hubs", [(12000, 64, 40), (30000, 80, 7), (64000, 50, 2000), (20000, 100, 2)])
 def test_sliced_product_on_skewed_degrees(n, deg, hubs, dev):
-    """Hub rows (up to ~170k entries, i.e. beyond 16-bit counters per tile only if a tile held > 65,535 of them) and a
-    long tail of short rows in the same launch: results against the float64 oracle and the gather kernel."""
+    """Hub rows (up to 500,000 entries: split into up to 64 lock-step parts) and a long tail of short rows in the same
+    launch: results against the float64 oracle."""
     from difformer_amd import gcn_conv, ops
     ei = _skewed_graph(n, deg, seed=7 * n, hubs=hubs)
     g = torch.Generator().manual_seed(n)
@@ -191,10 +233,9 @@ def test_sliced_product_on_skewed_degrees(n, deg, hubs, dev):
     ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), None)
     out = gcn_conv(xd, eid, None)
     assert rel_err(out.cpu().numpy(), ref) < 1e-5
-    if hubs >= 40:
-        assert sl is not None and sl.order is not None
-    if hubs == 2:
-        assert sl is None          # 500,000 entries on one row: a (row, tile) group beyond the 16-bit counters -> gather kernels
+    assert sl is not None and sl.order is not None and sl.parts is not None
+    # hubs == 2: 500,000 entries on one row -- 64 lock-step parts of ~7,800 (a single lane could not hold a
+    # (row, tile) group beyond the 16-bit counters, and would run alone for a millisecond)
     assert torch.equal(gcn_conv(xd, eid, None), out)
 
 

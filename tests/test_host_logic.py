@@ -303,3 +303,35 @@ def test_v2_training_backward_matches_reference_expression(fake_backend):
         expr(lay)(q2, k2, v2).backward(g.double())
         for a, b in ((q, q2), (k, k2), (v, v2)):
             assert rel_err(a.grad.numpy(), b.grad.numpy()) < 1e-5
+
+
+def test_split_positions_layout():
+    """Row positions of the feature-sliced format when hub rows are split (ops.split_positions; "row positions" in
+    include/difformer_hip.h): P = min(ceil(d / cap), 64) consecutive positions of one slot per row, part 0 first."""
+    import numpy as np
+    from difformer_amd.ops import split_positions
+    g = torch.Generator().manual_seed(0)
+    deg = torch.cat([torch.tensor([100000, 5000, 4999, 1300, 1201, 1200, 601, 601, 601]),
+                     torch.randint(0, 600, (3000,), generator=g)])
+    deg, idx = torch.sort(deg, descending=True, stable=True)
+    order = torch.randperm(deg.numel(), generator=g).to(torch.int32)     # any row ids
+    cap = 600
+    order2, parts, n_pos = split_positions(deg, order, cap)
+    order2, parts = order2.numpy().astype(np.int64), parts.numpy().view(np.uint16).astype(np.int64)
+    assert order2.size == parts.size == n_pos
+    p, P = parts & 0xFF, parts >> 8
+    live = order2 >= 0
+    want_P = np.minimum(-(-deg.numpy() // cap), 64).clip(min=1)
+    heads = np.nonzero(live & (p == 0))[0]
+    assert np.array_equal(np.sort(order2[heads]), np.sort(order.numpy()))            # every row once
+    by_row = {int(r): int(k) for r, k in zip(order.numpy(), want_P)}
+    for h in heads:
+        k = by_row[int(order2[h])]
+        assert P[h] == k and h // 64 == (h + k - 1) // 64
+        assert np.all(order2[h:h + k] == order2[h]) and np.array_equal(p[h:h + k], np.arange(k)) and np.all(P[h:h + k] == k)
+    assert int(live.sum()) == int(want_P.sum())
+    assert np.all(P[~live] == 1) and np.all(p[~live] == 0)
+    # the unsplit rows keep their (descending-degree) order after the hub slots
+    n_hub = int((want_P > 1).sum())
+    tail = order2[n_pos - (deg.numel() - n_hub):]
+    assert np.array_equal(tail, order.numpy()[n_hub:])
