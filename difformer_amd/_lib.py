@@ -35,6 +35,11 @@ SIGNATURES = {
     "dif_sigmoid_workspace_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
     "dif_sigmoid_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int,
                                      c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "dif_sigmoid_attn_fwd_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int,
+                                         c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "dif_sigmoid_bwd_workspace_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
+    "dif_sigmoid_attn_bwd_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64,
+                                         c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "dif_batched_simple_workspace_bytes": (c_sz, []),
     "dif_batched_simple_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int,
                                             c_vp, c_i64, c_vp, c_sz, c_vp]),
@@ -87,7 +92,7 @@ SIGNATURES = {
                                       c_int, c_vp, c_i64, c_vp]),
 }
 # bfloat16 storage variants share the argument lists of their float32 twins
-for _n in ("dif_linear", "dif_project_reduce", "dif_simple_reduce", "dif_simple_apply", "dif_layer_tail"):
+for _n in ("dif_linear", "dif_project_reduce", "dif_simple_reduce", "dif_simple_apply", "dif_layer_tail", "dif_sigmoid_attn"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f32"]
 SIGNATURES["dif_gcn_spmm_part_bf16"] = SIGNATURES["dif_gcn_spmm_part_f32"]
 SIGNATURES["dif_gcn_spmm_tail_bf16"] = (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64,

@@ -1,8 +1,8 @@
 """Autograd glue so the reference's unchanged training scripts (`main.py:130` loss.backward())
-keep working: the FORWARD of every operator is the HIP kernel; the BACKWARD of the simple attention,
-the aggregation (adjoint product on the same SpMM kernels), the layer tail (LayerNorm / residual / head
-mean) and the weight gradients of the Linear layers are HIP kernels too;
-sigmoid and the batched (v2) attention re-derive their gradient on the device with tensor ops.
+keep working: the FORWARD of every operator is the HIP kernel; the BACKWARD of the simple and the sigmoid
+attention, the aggregation (adjoint product on the same SpMM kernels), the layer tail (LayerNorm / residual /
+head mean) and the weight gradients of the Linear layers are HIP kernels too;
+the batched (v2) attention and heads wider than 64 re-derive their gradient on the device with tensor ops.
 Under torch.no_grad() / eval these wrappers are pass-throughs to ops.py.  Nothing here touches the CPU.
 """
 from __future__ import annotations
@@ -87,13 +87,26 @@ class _SimpleAttention(torch.autograd.Function):
 
 
 class _SigmoidAttention(torch.autograd.Function):
+    """Forward and (fp32, M, D <= 64) backward on the HIP kernels: the forward leaves the row sums, the backward
+    recomputes sigma tile by tile (csrc/sigmoid_attn_bwd.hip).  Other shapes re-derive the gradient with tensor ops."""
+
     @staticmethod
     def forward(ctx, q, k, v):
+        be = ops.get_backend()
+        ctx.hip = (q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32 and
+                   q.shape[2] <= 64 and v.shape[2] <= 64 and hasattr(be, "sigmoid_backward"))
+        if ctx.hip:
+            out, den = be.sigmoid_attention(q, k, v, want_den=True)
+            ctx.save_for_backward(q, k, v, out, den)
+            return out
         ctx.save_for_backward(q, k, v)
         return ops.sigmoid_attention(q, k, v)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.hip:
+            q, k, v, out, den = ctx.saved_tensors
+            return ops.get_backend().sigmoid_backward(q, k, v, out, den, g)
         return _grad_by_recompute(_sigmoid_expr, ctx.saved_tensors, g.contiguous())
 
 

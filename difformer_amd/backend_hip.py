@@ -227,25 +227,56 @@ class HipBackend:
         return dq, dk, dv
 
     # ---- a2 --------------------------------------------------------------------------------
-    def sigmoid_attention(self, q, k, v):
+    def sigmoid_attention(self, q, k, v, want_den=False):
+        """-> out [N,H,D]; want_den (fp32, training): (out, den float32 [N,H]) for sigmoid_backward."""
         dev = _require_device(q, k, v)
         N, H, M = q.shape
         L, D = k.shape[0], v.shape[2]
-        for t_, nm in ((q, "q"), (k, "k"), (v, "v")):
-            if t_.dtype != torch.float32:
-                raise TypeError(f"difformer_amd: the sigmoid kernel is float32-only (got {t_.dtype} for {nm}); the "
-                                "bfloat16 storage variant covers the simple kernel path (BASELINE config C5)")
+        dt, sfx = _storage(q, k, v)          # bfloat16: storage only, scores / sigma / sums in fp32
         q, ldq = _row_major(q, H * M)
         k, ldk = _row_major(k, H * M)
         v, ldv = _row_major(v, H * D)
-        out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
+        out = torch.empty((N, H, D), dtype=dt, device=dev)
         ws_bytes = self.lib.dif_sigmoid_workspace_bytes(N, L, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        with _Timed(self, "dif_sigmoid_attn_f32", dev):
-            rc = self.lib.dif_sigmoid_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, N, L, H, M, D,
-                                               _ptr(out), H * D, _ptr(ws), ws_bytes, _stream(dev))
-        _lib.check(rc, "dif_sigmoid_attn_f32")
+        if want_den:
+            _f32(q, "q")
+            den = torch.empty((N, H), dtype=torch.float32, device=dev)
+            with _Timed(self, "dif_sigmoid_attn_fwd_f32", dev):
+                rc = self.lib.dif_sigmoid_attn_fwd_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, N, L, H, M, D, _ptr(out),
+                                                       H * D, _ptr(den), _ptr(ws), ws_bytes, _stream(dev))
+            _lib.check(rc, "dif_sigmoid_attn_fwd_f32")
+            return out, den
+        name = "dif_sigmoid_attn_" + sfx
+        with _Timed(self, name, dev):
+            rc = getattr(self.lib, name)(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, N, L, H, M, D, _ptr(out), H * D, _ptr(ws),
+                                         ws_bytes, _stream(dev))
+        _lib.check(rc, name)
         return out
+
+    def sigmoid_backward(self, q, k, v, out, den, g):
+        """(dq, dk, dv) of the sigmoid kernel for fp32 q [N,H,M], k [L,H,M], v [L,H,D], out / g [N,H,D], den [N,H];
+        M, D <= 64 (csrc/sigmoid_attn_bwd.hip: sigma recomputed tile by tile, nothing of size N x L stored)."""
+        dev = _require_device(q, k, v, out, den, g)
+        N, H, M = q.shape
+        L, D = k.shape[0], v.shape[2]
+        for t_, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (den, "den"), (g, "grad")):
+            _f32(t_, nm)
+        q, ldq = _row_major(q, H * M)
+        k, ldk = _row_major(k, H * M)
+        v, ldv = _row_major(v, H * D)
+        g, ldg = _row_major(g, H * D)
+        out, den = out.contiguous(), den.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        dq, dk, dv = torch.empty((N, H, M), **f32), torch.empty((L, H, M), **f32), torch.empty((L, H, D), **f32)
+        ws_bytes = self.lib.dif_sigmoid_bwd_workspace_bytes(N, L, H, M, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_sigmoid_attn_bwd_f32", dev):
+            rc = self.lib.dif_sigmoid_attn_bwd_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(out), H * D, _ptr(den),
+                                                   _ptr(g), ldg, N, L, H, M, D, _ptr(dq), H * M, _ptr(dk), H * M, _ptr(dv),
+                                                   H * D, _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_sigmoid_attn_bwd_f32")
+        return dq, dk, dv
 
     # ---- f4: batch of graphs (physical particle/difformer-v2.py:71-137) ---------------------
     def batched_simple_attention(self, q, k, v, graph_ptr):

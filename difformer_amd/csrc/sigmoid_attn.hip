@@ -25,19 +25,19 @@ constexpr int kDTile = 64;    // output columns per workgroup (grid.y covers hea
 // Branch-free fragment load: out-of-range rows / columns are read from a clamped (valid) address and
 // zeroed afterwards, so the compiler can issue all of a tile's loads back to back (a guarded load is
 // its own exec-masked branch region and serialises).
-template <bool VEC>
-__device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld, int64_t rc, bool rok,
+template <bool VEC, typename T>
+__device__ __forceinline__ f32x4 ld4(const T* __restrict__ base, int64_t ld, int64_t rc, bool rok,
                                      int col0, int c, int width) {
     f32x4 z;
     if (VEC) {
         const bool cok = c < width;                       // width % 4 == 0 here
-        z = *reinterpret_cast<const f32x4*>(base + rc * ld + col0 + (cok ? c : 0));
+        z = dif::Elem<T>::ld4(base + rc * ld + col0 + (cok ? c : 0));
         if (!(rok && cok)) z = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool cok = c + i < width;
-            const float t = base[rc * ld + col0 + (cok ? c + i : 0)];
+            const float t = dif::Elem<T>::ld(base + rc * ld + col0 + (cok ? c + i : 0));
             z[i] = (rok && cok) ? t : 0.f;
         }
     }
@@ -60,13 +60,14 @@ __device__ __forceinline__ float sigmoidf(float x) {
 // (descending), so those are exactly ranks 0 .. seg_cnt[p]-1 and local row r is node seg_first[r] + p
 // (seg_first[r] = first node of the r-th largest graph).  The n_graphs - seg_cnt[p] shorter graphs are the
 // reference's zero padding: sigma(0) = 0.5 each in the denominator (+1e-9), nothing in the numerator.
-template <bool VEC, bool QREG, bool SEG>
-__global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restrict__ q, int64_t ldq,
-                                                           const float* __restrict__ k, int64_t ldk,
-                                                           const float* __restrict__ v, int64_t ldv,
+template <bool VEC, bool QREG, bool SEG, typename T = float>
+__global__ __launch_bounds__(512) void sigmoid_attn_kernel(const T* __restrict__ q, int64_t ldq,
+                                                           const T* __restrict__ k, int64_t ldk,
+                                                           const T* __restrict__ v, int64_t ldv,
                                                            int64_t N, int64_t L, int H, int M, int D,
-                                                           float* __restrict__ out, int64_t ldo,
+                                                           T* __restrict__ out, int64_t ldo,
                                                            float* __restrict__ part, float* __restrict__ pden,
+                                                           float* __restrict__ den_out,
                                                            const int32_t* __restrict__ seg_first,
                                                            const int32_t* __restrict__ seg_cnt, int n_graphs) {
     __shared__ __attribute__((aligned(16))) float sm_o[kWaves][kQGroup * kDTile];   // 64 KiB
@@ -155,12 +156,12 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restri
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t key = kbase + 4 * lg + reg;
             const bool kok = key < L;
-            const float* vrow = v + krow(key) * ldv + h * D;
+            const T* vrow = v + krow(key) * ldv + h * D;
 #pragma unroll
             for (int dtl = 0; dtl < 4; ++dtl) {
                 const int d = dt * kDTile + 16 * dtl + l15;
                 const bool dok = d < D;
-                const float t = vrow[dok ? d : 0];
+                const float t = dif::Elem<T>::ld(vrow + (dok ? d : 0));
                 vf[dtl][reg] = (kok && dok) ? t : 0.f;
             }
         }
@@ -206,9 +207,10 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restri
         if (row < N && d < D) {
             if (SEG) {
                 // difformer-v2.py:127-134: padded graphs add sigma(0) each, then + epsilon
-                out[qrow(row) * ldo + h * D + d] = o / (dn + 0.5f * static_cast<float>(n_graphs - N) + 1e-9f);
+                dif::Elem<T>::st(out + qrow(row) * ldo + h * D + d, o / (dn + 0.5f * static_cast<float>(n_graphs - N) + 1e-9f));
             } else if (S == 1) {
-                out[row * ldo + h * D + d] = o / dn;                       // :55-56
+                dif::Elem<T>::st(out + row * ldo + h * D + d, o / dn);     // :55-56
+                if (den_out && d == 0) den_out[row * H + h] = dn;          // kept for the backward pass
             } else {
                 part[(static_cast<int64_t>(split) * N + row) * (H * D) + h * D + d] = o;
                 if (dl == 0) pden[(static_cast<int64_t>(split) * N + row) * (H * DT) + h * DT + dt] = dn;
@@ -218,9 +220,11 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const float* __restri
 }
 
 // S > 1: out = (sum_s part[s]) / (sum_s pden[s])
+template <typename T>
 __global__ __launch_bounds__(256) void sigmoid_combine_kernel(const float* __restrict__ part,
                                                               const float* __restrict__ pden, int64_t N, int H,
-                                                              int D, int S, float* __restrict__ out, int64_t ldo) {
+                                                              int D, int S, T* __restrict__ out, int64_t ldo,
+                                                              float* __restrict__ den_out) {
     const int DT = (D + kDTile - 1) / kDTile;
     const int64_t total = N * H * D;
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total;
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(256) void sigmoid_combine_kernel(const float* __res
             o += part[(static_cast<int64_t>(s) * N + row) * (H * D) + c];
             dn += pden[(static_cast<int64_t>(s) * N + row) * (H * DT) + h * DT + d / kDTile];
         }
-        out[row * ldo + c] = o / dn;
+        dif::Elem<T>::st(out + row * ldo + c, o / dn);
+        if (den_out && d == 0) den_out[row * H + h] = dn;
     }
 }
 
@@ -270,31 +275,32 @@ extern "C" size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M
     return static_cast<size_t>(S) * N * H * (static_cast<size_t>(D) + DT) * sizeof(float);
 }
 
-extern "C" int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
-                                    const float* v, int64_t ldv, int64_t N, int64_t L, int H, int M, int D,
-                                    float* out, int64_t ldo, void* workspace, size_t workspace_bytes,
-                                    dif_stream_t stream) {
-    DIF_REQUIRE(N > 0 && L > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG,
-                "dif_sigmoid_attn_f32: N, L, H, M, D must be positive");
-    DIF_REQUIRE(q && k && v && out, DIF_E_BADARG, "dif_sigmoid_attn_f32: null pointer");
+namespace {
+
+template <typename T>
+int sigmoid_attn(const char* who, const T* q, int64_t ldq, const T* k, int64_t ldk, const T* v, int64_t ldv, int64_t N,
+                 int64_t L, int H, int M, int D, T* out, int64_t ldo, float* den, void* workspace, size_t workspace_bytes,
+                 dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && L > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG, "%s: N, L, H, M, D must be positive", who);
+    DIF_REQUIRE(q && k && v && out, DIF_E_BADARG, "%s: null pointer", who);
     DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D && ldo >= H * D, DIF_E_BADARG,
-                "dif_sigmoid_attn_f32: leading dimension smaller than a row");
+                "%s: leading dimension smaller than a row", who);
     const int64_t gx = (N + kQGroup - 1) / kQGroup;
     const int64_t gy = static_cast<int64_t>(H) * ((D + kDTile - 1) / kDTile);
-    DIF_REQUIRE(gx < (1ll << 31) && gy <= 65535, DIF_E_RANGE, "dif_sigmoid_attn_f32: grid too large");
+    DIF_REQUIRE(gx < (1ll << 31) && gy <= 65535, DIF_E_RANGE, "%s: grid too large", who);
     const int S = key_splits(N, L, H, D);
     const size_t need = dif_sigmoid_workspace_bytes(N, L, H, M, D);
-    DIF_REQUIRE(S == 1 || (workspace && workspace_bytes >= need), DIF_E_WORKSPACE,
-                "dif_sigmoid_attn_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
-    const bool vec = (M % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && dif::aligned16(q) && dif::aligned16(k);
+    DIF_REQUIRE(S == 1 || (workspace && workspace_bytes >= need), DIF_E_WORKSPACE, "%s: workspace too small (%zu < %zu)", who,
+                workspace_bytes, need);
+    const bool vec = (M % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && dif::aligned_v4<T>(q) && dif::aligned_v4<T>(k);
     const bool qreg = (M <= 64);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(workspace);
     float* pden = (S > 1) ? part + static_cast<size_t>(S) * N * H * D : nullptr;
     dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), S), block(512);
 #define DIF_LAUNCH_SIG(V, Q) \
-    hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q, false>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, \
-                       ldo, part, pden, nullptr, nullptr, 0)
+    hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q, false, T>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, \
+                       ldo, part, pden, den, nullptr, nullptr, 0)
     if (vec && qreg) DIF_LAUNCH_SIG(true, true);
     else if (vec) DIF_LAUNCH_SIG(true, false);
     else if (qreg) DIF_LAUNCH_SIG(false, true);
@@ -304,11 +310,40 @@ extern "C" int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k,
     if (S > 1) {
         int64_t g = (N * H * D + 255) / 256;
         if (g > 8 * dif::kCUs) g = 8 * dif::kCUs;
-        hipLaunchKernelGGL(sigmoid_combine_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, part, pden, N, H, D, S,
-                           out, ldo);
+        hipLaunchKernelGGL(sigmoid_combine_kernel<T>, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, part, pden, N, H, D, S,
+                           out, ldo, den);
         return dif::launch_status("sigmoid_combine_kernel");
     }
     return 0;
+}
+
+}  // namespace
+
+extern "C" int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                                    const float* v, int64_t ldv, int64_t N, int64_t L, int H, int M, int D,
+                                    float* out, int64_t ldo, void* workspace, size_t workspace_bytes,
+                                    dif_stream_t stream) {
+    return sigmoid_attn<float>("dif_sigmoid_attn_f32", q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, ldo, nullptr, workspace,
+                               workspace_bytes, stream);
+}
+
+// training forward: also leaves den[n,h] = sum_l sigmoid(q_n . k_l) (float [N,H]) for dif_sigmoid_attn_bwd_f32
+extern "C" int dif_sigmoid_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                        int64_t N, int64_t L, int H, int M, int D, float* out, int64_t ldo, float* den,
+                                        void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(den != nullptr, DIF_E_BADARG, "dif_sigmoid_attn_fwd_f32: den is null");
+    return sigmoid_attn<float>("dif_sigmoid_attn_fwd_f32", q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, ldo, den, workspace,
+                               workspace_bytes, stream);
+}
+
+// bfloat16 storage (q, k, v, out), fp32 scores / sigma / accumulation -- SURVEY.md 8b lists the {f32, bf16} pair
+extern "C" int dif_sigmoid_attn_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                     int64_t N, int64_t L, int H, int M, int D, void* out, int64_t ldo, void* workspace,
+                                     size_t workspace_bytes, dif_stream_t stream) {
+    using B = dif::bf16;
+    return sigmoid_attn<B>("dif_sigmoid_attn_bf16", static_cast<const B*>(q), ldq, static_cast<const B*>(k), ldk,
+                           static_cast<const B*>(v), ldv, N, L, H, M, D, static_cast<B*>(out), ldo, nullptr, workspace,
+                           workspace_bytes, stream);
 }
 
 // f4: TransConv.full_attention(kernel='sigmoid') over a batch of graphs -- physical particle/difformer-v2.py:113-135.
@@ -332,7 +367,7 @@ extern "C" int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const f
     dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), static_cast<unsigned>(max_nodes)), block(512);
 #define DIF_LAUNCH_SEG(V, Q) \
     hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, int64_t{0}, \
-                       int64_t{0}, H, M, D, out, ldo, nullptr, nullptr, ranked_first, pos_count, n_graphs)
+                       int64_t{0}, H, M, D, out, ldo, nullptr, nullptr, nullptr, ranked_first, pos_count, n_graphs)
     if (vec && qreg) DIF_LAUNCH_SEG(true, true);
     else if (vec) DIF_LAUNCH_SEG(true, false);
     else if (qreg) DIF_LAUNCH_SEG(false, true);

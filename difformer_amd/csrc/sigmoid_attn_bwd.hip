@@ -1,0 +1,331 @@
+// f3: backward of full_attention_conv(..., kernel='sigmoid')  -- node classification/difformer.py:45-56 under
+// loss.backward() (main.py:130).  With S = Q K^T, P = sigma(S), den_n = sum_l P_nl, out_n = sum_l P_nl v_l / den_n and
+// g = dL/dout:
+//     delta_n = g_n . out_n                          c_n = 1 / den_n
+//     dV_l    = sum_n (c_n P_nl) g_n
+//     dS_nl   = c_n (g_n . v_l - delta_n) P_nl (1 - P_nl)
+//     dQ_n    = sum_l dS_nl k_l                      dK_l = sum_n dS_nl q_n
+// As in the forward kernel the [N,L,H] tensors never leave registers: sigma is recomputed tile by tile.  ONE sweep
+// kernel serves both halves; it keeps 32 rows of the STATIONARY side in registers (as MFMA B operands) and streams the
+// other side past them, 8 waves splitting the stream:
+//     MODE 0 (dQ):      stationary = queries (q, g),  swept = keys    (k, v);  accumulates dQ^T += K^T dS^T
+//     MODE 1 (dK, dV):  stationary = keys    (k, v),  swept = queries (q, g);  accumulates dV^T += G^T (cP), dK^T += Q^T dS
+// Both score tiles are computed TRANSPOSED, T^T[swept row][stationary row] (v_mfma_f32_16x16x4_f32: swept fragment =
+// A operand, stationary fragment = B operand), so that a lane's four results are four SWEPT rows -- exactly the k-index
+// of the second contraction, whose B operand they become without a shuffle (the forward kernel's trick).
+// Covers M, D <= 64 (one fragment set per side); wider heads re-derive the gradient with tensor ops on the host side.
+// FLOPs: 14 N L H D against the forward's 4 N L H D.
+#include "dif_common.h"
+
+namespace {
+
+using dif::f32x4;
+
+constexpr int kWaves = 8;
+constexpr int kXT = 2;                  // 16-row tiles of the stationary side per workgroup
+constexpr int kXGroup = 16 * kXT;
+constexpr int kCols = 64;               // M, D <= 64
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld, int64_t rc, bool rok, int col0, int c,
+                                     int width) {
+    f32x4 z;
+    if (VEC) {
+        const bool cok = c < width;
+        z = *reinterpret_cast<const f32x4*>(base + rc * ld + col0 + (cok ? c : 0));
+        if (!(rok && cok)) z = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool cok = c + i < width;
+            const float t = base[rc * ld + col0 + (cok ? c + i : 0)];
+            z[i] = (rok && cok) ? t : 0.f;
+        }
+    }
+    return z;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+// cinv[n,h] = 1 / den[n,h], delta[n,h] = g[n,h,:] . out[n,h,:]
+__global__ __launch_bounds__(256) void sigmoid_bwd_prep_kernel(const float* __restrict__ g, int64_t ldg,
+                                                               const float* __restrict__ out, int64_t ldo,
+                                                               const float* __restrict__ den, int64_t n_rows, int H, int D,
+                                                               float* __restrict__ cinv, float* __restrict__ delta) {
+    const int64_t total = n_rows * H;
+    const int sub = threadIdx.x & 15;           // 16 lanes per (row, head)
+    for (int64_t e = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 4; e < ((total + 15) & ~int64_t(15));
+         e += static_cast<int64_t>(gridDim.x) * 16) {
+        const bool ok = e < total;
+        const int64_t row = ok ? e / H : 0;
+        const int h = ok ? static_cast<int>(e % H) : 0;
+        float s = 0.f;
+        if (ok)
+            for (int d = sub; d < D; d += 16) s += g[row * ldg + h * D + d] * out[row * ldo + h * D + d];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (ok && sub == 0) {
+            delta[e] = s;
+            cinv[e] = 1.0f / den[e];
+        }
+    }
+}
+
+// grid: (ceil(X / 32), H, S splits of the swept side); block 512.
+// x*: stationary operands, y*: swept operands; 1 = the score pair (q / k), 2 = the value pair (g / v).
+// S == 1: results written to o1 (and o2); S > 1: partials to part1 [S][X][H*M] (part2 [S][X][H*D]), summed by
+// sum_parts_kernel.
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restrict__ x1, int64_t ldx1,
+                                                          const float* __restrict__ x2, int64_t ldx2,
+                                                          const float* __restrict__ y1, int64_t ldy1,
+                                                          const float* __restrict__ y2, int64_t ldy2,
+                                                          const float* __restrict__ cinv, const float* __restrict__ delta,
+                                                          int64_t X, int64_t Y, int H, int M, int D,
+                                                          float* __restrict__ o1, int64_t ldo1, float* __restrict__ o2,
+                                                          int64_t ldo2, float* __restrict__ part1,
+                                                          float* __restrict__ part2) {
+    __shared__ __attribute__((aligned(16))) float sm_o[kWaves][kXGroup * kCols];   // 64 KiB
+    const int h = blockIdx.y;
+    const int S = gridDim.z, split = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int64_t x0 = static_cast<int64_t>(blockIdx.x) * kXGroup;
+
+    // stationary fragments (B operands): row = x0 + 16 t + l15, columns 16 c + 4 lg .. + 3
+    f32x4 xs1[kXT][4], xs2[kXT][4];
+    float cx[kXT], dx[kXT];
+#pragma unroll
+    for (int t = 0; t < kXT; ++t) {
+        const int64_t r = x0 + 16 * t + l15;
+        const bool ok = r < X;
+        const int64_t rc = ok ? r : X - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xs1[t][c] = ld4<VEC>(x1, ldx1, rc, ok, h * M, 16 * c + 4 * lg, M);
+            xs2[t][c] = ld4<VEC>(x2, ldx2, rc, ok, h * D, 16 * c + 4 * lg, D);
+        }
+        if (MODE == 0) {                         // per-query scalars ride with the stationary row
+            cx[t] = ok ? cinv[rc * H + h] : 0.f;
+            dx[t] = ok ? delta[rc * H + h] : 0.f;
+        }
+    }
+    f32x4 acc1[kXT][4];                          // MODE 0: dQ^T tiles; MODE 1: dK^T tiles   (16-column tiles of M)
+    f32x4 acc2[kXT][4];                          // MODE 1: dV^T tiles                        (16-column tiles of D)
+#pragma unroll
+    for (int t = 0; t < kXT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc1[t][i] = acc2[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int64_t n_tiles = (Y + 15) / 16;
+    const int64_t per = (n_tiles + S - 1) / S;
+    const int64_t t0 = split * per;
+    const int64_t t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    for (int64_t yt = t0 + wave; yt < t1; yt += kWaves) {
+        const int64_t ybase = yt * 16;
+        // ---- swept fragments (A operands of the two score products): row = ybase + l15 ----
+        const int64_t yr = ybase + l15;
+        const bool yok = yr < Y;
+        const int64_t yrc = yok ? yr : Y - 1;
+        f32x4 ya1[4], ya2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ya1[c] = ld4<VEC>(y1, ldy1, yrc, yok, h * M, 16 * c + 4 * lg, M);
+            ya2[c] = ld4<VEC>(y2, ldy2, yrc, yok, h * D, 16 * c + 4 * lg, D);
+        }
+        f32x4 s[kXT], r[kXT];
+#pragma unroll
+        for (int t = 0; t < kXT; ++t) s[t] = r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < kXT; ++t) {
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya1[c][u], xs1[t][c][u], s[t], 0, 0, 0);      // q . k
+                    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya2[c][u], xs2[t][c][u], r[t], 0, 0, 0);      // g . v
+                }
+        // ---- second-contraction A operands: A[i = l15 <-> column][k = swept row 4 lg + reg] ----
+        float zf1[4][4], zf2[4][4];              // [column tile][reg]
+        float cy[4], dy[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t yy = ybase + 4 * lg + reg;
+            const bool ok = yy < Y;
+            const int64_t yc = ok ? yy : Y - 1;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int col = 16 * ct + l15;
+                // dQ^T += K^T dS (MODE 0: y1 = k)   |   dK^T += Q^T dS (MODE 1: y1 = q)
+                const float a = y1[yc * ldy1 + h * M + (col < M ? col : 0)];
+                zf1[ct][reg] = (ok && col < M) ? a : 0.f;
+                if (MODE == 1) {                 // dV^T += G^T (c P)   (y2 = g)
+                    const float b = y2[yc * ldy2 + h * D + (col < D ? col : 0)];
+                    zf2[ct][reg] = (ok && col < D) ? b : 0.f;
+                }
+            }
+            if (MODE == 1) {                     // per-query scalars ride with the swept row
+                cy[reg] = ok ? cinv[yc * H + h] : 0.f;
+                dy[reg] = ok ? delta[yc * H + h] : 0.f;
+            }
+        }
+        // ---- weights: lane holds T^T[swept row 4 lg + reg][stationary row l15] ----
+        f32x4 ds[kXT], pc[kXT];
+#pragma unroll
+        for (int t = 0; t < kXT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const bool ok = ybase + 4 * lg + reg < Y;
+                const float p = ok ? sigmoidf(s[t][reg]) : 0.f;
+                const float c = (MODE == 0) ? cx[t] : cy[reg];
+                const float dl = (MODE == 0) ? dx[t] : dy[reg];
+                pc[t][reg] = p * c;
+                ds[t][reg] = pc[t][reg] * (r[t][reg] - dl) * (1.0f - p);
+            }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int t = 0; t < kXT; ++t) {
+                    acc1[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf1[ct][reg], ds[t][reg], acc1[t][ct], 0, 0, 0);
+                    if (MODE == 1)
+                        acc2[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf2[ct][reg], pc[t][reg], acc2[t][ct], 0, 0, 0);
+                }
+    }
+
+    // fold the 8 waves through LDS; lane holds O^T[col = 16 ct + 4 lg + reg][row = 16 t + l15] -> stored as [row][col]
+    auto fold_store = [&](f32x4 (&acc)[kXT][4], int width, float* __restrict__ dst, int64_t ldd, float* __restrict__ part) {
+#pragma unroll
+        for (int t = 0; t < kXT; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                *reinterpret_cast<f32x4*>(&sm_o[wave][(16 * t + l15) * kCols + 16 * ct + 4 * lg]) = acc[t][ct];
+        __syncthreads();
+        for (int e = threadIdx.x; e < kXGroup * kCols; e += 512) {
+            const int ri = e / kCols, col = e % kCols;
+            float o = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) o += sm_o[w][e];
+            const int64_t row = x0 + ri;
+            if (row < X && col < width) {
+                if (S == 1) dst[row * ldd + h * width + col] = o;
+                else part[(static_cast<int64_t>(split) * X + row) * (static_cast<int64_t>(H) * width) + h * width + col] = o;
+            }
+        }
+        __syncthreads();
+    };
+    fold_store(acc1, M, o1, ldo1, part1);
+    if (MODE == 1) fold_store(acc2, D, o2, ldo2, part2);
+}
+
+// out[row, :width] = sum_s part[s][row][:width]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int S, int64_t rows, int width,
+                                                        float* __restrict__ out, int64_t ldo) {
+    const int64_t total = rows * width;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * 256) {
+        float o = 0.f;
+        for (int s = 0; s < S; ++s) o += part[static_cast<int64_t>(s) * total + e];
+        out[(e / width) * ldo + e % width] = o;
+    }
+}
+
+// splits of the swept side: fill the chip when the stationary side has few 32-row groups (Cora: 85)
+int sweep_splits(int64_t X, int64_t Y, int H) {
+    const int64_t groups = ((X + kXGroup - 1) / kXGroup) * H;
+    const int64_t n_tiles = (Y + 15) / 16;
+    int64_t smax = (n_tiles + kWaves - 1) / kWaves;
+    if (smax > 16) smax = 16;
+    int best = 1;
+    double best_cost = -1.0;
+    for (int64_t s = 1; s <= smax; ++s) {
+        const int64_t rounds = (groups * s + dif::kCUs - 1) / dif::kCUs;            // one workgroup per CU (64 KiB of LDS, ~200 VGPRs)
+        const double cost = static_cast<double>(rounds) * (static_cast<double>(n_tiles) / (kWaves * s) + 4.0);
+        if (best_cost < 0 || cost < best_cost * 0.98) { best_cost = cost; best = static_cast<int>(s); }
+    }
+    return best;
+}
+
+size_t align16(size_t b) { return (b + 15) & ~size_t(15); }
+
+}  // namespace
+
+extern "C" size_t dif_sigmoid_bwd_workspace_bytes(int64_t N, int64_t L, int H, int M, int D) {
+    if (N <= 0 || L <= 0 || H <= 0 || M <= 0 || D <= 0) return 0;
+    const size_t S0 = sweep_splits(N, L, H), S1 = sweep_splits(L, N, H);
+    size_t b = 2 * align16(static_cast<size_t>(N) * H * sizeof(float));                        // cinv, delta
+    if (S0 > 1) b += align16(S0 * N * H * M * sizeof(float));
+    if (S1 > 1) b += align16(S1 * L * H * M * sizeof(float)) + align16(S1 * L * H * D * sizeof(float));
+    return b;
+}
+
+extern "C" int dif_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                        int64_t ldv, const float* out, int64_t ldo, const float* den, const float* g,
+                                        int64_t ldg, int64_t N, int64_t L, int H, int M, int D, float* dq, int64_t lddq,
+                                        float* dk, int64_t lddk, float* dv, int64_t lddv, void* workspace,
+                                        size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && L > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG, "dif_sigmoid_attn_bwd_f32: sizes must be positive");
+    DIF_REQUIRE(M <= kCols && D <= kCols, DIF_E_SHAPE, "dif_sigmoid_attn_bwd_f32: covers M, D <= 64 (got %d, %d)", M, D);
+    DIF_REQUIRE(q && k && v && out && den && g && dq && dk && dv && workspace, DIF_E_BADARG,
+                "dif_sigmoid_attn_bwd_f32: null pointer");
+    DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D && ldo >= H * D && ldg >= H * D && lddq >= H * M &&
+                    lddk >= H * M && lddv >= H * D, DIF_E_BADARG, "dif_sigmoid_attn_bwd_f32: leading dimension smaller than a row");
+    DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_sigmoid_attn_bwd_f32: too many heads");
+    DIF_REQUIRE(workspace_bytes >= dif_sigmoid_bwd_workspace_bytes(N, L, H, M, D) && dif::aligned16(workspace), DIF_E_WORKSPACE,
+                "dif_sigmoid_attn_bwd_f32: workspace too small or not 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int S0 = sweep_splits(N, L, H), S1 = sweep_splits(L, N, H);
+    char* w = static_cast<char*>(workspace);
+    float* cinv = reinterpret_cast<float*>(w);
+    w += align16(static_cast<size_t>(N) * H * sizeof(float));
+    float* delta = reinterpret_cast<float*>(w);
+    w += align16(static_cast<size_t>(N) * H * sizeof(float));
+    float* pq = nullptr, *pk = nullptr, *pv = nullptr;
+    if (S0 > 1) { pq = reinterpret_cast<float*>(w); w += align16(static_cast<size_t>(S0) * N * H * M * sizeof(float)); }
+    if (S1 > 1) {
+        pk = reinterpret_cast<float*>(w); w += align16(static_cast<size_t>(S1) * L * H * M * sizeof(float));
+        pv = reinterpret_cast<float*>(w);
+    }
+    int64_t pg = (N * H * 16 + 255) / 256;
+    if (pg > 8 * dif::kCUs) pg = 8 * dif::kCUs;
+    hipLaunchKernelGGL(sigmoid_bwd_prep_kernel, dim3(static_cast<unsigned>(pg)), dim3(256), 0, st, g, ldg, out, ldo, den, N, H, D,
+                       cinv, delta);
+    if (int rc = dif::launch_status("sigmoid_bwd_prep_kernel")) return rc;
+    auto al = [](const void* p, int64_t ld) { return ld % 4 == 0 && dif::aligned16(p); };
+    const bool vec = (M % 4 == 0) && (D % 4 == 0) && al(q, ldq) && al(k, ldk) && al(v, ldv) && al(g, ldg);
+    // dQ: stationary queries (q, g), swept keys (k, v)
+    {
+        dim3 grid(static_cast<unsigned>((N + kXGroup - 1) / kXGroup), H, S0), block(512);
+        if (vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<0, true>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv, cinv, delta,
+                                    N, L, H, M, D, dq, lddq, nullptr, int64_t{0}, pq, nullptr);
+        else hipLaunchKernelGGL((sigmoid_bwd_kernel<0, false>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv, cinv, delta,
+                                N, L, H, M, D, dq, lddq, nullptr, int64_t{0}, pq, nullptr);
+        if (int rc = dif::launch_status("sigmoid_bwd_kernel<dQ>")) return rc;
+    }
+    // dK, dV: stationary keys (k, v), swept queries (q, g)
+    {
+        dim3 grid(static_cast<unsigned>((L + kXGroup - 1) / kXGroup), H, S1), block(512);
+        if (vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<1, true>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg, cinv, delta,
+                                    L, N, H, M, D, dk, lddk, dv, lddv, pk, pv);
+        else hipLaunchKernelGGL((sigmoid_bwd_kernel<1, false>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg, cinv, delta,
+                                L, N, H, M, D, dk, lddk, dv, lddv, pk, pv);
+        if (int rc = dif::launch_status("sigmoid_bwd_kernel<dK,dV>")) return rc;
+    }
+    auto combine = [&](const float* part, int S, int64_t rows, int width, float* o, int64_t ldo_) -> int {
+        int64_t gsz = (rows * width + 255) / 256;
+        if (gsz > 8 * dif::kCUs) gsz = 8 * dif::kCUs;
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(static_cast<unsigned>(gsz)), dim3(256), 0, st, part, S, rows, width, o, ldo_);
+        return dif::launch_status("sum_parts_kernel");
+    };
+    if (S0 > 1) if (int rc = combine(pq, S0, N, H * M, dq, lddq)) return rc;
+    if (S1 > 1) {
+        if (int rc = combine(pk, S1, L, H * M, dk, lddk)) return rc;
+        if (int rc = combine(pv, S1, L, H * D, dv, lddv)) return rc;
+    }
+    return 0;
+}

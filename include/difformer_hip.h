@@ -89,6 +89,20 @@ int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ld
                          const float* v, int64_t ldv, int64_t N, int64_t L, int H, int M, int D,
                          float* out, int64_t ldo, void* workspace, size_t workspace_bytes,
                          dif_stream_t stream);
+/* f3 (training, main.py:117-131): dif_sigmoid_attn_fwd_f32 = dif_sigmoid_attn_f32 that also leaves the row sums
+ * den float[N,H] = sum_l sigmoid(q_n . k_l); dif_sigmoid_attn_bwd_f32 turns g = dL/dout [N,H,D] into dq [N,H,M],
+ * dk [L,H,M], dv [L,H,D] (M, D <= 64; DIF_E_SHAPE otherwise) by recomputing sigma tile by tile -- the [N,L,H] tensors are
+ * never materialised:  delta_n = g_n . out_n,  dV_l = sum_n (P_nl / den_n) g_n,
+ * dS_nl = (g_n . v_l - delta_n) P_nl (1 - P_nl) / den_n,  dQ = dS K,  dK = dS^T Q.  Deterministic.
+ * workspace: dif_sigmoid_bwd_workspace_bytes(N, L, H, M, D), 16-byte aligned. */
+int dif_sigmoid_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                             int64_t N, int64_t L, int H, int M, int D, float* out, int64_t ldo, float* den,
+                             void* workspace, size_t workspace_bytes, dif_stream_t stream);
+size_t dif_sigmoid_bwd_workspace_bytes(int64_t N, int64_t L, int H, int M, int D);
+int dif_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                             const float* out, int64_t ldo, const float* den, const float* g, int64_t ldg, int64_t N,
+                             int64_t L, int H, int M, int D, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                             int64_t lddv, void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * f4  TransConv.full_attention over a batch of graphs    physical particle/difformer-v2.py:71-137
@@ -429,6 +443,9 @@ int dif_simple_reduce_bf16(const void* q, int64_t ldq, const void* k, int64_t ld
 int dif_simple_apply_bf16(const void* q, int64_t ldq, const float* reduced, int64_t n_rows,
                           int64_t n_global, int H, int M, int D, void* out, int64_t ldo,
                           dif_stream_t stream);
+int dif_sigmoid_attn_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          int64_t N, int64_t L, int H, int M, int D, void* out, int64_t ldo, void* workspace,
+                          size_t workspace_bytes, dif_stream_t stream);
 int dif_gcn_spmm_tail_bf16(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
                            const int32_t* src, const float* val, int64_t n_nodes, int64_t nnz,
                            const void* x, int64_t ldx, int64_t row_begin, int64_t n_rows, int F,
