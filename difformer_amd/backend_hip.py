@@ -725,6 +725,53 @@ class HipBackend:
         _lib.check(rc, "dif_layer_tail_bwd_f32")
         return (d_conv, d_x0, d_prev, None if d_ln is None else d_ln[:D], None if d_ln is None else d_ln[D:2 * D])
 
+    def gram_sym(self, x):
+        """x [n, C] fp32 -> record [C*C + 2*C + 2]: X^T X (blocks of 64 on and above the diagonal valid) | sum x | unused
+        (csrc/simple_attn.hip, dif_gram_sym_f32) -- the Gram record of the closed form at the scripts' widths."""
+        dev = _require_device(x)
+        _f32(x, "x")
+        n, C = x.shape
+        x, ldx = _row_major(x, C)
+        rec = torch.empty(self.lib.dif_simple_reduced_len(1, C, C), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.dif_simple_workspace_bytes(n, 1, C, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _Timed(self, "dif_gram_sym_f32", dev):
+            rc = self.lib.dif_gram_sym_f32(_ptr(x), ldx, n, C, _ptr(rec), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_gram_sym_f32")
+        return rec
+
+    def layer_tail_mix(self, Z, D, den_col, conv_scale, add, add_scale, rs, bv, x0, prev, alpha, ln_weight, ln_bias, eps,
+                       relu=False):
+        """Tail of the closed form at the scripts' widths (dif_layer_tail_mix_f32): Z [n, >= D + 1] fp32 holds the
+        numerator in columns [0, D) and the denominator in column den_col; add [n, D] / rs [n] / bv [D] optional."""
+        dev = _require_device(Z, add, rs, bv, x0, prev, ln_weight, ln_bias)
+        n, ldz = Z.shape
+        for t_, nm in ((Z, "Z"), (add, "add"), (rs, "rs"), (bv, "bv"), (x0, "x0"), (prev, "prev")):
+            if t_ is not None:
+                _f32(t_, nm)
+        if not Z.is_contiguous() or ldz % 4:
+            raise ValueError("difformer_amd: layer_tail_mix needs a contiguous Z with a row length that is a multiple of 4")
+        lda = ldx0 = ldp = 0
+        if add is not None:
+            add, lda = _row_major(add, D)
+        if x0 is not None:
+            x0, ldx0 = _row_major(x0, D)
+        if prev is not None:
+            prev, ldp = _row_major(prev, D)
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        if rs is not None:
+            rs, bv = rs.contiguous(), bv.contiguous()
+        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        den_ptr = None if den_col is None else Z.data_ptr() + 4 * int(den_col)
+        with _Timed(self, "dif_layer_tail_mix_f32", dev):
+            rc = self.lib.dif_layer_tail_mix_f32(_ptr(Z), ldz, den_ptr, ldz, float(conv_scale), _ptr(add), lda,
+                                                 float(add_scale), _ptr(rs), _ptr(bv), n, D, _ptr(x0), ldx0, _ptr(prev), ldp,
+                                                 float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps), int(bool(relu)),
+                                                 _ptr(out), D, _stream(dev))
+        _lib.check(rc, "dif_layer_tail_mix_f32")
+        return out
+
     def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         dev = _require_device(conv, x0, prev, ln_weight, ln_bias)
         n, H, D = conv.shape

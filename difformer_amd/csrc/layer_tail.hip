@@ -14,14 +14,28 @@ using dif::Elem;
 
 // G lanes x V x 4 elements hold one row (D <= 4 G V, D % 4 == 0; V = 2 only with G = 64: rows of 260..512 elements, the
 // widths of image and text/run.sh); 256/G rows per block.  T = float | dif::bf16 (storage).
-template <int G, int V, typename T>
+// MIX (closed form at the scripts' widths, H == 1, fp32): the propagation result is assembled here as
+//   conv_scale * conv[row] / den[row] + add_scale * (add[row] + rs[row] * bv)        (difformer.py:36-39, :75-78, :130-134)
+// from the row GEMM outputs (numerator | denominator, aggregated values) -- no intermediate pass.
+struct Mix {
+    const float* den;       // per-row divisor, element row * ldden (NULL: none)
+    int64_t ldden;
+    float conv_scale;
+    const float* add;       // [n, D] second operand (NULL: none)
+    int64_t lda;
+    float add_scale;
+    const float* rs;        // [n] with bv [D]: rank-one term rs[row] * bv[col] inside the second operand (NULL: none)
+    const float* bv;
+};
+
+template <int G, int V, typename T, bool MIX = false>
 __global__ __launch_bounds__(256) void layer_tail_vec_kernel(const T* __restrict__ conv, int64_t ldc,
                                                              int64_t n_rows, int H, int D,
                                                              const T* __restrict__ x0, int64_t ldx0,
                                                              const T* __restrict__ prev, int64_t ldp, float alpha,
                                                              const T* __restrict__ ln_w,
                                                              const T* __restrict__ ln_b, float eps, int relu,
-                                                             T* __restrict__ out, int64_t ldo) {
+                                                             T* __restrict__ out, int64_t ldo, Mix mix = Mix{}) {
     constexpr int RPB = 256 / G;
     const int li = threadIdx.x % G;
     const float inv_h = 1.0f / static_cast<float>(H);
@@ -51,6 +65,16 @@ __global__ __launch_bounds__(256) void layer_tail_vec_kernel(const T* __restrict
                 const T* c = conv + row * ldc + col[v];
                 for (int h = 0; h < H; ++h) z[v] += Elem<T>::ld4(c + static_cast<int64_t>(h) * D);
                 if (H > 1) z[v] *= inv_h;                                                              // :137
+                if (MIX) {
+                    float sc = mix.conv_scale;
+                    if (mix.den) sc /= mix.den[row * mix.ldden];
+                    z[v] *= sc;
+                    if (mix.add) {
+                        f32x4 a = *reinterpret_cast<const f32x4*>(mix.add + row * mix.lda + col[v]);
+                        if (mix.rs) a += mix.rs[row] * *reinterpret_cast<const f32x4*>(mix.bv + col[v]);
+                        z[v] += mix.add_scale * a;
+                    }
+                }
                 if (x0) z[v] += Elem<T>::ld4(x0 + row * ldx0 + col[v]);                                // :139-140
                 if (prev) z[v] = alpha * z[v] + (1.0f - alpha) * Elem<T>::ld4(prev + row * ldp + col[v]);  // :201
             }
@@ -186,6 +210,41 @@ extern "C" int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows
                                   dif_stream_t stream) {
     return layer_tail_entry<float>(conv, ldc, n_rows, H, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, relu,
                                    out, ldo, stream);
+}
+
+// closed form at the scripts' widths: see struct Mix.  fp32, H == 1, D % 4 == 0, D <= 512, 16-byte aligned rows.
+extern "C" int dif_layer_tail_mix_f32(const float* conv, int64_t ldc, const float* den, int64_t ldden, float conv_scale,
+                                      const float* add, int64_t lda, float add_scale, const float* rs, const float* bv,
+                                      int64_t n_rows, int D, const float* x0, int64_t ldx0, const float* prev, int64_t ldp,
+                                      float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                                      float* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && D > 0 && D % 4 == 0 && D <= 512, DIF_E_SHAPE,
+                "dif_layer_tail_mix_f32: covers D %% 4 == 0, D <= 512 (got %d)", D);
+    DIF_REQUIRE(conv && out && ((rs == nullptr) == (bv == nullptr)) && (!rs || add), DIF_E_BADARG,
+                "dif_layer_tail_mix_f32: null pointer (rs and bv come together, with add)");
+    DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
+                "dif_layer_tail_mix_f32: ln_weight and ln_bias must be given together");
+    auto rows_ok = [&](const float* p, int64_t ld) { return !p || (ld >= D && ld % 4 == 0 && dif::aligned16(p)); };
+    DIF_REQUIRE(rows_ok(conv, ldc) && rows_ok(add, lda) && rows_ok(x0, ldx0) && rows_ok(prev, ldp) && rows_ok(out, ldo) &&
+                    rows_ok(ln_weight, D) && rows_ok(ln_bias, D) && rows_ok(bv, D) && (!den || ldden >= 1), DIF_E_BADARG,
+                "dif_layer_tail_mix_f32: rows must be 16-byte aligned with ld >= D, ld %% 4 == 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Mix mix = {den, ldden, conv_scale, add, lda, add_scale, rs, bv};
+    const int64_t cap = 8 * dif::kCUs;
+    const int q = D / 4;
+#define DIF_MIX(G, V)                                                                                              \
+    do {                                                                                                           \
+        int64_t gx = (n_rows + (256 / G) - 1) / (256 / G);                                                         \
+        if (gx > cap) gx = cap;                                                                                    \
+        hipLaunchKernelGGL((layer_tail_vec_kernel<G, V, float, true>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, conv, \
+                           ldc, n_rows, 1, D, x0, ldx0, prev, ldp, alpha, ln_weight, ln_bias, ln_eps, relu, out, ldo, mix); \
+    } while (0)
+    if (q <= 16) DIF_MIX(16, 1);
+    else if (q <= 32) DIF_MIX(32, 1);
+    else if (q <= 64) DIF_MIX(64, 1);
+    else DIF_MIX(64, 2);
+#undef DIF_MIX
+    return dif::launch_status("layer_tail_vec_kernel<mix>");
 }
 
 extern "C" int dif_layer_tail_bf16(const void* conv, int64_t ldc, int64_t n_rows, int H, int D, const void* x0,

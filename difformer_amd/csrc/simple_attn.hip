@@ -60,7 +60,10 @@ __device__ __forceinline__ f32x4 load_row4(const T* __restrict__ base, int64_t l
 // and MFMA (t,u) accumulates  D[i][j] += sum_k A[i][k] B[k][j]  with A[i=lane%16][k=lane/16] =
 // kx[t], B[k][j=lane%16] = vx[u], i.e. KtV[m0 + 4i + t][d0 + 4j + u].
 // ------------------------------------------------------------------------------------------
-template <bool VEC, typename T>
+// SYM (Gram record X^T X of the closed form at the scripts' widths: q = k = v = x, one head, M == D): only the tiles
+// with mt <= dt are computed (blockIdx.y enumerates them row by row), a diagonal tile loads its rows once and also
+// yields the column sums of its block; the strictly lower tiles of the record stay unwritten (the caller mirrors).
+template <bool VEC, typename T, bool SYM = false>
 __global__ __launch_bounds__(256) void simple_reduce_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk,
     const T* __restrict__ v, int64_t ldv, int64_t n_rows, Shape sh, float* __restrict__ ws,
@@ -71,18 +74,24 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     __shared__ float sm_s[kRedWaves][2];
 
     const int y = blockIdx.y;
-    const int dt = y % sh.DT;
-    const int mt = (y / sh.DT) % sh.MT;
-    const int h = y / (sh.DT * sh.MT);
+    int dt = y % sh.DT;
+    int mt = (y / sh.DT) % sh.MT;
+    const int h = SYM ? 0 : y / (sh.DT * sh.MT);
+    if (SYM) {                                   // y -> (mt, dt), mt <= dt, row by row
+        int rest = y;
+        mt = 0;
+        while (rest >= sh.MT - mt) { rest -= sh.MT - mt; ++mt; }
+        dt = mt + rest;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l15 = lane & 15;
     const int lg = lane >> 4;
     const int mc = mt * kTile + 4 * l15;  // this lane's first m column inside head h
     const int dc = dt * kTile + 4 * l15;
-    const bool do_k = (dt == 0);
-    const bool do_v = (mt == 0);
-    const bool do_q = do_k;  // every m-tile of a head squares its own q columns exactly once
+    const bool do_k = SYM ? (dt == mt) : (dt == 0);
+    const bool do_v = SYM ? false : (mt == 0);
+    const bool do_q = SYM ? false : do_k;  // every m-tile of a head squares its own q columns exactly once
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -103,7 +112,8 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
         for (int s = 0; s < kRedUnroll; ++s) {
             const int64_t r = (it * kRedUnroll + s) * 4 + lg;
             kx[s] = load_row4<VEC>(k, ldk, r, n_rows, h * sh.M, mc, sh.M);
-            vx[s] = load_row4<VEC>(v, ldv, r, n_rows, h * sh.D, dc, sh.D);
+            if (SYM && dt == mt) vx[s] = kx[s];
+            else vx[s] = load_row4<VEC>(v, ldv, r, n_rows, h * sh.D, dc, sh.D);
             if (do_q) qx[s] = load_row4<VEC>(q, ldq, r, n_rows, h * sh.M, mc, sh.M);
         }
 #pragma unroll
@@ -444,11 +454,17 @@ __global__ __launch_bounds__(64 * kWideWaves) void simple_apply_wide_kernel(cons
     }
 }
 
-int reduce_chunks(int64_t n_rows) {
+// Row chunks (= partial records = workgroups along x).  One 64 x 64 tile (narrow heads): up to 512 chunks fill the
+// chip.  Many tiles (hidden 300: 25 of them): every chunk writes a whole partial record, so the chunk count is cut to
+// ~1024 workgroups in all -- at 512 chunks the partials alone were 185 MB written and read back (profiles/r02_experiments.md).
+int reduce_chunks(int64_t n_rows, int tiles) {
     const int64_t n_iters = ((n_rows + 3) / 4 + kRedUnroll - 1) / kRedUnroll;
     int64_t p = (n_iters + kRedWaves - 1) / kRedWaves;
+    int64_t cap = kMaxChunks;
+    if (tiles > 2) cap = (4 * dif::kCUs + tiles - 1) / tiles;
+    if (cap < 8) cap = 8;
+    if (p > cap) p = cap;
     if (p < 1) p = 1;
-    if (p > kMaxChunks) p = kMaxChunks;
     return static_cast<int>(p);
 }
 
@@ -475,7 +491,7 @@ int simple_reduce_entry(const T* q, int64_t ldq, const T* k, int64_t ldk, const 
                 dif_simple_workspace_bytes(n_rows, H, M, D));
     DIF_REQUIRE(dif::aligned16(workspace), DIF_E_BADARG, "dif_simple_reduce: workspace not 16-byte aligned");
     const Shape sh = make_shape(H, M, D);
-    const int P = reduce_chunks(n_rows);
+    const int P = reduce_chunks(n_rows, sh.tiles);
     const int64_t rec = (static_cast<int64_t>(sh.t_main) + 2 * sh.tiles + 3) & ~int64_t(3);
     const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) &&
                      dif::aligned_v4<T>(q) && dif::aligned_v4<T>(k) && dif::aligned_v4<T>(v);
@@ -546,6 +562,30 @@ int simple_apply_entry(const T* q, int64_t ldq, const float* reduced, int64_t n_
 
 }  // namespace
 
+// Gram record of the closed form at the scripts' widths: record = [X^T X (C x C) | sum x (C) | unused (C) | 2 unused];
+// of X^T X only the 64 x 64 blocks on and above the diagonal are written.  Layout and workspace as
+// dif_simple_reduce_f32(x, x, x) with H = 1, M = D = C.
+extern "C" int dif_gram_sym_f32(const float* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
+                                size_t workspace_bytes, dif_stream_t stream) {
+    if (int rc = check_shape(n_rows, 1, C, C)) return rc;
+    DIF_REQUIRE(x && record && workspace, DIF_E_BADARG, "dif_gram_sym_f32: null pointer");
+    DIF_REQUIRE(ldx >= C, DIF_E_BADARG, "dif_gram_sym_f32: leading dimension smaller than a row");
+    DIF_REQUIRE(workspace_bytes >= dif_simple_workspace_bytes(n_rows, 1, C, C) && dif::aligned16(workspace), DIF_E_WORKSPACE,
+                "dif_gram_sym_f32: workspace too small or not 16-byte aligned");
+    const Shape sh = make_shape(1, C, C);
+    const int tiles_sym = sh.MT * (sh.MT + 1) / 2;
+    const int P = reduce_chunks(n_rows, sh.tiles);          // as dif_simple_workspace_bytes sizes it
+    const int64_t rec = (static_cast<int64_t>(sh.t_main) + 2 * sh.tiles + 3) & ~int64_t(3);
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && dif::aligned16(x);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* ws = static_cast<float*>(workspace);
+    dim3 grid(P, tiles_sym), block(256);
+    if (vec) hipLaunchKernelGGL((simple_reduce_kernel<true, float, true>), grid, block, 0, st, x, ldx, x, ldx, x, ldx, n_rows, sh, ws, rec);
+    else hipLaunchKernelGGL((simple_reduce_kernel<false, float, true>), grid, block, 0, st, x, ldx, x, ldx, x, ldx, n_rows, sh, ws, rec);
+    if (int rc = dif::launch_status("simple_reduce_kernel<sym>")) return rc;
+    return dif::launch_record_finalize(ws, P, rec, sh.t_main, tiles_sym, record, st);
+}
+
 extern "C" size_t dif_simple_reduced_len(int H, int M, int D) {
     if (H <= 0 || M <= 0 || D <= 0) return 0;
     return static_cast<size_t>(make_shape(H, M, D).t_main) + 2;
@@ -555,7 +595,7 @@ extern "C" size_t dif_simple_workspace_bytes(int64_t n_rows, int H, int M, int D
     if (n_rows <= 0 || H <= 0 || M <= 0 || D <= 0) return 0;
     const Shape sh = make_shape(H, M, D);
     const size_t rec = (static_cast<size_t>(sh.t_main) + 2 * static_cast<size_t>(sh.tiles) + 3) & ~size_t(3);
-    return rec * sizeof(float) * static_cast<size_t>(reduce_chunks(n_rows));
+    return rec * sizeof(float) * static_cast<size_t>(reduce_chunks(n_rows, sh.tiles));
 }
 
 extern "C" int dif_simple_reduce_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,

@@ -78,6 +78,7 @@ class DIFFormerConv(nn.Module):
         self.use_source = use_source
         self.row_shard = None  # set through DIFFormer.set_row_shard for multi-GPU runs
         self._fused_wb = None  # (key, weight, bias) of the concatenated projections (inference only)
+        self._wide = None      # (key, ops.WideCoefficients): weight-only factors of the closed form at hidden > 64
 
     def reset_parameters(self):
         self.Wk.reset_parameters()
@@ -132,8 +133,13 @@ class DIFFormerConv(nn.Module):
         x = source_input
         if not (self.kernel == 'simple' and query_input is source_input and self.num_heads == 1 and not want_qk):
             return False
-        if x.dim() != 2 or x.dtype != torch.float32 or x.shape[1] > 64 or x.shape[1] % 4 or self.out_channels > 64:
+        if x.dim() != 2 or x.dtype != torch.float32 or x.shape[1] % 4:
             return False
+        wide = x.shape[1] > 64 or self.out_channels > 64
+        if wide and (self.row_shard is not None or max(x.shape[1], self.out_channels) > ops.CLOSED_FORM_WIDE_MAX or
+                     x.shape[1] <= ops.CLOSED_FORM_WIDE_MIN or x.shape[0] < 4 * x.shape[1]):
+            return False          # the record is C x C: it only pays with many more rows than columns, and from
+                                  # hidden ~256 up (at 128 the two row GEMMs cost what the operator path does)
         if not self.use_weight and x.shape[1] != self.out_channels:
             return False
         if prev is not None and (prev is not x or x.shape[1] != self.out_channels):
@@ -163,6 +169,16 @@ class DIFFormerConv(nn.Module):
             if not self.use_graph:
                 a_s = 1.0                                       # difformer.py:130-136: the mix only exists with a graph
             Wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
+            if x.shape[1] > 64 or self.out_channels > 64:          # the scripts' widths (hidden 128 / 300 / 400)
+                params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias] + ([Wv, bv] if self.use_weight else [])
+                key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in params)
+                if self._wide is None or self._wide[0] != key:      # weight-only factors: rebuilt when a parameter changes
+                    with torch.no_grad():
+                        self._wide = (key, ops.WideCoefficients(self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias,
+                                                                Wv, bv))
+                out = ops.simple_layer_closed_form_wide(x, self._wide[1], Wv, bv, csr, a_s, g_s, x0, prev is not None, alpha,
+                                                        ln_weight, ln_bias, eps)
+                return out, None, None
             out = ops.simple_layer_closed_form(x, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv, csr,
                                                a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps, carry=carry,
                                                shard=shard)

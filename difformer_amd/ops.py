@@ -523,6 +523,79 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     return out
 
 
+CLOSED_FORM_WIDE_MAX = 512      # widest layer the Gram-record formulation is used for (record = C x C floats)
+CLOSED_FORM_WIDE_MIN = 128      # up to here the q / k / v operator path is as fast (pokec-batch-h128: 1.04 vs 1.2 ms)
+
+
+class WideCoefficients:
+    """Weight-only factors of the closed form at the scripts' widths, float64, rebuilt when a parameter changes.
+    With the augmented matrices  X~ = [X | 1],  W~ = [W | b]  (so q = X~ W~q^T etc.) and  G~ = X~^T X~ = [[G, sx], [sx^T, N]]:
+        |Q|^2 = <W~q^T W~q, G~>,   |K|^2 = <W~k^T W~k, G~>                       (difformer.py:20-21)
+        T = G~ V~,    V~ = [W~v^T | e_last | 0 0 0]     -> last row of T = [sum v | N | 0 0 0]
+        R = P~ T,     P~ = W~q^T W~k                     -> rows 0..C-1 = [Mn | u] / s,  last row = [bq KtV | bq.ksum] / s
+    num = x Mn + cn, den = x.u + cd  with  [cn | cd] = s R[C] + T[C]              (:25-38)"""
+
+    def __init__(self, Wq, bq, Wk, bk, Wv, bv):
+        f64 = torch.float64
+        aug = lambda W, b: torch.cat([W.to(f64), b.to(f64)[:, None]], dim=1)
+        Wq_, Wk_ = aug(Wq, bq), aug(Wk, bk)
+        D, C1 = Wq_.shape
+        if Wv is not None:
+            Wv_ = aug(Wv, bv)
+        else:                                                           # use_weight = False: v = x (difformer.py:120)
+            Wv_ = torch.cat([torch.eye(C1 - 1, dtype=f64, device=Wq.device), torch.zeros(C1 - 1, 1, dtype=f64, device=Wq.device)], 1)
+        self.D = Wv_.shape[0]
+        self.S = torch.stack([(Wq_.t() @ Wq_).reshape(-1), (Wk_.t() @ Wk_).reshape(-1)])           # [2, (C+1)^2]
+        self.P = (Wq_.t() @ Wk_).contiguous()                                                      # [(C+1), (C+1)]
+        V = torch.zeros((C1, self.D + 4), dtype=f64, device=Wq.device)
+        V[:, : self.D] = Wv_.t()
+        V[C1 - 1, self.D] = 1.0
+        self.V = V
+        blk = torch.arange(C1 - 1, device=Wq.device) // 64
+        self.upper = blk[:, None] <= blk[None, :]                       # the blocks of X^T X that dif_gram_sym_f32 writes
+
+
+def simple_layer_closed_form_wide(x, coeffs: WideCoefficients, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha,
+                                  ln_weight, ln_bias, eps):
+    """The closed form of simple_layer_closed_form at the widths the reference's scripts train with (hidden 128 / 300 /
+    400: run.sh): query == source == x [n, C] fp32, one head, single GPU, inference.
+        G~ = [X | 1]^T [X | 1]             one streaming pass (dif_gram_sym_f32: the upper 64-blocks of X^T X on the fp32 MFMA)
+        [Mn | u], [cn | cd]                two float64 library GEMMs on (C + 1)-square matrices (WideCoefficients)
+        Z = x [Mn | u] + [cn | cd]         ONE row GEMM: numerator | denominator
+        gcn = (A_hat x) Wv^T               SpMM on x, one row GEMM  (+ (A_hat 1) bv^T inside the tail)
+        tail                               num / den, combine, + x0, residual, LayerNorm in one pass (dif_layer_tail_mix_f32)
+    instead of three projections (3 N C D), the K^T V reduce (N D^2) and the Q-side apply (N D^2): 2-3x fewer FLOPs and
+    q, k, v never written."""
+    be = get_backend()
+    n, C = x.shape
+    D = coeffs.D
+    x3 = x.reshape(n, 1, C)
+    rec = be.gram_sym(x)                                                # [X^T X (upper blocks) | sum x | ...]
+    f64 = torch.float64
+    Gt = torch.empty((C + 1, C + 1), dtype=f64, device=x.device)
+    Graw = rec[: C * C].view(C, C)
+    Gt[:C, :C] = torch.where(coeffs.upper, Graw, Graw.t())
+    Gt[:C, C] = rec[C * C: C * C + C]
+    Gt[C, :C] = rec[C * C: C * C + C]
+    Gt[C, C] = float(n)
+    norms = coeffs.S @ Gt.reshape(-1)                                   # |Q|^2, |K|^2
+    s = torch.rsqrt(norms[0] * norms[1])
+    T = Gt @ coeffs.V                                                   # [(C+1), D+4]
+    R = coeffs.P @ T
+    B = (s * R[:C]).to(torch.float32)                                   # [Mn | u | 0 0 0]
+    bias = (s * R[C] + T[C]).to(torch.float32)                          # [cn | cd | 0 0 0]
+    Z = torch.addmm(bias, x, B)                                         # [n, D + 4]: numerator | denominator
+    gcn = rs = None
+    if csr is not None:
+        ax = gcn_aggregate(csr, x3, None, 1.0, 1.0).reshape(n, C)       # sliced or gather kernels, whichever the graph takes
+        if Wv is not None:
+            gcn, rs = torch.mm(ax, Wv.t()), csr.row_sums()
+        else:
+            gcn = ax
+    return be.layer_tail_mix(Z, D, D, attn_scale, gcn, gcn_scale, rs, bv if rs is not None else None, x0,
+                             x if residual else None, alpha, ln_weight, ln_bias, eps)
+
+
 # ------------------------------------------------------------------------------------------
 # f4: batch of graphs stored back to back (physical particle/difformer-v2.py:71-137)
 # ------------------------------------------------------------------------------------------

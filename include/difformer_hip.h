@@ -362,6 +362,21 @@ int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, in
                        const float* x0, int64_t ldx0, const float* prev, int64_t ldp,
                        float alpha, const float* ln_weight, const float* ln_bias, float ln_eps,
                        int relu, float* out, int64_t ldo, dif_stream_t stream);
+/* The same tail with the propagation result assembled in the pass (closed form of the simple kernel at the widths of
+ * the reference's scripts, hidden 128 / 300 / 400; one head, fp32):
+ *   z = conv_scale * conv[row,:] / den[row * ldden] + add_scale * (add[row,:] + rs[row] * bv[:])      (:36-39, :75-78, :130-134)
+ * then + x0, the alpha-residual with prev, LayerNorm, ReLU as dif_layer_tail_f32.  den / add / (rs, bv) may be NULL.
+ * conv and den are typically the numerator columns and the denominator column of ONE row-GEMM output. */
+/* Gram record of that closed form: record float[dif_simple_reduced_len(1, C, C)] = [X^T X (C x C, row-major) | sum x (C) |
+ * C + 2 unused]; of X^T X only the 64 x 64 blocks on and above the diagonal are written (symmetric: the caller mirrors).
+ * One streaming pass on the fp32 MFMA; workspace: dif_simple_workspace_bytes(n_rows, 1, C, C), 16-byte aligned. */
+int dif_gram_sym_f32(const float* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
+                     size_t workspace_bytes, dif_stream_t stream);
+int dif_layer_tail_mix_f32(const float* conv, int64_t ldc, const float* den, int64_t ldden, float conv_scale,
+                           const float* add, int64_t lda, float add_scale, const float* rs, const float* bv,
+                           int64_t n_rows, int D, const float* x0, int64_t ldx0, const float* prev, int64_t ldp,
+                           float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                           float* out, int64_t ldo, dif_stream_t stream);
 
 /* dif_gcn_spmm_f32 with the tail above fused into its epilogue (H == 1 layers: conv row = feature
  * row, F = D <= 256): out = tail(gcn_scale * A_hat x (+ attn_scale * attn)).  Saves the [n,D] round

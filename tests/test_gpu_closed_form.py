@@ -93,7 +93,12 @@ def test_closed_form_attention_matches_the_simple_kernel(n, c, d, use_weight, de
                           (3000, 8, 64, True, 0.3, True, True, True),            # lane-group SpMM, convex mix, + x0
                           (9000, 70, 64, False, -1, False, True, True),          # use_weight = False
                           (4000, 10, 32, True, -1, False, False, False),         # narrow, no tail
-                          (2500, 6, 64, True, -1, True, False, True)])
+                          (2500, 6, 64, True, -1, True, False, True),
+                          # the scripts' widths (run.sh: hidden 300 / 400; beyond 128 columns): Gram record + row GEMMs
+                          (6000, 8, 192, True, -1, False, True, True),
+                          (5000, 5, 300, True, 0.4, True, True, True),
+                          (4000, 6, 400, False, -1, False, True, False),
+                          (9000, 60, 132, True, -1, False, True, True)])        # wide rows on the sliced product
 def test_closed_form_layer_vs_oracle(n, deg, c, use_weight, graph_weight, use_source, ln, residual, dev):
     from difformer_amd import DIFFormerConv
     torch.manual_seed(n)
@@ -118,6 +123,11 @@ def test_closed_form_layer_vs_oracle(n, deg, c, use_weight, graph_weight, use_so
     if ln:
         z = orc.layer_norm(z, lw.double().numpy(), lb.double().numpy())
     assert rel_err(out.cpu().numpy(), z) < TOL
+    if c > 64:      # wide: same numbers as the q / k / v operator path (want_qk forces it)
+        with torch.no_grad():
+            old, q, _ = conv._layer(xd, xd, ei.to(dev), None, x0.to(dev) if use_source else None, xd if residual else None,
+                                    0.4, lw.to(dev) if ln else None, lb.to(dev) if ln else None, 1e-5, want_qk=True)
+        assert q is not None and rel_err(out.cpu().numpy(), old.cpu().numpy()) < 1e-5
 
 
 def test_closed_form_layer_without_graph_matches_the_operator_path(dev):
