@@ -577,7 +577,7 @@ def simple_layer_closed_form_wide(x, coeffs: WideCoefficients, Wv, bv, csr, attn
     Gt[:C, :C] = torch.where(coeffs.upper, Graw, Graw.t())
     Gt[:C, C] = rec[C * C: C * C + C]
     Gt[C, :C] = rec[C * C: C * C + C]
-    Gt[C, C] = float(n)
+    Gt[C, C].fill_(float(n))                                            # (a fill kernel: capturable, no host copy)
     norms = coeffs.S @ Gt.reshape(-1)                                   # |Q|^2, |K|^2
     s = torch.rsqrt(norms[0] * norms[1])
     T = Gt @ coeffs.V                                                   # [(C+1), D+4]

@@ -531,12 +531,14 @@ def test_training_step_gradients_match_float64_autograd(dev):
         assert rel_err(prm.grad.cpu().numpy(), p64[k].grad.numpy()) < 1e-4, k
 
 
-def test_graphed_forward_replays_match_eager(dev):
-    """hipGraph capture of the whole forward: replays equal the eager result, also after the input changes."""
+@pytest.mark.parametrize("hidden", [64, 300])
+def test_graphed_forward_replays_match_eager(hidden, dev):
+    """hipGraph capture of the whole forward: replays equal the eager result, also after the input changes (hidden 300:
+    the closed form at the scripts' widths, whose coefficient algebra runs as library GEMMs inside the capture)."""
     from difformer_amd import DIFFormer, GraphedForward
     torch.manual_seed(3)
     n = 3000
-    model = DIFFormer(40, 64, 6, num_layers=3, kernel="simple").to(dev).eval()
+    model = DIFFormer(40, hidden, 6, num_layers=3, kernel="simple").to(dev).eval()
     g = torch.Generator().manual_seed(1)
     x1, x2 = torch.randn(n, 40, generator=g).to(dev), torch.randn(n, 40, generator=g).to(dev)
     ei = torch.cat([torch.randint(0, n, (2, 20000), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
