@@ -25,6 +25,7 @@
 // The same adjacency slice is swept by the 16 slice-workgroups of a panel, which sit on one XCD (block b -> XCD b % 8),
 // so the entry stream comes from HBM once.
 // Measured at C4 (79.3 M entries): 0.33 ms per launch against 1.12 ms (profiles/r02_experiments.md).
+#include <stdlib.h>
 #include "dif_common.h"
 
 namespace {
@@ -407,6 +408,9 @@ struct Epilogue {
     float attn_scale, gcn_scale;
     float* out;
     int64_t ldo;
+#ifdef DIF_SLICED_TRACE
+    long long* trace;      // measurement build only (scripts/exp_sliced_trace.py): per-tile wall-clock stamps of the first and last wave
+#endif
 };
 
 // one block of a round: eight entries (four packed dwords), 16-bit row number -> LDS byte address with one SDWA shift
@@ -482,6 +486,13 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
     for (int tt = 0; tt < pl.NT; ++tt) {
         int t = tt + t0;                                                      // XCDs start on different tiles (t0)
         if (t >= pl.NT) t -= pl.NT;
+#ifdef DIF_SLICED_TRACE
+        const int tw = (threadIdx.x >> 6) == 0 ? 0 : ((static_cast<int>(threadIdx.x >> 6) == pl.W - 1) ? 1 : -1);
+        long long* tr4 = (tw >= 0 && lane == 0) ? ep.trace + ((static_cast<int64_t>(blockIdx.x) * 2 + tw) * pl.NT + tt) * 4 : nullptr;
+#define DIF_STAMP(i) do { if (tr4) tr4[i] = wall_clock64(); } while (0)
+#else
+#define DIF_STAMP(i) do { } while (0)
+#endif
         uint4 e[NA];
         int nb[NA];
         const uint4* cur = ell;
@@ -508,7 +519,9 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
                 const f32x4* su = src + u * nth;
                 r[u] = (u * nth + static_cast<int>(tid) < T) ? su[tid] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            DIF_STAMP(0);
             __syncthreads();                                                  // everyone is done with the previous tile
+            DIF_STAMP(1);
 #pragma unroll
             for (int b = 0; b < 11; b += U) {                                 // batches of U rows per thread, 11 in all
 #pragma unroll
@@ -530,11 +543,14 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
         // (the LDS stores consumed them, and the entry loads were issued before them): say so.
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
         __syncthreads();
+        DIF_STAMP(2);
         if (NR > 0) {
             int k = 0;
             Phases<NR, NA>::run(tile, k, cur, e, acc, nb);
         }
+        DIF_STAMP(3);
     }
+#undef DIF_STAMP
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int64_t pos = slot_of(j, pw, pl.PW) * 64 + lane;
@@ -714,7 +730,14 @@ extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table
     DIF_REQUIRE(dif::aligned16(entries) && dif::aligned16(ys), DIF_E_BADARG, "dif_sliced_spmm: entries / ys must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t npad = static_cast<int64_t>(pl.T) * pl.NT;
+#ifdef DIF_SLICED_TRACE
+    const char* tp = getenv("DIF_SLICED_TRACE");
+    DIF_REQUIRE(tp != nullptr, DIF_E_BADARG, "trace build: DIF_SLICED_TRACE = device address of int64[blocks * 2 * tiles * 4]");
+    const Epilogue ep = {rowptr, dinv, row_order, parts, row_begin, n_pos, attn, lda, attn_scale, gcn_scale, out, ldo,
+                         reinterpret_cast<long long*>(strtoull(tp, nullptr, 0))};
+#else
     const Epilogue ep = {rowptr, dinv, row_order, parts, row_begin, n_pos, attn, lda, attn_scale, gcn_scale, out, ldo};
+#endif
     const uint4* e4 = reinterpret_cast<const uint4*>(entries);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(ys);
     switch (pl.R) {
