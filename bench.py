@@ -44,6 +44,7 @@ WORKLOADS = {
     "cifar50k-s": (50000, 0, 512, 10, 64, 4, "simple", False),
     # C5: one Pokec-shaped mini-batch (main-batch.py path), bf16 storage / fp32 accumulate; 8 GPUs = 8 replicas
     "pokec-batch-s-bf16": (100000, 115000, 65, 2, 64, 3, "simple", True),
+    "pokec-batch-s": (100000, 115000, 65, 2, 64, 3, "simple", True),            # the same batch in fp32 (closed-form layers)
     # not a BASELINE config: the C4 graph in bf16 storage, to show what the gather-bound SpMM does at half the bytes
     "ogbn-proteins-s-bf16": (132534, 39561252, 8, 112, 64, 4, "simple", True),
     # the C4 graph with a skewed (Zipf-like) degree profile, max / mean degree ~13 as in the real
@@ -106,7 +107,8 @@ def shard_plan(workload, world, rank):
     else:
         counts = split_rows(n, world)
         begin, count = sum(counts[:rank]), counts[rank]
-    return {"replicas": replicas, "row_begin": begin, "n_local": count, "scaling": "weak" if replicas else "strong",
+    return {"replicas": replicas, "row_begin": begin, "n_local": count,
+            "scaling": "weak" if workload.startswith("pokec-batch") else "strong",       # what adding GPUs does to this workload
             "parallelism": (f"replicas x{world}" if replicas else f"row-shard x{world}") if world > 1 else "single GPU"}
 
 

@@ -517,14 +517,21 @@ class HipBackend:
         """x [n, C] fp32 -> (record [C*C + C + 2] = {X^T X, column sums}, ys | None).  With rowptr + plan the pass also
         writes the slice-major copy of x scaled by deg^-1/2 that sliced_spmm reads."""
         dev = _require_device(x, rowptr)
-        _f32(x, "x")
+        dt, sfx = _storage(x)
         n, C = x.shape
         x, ldx = _row_major(x, C)
-        if ldx % 4 or x.data_ptr() % 16:
+        if ldx % 4 or x.data_ptr() % (4 * x.element_size()):
             x, ldx = x.contiguous(), C
         record = torch.empty(C * C + C + 2, dtype=torch.float32, device=dev)
         ws_bytes = self.lib.dif_gram_workspace_bytes(n, C)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        if sfx == "bf16":        # bfloat16 rows, float32 record; no slice-major copy (the sliced product is float32-only)
+            if plan is not None:
+                raise TypeError("difformer_amd: the slice-major copy of the sliced product is float32-only")
+            with _Timed(self, "dif_gram_f32", dev):
+                rc = self.lib.dif_gram_bf16(_ptr(x), ldx, n, C, _ptr(record), _ptr(ws), ws_bytes, _stream(dev))
+            _lib.check(rc, "dif_gram_bf16")
+            return record, None
         ys = None
         if plan is not None:
             ys = torch.empty((C // 4, int(plan[6]) * int(plan[7]), 4), dtype=torch.float32, device=dev)
@@ -550,9 +557,13 @@ class HipBackend:
         """-> out [n, D]; with next_plan -> (out, ys, record | None): also the slice-major scaled copy of `out` for the
         next layer's SpMM (see gram()), and with next_record its Gram record from the same pass."""
         dev = _require_device(x, coef, ax, Wv, bv, row_sums, x0, ln_weight, ln_bias)
+        dt, sfx = _storage(x, ax, x0)              # activations: float32 or bfloat16; parameters always float32 here
+        for t_, nm in ((coef, "coef"), (Wv, "Wv"), (bv, "bv"), (ln_weight, "ln_weight"), (ln_bias, "ln_bias"), (row_sums, "row_sums")):
+            if t_ is not None:
+                _f32(t_, nm)
         n, C = x.shape
         x, ldx = _row_major(x, C)
-        if ldx % 4 or x.data_ptr() % 16:
+        if ldx % 4 or x.data_ptr() % (4 * x.element_size()):
             x, ldx = x.contiguous(), C
         ldax = ldx0 = 0
         if ax is not None:
@@ -563,9 +574,19 @@ class HipBackend:
             Wv, bv = Wv.contiguous(), bv.contiguous()
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
-        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        out = torch.empty((n, D), dtype=dt, device=dev)
         record = ys = ws = None
         ws_bytes = 0
+        if sfx == "bf16":
+            if next_plan is not None or next_record:
+                raise TypeError("difformer_amd: products for the next layer are float32-only")
+            with _Timed(self, "dif_simple_layer_f32", dev):
+                rc = self.lib.dif_simple_layer_bf16(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
+                                                    _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
+                                                    float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
+                                                    int(bool(relu)), _ptr(out), D, _stream(dev))
+            _lib.check(rc, "dif_simple_layer_bf16")
+            return out
         if next_plan is not None:
             ys = torch.empty((D // 4, int(next_plan[6]) * int(next_plan[7]), 4), dtype=torch.float32, device=dev)
         if next_record:

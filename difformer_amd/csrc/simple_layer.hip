@@ -22,6 +22,7 @@
 namespace {
 
 using dif::f32x4;
+using dif::Elem;
 
 constexpr int kWaves = 4;
 constexpr int kWStride = 68;     // padded LDS row (floats): 16 lanes x b128 land on 64 distinct banks
@@ -43,8 +44,8 @@ __device__ __forceinline__ float dinv_of(const int32_t* __restrict__ rowptr, int
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kGramWaves = 8;
 
-template <bool WRITE_YS>
-__global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C,
+template <bool WRITE_YS, typename T = float>
+__global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const T* __restrict__ x, int64_t ldx, int64_t n_rows, int C,
                                                                   const int32_t* __restrict__ rowptr, f32x4* __restrict__ ys,
                                                                   int64_t npad, float* __restrict__ ws, int64_t ws_stride) {
     __shared__ float sm_f[4 * 40 * 64];          // fold buffer: 40 accumulator registers x 64 lanes for up to 4 waves
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const float* _
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t row = tile * 16 + 4 * u + lg;
-            xv[u] = (row < n_rows && col_ok) ? *reinterpret_cast<const f32x4*>(x + row * ldx + 4 * l15) : zero4();
+            xv[u] = (row < n_rows && col_ok) ? Elem<T>::ld4(x + row * ldx + 4 * l15) : zero4();
         }
     };
     f32x4 nxt[4];
@@ -331,33 +332,36 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
 // i.e. the very layout of the loaded x fragment.  So the residual operand is already in registers, the denominator of
 // the row is in the lane, LayerNorm folds over the four lane groups with two shuffles and rows leave as 16-byte stores.
 // ------------------------------------------------------------------------------------------------------------
-struct LayerArgs {
-    const float* x; int64_t ldx;          // layer input [n, C]
-    const float* ax; int64_t ldax;        // g_s * A_hat x [n, C] or null (use_graph = False)
+// T: storage type of the ACTIVATIONS (x, ax, x0, out: float or bfloat16); coefficients and parameters are float32
+template <typename T>
+struct LayerArgsT {
+    const T* x; int64_t ldx;              // layer input [n, C]
+    const T* ax; int64_t ldax;            // g_s * A_hat x [n, C] or null (use_graph = False)
     const float* coef;                    // dif_simple_coeffs_f32 output
     const float* Wv; const float* bv;     // [D, C], [D] or null (use_weight = False: the graph term is ax itself)
     const float* rs; float gcn_scale;     // row sums of A_hat (for the bias of the value projection) or null
-    const float* x0; int64_t ldx0;        // use_source
+    const T* x0; int64_t ldx0;            // use_source
     int residual; float alpha;            // alpha * z + (1 - alpha) * x
     const float* ln_w; const float* ln_b; float eps; int relu;
-    float* out; int64_t ldo;
+    T* out; int64_t ldo;
     int64_t n_rows; int C, D;
     // NEXT: the Gram record of `out` (the next layer's input) and its slice-major pre-scaled copy, from the same pass
     const int32_t* rowptr; f32x4* ys_next; int64_t npad; float* ws; int64_t ws_stride;
 };
+using LayerArgs = LayerArgsT<float>;
 
-template <bool GUARD>
-__device__ __forceinline__ void load_rows(f32x4 (&xa)[4], const float* __restrict__ x, int64_t ldx, int64_t r, int64_t n, int lg,
+template <bool GUARD, typename T>
+__device__ __forceinline__ void load_rows(f32x4 (&xa)[4], const T* __restrict__ x, int64_t ldx, int64_t r, int64_t n, int lg,
                                           int C) {
     if (!GUARD) {
-        const float* p = x + r * ldx + 4 * lg;
+        const T* p = x + r * ldx + 4 * lg;
 #pragma unroll
-        for (int cq = 0; cq < 4; ++cq) xa[cq] = *reinterpret_cast<const f32x4*>(p + 16 * cq);
+        for (int cq = 0; cq < 4; ++cq) xa[cq] = Elem<T>::ld4(p + 16 * cq);
     } else {
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
             const int c = 16 * cq + 4 * lg;
-            xa[cq] = (r < n && c < C) ? *reinterpret_cast<const f32x4*>(x + r * ldx + c) : zero4();
+            xa[cq] = (r < n && c < C) ? Elem<T>::ld4(x + r * ldx + c) : zero4();
         }
     }
 }
@@ -377,8 +381,8 @@ __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], c
     }
 }
 
-template <bool EXACT, bool GRAPH_W, bool NEXT>
-__global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel(LayerArgs a) {
+template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float>
+__global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel(LayerArgsT<T> a) {
     __shared__ __attribute__((aligned(16))) float sm_w[2][64 * kWStride];   // MnT, Wv (zero padded)
     __shared__ __attribute__((aligned(16))) float sm_cn[64], sm_u[64], sm_bv[64], sm_lw[64], sm_lb[64];
     __shared__ __attribute__((aligned(16))) float sm_t[NEXT ? kWaves : 1][16 * kWStride];   // NEXT: a wave's finished tile
@@ -471,9 +475,9 @@ __global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel
             for (int ft = 0; ft < 4; ++ft) {
                 const int f = 16 * ft + 4 * lg;
                 if (row_ok && (EXACT || f < D)) {
-                    if (EXACT || ((a.ldx0 & 3) == 0 && f + 3 < D)) y[ft] += *reinterpret_cast<const f32x4*>(a.x0 + row * a.ldx0 + f);
+                    if (EXACT || ((a.ldx0 & 3) == 0 && f + 3 < D)) y[ft] += Elem<T>::ld4(a.x0 + row * a.ldx0 + f);
                     else
-                        for (int r = 0; r < 4; ++r) if (f + r < D) y[ft][r] += a.x0[row * a.ldx0 + f + r];
+                        for (int r = 0; r < 4; ++r) if (f + r < D) y[ft][r] += Elem<T>::ld(a.x0 + row * a.ldx0 + f + r);
                 }
             }
         }
@@ -518,9 +522,9 @@ __global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             if (row_ok && (EXACT || f < D)) {
-                if (EXACT || ((a.ldo & 3) == 0 && f + 3 < D)) *reinterpret_cast<f32x4*>(a.out + row * a.ldo + f) = v;
+                if (EXACT || ((a.ldo & 3) == 0 && f + 3 < D)) Elem<T>::st4(a.out + row * a.ldo + f, v);
                 else
-                    for (int r = 0; r < 4; ++r) if (f + r < D) a.out[row * a.ldo + f + r] = v[r];
+                    for (int r = 0; r < 4; ++r) if (f + r < D) Elem<T>::st(a.out + row * a.ldo + f + r, v[r]);
             }
             if (!NEXT && a.ys_next) {
                 // slice-major pre-scaled copy for the next layer's SpMM straight from the registers: this lane holds
@@ -639,14 +643,16 @@ extern "C" size_t dif_gram_workspace_bytes(int64_t n_rows, int C) {
 }
 
 // record = [G: C x C][sx: C][2 unused floats]; ys / rowptr / plan may be null (no slice-major copy).
-extern "C" int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, const int32_t* rowptr, const int32_t* plan,
-                            float* ys, float* record, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+namespace {
+template <typename T>
+int gram_entry(const T* x, int64_t ldx, int64_t n_rows, int C, const int32_t* rowptr, const int32_t* plan, float* ys,
+               float* record, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
     DIF_REQUIRE(x && record && workspace && n_rows > 0, DIF_E_BADARG, "dif_gram: null pointer or no rows");
     DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0, DIF_E_SHAPE, "dif_gram: covers C <= 64, C %% 4 == 0 (got %d)", C);
-    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned16(x), DIF_E_BADARG, "dif_gram: rows of x must be 16-byte aligned");
+    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned_v4<T>(x), DIF_E_BADARG, "dif_gram: rows of x must be aligned to 4 elements");
     DIF_REQUIRE(workspace_bytes >= dif_gram_workspace_bytes(n_rows, C), DIF_E_WORKSPACE, "dif_gram: workspace too small");
-    DIF_REQUIRE((ys == nullptr) || (rowptr && plan && dif::aligned16(ys)), DIF_E_BADARG,
-                "dif_gram: the slice-major copy needs rowptr, the plan and a 16-byte aligned buffer");
+    DIF_REQUIRE((ys == nullptr) || (rowptr && plan && dif::aligned16(ys) && std::is_same<T, float>::value), DIF_E_BADARG,
+                "dif_gram: the slice-major copy needs float32 rows, rowptr, the plan and a 16-byte aligned buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int P = gram_chunks(n_rows);
     const int64_t rec = (static_cast<int64_t>(C) * C + C + 3) & ~int64_t(3);
@@ -654,14 +660,27 @@ extern "C" int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, 
     if (ys) {
         const int64_t npad = static_cast<int64_t>(plan[6]) * plan[7];
         DIF_REQUIRE(plan[0] == C / 4 && npad >= n_rows, DIF_E_BADARG, "dif_gram: plan does not match C / n_rows");
-        hipLaunchKernelGGL((gram_kernel<true>), dim3(P), dim3(64 * kGramWaves), 0, st, x, ldx, n_rows, C, rowptr,
+        hipLaunchKernelGGL((gram_kernel<true, T>), dim3(P), dim3(64 * kGramWaves), 0, st, x, ldx, n_rows, C, rowptr,
                            reinterpret_cast<f32x4*>(ys), npad, ws, rec);
     } else {
-        hipLaunchKernelGGL((gram_kernel<false>), dim3(P), dim3(64 * kGramWaves), 0, st, x, ldx, n_rows, C, nullptr, nullptr,
+        hipLaunchKernelGGL((gram_kernel<false, T>), dim3(P), dim3(64 * kGramWaves), 0, st, x, ldx, n_rows, C, nullptr, nullptr,
                            int64_t(0), ws, rec);
     }
     if (int rc = dif::launch_status("gram_kernel")) return rc;
     return dif::launch_record_finalize(ws, P, rec, C * C + C, 0, record, st);
+}
+}  // namespace
+
+extern "C" int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, const int32_t* rowptr, const int32_t* plan,
+                            float* ys, float* record, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    return gram_entry<float>(x, ldx, n_rows, C, rowptr, plan, ys, record, workspace, workspace_bytes, stream);
+}
+
+// bfloat16 rows (BASELINE config C5), float32 record; no slice-major copy (the sliced product is float32-only)
+extern "C" int dif_gram_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
+                             size_t workspace_bytes, dif_stream_t stream) {
+    return gram_entry<dif::bf16>(static_cast<const dif::bf16*>(x), ldx, n_rows, C, nullptr, nullptr, nullptr, record, workspace,
+                                 workspace_bytes, stream);
 }
 
 extern "C" size_t dif_simple_coeffs_len(int C, int D) {
@@ -681,25 +700,29 @@ extern "C" int dif_simple_coeffs_f32(const float* record, int64_t n_global, int 
     return dif::launch_status("coeffs_kernel");
 }
 
-extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
-                                    const float* ax, int64_t ldax, const float* Wv, const float* bv, const float* row_sums,
-                                    float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,
-                                    const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out,
-                                    int64_t ldo, float* next_record, const int32_t* rowptr, const int32_t* plan,
-                                    float* next_ys, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+namespace {
+template <typename T>
+int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const T* ax, int64_t ldax,
+                const float* Wv, const float* bv, const float* row_sums, float gcn_scale, const T* x0, int64_t ldx0,
+                int residual, float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu, T* out,
+                int64_t ldo, float* next_record, const int32_t* rowptr, const int32_t* plan, float* next_ys, void* workspace,
+                size_t workspace_bytes, dif_stream_t stream) {
     DIF_REQUIRE(x && coef && out && n_rows > 0, DIF_E_BADARG, "dif_simple_layer: null pointer or no rows");
     DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0 && D > 0 && D <= 64, DIF_E_SHAPE,
                 "dif_simple_layer: covers C <= 64 (C %% 4 == 0) and D <= 64 (got %d, %d)", C, D);
-    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned16(x) && ldo >= D, DIF_E_BADARG,
-                "dif_simple_layer: rows of x must be 16-byte aligned, ldo >= D");
-    DIF_REQUIRE(dif::aligned16(out) && (!x0 || dif::aligned16(x0)), DIF_E_BADARG, "dif_simple_layer: out / x0 must be 16-byte aligned");
-    DIF_REQUIRE(!ax || (ldax >= C && ldax % 4 == 0 && dif::aligned16(ax)), DIF_E_BADARG,
-                "dif_simple_layer: rows of ax must be 16-byte aligned");
+    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned_v4<T>(x) && ldo >= D, DIF_E_BADARG,
+                "dif_simple_layer: rows of x must be aligned to 4 elements, ldo >= D");
+    DIF_REQUIRE(dif::aligned_v4<T>(out) && (!x0 || dif::aligned_v4<T>(x0)), DIF_E_BADARG,
+                "dif_simple_layer: out / x0 must be aligned to 4 elements");
+    DIF_REQUIRE(!ax || (ldax >= C && ldax % 4 == 0 && dif::aligned_v4<T>(ax)), DIF_E_BADARG,
+                "dif_simple_layer: rows of ax must be aligned to 4 elements");
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG, "dif_simple_layer: ln_weight and ln_bias go together");
     DIF_REQUIRE((Wv == nullptr) == (bv == nullptr), DIF_E_BADARG, "dif_simple_layer: Wv and bv go together");
     DIF_REQUIRE(Wv != nullptr || !ax || C == D, DIF_E_SHAPE, "dif_simple_layer: without a value projection C must equal D");
     DIF_REQUIRE(!residual || C == D, DIF_E_SHAPE, "dif_simple_layer: the residual needs C == D");
     DIF_REQUIRE(!x0 || ldx0 >= D, DIF_E_BADARG, "dif_simple_layer: ldx0 smaller than a row");
+    const bool f32 = std::is_same<T, float>::value;
+    DIF_REQUIRE(f32 || (!next_record && !next_ys), DIF_E_BADARG, "dif_simple_layer: products for the next layer are float32-only");
     const bool next = next_record != nullptr;          // Gram record of the output from the same pass (slower)
     const int P = row_chunks(n_rows, next ? kRecordChunksPerCU : 4);
     const int64_t rec = (static_cast<int64_t>(D) * D + D + 3) & ~int64_t(3);
@@ -717,13 +740,13 @@ extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows,
             DIF_REQUIRE(plan[0] == D / 4 && npad >= n_rows, DIF_E_BADARG, "dif_simple_layer: plan does not match D / n_rows");
         }
     }
-    LayerArgs a = {x, ldx, ax, ldax, coef, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha, ln_weight, ln_bias, ln_eps,
-                   relu, out, ldo, n_rows, C, D, rowptr, reinterpret_cast<f32x4*>(next_ys), npad, static_cast<float*>(workspace), rec};
+    LayerArgsT<T> a = {x, ldx, ax, ldax, coef, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha, ln_weight, ln_bias, ln_eps,
+                       relu, out, ldo, n_rows, C, D, rowptr, reinterpret_cast<f32x4*>(next_ys), npad, static_cast<float*>(workspace), rec};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
     const bool gw = ax != nullptr && Wv != nullptr;
-#define DIF_LAYER(E, G, N) hipLaunchKernelGGL((simple_layer_kernel<E, G, N>), dim3(P), dim3(64 * kWaves), 0, st, a)
-#define DIF_LAYER2(E, G) do { if (next) DIF_LAYER(E, G, true); else DIF_LAYER(E, G, false); } while (0)
+#define DIF_LAYER(E, G, N) hipLaunchKernelGGL((simple_layer_kernel<E, G, N, T>), dim3(P), dim3(64 * kWaves), 0, st, a)
+#define DIF_LAYER2(E, G) do { if (f32 && next) DIF_LAYER(E, G, (std::is_same<T, float>::value)); else DIF_LAYER(E, G, false); } while (0)
     if (exact) { if (gw) DIF_LAYER2(true, true); else DIF_LAYER2(true, false); }
     else { if (gw) DIF_LAYER2(false, true); else DIF_LAYER2(false, false); }
 #undef DIF_LAYER2
@@ -731,4 +754,28 @@ extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows,
     if (int rc = dif::launch_status("simple_layer_kernel")) return rc;
     if (next) return dif::launch_record_finalize(static_cast<float*>(workspace), P, rec, D * D + D, 0, next_record, st);
     return 0;
+}
+}  // namespace
+
+extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                    const float* ax, int64_t ldax, const float* Wv, const float* bv, const float* row_sums,
+                                    float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,
+                                    const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out,
+                                    int64_t ldo, float* next_record, const int32_t* rowptr, const int32_t* plan,
+                                    float* next_ys, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    return layer_entry<float>(x, ldx, n_rows, C, D, coef, ax, ldax, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha,
+                              ln_weight, ln_bias, ln_eps, relu, out, ldo, next_record, rowptr, plan, next_ys, workspace,
+                              workspace_bytes, stream);
+}
+
+// bfloat16 ACTIVATIONS (x, ax, x0, out); coefficients and parameters (Wv, bv, LayerNorm) float32 -- the host keeps exact
+// float32 copies of the bfloat16 parameters.  All arithmetic float32 (BASELINE config C5).
+extern "C" int dif_simple_layer_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const void* ax,
+                                     int64_t ldax, const float* Wv, const float* bv, const float* row_sums, float gcn_scale,
+                                     const void* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,
+                                     const float* ln_bias, float ln_eps, int relu, void* out, int64_t ldo, dif_stream_t stream) {
+    using B = dif::bf16;
+    return layer_entry<B>(static_cast<const B*>(x), ldx, n_rows, C, D, coef, static_cast<const B*>(ax), ldax, Wv, bv, row_sums,
+                          gcn_scale, static_cast<const B*>(x0), ldx0, residual, alpha, ln_weight, ln_bias, ln_eps, relu,
+                          static_cast<B*>(out), ldo, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }

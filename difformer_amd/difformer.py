@@ -133,9 +133,11 @@ class DIFFormerConv(nn.Module):
         x = source_input
         if not (self.kernel == 'simple' and query_input is source_input and self.num_heads == 1 and not want_qk):
             return False
-        if x.dim() != 2 or x.dtype != torch.float32 or x.shape[1] % 4:
+        if x.dim() != 2 or x.dtype not in (torch.float32, torch.bfloat16) or x.shape[1] % 4:
             return False
         wide = x.shape[1] > 64 or self.out_channels > 64
+        if x.dtype == torch.bfloat16 and (wide or self.row_shard is not None or self.Wq.weight.dtype != torch.bfloat16):
+            return False          # bfloat16 storage: the narrow single-GPU closed form (BASELINE config C5)
         if wide and (self.row_shard is not None or max(x.shape[1], self.out_channels) > ops.CLOSED_FORM_WIDE_MAX or
                      x.shape[1] <= ops.CLOSED_FORM_WIDE_MIN or x.shape[0] < 4 * x.shape[1]):
             return False          # the record is C x C: it only pays with many more rows than columns, and from
@@ -164,7 +166,8 @@ class DIFFormerConv(nn.Module):
             csr = None
             if self.use_graph:
                 n_global = shard.n_global if shard is not None else x.shape[0]
-                csr = ops.csr_cache.get(edge_index, edge_weight, n_global, x.shape[1] * 4, shard, 4)
+                esz = x.element_size()
+                csr = ops.csr_cache.get(edge_index, edge_weight, n_global, x.shape[1] * esz, shard, esz)
             a_s, g_s = (1.0 - self.graph_weight, float(self.graph_weight)) if self.graph_weight > 0 else (1.0, 1.0)
             if not self.use_graph:
                 a_s = 1.0                                       # difformer.py:130-136: the mix only exists with a graph

@@ -464,6 +464,26 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
     return out.reshape(n_rows, H, D)
 
 
+_F32_PARAMS = OrderedDict()
+
+
+def f32_param(t):
+    """Exact float32 copy of a bfloat16 parameter, cached until the parameter changes (identity + version keyed, like
+    the CSR cache); float32 tensors pass through.  The closed-form kernels take their coefficients in float32."""
+    if t is None or t.dtype == torch.float32:
+        return t
+    key = (id(t), t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+    hit = _F32_PARAMS.get(key)
+    if hit is not None and hit[0]() is t:
+        _F32_PARAMS.move_to_end(key)
+        return hit[1]
+    c = t.detach().to(torch.float32).contiguous()
+    _F32_PARAMS[key] = (weakref.ref(t), c)
+    while len(_F32_PARAMS) > 256:
+        _F32_PARAMS.popitem(last=False)
+    return c
+
+
 def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
                              ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None):
     """One DIFFormer layer with the `simple` kernel, query == source == x [n, C] (this rank's rows), one head
@@ -478,10 +498,12 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     be = get_backend()
     n, C = x.shape
     D = Wq.shape[0]
+    # bfloat16 activations (BASELINE config C5): the parameters go in as exact float32 copies, all arithmetic is float32
+    Wq, bq, Wk, bk, Wv, bv, ln_weight, ln_bias = (f32_param(t) for t in (Wq, bq, Wk, bk, Wv, bv, ln_weight, ln_bias))
     sharded = shard is not None and shard.world > 1
     n_global, row_begin = (shard.n_global, shard.row_begin) if sharded else (n, 0)
     sl = None
-    if csr is not None and (sharded or n == csr.num_nodes):
+    if csr is not None and (sharded or n == csr.num_nodes) and x.dtype == torch.float32:
         sl = csr.sliced(row_begin, n, C)
     handle = shard.all_gather_rows_async(x) if (sharded and csr is not None) else None
     have = carry.get("products") if (carry is not None and not sharded) else None
@@ -510,7 +532,8 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
             rs = csr.row_sums()
             if sharded:
                 rs = rs[row_begin: row_begin + n]
-    want_next = (carry is not None and not sharded and carry.get("want_next", False) and D % 4 == 0 and D == C)
+    want_next = (carry is not None and not sharded and carry.get("want_next", False) and D % 4 == 0 and D == C and
+                 x.dtype == torch.float32)
     want_rec = want_next and carry.get("next_record", False)
     if carry is not None:
         carry["products"] = None

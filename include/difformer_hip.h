@@ -458,6 +458,15 @@ int dif_simple_reduce_bf16(const void* q, int64_t ldq, const void* k, int64_t ld
 int dif_simple_apply_bf16(const void* q, int64_t ldq, const float* reduced, int64_t n_rows,
                           int64_t n_global, int H, int M, int D, void* out, int64_t ldo,
                           dif_stream_t stream);
+/* closed form of the simple layer with bfloat16 ACTIVATIONS (x, ax, x0, out); the record, the coefficients and the
+ * parameters (Wv, bv, LayerNorm) are float32 -- the host keeps exact float32 copies of its bfloat16 parameters and calls
+ * dif_simple_coeffs_f32 with them.  No products for a next layer (the sliced format is float32-only). */
+int dif_gram_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
+                  size_t workspace_bytes, dif_stream_t stream);
+int dif_simple_layer_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const void* ax,
+                          int64_t ldax, const float* Wv, const float* bv, const float* row_sums, float gcn_scale,
+                          const void* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,
+                          const float* ln_bias, float ln_eps, int relu, void* out, int64_t ldo, dif_stream_t stream);
 int dif_sigmoid_attn_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                           int64_t N, int64_t L, int H, int M, int D, void* out, int64_t ldo, void* workspace,
                           size_t workspace_bytes, dif_stream_t stream);

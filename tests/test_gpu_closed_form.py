@@ -241,3 +241,40 @@ def test_closed_form_layer_row_sharded_rank_by_rank(world, n, deg, dev):
             assert csr.sliced(lo, counts[r], c) is not None        # the shard has its own sliced format
         assert rel_err(out.cpu().numpy(), full[lo: lo + counts[r]].cpu().numpy()) < 1e-5, (world, r)
         lo += counts[r]
+
+
+@pytest.mark.parametrize("n,deg,c,use_weight,use_source", [(30000, 3, 64, True, False), (5000, 6, 64, False, True),
+                                                            (7000, 4, 32, True, True)])
+def test_closed_form_layer_bf16_storage(n, deg, c, use_weight, use_source, dev):
+    """BASELINE config C5: bfloat16 activations and parameters, float32 arithmetic (dif_gram_bf16, dif_simple_layer_bf16,
+    coefficients from exact float32 copies of the parameters) -- against the float64 oracle on the bf16-rounded operands,
+    and against the float32 closed form on the same rounded operands (differs only by the rounding of the output and of
+    the aggregated rows)."""
+    from difformer_amd import DIFFormerConv, ops
+    torch.manual_seed(n)
+    g = torch.Generator().manual_seed(n + 1)
+    conv = DIFFormerConv(c, c, 1, kernel="simple", use_graph=True, use_weight=use_weight, use_source=use_source)
+    conv = conv.to(torch.bfloat16).to(dev).eval()
+    bf = lambda t: t.to(torch.bfloat16)
+    x, x0 = bf(torch.randn(n, c, generator=g)), bf(torch.randn(n, c, generator=g))
+    lw, lb = bf(torch.rand(c, generator=g) + 0.5), bf(torch.randn(c, generator=g))
+    ei = torch.cat([torch.randint(0, n, (2, n * deg), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+    xd, eid = x.to(dev), ei.to(dev)
+    be = ops.get_backend()
+    be.kernel_events = {}
+    with torch.no_grad():
+        out, _, _ = conv._layer(xd, xd, eid, None, x0.to(dev) if use_source else None, xd, 0.4, lw.to(dev), lb.to(dev), 1e-5)
+    launched, be.kernel_events = set(be.kernel_events), None
+    assert out.dtype == torch.bfloat16 and "dif_simple_layer_f32" in launched and "dif_simple_apply_f32" not in launched
+    p = {"c." + k: v.detach().cpu().double().numpy() for k, v in conv.state_dict().items()}
+    cfg = dict(num_heads=1, kernel="simple", use_graph=True, use_weight=use_weight, graph_weight=-1,
+               use_source=use_source, hidden_channels=c)
+    x64 = x.double().numpy()
+    z = orc.difformer_conv(p, "c.", x64, x64, ei.numpy(), None, x0.double().numpy(), cfg)
+    z = orc.layer_norm(0.4 * z + 0.6 * x64, lw.double().numpy(), lb.double().numpy())
+    assert rel_err(out.float().cpu().numpy(), z) < 1e-2
+    conv32 = conv.float()
+    with torch.no_grad():
+        ref32, _, _ = conv32._layer(xd.float(), xd.float(), eid, None, x0.float().to(dev) if use_source else None, xd.float(), 0.4,
+                                    lw.float().to(dev), lb.float().to(dev), 1e-5)
+    assert rel_err(out.float().cpu().numpy(), ref32.cpu().numpy()) < 1e-2
