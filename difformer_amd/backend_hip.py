@@ -746,6 +746,34 @@ class HipBackend:
         _lib.check(rc, "dif_layer_tail_bwd_f32")
         return (d_conv, d_x0, d_prev, None if d_ln is None else d_ln[:D], None if d_ln is None else d_ln[D:2 * D])
 
+    def coeffs_bg(self, x, record, n_global, factors, C, D, attn_scale):
+        """Coefficients of the closed-form layer through the background kernels (csrc/side_chain.hip), enqueued on the
+        CURRENT stream (the caller puts a side stream there): from x [n, C] (one pass: Gram partials per wave), or from a
+        finished `record` [X^T X | sum x] when the layer input's Gram pass has already run.  factors:
+        ops.NarrowFactors (pt, vtt, st float32 [80 * 80]).  -> coef (layout of simple_coeffs)."""
+        dev = _require_device(x, record, factors.pt)
+        f32 = dict(dtype=torch.float32, device=dev)
+        gt = torch.empty(80 * 80, **f32)
+        if record is not None:
+            ws, ws_bytes, xp, ldx, n = record, record.numel() * 4, None, 0, 1
+        else:
+            _f32(x, "x")
+            n = x.shape[0]
+            x, ldx = _row_major(x, C)
+            ws_bytes = self.lib.dif_gram_bg_workspace_bytes(n, C)
+            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+            xp = x
+        with _Timed(self, "dif_gram_bg_f32", dev):
+            rc = self.lib.dif_gram_bg_f32(_ptr(xp), ldx, n, C, int(n_global), _ptr(gt), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_gram_bg_f32")
+        scratch = torch.empty(80 * 80 + 4, **f32)
+        coef = torch.empty(self.lib.dif_simple_coeffs_len(C, D), **f32)
+        with _Timed(self, "dif_simple_coeffs_bg_f32", dev):
+            rc = self.lib.dif_simple_coeffs_bg_f32(_ptr(gt), _ptr(factors.pt), _ptr(factors.vtt), _ptr(factors.st), C, D,
+                                                   float(attn_scale), _ptr(scratch), _ptr(coef), _stream(dev))
+        _lib.check(rc, "dif_simple_coeffs_bg_f32")
+        return coef
+
     def gram_sym(self, x):
         """x [n, C] fp32 -> record [C*C + 2*C + 2]: X^T X (blocks of 64 on and above the diagonal valid) | sum x | unused
         (csrc/simple_attn.hip, dif_gram_sym_f32) -- the Gram record of the closed form at the scripts' widths."""

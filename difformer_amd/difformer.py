@@ -79,6 +79,7 @@ class DIFFormerConv(nn.Module):
         self.row_shard = None  # set through DIFFormer.set_row_shard for multi-GPU runs
         self._fused_wb = None  # (key, weight, bias) of the concatenated projections (inference only)
         self._wide = None      # (key, ops.WideCoefficients): weight-only factors of the closed form at hidden > 64
+        self._narrow = None    # (key, ops.NarrowFactors): weight-only factors of the background coefficient chain
 
     def reset_parameters(self):
         self.Wk.reset_parameters()
@@ -182,9 +183,18 @@ class DIFFormerConv(nn.Module):
                 out = ops.simple_layer_closed_form_wide(x, self._wide[1], Wv, bv, csr, a_s, g_s, x0, prev is not None, alpha,
                                                         ln_weight, ln_bias, eps)
                 return out, None, None
+            factors = None
+            if csr is not None and shard is None and x.dtype == torch.float32 and hasattr(ops.get_backend(), "coeffs_bg"):
+                params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias] + ([Wv, bv] if self.use_weight else [])
+                key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in params)
+                if self._narrow is None or self._narrow[0] != key:   # weight-only factors of the background coefficient chain
+                    with torch.no_grad():
+                        self._narrow = (key, ops.NarrowFactors(self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias,
+                                                               Wv, bv))
+                factors = self._narrow[1]
             out = ops.simple_layer_closed_form(x, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv, csr,
                                                a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps, carry=carry,
-                                               shard=shard)
+                                               shard=shard, factors=factors)
             return out, None, None
         if not want_qk and self._fusable_projection(query_input, source_input):
             attn, v = ops.project_simple_attention(source_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,

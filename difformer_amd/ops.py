@@ -13,6 +13,8 @@ import weakref
 from collections import OrderedDict
 from typing import Optional
 
+import os
+
 import torch
 
 from .dist import RowShard
@@ -464,6 +466,48 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
     return out.reshape(n_rows, H, D)
 
 
+class NarrowFactors:
+    """Weight-only factors of the background coefficient chain (csrc/side_chain.hip), float32 [80 x 80] zero padded,
+    augmented index 64: pt = W~q^T W~k, vtt = [W~v^T | e]^T, st = [W~q^T W~q ; W~k^T W~k] with W~ = [W | b].  Computed in
+    float64 once per parameter version (the module caches the object)."""
+
+    def __init__(self, Wq, bq, Wk, bk, Wv, bv):
+        f64, B, A = torch.float64, 80, 64
+        D, C = Wq.shape
+        dev = Wq.device
+
+        def aug(W, b):
+            M = torch.zeros((W.shape[0], B), dtype=f64, device=dev)
+            M[:, : W.shape[1]] = W.to(f64)
+            M[:, A] = b.to(f64)
+            return M
+        Wq_, Wk_ = aug(Wq, bq), aug(Wk, bk)
+        if Wv is not None:
+            Wv_ = aug(Wv, bv)
+        else:                                                           # use_weight = False: v = x (difformer.py:120)
+            Wv_ = torch.zeros((C, B), dtype=f64, device=dev)
+            Wv_[torch.arange(C), torch.arange(C)] = 1.0
+        self.pt = (Wq_.t() @ Wk_).to(torch.float32).contiguous().reshape(-1)
+        self.st = torch.stack([(Wq_.t() @ Wq_).reshape(-1), (Wk_.t() @ Wk_).reshape(-1)]).to(torch.float32).contiguous().reshape(-1)
+        vtt = torch.zeros((B, B), dtype=f64, device=dev)
+        vtt[: Wv_.shape[0]] = Wv_
+        vtt[A, A] = 1.0
+        self.vtt = vtt.to(torch.float32).contiguous().reshape(-1)
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(dev):
+    """The second stream the background coefficient chain runs on (one per device)."""
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+    return _SIDE_STREAMS[key]
+
+
+SIDE_CHAIN = os.environ.get("DIFFORMER_SIDE_CHAIN", "1") != "0"
+
 _F32_PARAMS = OrderedDict()
 
 
@@ -485,7 +529,7 @@ def f32_param(t):
 
 
 def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
-                             ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None):
+                             ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None, factors=None):
     """One DIFFormer layer with the `simple` kernel, query == source == x [n, C] (this rank's rows), one head
     (csrc/simple_layer.hip): Gram record -> coefficients -> SpMM on x -> the layer kernel.  q, k, v and the attention
     output never reach memory.  csr = None: use_graph = False.  Wv = None: use_weight = False.
@@ -511,13 +555,26 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
         have = None
     record = have["record"] if have is not None else None
     ys = have["ys"] if have is not None else None
-    if record is None:
-        need_ys = sl is not None and ys is None and not sharded
-        record, ys2 = be.gram(x, csr.rowptr if need_ys else None, sl.plan if need_ys else None)
-        ys = ys2 if need_ys else ys
-    if sharded:
-        shard.all_reduce_sum(record)
-    coef = be.simple_coeffs(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
+    # With the sliced product ahead (0.3 ms that does not need the coefficients) the chain Gram -> coefficients runs as
+    # single-wave background kernels on a second stream, UNDER the product (csrc/side_chain.hip).
+    background = (SIDE_CHAIN and factors is not None and sl is not None and not sharded and x.dtype == torch.float32 and
+                  C % 4 == 0 and D % 4 == 0 and x.is_cuda and hasattr(be, "coeffs_bg"))
+    coef = join = None
+    if background:
+        if record is None and ys is None:          # first layer: the Gram pass also writes the slice-major copy the product reads
+            record, ys = be.gram(x, csr.rowptr, sl.plan)
+        main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
+        side.wait_stream(main)                     # the chain may start once x (and the record) exist ...
+        join = (main, side)                        # ... but is ENQUEUED after the product (below): its workgroups then take the
+                                                   # wave slot the product leaves free on every CU instead of delaying its start
+    else:
+        if record is None:
+            need_ys = sl is not None and ys is None and not sharded
+            record, ys2 = be.gram(x, csr.rowptr if need_ys else None, sl.plan if need_ys else None)
+            ys = ys2 if need_ys else ys
+        if sharded:
+            shard.all_reduce_sum(record)
+        coef = be.simple_coeffs(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
     ax = rs = None
     if csr is not None:
         x_src = handle.wait() if sharded else x
@@ -525,6 +582,9 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
             if ys is None:
                 ys = be.sliced_prescale(x_src, csr.rowptr, csr.num_nodes, sl.plan)
             ax = be.sliced_spmm(sl, ys, csr.rowptr, csr.num_nodes, row_begin, n, C, None, 1.0, gcn_scale)
+            if join is not None:
+                with torch.cuda.stream(join[1]):
+                    coef = be.coeffs_bg(None if record is not None else x, record, n_global, factors, C, D, attn_scale)
         else:
             ax = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, csr.num_nodes, csr.nnz, x_src, row_begin, n,
                          None, 1.0, gcn_scale, None, csr.row_order(row_begin, n))
@@ -532,6 +592,9 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
             rs = csr.row_sums()
             if sharded:
                 rs = rs[row_begin: row_begin + n]
+    if join is not None:                           # the layer kernel needs the coefficients: the side stream joins
+        join[0].wait_stream(join[1])
+        coef.record_stream(join[0])
     want_next = (carry is not None and not sharded and carry.get("want_next", False) and D % 4 == 0 and D == C and
                  x.dtype == torch.float32)
     want_rec = want_next and carry.get("next_record", False)

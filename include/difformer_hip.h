@@ -367,6 +367,19 @@ int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, in
  *   z = conv_scale * conv[row,:] / den[row * ldden] + add_scale * (add[row,:] + rs[row] * bv[:])      (:36-39, :75-78, :130-134)
  * then + x0, the alpha-residual with prev, LayerNorm, ReLU as dif_layer_tail_f32.  den / add / (rs, bv) may be NULL.
  * conv and den are typically the numerator columns and the denominator column of ONE row-GEMM output. */
+/* The coefficient chain of the closed form as BACKGROUND kernels (csrc/side_chain.hip): single-wave workgroups without LDS,
+ * the footprint that fits beside a workgroup of the feature-sliced product, so that on a second stream the chain runs
+ * under the product instead of in front of it (neither depends on the other).  Augmented formulation: X~ = [X | 1],
+ * W~ = [W | b]; all matrices float[80 * 80], zero padded, augmented index 64.
+ *   dif_gram_bg_f32          gt = G~ = [[X^T X, sum x], [sum x^T, n_global]] from one pass over x (x == NULL: `workspace`
+ *                            holds one finished record [X^T X | sum x], e.g. dif_gram_f32's, and is only re-laid)
+ *   dif_simple_coeffs_bg_f32 coef (layout of dif_simple_coeffs_f32) from gt and the weight-only factors
+ *                            pt = W~q^T W~k, vtt = [W~v^T | e]^T, st = [W~q^T W~q ; W~k^T W~k]; scratch float[80 * 80 + 4]. */
+size_t dif_gram_bg_workspace_bytes(int64_t n_rows, int C);
+int dif_gram_bg_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int64_t n_global, float* gt, void* workspace,
+                    size_t workspace_bytes, dif_stream_t stream);
+int dif_simple_coeffs_bg_f32(const float* gt, const float* pt, const float* vtt, const float* st, int C, int D,
+                             float attn_scale, float* scratch, float* coef, dif_stream_t stream);
 /* Gram record of that closed form: record float[dif_simple_reduced_len(1, C, C)] = [X^T X (C x C, row-major) | sum x (C) |
  * C + 2 unused]; of X^T X only the 64 x 64 blocks on and above the diagonal are written (symmetric: the caller mirrors).
  * One streaming pass on the fp32 MFMA; workspace: dif_simple_workspace_bytes(n_rows, 1, C, C), 16-byte aligned. */

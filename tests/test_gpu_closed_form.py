@@ -278,3 +278,26 @@ def test_closed_form_layer_bf16_storage(n, deg, c, use_weight, use_source, dev):
         ref32, _, _ = conv32._layer(xd.float(), xd.float(), eid, None, x0.float().to(dev) if use_source else None, xd.float(), 0.4,
                                     lw.float().to(dev), lb.float().to(dev), 1e-5)
     assert rel_err(out.float().cpu().numpy(), ref32.cpu().numpy()) < 1e-2
+
+
+@pytest.mark.parametrize("n,c,d,use_weight", [(20000, 64, 64, True), (5000, 32, 32, True), (9000, 64, 64, False),
+                                              (3000, 48, 64, True), (70, 64, 32, True)])
+def test_background_coefficient_chain_matches_the_coefficient_kernel(n, c, d, use_weight, dev):
+    """csrc/side_chain.hip (single-wave workgroups without LDS, made to run beside the sliced product): Gram partials
+    per wave -> padded augmented Gram matrix -> two tiled 80 x 80 products against the cached weight-only factors give
+    the same coefficients as dif_gram_f32 + dif_simple_coeffs_f32 -- from x and from a finished record."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g).to(dev)
+    p = {k: (None if v is None else v.to(dev)) for k, v in _params(c, d, g, use_weight).items()}
+    be = ops.get_backend()
+    rec, _ = be.gram(x)
+    want = be.simple_coeffs(rec, n, c, d, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], 0.7).cpu().numpy().astype(np.float64)
+    f = ops.NarrowFactors(p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"])
+    for got in (be.coeffs_bg(x, None, n, f, c, d, 0.7), be.coeffs_bg(None, rec, n, f, c, d, 0.7)):
+        got = got.cpu().numpy().astype(np.float64)
+        MnT, cn, u, tail = slice(0, d * c), slice(d * c, d * c + d), slice(d * c + d, d * c + d + c), slice(d * c + d + c, None)
+        for part in (MnT, cn, u):
+            assert rel_err(got[part], want[part]) < 2e-5
+        assert np.allclose(got[tail], want[tail], rtol=2e-5, atol=0)
+    assert torch.equal(be.coeffs_bg(x, None, n, f, c, d, 0.7), be.coeffs_bg(x, None, n, f, c, d, 0.7))      # deterministic

@@ -552,6 +552,33 @@ def test_graphed_forward_replays_match_eager(hidden, dev):
         fwd(x1[:10])
 
 
+def test_graphed_forward_with_the_background_coefficient_chain(dev):
+    """A dense graph takes the sliced product, and with it the coefficient chain on a second stream (csrc/side_chain.hip):
+    the fork / join is captured into the hipGraph; replays equal the eager result and the single-stream result."""
+    from difformer_amd import DIFFormer, GraphedForward, ops
+    torch.manual_seed(5)
+    n = 9000
+    model = DIFFormer(24, 64, 5, num_layers=3, kernel="simple").to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    x1, x2 = torch.randn(n, 24, generator=g).to(dev), torch.randn(n, 24, generator=g).to(dev)
+    ei = torch.cat([torch.randint(0, n, (2, 60 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    be = ops.get_backend()
+    be.kernel_events = {}
+    with torch.no_grad():
+        e1, e2 = model(x1, ei).clone(), model(x2, ei).clone()
+    launched, be.kernel_events = set(be.kernel_events), None
+    assert {"dif_sliced_spmm_f32", "dif_simple_coeffs_bg_f32", "dif_gram_bg_f32"} <= launched
+    fwd = GraphedForward(model, x1, ei)
+    assert torch.equal(fwd(x1), e1) and torch.equal(fwd(x2), e2) and torch.equal(fwd(x1), e1)
+    old, ops.SIDE_CHAIN = ops.SIDE_CHAIN, False
+    try:
+        with torch.no_grad():
+            single = model(x1, ei)
+    finally:
+        ops.SIDE_CHAIN = old
+    assert rel_err(e1.cpu().numpy(), single.cpu().numpy()) < 1e-5
+
+
 def test_rccl_single_rank_collectives(dev):
     """The collectives the sharded path uses work on this box (RCCL, one rank; multi-rank logic is covered by the
     gloo tests)."""
