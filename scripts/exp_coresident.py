@@ -1,5 +1,6 @@
 """Experiment: do single-wave workgroups without LDS run BESIDE the sliced product (one 15-wave, 160-KiB workgroup per CU)?
-A spin kernel (scripts/bin/libspin.so: 256..1024 workgroups of 64 threads, pure VALU) on a second stream while the product
+A spin kernel (scripts/exp_spin.hip -> scripts/bin/libspin.so: hipcc --offload-arch=gfx950 -O3 -shared -fPIC scripts/exp_spin.hip -o scripts/bin/libspin.so;
+256..1024 workgroups of 64 threads, pure VALU) on a second stream while the product
 runs on the first.   python scripts/exp_coresident.py"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
