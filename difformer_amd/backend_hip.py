@@ -753,7 +753,7 @@ class HipBackend:
         ops.NarrowFactors (pt, vtt, st float32 [80 * 80]).  -> coef (layout of simple_coeffs)."""
         dev = _require_device(x, record, factors.pt)
         f32 = dict(dtype=torch.float32, device=dev)
-        gt = torch.empty(80 * 80, **f32)
+        gt = torch.empty(80 * 80 + 400, **f32)           # G~ + 100 float64 pairs of partial norm products
         if record is not None:
             ws, ws_bytes, xp, ldx, n = record, record.numel() * 4, None, 0, 1
         else:
@@ -764,7 +764,8 @@ class HipBackend:
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
             xp = x
         with _Timed(self, "dif_gram_bg_f32", dev):
-            rc = self.lib.dif_gram_bg_f32(_ptr(xp), ldx, n, C, int(n_global), _ptr(gt), _ptr(ws), ws_bytes, _stream(dev))
+            rc = self.lib.dif_gram_bg_f32(_ptr(xp), ldx, n, C, int(n_global), _ptr(factors.st), _ptr(gt), _ptr(ws), ws_bytes,
+                                          _stream(dev))
         _lib.check(rc, "dif_gram_bg_f32")
         scratch = torch.empty(80 * 80 + 4, **f32)
         coef = torch.empty(self.lib.dif_simple_coeffs_len(C, D), **f32)

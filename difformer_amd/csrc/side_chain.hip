@@ -88,10 +88,11 @@ __global__ __launch_bounds__(64) void gram_bg_kernel(const float* __restrict__ x
 }
 
 // ---- G~ (kB x kB, zero padded) from P partial records, one entry per lane ------------------------------------
+// Each workgroup also leaves its share of the two norm products <S~q, G~>, <S~k, G~> (float64) in npart[2 * block].
 __global__ __launch_bounds__(64) void finalize_bg_kernel(const float* __restrict__ ws, int P, int64_t ws_stride, int C,
-                                                         float n_global, float* __restrict__ gt) {
-    const int e = blockIdx.x * 64 + threadIdx.x;
-    if (e >= kB * kB) return;
+                                                         float n_global, const float* __restrict__ st,
+                                                         float* __restrict__ gt, double* __restrict__ npart) {
+    const int e = blockIdx.x * 64 + threadIdx.x;          // kB * kB is a multiple of 64: every lane owns an entry
     const int i = e / kB, k = e % kB;
     int col = -1;                                         // entry of the partial records this element sums
     if (i < C && k < C) col = i * C + k;
@@ -112,6 +113,13 @@ __global__ __launch_bounds__(64) void finalize_bg_kernel(const float* __restrict
         a = n_global;
     }
     gt[e] = a;
+    double q2 = static_cast<double>(st[e]) * a, k2 = static_cast<double>(st[kB * kB + e]) * a;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        q2 += __shfl_xor(q2, off, 64);
+        k2 += __shfl_xor(k2, off, 64);
+    }
+    if (threadIdx.x == 0) { npart[2 * blockIdx.x] = q2; npart[2 * blockIdx.x + 1] = k2; }
 }
 
 // one 16 x 16 tile of M1 M2 (both kB x kB): A = M1[i][k], B = M2^T[j][k]; lane holds D[16ti + 4lg + reg][16tj + l15]
@@ -136,7 +144,8 @@ template <int STAGE>
 __global__ __launch_bounds__(64) void coeffs_bg_kernel(const float* __restrict__ gt, const float* __restrict__ pt,
                                                        const float* __restrict__ vtt, const float* __restrict__ st,
                                                        int C, int D, float attn_scale, float* __restrict__ tt,
-                                                       float* __restrict__ scal, float* __restrict__ coef) {
+                                                       float* __restrict__ scal, const double* __restrict__ npart,
+                                                       float* __restrict__ coef) {
     const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
     constexpr int kT = kB / 16;
     const int b = blockIdx.x;
@@ -146,11 +155,10 @@ __global__ __launch_bounds__(64) void coeffs_bg_kernel(const float* __restrict__
             const f32x4 d = tile_kk(gt, vtt, ti, tj, l15, lg);                   // T[i][j]
             *reinterpret_cast<f32x4*>(tt + (16 * tj + l15) * kB + 16 * ti + 4 * lg) = d;      // T^T[j][i .. i + 3]
         } else {
-            double q2 = 0.0, k2 = 0.0;                                            // <S~q, G~>, <S~k, G~>
-            for (int e = lane; e < kB * kB; e += 64) {
-                const double g = gt[e];
-                q2 += static_cast<double>(st[e]) * g;
-                k2 += static_cast<double>(st[kB * kB + e]) * g;
+            double q2 = 0.0, k2 = 0.0;                                            // <S~q, G~>, <S~k, G~>: the 100 partials of finalize_bg
+            for (int e = lane; e < kB * kB / 64; e += 64) {
+                q2 += npart[2 * e];
+                k2 += npart[2 * e + 1];
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -203,11 +211,13 @@ extern "C" size_t dif_gram_bg_workspace_bytes(int64_t n_rows, int C) {
     return static_cast<size_t>(rec_stride(C)) * sizeof(float) * static_cast<size_t>(bg_chunks(n_rows));
 }
 
-// gt float[80 * 80] = zero-padded G~ = [[X^T X, sum x], [sum x^T, n_global]] (augmented index 64).  x == NULL: `workspace`
+// gt float[80 * 80 + 400]: the zero-padded G~ = [[X^T X, sum x], [sum x^T, n_global]] (augmented index 64), followed by the 100
+// float64 pairs of partial norm products <S~q, G~>, <S~k, G~> (sfac = st of dif_simple_coeffs_bg_f32).  x == NULL: `workspace`
 // already holds ONE record [G | sx] (e.g. dif_gram_f32's, whose pass also wrote the slice-major copy) and is only re-laid.
-extern "C" int dif_gram_bg_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int64_t n_global, float* gt, void* workspace,
-                               size_t workspace_bytes, dif_stream_t stream) {
-    DIF_REQUIRE(gt && workspace && n_rows > 0 && n_global > 0, DIF_E_BADARG, "dif_gram_bg: null pointer or no rows");
+extern "C" int dif_gram_bg_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int64_t n_global, const float* sfac, float* gt,
+                               void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(gt && sfac && workspace && n_rows > 0 && n_global > 0, DIF_E_BADARG, "dif_gram_bg: null pointer or no rows");
+    DIF_REQUIRE(dif::aligned16(gt), DIF_E_BADARG, "dif_gram_bg: gt must be 16-byte aligned");
     DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0, DIF_E_SHAPE, "dif_gram_bg: covers C <= 64, C %% 4 == 0 (got %d)", C);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* ws = static_cast<float*>(workspace);
@@ -221,8 +231,8 @@ extern "C" int dif_gram_bg_f32(const float* x, int64_t ldx, int64_t n_rows, int 
     } else {
         DIF_REQUIRE(workspace_bytes >= static_cast<size_t>(C * C + C) * sizeof(float), DIF_E_WORKSPACE, "dif_gram_bg: record too small");
     }
-    hipLaunchKernelGGL(finalize_bg_kernel, dim3((kB * kB + 63) / 64), dim3(64), 0, st, ws, P, rec_stride(C), C,
-                       static_cast<float>(n_global), gt);
+    hipLaunchKernelGGL(finalize_bg_kernel, dim3(kB * kB / 64), dim3(64), 0, st, ws, P, rec_stride(C), C,
+                       static_cast<float>(n_global), sfac, gt, reinterpret_cast<double*>(gt + kB * kB));
     return dif::launch_status("finalize_bg_kernel");
 }
 
@@ -239,9 +249,10 @@ extern "C" int dif_simple_coeffs_bg_f32(const float* gt, const float* pt, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* tt = scratch;
     float* scal = scratch + kB * kB;
+    const double* npart = reinterpret_cast<const double*>(gt + kB * kB);
     constexpr int kT = kB / 16;
-    hipLaunchKernelGGL((coeffs_bg_kernel<0>), dim3(kT * kT + 1), dim3(64), 0, s, gt, pt, vtt, st, C, D, attn_scale, tt, scal, coef);
+    hipLaunchKernelGGL((coeffs_bg_kernel<0>), dim3(kT * kT + 1), dim3(64), 0, s, gt, pt, vtt, st, C, D, attn_scale, tt, scal, npart, coef);
     if (int rc = dif::launch_status("coeffs_bg_kernel<0>")) return rc;
-    hipLaunchKernelGGL((coeffs_bg_kernel<1>), dim3(kT * kT), dim3(64), 0, s, gt, pt, vtt, st, C, D, attn_scale, tt, scal, coef);
+    hipLaunchKernelGGL((coeffs_bg_kernel<1>), dim3(kT * kT), dim3(64), 0, s, gt, pt, vtt, st, C, D, attn_scale, tt, scal, npart, coef);
     return dif::launch_status("coeffs_bg_kernel<1>");
 }

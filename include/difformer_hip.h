@@ -371,13 +371,14 @@ int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, in
  * the footprint that fits beside a workgroup of the feature-sliced product, so that on a second stream the chain runs
  * under the product instead of in front of it (neither depends on the other).  Augmented formulation: X~ = [X | 1],
  * W~ = [W | b]; all matrices float[80 * 80], zero padded, augmented index 64.
- *   dif_gram_bg_f32          gt = G~ = [[X^T X, sum x], [sum x^T, n_global]] from one pass over x (x == NULL: `workspace`
- *                            holds one finished record [X^T X | sum x], e.g. dif_gram_f32's, and is only re-laid)
+ *   dif_gram_bg_f32          gt float[80 * 80 + 400] = G~ = [[X^T X, sum x], [sum x^T, n_global]] from one pass over x, followed
+ *                            by 100 float64 pairs of partial norm products <st, G~> (x == NULL: `workspace` holds one
+ *                            finished record [X^T X | sum x], e.g. dif_gram_f32's, and is only re-laid)
  *   dif_simple_coeffs_bg_f32 coef (layout of dif_simple_coeffs_f32) from gt and the weight-only factors
  *                            pt = W~q^T W~k, vtt = [W~v^T | e]^T, st = [W~q^T W~q ; W~k^T W~k]; scratch float[80 * 80 + 4]. */
 size_t dif_gram_bg_workspace_bytes(int64_t n_rows, int C);
-int dif_gram_bg_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int64_t n_global, float* gt, void* workspace,
-                    size_t workspace_bytes, dif_stream_t stream);
+int dif_gram_bg_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int64_t n_global, const float* st, float* gt,
+                    void* workspace, size_t workspace_bytes, dif_stream_t stream);
 int dif_simple_coeffs_bg_f32(const float* gt, const float* pt, const float* vtt, const float* st, int C, int D,
                              float attn_scale, float* scratch, float* coef, dif_stream_t stream);
 /* Gram record of that closed form: record float[dif_simple_reduced_len(1, C, C)] = [X^T X (C x C, row-major) | sum x (C) |
