@@ -289,11 +289,15 @@ def norm_relu(x, ln_weight, ln_bias, eps):
 
 
 def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
-    """nn.Linear (-> LayerNorm) (-> ReLU).  Narrow inputs (C_in <= 128) run the fused HIP kernel when no gradient is
-    needed; wide ones use the vendor GEMM (rocBLAS via F.linear) followed by the fused LayerNorm/ReLU kernel."""
+    """nn.Linear (-> LayerNorm) (-> ReLU).  Narrow inputs (C_in <= 128), and long rows into a narrow layer on big inputs
+    (C_in % 4 == 0 up to 8192 -> C_out <= 64 from 16,384 rows: 512 -> 64 at CIFAR scale), run the fused HIP kernels when
+    no gradient is needed; the rest uses the vendor GEMM (rocBLAS via F.linear) followed by the fused LayerNorm/ReLU kernel."""
     fn = torch.nn.functional
     grad = _needs_grad(x, weight, bias, ln_weight, ln_bias)
     if not grad and x.dim() == 2 and x.shape[1] <= 128 and (ln_weight is None or weight.shape[0] <= 64):
+        return ops.linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
+    if (not grad and x.dim() == 2 and 128 < x.shape[1] <= 8192 and x.shape[1] % 4 == 0 and weight.shape[0] <= 64 and
+            x.shape[0] >= 16384 and bias is not None):
         return ops.linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
     y = _row_linear(x, weight, bias) if grad else fn.linear(x, weight, bias)
     if ln_weight is not None:

@@ -698,6 +698,8 @@ class HipBackend:
         Co = weight.shape[0]
         dt, sfx = _storage(x, weight, bias, ln_weight, ln_bias)
         x, ldx = _row_major(x, C)
+        if C > 128 and (ldx % 4 or x.data_ptr() % (4 * x.element_size())):      # long rows: 4-element aligned rows
+            x, ldx = x.contiguous(), C
         weight, bias = weight.contiguous(), bias.contiguous()
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()

@@ -1,6 +1,6 @@
 // a5 ends: the input MLP (node classification/difformer.py:188-191  Linear -> LayerNorm -> ReLU) and the
 // output Linear (:208) for the narrow shapes DIFFormer uses (C_in <= 128: ogbn-proteins 8->64, hidden->classes
-// 64->112).  One pass: x read once, y written once, LayerNorm/ReLU applied in registers.  Vendor GEMMs are
+// 64->112; long_linear_kernel below: long rows into a narrow layer, e.g. 512 -> 64).  One pass: x read once, y written once, LayerNorm/ReLU applied in registers.  Vendor GEMMs are
 // tuned for large K and spend ~100 us on these (K = 8: 4 MB in, 34 MB out).
 //
 // MFMA plan (v_mfma_f32_16x16x4_f32, exact fp32), per wave and 16-row tile.  A workgroup keeps up to 256 output
@@ -24,6 +24,151 @@ using dif::Elem;
 constexpr int lin_stride(int kq) { return kq <= 4 ? 68 : 132; }
 constexpr int lin_channels(int kq) { return kq <= 4 ? 64 : 128; }
 constexpr int lin_max_blocks(int kq) { return kq <= 4 ? 4 : 2; }
+
+// Epilogue of one 16-row x 64-feature tile: lane holds y[ft][reg] = out[r0 + 4 lg + reg][fb + 4 l15 + ft].  LayerNorm over the
+// features of each row (C_out <= 64: one block), ReLU, 16-byte stores.
+template <typename T>
+__device__ __forceinline__ void finish_tile(f32x4 (&y)[4], int64_t r0, int fb, int l15, int lg, int C_out, bool has_ln,
+                                            const f32x4& lw, const f32x4& lb, float inv_c, float eps, int relu,
+                                            T* __restrict__ out, int64_t ldo, int64_t n_rows, int ovec) {
+    if (has_ln) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            float s = 0.f;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+                if (4 * l15 + ft < C_out) s += y[ft][reg];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+            const float mu = s * inv_c;
+            float v = 0.f;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+                if (4 * l15 + ft < C_out) { const float dz = y[ft][reg] - mu; v += dz * dz; }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+            const float rstd = 1.0f / sqrtf(v * inv_c + eps);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) y[ft][reg] = (y[ft][reg] - mu) * rstd * lw[ft] + lb[ft];
+        }
+    }
+    const bool vst = ovec && (fb + 4 * l15 + 3 < C_out);   // this lane's 4 features are all real
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t rr = r0 + 4 * lg + reg;
+        if (rr >= n_rows) continue;
+        f32x4 o = {y[0][reg], y[1][reg], y[2][reg], y[3][reg]};
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
+        }
+        T* dst = out + rr * ldo + fb + 4 * l15;
+        if (vst) {
+            Elem<T>::st4(dst, o);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (fb + 4 * l15 + i < C_out) Elem<T>::st(dst + i, o[i]);
+        }
+    }
+}
+
+// Long rows into a narrow layer (C_in up to a few thousand -> C_out <= 64: the input MLP on image / text embeddings,
+// image and text/run.sh; 512 -> 64 at BASELINE config C3).  W does not fit the registers-per-tile scheme above, so K runs
+// in chunks of 64 channels: the four waves of a workgroup (one 16-row tile each) share the chunk's 64 x 64 weights in LDS
+// (double buffered: the next chunk's global loads fly under this chunk's 64 MFMAs per wave), x arrives chunk by chunk as
+// the same coalesced 16-byte loads.  One pass: x read once, LayerNorm / ReLU in registers (the vendor GEMM + a separate
+// tail pass took 51 + 6 us for 50,000 x 512 -> 64).  Needs C_in % 4 == 0 and 16-byte aligned rows of x and W.
+constexpr int kLongStride = 68;
+
+template <typename T>
+__global__ __launch_bounds__(256) void long_linear_kernel(const T* __restrict__ x, int64_t ldx, int64_t n_rows, int C_in,
+                                                          const T* __restrict__ W, const T* __restrict__ bias, int C_out,
+                                                          const T* __restrict__ ln_w, const T* __restrict__ ln_b, float eps,
+                                                          int relu, T* __restrict__ out, int64_t ldo, int ovec) {
+    __shared__ __attribute__((aligned(16))) float sm_w[2][64 * kLongStride];
+    __shared__ float sm_b[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    if (threadIdx.x < 64) sm_b[threadIdx.x] = threadIdx.x < C_out ? Elem<T>::ld(bias + threadIdx.x) : 0.f;
+    f32x4 lw = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};
+    if (ln_w) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f = 4 * l15 + ft;
+            if (f < C_out) { lw[ft] = Elem<T>::ld(ln_w + f); lb[ft] = Elem<T>::ld(ln_b + f); }
+        }
+    }
+    const float inv_c = 1.0f / static_cast<float>(C_out);
+    const int n_chunks = (C_in + 63) / 64;
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t n_groups = (n_tiles + 3) / 4;
+    // staging of a weight chunk: thread t owns four 16-byte units (feature e / 16, channels 4 (e % 16) .. + 3)
+    auto load_w = [&](f32x4 (&wv)[4], int ch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int f = e >> 4, c = 64 * ch + 4 * (e & 15);
+            wv[u] = (f < C_out && c < C_in) ? Elem<T>::ld4(W + static_cast<int64_t>(f) * C_in + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_w = [&](const f32x4 (&wv)[4], int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int f = e >> 4, c = 4 * (e & 15);
+            *reinterpret_cast<f32x4*>(&sm_w[buf][(16 * (f & 3) + (f >> 2)) * kLongStride + c]) = wv[u];
+        }
+    };
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t tile = grp * 4 + wave;
+        const int64_t r0 = tile * 16, r = r0 + l15;
+        const bool rok = r < n_rows;
+        auto load_x = [&](f32x4 (&xa)[4], int ch) {
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                const int c = 64 * ch + 16 * cq + 4 * lg;
+                xa[cq] = (rok && c < C_in) ? Elem<T>::ld4(x + r * ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        f32x4 wv[4], xa[4], xn[4];
+        load_w(wv, 0);
+        load_x(xa, 0);
+        __syncthreads();                       // the previous group is done with both buffers (and sm_b is there)
+        store_w(wv, 0);
+        __syncthreads();
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sm_b + 4 * l15);
+        f32x4 y[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] = f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const bool more = ch + 1 < n_chunks;
+            if (more) { load_w(wv, ch + 1); load_x(xn, ch + 1); }              // in flight under this chunk's MFMAs
+            const float* wrow = sm_w[ch & 1] + l15 * kLongStride + 4 * lg;
+            f32x4 wf[4][4];                    // all 16 weight fragments of the chunk: the LDS latency is paid once
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    wf[cq][ft] = *reinterpret_cast<const f32x4*>(wrow + 16 * ft * kLongStride + 16 * cq);
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft)      // four independent accumulator chains back to back
+                        y[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cq][t], wf[cq][ft][t], y[ft], 0, 0, 0);
+            if (more) {
+                store_w(wv, (ch + 1) & 1);     // last read in iteration ch - 1, which every wave left at the barrier below
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) xa[cq] = xn[cq];
+            }
+            __syncthreads();
+        }
+        if (tile < n_tiles)
+            finish_tile<T>(y, r0, 0, l15, lg, C_out, ln_w != nullptr, lw, lb, inv_c, eps, relu, out, ldo, n_rows, ovec);
+    }
+}
 
 // grid (row chunks, ceil(C_out/256)); 256 threads; dynamic LDS = blocks * 64 * (kLinStride + 1) floats.
 // KQ = number of 16-channel groups of C_in actually used (1..8).
@@ -143,46 +288,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
                     for (int t = 0; t < 4; ++t)
                         y[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cq][t], wf[t], y[ft], 0, 0, 0);
                 }
-            if (ln_w) {   // LayerNorm over the features of each row (row = 4*lg + reg; features over 16 lanes x 4 tiles)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int ft = 0; ft < 4; ++ft)
-                        if (4 * l15 + ft < C_out) s += y[ft][reg];
-#pragma unroll
-                    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
-                    const float mu = s * inv_c;
-                    float v = 0.f;
-#pragma unroll
-                    for (int ft = 0; ft < 4; ++ft)
-                        if (4 * l15 + ft < C_out) { const float dz = y[ft][reg] - mu; v += dz * dz; }
-#pragma unroll
-                    for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
-                    const float rstd = 1.0f / sqrtf(v * inv_c + eps);
-#pragma unroll
-                    for (int ft = 0; ft < 4; ++ft) y[ft][reg] = (y[ft][reg] - mu) * rstd * lw[ft] + lb[ft];
-                }
-            }
-            const bool vst = ovec && (fb + 4 * l15 + 3 < C_out);   // this lane's 4 features are all real
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int64_t rr = r0 + 4 * lg + reg;
-                if (rr >= n_rows) continue;
-                f32x4 o = {y[0][reg], y[1][reg], y[2][reg], y[3][reg]};
-                if (relu) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
-                }
-                T* dst = out + rr * ldo + fb + 4 * l15;
-                if (vst) {
-                    Elem<T>::st4(dst, o);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (fb + 4 * l15 + i < C_out) Elem<T>::st(dst + i, o[i]);
-                }
-            }
+            finish_tile<T>(y, r0, fb, l15, lg, C_out, ln_w != nullptr, lw, lb, inv_c, eps, relu, out, ldo, n_rows, ovec);
         }
 #pragma unroll
         for (int cq = 0; cq < KQ; ++cq) xa[cq] = xn[cq];
@@ -194,7 +300,20 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
                  const T* ln_weight, const T* ln_bias, float ln_eps, int relu, T* out, int64_t ldo, dif_stream_t stream) {
     DIF_REQUIRE(n_rows > 0 && C_in > 0 && C_out > 0, DIF_E_BADARG, "dif_linear: n_rows, C_in, C_out must be positive");
     DIF_REQUIRE(x && W && bias && out, DIF_E_BADARG, "dif_linear: null pointer");
-    DIF_REQUIRE(C_in <= 128, DIF_E_SHAPE, "dif_linear: covers C_in <= 128 (got %d); use the vendor GEMM", C_in);
+    if (C_in > 128) {                                     // long rows into a narrow layer
+        DIF_REQUIRE(C_out <= 64 && C_in % 4 == 0 && C_in <= 8192 && ldx % 4 == 0 && dif::aligned_v4<T>(x) && dif::aligned_v4<T>(W),
+                    DIF_E_SHAPE, "dif_linear: C_in > 128 needs C_out <= 64, C_in %% 4 == 0 (<= 8192) and rows of x / W aligned to "
+                    "4 elements (got %d -> %d); use the vendor GEMM", C_in, C_out);
+        DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
+                    "dif_linear: ln_weight and ln_bias must be given together");
+        DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear: leading dimension smaller than a row");
+        const int64_t groups = ((n_rows + 15) / 16 + 3) / 4;
+        int64_t g = groups < 4 * dif::kCUs ? groups : 4 * dif::kCUs;      // 35 KB of LDS: four workgroups per CU
+        const int ov = (ldo % 4 == 0) && dif::aligned_v4<T>(out);
+        hipLaunchKernelGGL((long_linear_kernel<T>), dim3(static_cast<unsigned>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                           ldx, n_rows, C_in, W, bias, C_out, ln_weight, ln_bias, ln_eps, relu, out, ldo, ov);
+        return dif::launch_status("long_linear_kernel");
+    }
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
                 "dif_linear: ln_weight and ln_bias must be given together");
     DIF_REQUIRE(!ln_weight || C_out <= 64, DIF_E_SHAPE, "dif_linear: fused LayerNorm needs C_out <= 64");

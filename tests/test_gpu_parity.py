@@ -423,6 +423,37 @@ def test_skinny_linear_vs_numpy(n, ci, co, ln, relu, dev):
     assert rel_err(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("n,ci,co,ln,relu", [(50000, 512, 64, True, True), (20000, 1432, 64, True, True), (3001, 132, 10, False, False),
+                                              (17, 516, 33, True, False), (40000, 300, 64, False, True), (5000, 2048, 7, True, True)])
+def test_long_linear_vs_numpy(n, ci, co, ln, relu, dev):
+    """Long rows into a narrow layer (the input MLP on image / text embeddings, difformer.py:188-191): K in 64-channel chunks
+    through double-buffered LDS weights; row counts that leave waves without a tile, widths that are not multiples of 64."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(ci * 100 + co)
+    x = torch.randn(n, ci, generator=g)
+    W, b = torch.randn(co, ci, generator=g) / np.sqrt(ci), torch.randn(co, generator=g)
+    lw, lb = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
+    be = ops.get_backend()
+    out = be.linear(x.to(dev), W.to(dev), b.to(dev), lw.to(dev) if ln else None, lb.to(dev) if ln else None, 1e-5, relu)
+    ref = x.double().numpy() @ W.double().numpy().T + b.double().numpy()
+    if ln:
+        ref = orc.layer_norm(ref, lw.double().numpy(), lb.double().numpy())
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5
+    assert torch.equal(out, be.linear(x.to(dev), W.to(dev), b.to(dev), lw.to(dev) if ln else None, lb.to(dev) if ln else None, 1e-5, relu))
+    if n >= 16384:      # bfloat16 storage of the same layer
+        bf = lambda t: t.to(torch.bfloat16)
+        ob = be.linear(bf(x).to(dev), bf(W).to(dev), bf(b).to(dev), bf(lw).to(dev) if ln else None, bf(lb).to(dev) if ln else None,
+                       1e-5, relu)
+        refb = bf(x).double().numpy() @ bf(W).double().numpy().T + bf(b).double().numpy()
+        if ln:
+            refb = orc.layer_norm(refb, bf(lw).double().numpy(), bf(lb).double().numpy())
+        if relu:
+            refb = np.maximum(refb, 0)
+        assert ob.dtype == torch.bfloat16 and rel_err(ob.float().cpu().numpy(), refb) < 1e-2
+
+
 def test_layer_tail_relu(dev):
     from difformer_amd import ops
     g = torch.Generator().manual_seed(2)
