@@ -129,8 +129,10 @@ def job_value(n, steps, elapsed, world, replicas):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the clocks need ~30 ms of load after an idle period to settle (the first 20 forwards after a pause run ~5 %
+    # slower: scripts/exp_host_time.py); 130 forwards are 0.2 s
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="ogbn-proteins-s", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",

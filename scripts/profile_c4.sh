@@ -2,7 +2,7 @@
 # Round-N evidence for the headline workload: bench line, rocprofv3 kernel stats of the same command, PMC traffic.
 #   scripts/profile_c4.sh <tag>      (run on the GPU box from the repo root; results under gpurun_out/<tag>/)
 R=$PWD; TAG=${1:-r02}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-python bench.py --steps 20 --warmup 3 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+python bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o c4 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1
 cp $OUT/stats/c4_kernel_stats.csv $OUT/bench_c4_kernel_stats.csv 2>/dev/null || find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_c4_kernel_stats.csv \;
