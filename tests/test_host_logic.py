@@ -335,3 +335,73 @@ def test_split_positions_layout():
     n_hub = int((want_P > 1).sum())
     tail = order2[n_pos - (deg.numel() - n_hub):]
     assert np.array_equal(tail, order.numpy()[n_hub:])
+
+
+def _attention_from_coefficients(x, Mn, u, cn, cd):
+    """out_i = (x_i Mn + cn) / (x_i . u + cd): the closed form of difformer.py:18-39 for query == source == x."""
+    return (x @ Mn + cn) / (x @ u + cd)[:, None]
+
+
+@pytest.mark.parametrize("use_weight", [True, False])
+def test_wide_coefficients_algebra_matches_the_oracle(use_weight):
+    """ops.WideCoefficients (weight-only factors of the closed form at the scripts' widths) + the two per-layer products
+    of ops.simple_layer_closed_form_wide, replayed on the CPU in float64, reproduce full_attention_conv(q, k, v, 'simple')
+    of the oracle -- every bias term of difformer.py:20-38 rides inside the augmented matrices."""
+    import numpy as np
+    from difformer_amd.ops import WideCoefficients
+    from oracle import difformer_oracle as orc
+    g = torch.Generator().manual_seed(3)
+    n, C = 500, 20
+    D = C
+    x = torch.randn(n, C, generator=g, dtype=torch.float64)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64) * 0.3
+    Wq, bq, Wk, bk = mk(D, C), mk(D), mk(D, C), mk(D)
+    Wv, bv = (mk(D, C), mk(D)) if use_weight else (None, None)
+    co = WideCoefficients(Wq, bq, Wk, bk, Wv, bv)
+    Gt = torch.zeros(C + 1, C + 1, dtype=torch.float64)
+    Gt[:C, :C], Gt[:C, C], Gt[C, :C], Gt[C, C] = x.t() @ x, x.sum(0), x.sum(0), float(n)
+    norms = co.S @ Gt.reshape(-1)
+    s = torch.rsqrt(norms[0] * norms[1])
+    T = Gt @ co.V
+    R = co.P @ T
+    B, bias = s * R[:C], s * R[C] + T[C]
+    out = _attention_from_coefficients(x, B[:, :D], B[:, D], bias[:D], bias[D]).numpy()
+    q, k = (x @ Wq.t() + bq).numpy(), (x @ Wk.t() + bk).numpy()
+    v = (x @ Wv.t() + bv).numpy() if use_weight else x.numpy()
+    assert abs(float(norms[0]) - (q * q).sum()) < 1e-9 * (q * q).sum() and abs(float(norms[1]) - (k * k).sum()) < 1e-9 * (k * k).sum()
+    ref = orc.simple_attention(q[:, None, :], k[:, None, :], v[:, None, :])[:, 0, :]
+    assert np.abs(out - ref).max() < 1e-10 * np.abs(ref).max()
+    assert co.upper.shape == (C, C) and bool(co.upper.all())          # one 64-block at this width: everything is "upper"
+
+
+@pytest.mark.parametrize("C,D,use_weight", [(64, 64, True), (32, 48, True), (24, 24, False)])
+def test_narrow_factors_algebra_matches_the_oracle(C, D, use_weight):
+    """ops.NarrowFactors (80 x 80 zero-padded, augmented index 64) + the products of csrc/side_chain.hip replayed with
+    numpy: T^T = (G~ V~)^T, R = P~ T, coef = [MnT | cn | u | cd] -- against the oracle's simple attention."""
+    import numpy as np
+    from difformer_amd.ops import NarrowFactors
+    from oracle import difformer_oracle as orc
+    g = torch.Generator().manual_seed(C + D)
+    n, B_, A_ = 300, 80, 64
+    x = torch.randn(n, C, generator=g)
+    mk = lambda *s: torch.randn(*s, generator=g) * 0.3
+    Wq, bq, Wk, bk = mk(D, C), mk(D), mk(D, C), mk(D)
+    Wv, bv = (mk(D, C), mk(D)) if use_weight else (None, None)
+    f = NarrowFactors(Wq, bq, Wk, bk, Wv, bv)
+    pt, vtt = f.pt.double().numpy().reshape(B_, B_), f.vtt.double().numpy().reshape(B_, B_)
+    st = f.st.double().numpy().reshape(2, B_ * B_)
+    x64 = x.double().numpy()
+    gt = np.zeros((B_, B_))
+    gt[:C, :C], gt[A_, :C], gt[:C, A_], gt[A_, A_] = x64.T @ x64, x64.sum(0), x64.sum(0), n
+    q2, k2 = st @ gt.reshape(-1)
+    s = 1.0 / np.sqrt(q2 * k2)
+    T = gt @ vtt.T                                   # tile_kk(gt, vtt): D[i][j] = sum_k gt[i][k] vtt[j][k]
+    R = pt @ T
+    Mn, u = s * R[:C, :D], s * R[:C, A_]
+    cn, cd = s * R[A_, :D] + T[A_, :D], s * R[A_, A_] + T[A_, A_]
+    out = (x64 @ Mn + cn) / (x64 @ u + cd)[:, None]
+    q, k = x64 @ Wq.double().numpy().T + bq.double().numpy(), x64 @ Wk.double().numpy().T + bk.double().numpy()
+    v = x64 @ Wv.double().numpy().T + bv.double().numpy() if use_weight else x64
+    ref = orc.simple_attention(q[:, None, :], k[:, None, :], v[:, None, :])[:, 0, :]
+    assert abs(q2 - (q * q).sum()) < 1e-5 * (q * q).sum()           # the factors are stored in float32
+    assert np.abs(out - ref).max() < 1e-5 * np.abs(ref).max()
