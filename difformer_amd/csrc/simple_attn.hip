@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk,
     const T* __restrict__ v, int64_t ldv, int64_t n_rows, Shape sh, float* __restrict__ ws,
     int64_t ws_stride) {
-    __shared__ __attribute__((aligned(16))) float sm_tile[kRedWaves][kTile * kTile];
+    __shared__ __attribute__((aligned(16))) float sm_tile[2][kTile * kTile];      // 32 KiB: three workgroups per CU (was 64 KiB: two)
     __shared__ float sm_k[kRedWaves][kTile];
     __shared__ float sm_v[kRedWaves][kTile];
     __shared__ float sm_s[kRedWaves][2];
@@ -133,16 +133,18 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     }
 
     // ---- fold the 4 waves (fixed order: deterministic) ---------------------------------
-    // lane owns KtV_local[16*lg + 4*reg + t][4*l15 + u]: for fixed (t,reg) the 4 u's are one float4.  Every wave parks
-    // its tile in its own LDS slab at once; after the barrier below the record write adds the four slabs in the order
-    // ((w0 + w1) + w2) + w3.
+    // lane owns KtV_local[16*lg + 4*reg + t][4*l15 + u]: for fixed (t,reg) the 4 u's are one float4.  The tiles go
+    // through two LDS slabs, summed in the order ((w0 + w1) + w2) + w3: slab 0 holds the running sum, slab 1 the next wave.
+    auto park = [&](int slab) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const f32x4 val = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
-            *reinterpret_cast<f32x4*>(&sm_tile[wave][(16 * lg + 4 * reg + t) * kTile + 4 * l15]) = val;
-        }
+            for (int reg = 0; reg < 4; ++reg) {
+                const f32x4 val = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+                *reinterpret_cast<f32x4*>(&sm_tile[slab][(16 * lg + 4 * reg + t) * kTile + 4 * l15]) = val;
+            }
+    };
+    if (wave < 2) park(wave);
     // column sums: fold the four 16-lane row groups, then the waves
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -155,13 +157,20 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     ksq = dif::wave_sum(ksq);
     if (lane == 0) { sm_s[wave][0] = qsq; sm_s[wave][1] = ksq; }
     __syncthreads();
+#pragma unroll 1
+    for (int w = 2; w < kRedWaves; ++w) {
+        for (int e = threadIdx.x; e < kTile * kTile; e += 256) sm_tile[0][e] += sm_tile[1][e];
+        __syncthreads();
+        if (wave == w) park(1);
+        __syncthreads();
+    }
 
     float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
     float* rec_ktv = rec + static_cast<int64_t>(h) * sh.M * sh.D;
     for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
         const int m = mt * kTile + e / kTile, d = dt * kTile + e % kTile;
         if (m < sh.M && d < sh.D)
-            rec_ktv[static_cast<int64_t>(m) * sh.D + d] = ((sm_tile[0][e] + sm_tile[1][e]) + sm_tile[2][e]) + sm_tile[3][e];
+            rec_ktv[static_cast<int64_t>(m) * sh.D + d] = sm_tile[0][e] + sm_tile[1][e];
     }
     if (threadIdx.x < kTile) {
         const int c = threadIdx.x;

@@ -610,7 +610,8 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
 
 
 CLOSED_FORM_WIDE_MAX = 512      # widest layer the Gram-record formulation is used for (record = C x C floats)
-CLOSED_FORM_WIDE_MIN = 128      # up to here the q / k / v operator path is as fast (pokec-batch-h128: 1.04 vs 1.2 ms)
+CLOSED_FORM_WIDE_MIN = 128      # up to here the q / k / v operator path is as fast (pokec-batch-h128: 1.01 vs 1.02 ms with the row
+                                # GEMMs on the hand-written Linear kernel, 1.2 ms on the library's)
 
 
 class WideCoefficients:
