@@ -81,6 +81,8 @@ SIGNATURES = {
                                     c_i64, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "dif_row_order_workspace_bytes": (c_sz, [c_i64]),
     "dif_row_order": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dif_simple_layer_head_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64,
+                                          c_int, c_f32, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_i64, c_vp]),
     "dif_gram_bg_workspace_bytes": (c_sz, [c_i64, c_int]),
     "dif_gram_bg_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_simple_coeffs_bg_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp, c_vp]),

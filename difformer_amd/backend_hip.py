@@ -553,9 +553,11 @@ class HipBackend:
 
     def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
                      alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, next_rowptr=None, next_plan=None,
-                     next_record=False):
+                     next_record=False, head=None):
         """-> out [n, D]; with next_plan -> (out, ys, record | None): also the slice-major scaled copy of `out` for the
-        next layer's SpMM (see gram()), and with next_record its Gram record from the same pass."""
+        next layer's SpMM (see gram()), and with next_record its Gram record from the same pass.
+        head = (Wo [Co, D], bo [Co]) float32, Co <= 128 (the model's output Linear, difformer.py:208): -> logits [n, Co]
+        from the same pass; the layer's rows themselves are not stored."""
         dev = _require_device(x, coef, ax, Wv, bv, row_sums, x0, ln_weight, ln_bias)
         dt, sfx = _storage(x, ax, x0)              # activations: float32 or bfloat16; parameters always float32 here
         for t_, nm in ((coef, "coef"), (Wv, "Wv"), (bv, "bv"), (ln_weight, "ln_weight"), (ln_bias, "ln_bias"), (row_sums, "row_sums")):
@@ -574,6 +576,20 @@ class HipBackend:
             Wv, bv = Wv.contiguous(), bv.contiguous()
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        if head is not None:
+            Wo, bo = (_f32(t_, "head").contiguous() for t_ in head)
+            Co = Wo.shape[0]
+            if sfx != "f32" or next_plan is not None or next_record or Co > 128 or Wo.shape[1] != D:
+                raise TypeError("difformer_amd: the fused output Linear needs float32 rows, Co <= 128, no next-layer products")
+            logits = torch.empty((n, Co), dtype=torch.float32, device=dev)
+            with _Timed(self, "dif_simple_layer_f32", dev):
+                rc = self.lib.dif_simple_layer_head_f32(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
+                                                        _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
+                                                        float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
+                                                        int(bool(relu)), None, 0, _ptr(Wo), _ptr(bo), Co, _ptr(logits), Co,
+                                                        _stream(dev))
+            _lib.check(rc, "dif_simple_layer_head_f32")
+            return logits
         out = torch.empty((n, D), dtype=dt, device=dev)
         record = ys = ws = None
         ws_bytes = 0

@@ -347,6 +347,8 @@ struct LayerArgsT {
     int64_t n_rows; int C, D;
     // NEXT: the Gram record of `out` (the next layer's input) and its slice-major pre-scaled copy, from the same pass
     const int32_t* rowptr; f32x4* ys_next; int64_t npad; float* ws; int64_t ws_stride;
+    // HEAD: the model's output Linear (difformer.py:208) applied to the finished rows in the same pass
+    const float* Wo; const float* bo; int Co; T* logits; int64_t ldl;
 };
 using LayerArgs = LayerArgsT<float>;
 
@@ -381,9 +383,11 @@ __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], c
     }
 }
 
-template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float>
-__global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel(LayerArgsT<T> a) {
+template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float, bool HEAD = false>
+__global__ __launch_bounds__(64 * kWaves, (NEXT || HEAD) ? 2 : 4) void simple_layer_kernel(LayerArgsT<T> a) {
     __shared__ __attribute__((aligned(16))) float sm_w[2][64 * kWStride];   // MnT, Wv (zero padded)
+    __shared__ __attribute__((aligned(16))) float sm_wo[HEAD ? 2 : 1][HEAD ? 64 * kWStride : 4];   // HEAD: up to 128 output classes
+    __shared__ __attribute__((aligned(16))) float sm_bo[HEAD ? 128 : 4];
     __shared__ __attribute__((aligned(16))) float sm_cn[64], sm_u[64], sm_bv[64], sm_lw[64], sm_lb[64];
     __shared__ __attribute__((aligned(16))) float sm_t[NEXT ? kWaves : 1][16 * kWStride];   // NEXT: a wave's finished tile
     __shared__ float sm_s[kWaves][64];
@@ -422,6 +426,13 @@ __global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel
         sm_lb[i] = (a.ln_b && i < D) ? a.ln_b[i] : 0.f;
     }
     if (threadIdx.x == 0) sm_cd = a.coef[D * C + D + C];
+    if (HEAD) {
+        for (int e = threadIdx.x; e < 2 * 64 * 64; e += 64 * kWaves) {
+            const int cls = e >> 6, c = e & 63;
+            sm_wo[cls >> 6][(cls & 63) * kWStride + c] = (cls < a.Co && c < D) ? a.Wo[cls * D + c] : 0.f;
+        }
+        if (threadIdx.x < 128) sm_bo[threadIdx.x] = threadIdx.x < a.Co ? a.bo[threadIdx.x] : 0.f;
+    }
     __syncthreads();
     const float cd = sm_cd;
     const float inv_d = 1.0f / static_cast<float>(D);
@@ -513,6 +524,36 @@ __global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel
         }
         float dscale = 0.f;
         if (!NEXT && a.ys_next && row_ok) dscale = dinv_of(a.rowptr, row);
+        if (HEAD) {
+            // logits^T = Wo out^T: the finished row piece has the layout of a loaded x fragment (features 16ft + 4lg .. + 3
+            // of row r0 + l15), so it is the B operand of the same transposed product; two blocks of 64 classes
+            f32x4 yo[4];
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                yo[ft] = y[ft];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (a.relu) yo[ft][r] = fmaxf(yo[ft][r], 0.f);
+                    if (!EXACT && 16 * ft + 4 * lg + r >= D) yo[ft][r] = 0.f;
+                }
+            }
+            const int nblk = (a.Co + 63) >> 6;
+            for (int blk = 0; blk < nblk; ++blk) {
+                f32x4 z[4];
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) z[ft] = *reinterpret_cast<const f32x4*>(&sm_bo[64 * blk + 16 * ft + 4 * lg]);
+                project_t(z, yo, sm_wo[blk], l15, lg);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    const int cls = 64 * blk + 16 * ft + 4 * lg;
+                    if (row_ok && cls < a.Co) {
+                        if ((a.ldl & 3) == 0 && cls + 3 < a.Co) Elem<T>::st4(a.logits + row * a.ldl + cls, z[ft]);
+                        else
+                            for (int r = 0; r < 4; ++r) if (cls + r < a.Co) Elem<T>::st(a.logits + row * a.ldl + cls + r, z[ft][r]);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
             const int f = 16 * ft + 4 * lg;
@@ -521,7 +562,7 @@ __global__ __launch_bounds__(64 * kWaves, NEXT ? 2 : 4) void simple_layer_kernel
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (row_ok && (EXACT || f < D)) {
+            if (a.out && row_ok && (EXACT || f < D)) {
                 if (EXACT || ((a.ldo & 3) == 0 && f + 3 < D)) Elem<T>::st4(a.out + row * a.ldo + f, v);
                 else
                     for (int r = 0; r < 4; ++r) if (f + r < D) Elem<T>::st(a.out + row * a.ldo + f + r, v[r]);
@@ -706,14 +747,19 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
                 const float* Wv, const float* bv, const float* row_sums, float gcn_scale, const T* x0, int64_t ldx0,
                 int residual, float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu, T* out,
                 int64_t ldo, float* next_record, const int32_t* rowptr, const int32_t* plan, float* next_ys, void* workspace,
-                size_t workspace_bytes, dif_stream_t stream) {
-    DIF_REQUIRE(x && coef && out && n_rows > 0, DIF_E_BADARG, "dif_simple_layer: null pointer or no rows");
+                size_t workspace_bytes, dif_stream_t stream, const float* Wo = nullptr, const float* bo = nullptr, int Co = 0,
+                T* logits = nullptr, int64_t ldl = 0) {
+    const bool head = Wo != nullptr;
+    DIF_REQUIRE(x && coef && (out || head) && n_rows > 0, DIF_E_BADARG, "dif_simple_layer: null pointer or no rows");
+    DIF_REQUIRE(!head || (bo && logits && Co > 0 && Co <= 128 && ldl >= Co && !next_record && !next_ys &&
+                          std::is_same<T, float>::value), DIF_E_BADARG,
+                "dif_simple_layer: the fused output Linear needs bo, logits, 1 <= Co <= 128, ldl >= Co, float32, no next-layer products");
     DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0 && D > 0 && D <= 64, DIF_E_SHAPE,
                 "dif_simple_layer: covers C <= 64 (C %% 4 == 0) and D <= 64 (got %d, %d)", C, D);
-    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned_v4<T>(x) && ldo >= D, DIF_E_BADARG,
+    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned_v4<T>(x) && (!out || ldo >= D), DIF_E_BADARG,
                 "dif_simple_layer: rows of x must be aligned to 4 elements, ldo >= D");
-    DIF_REQUIRE(dif::aligned_v4<T>(out) && (!x0 || dif::aligned_v4<T>(x0)), DIF_E_BADARG,
-                "dif_simple_layer: out / x0 must be aligned to 4 elements");
+    DIF_REQUIRE((!out || dif::aligned_v4<T>(out)) && (!x0 || dif::aligned_v4<T>(x0)) && (!logits || dif::aligned_v4<T>(logits)),
+                DIF_E_BADARG, "dif_simple_layer: out / x0 / logits must be aligned to 4 elements");
     DIF_REQUIRE(!ax || (ldax >= C && ldax % 4 == 0 && dif::aligned_v4<T>(ax)), DIF_E_BADARG,
                 "dif_simple_layer: rows of ax must be aligned to 4 elements");
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG, "dif_simple_layer: ln_weight and ln_bias go together");
@@ -741,15 +787,18 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
         }
     }
     LayerArgsT<T> a = {x, ldx, ax, ldax, coef, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha, ln_weight, ln_bias, ln_eps,
-                       relu, out, ldo, n_rows, C, D, rowptr, reinterpret_cast<f32x4*>(next_ys), npad, static_cast<float*>(workspace), rec};
+                       relu, out, ldo, n_rows, C, D, rowptr, reinterpret_cast<f32x4*>(next_ys), npad, static_cast<float*>(workspace), rec,
+                       Wo, bo, Co, logits, ldl};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
     const bool gw = ax != nullptr && Wv != nullptr;
 #define DIF_LAYER(E, G, N) hipLaunchKernelGGL((simple_layer_kernel<E, G, N, T>), dim3(P), dim3(64 * kWaves), 0, st, a)
-#define DIF_LAYER2(E, G) do { if (f32 && next) DIF_LAYER(E, G, (std::is_same<T, float>::value)); else DIF_LAYER(E, G, false); } while (0)
+#define DIF_LAYER_HEAD(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, (std::is_same<T, float>::value)>), dim3(P), dim3(64 * kWaves), 0, st, a)
+#define DIF_LAYER2(E, G) do { if (head) DIF_LAYER_HEAD(E, G); else if (f32 && next) DIF_LAYER(E, G, (std::is_same<T, float>::value)); else DIF_LAYER(E, G, false); } while (0)
     if (exact) { if (gw) DIF_LAYER2(true, true); else DIF_LAYER2(true, false); }
     else { if (gw) DIF_LAYER2(false, true); else DIF_LAYER2(false, false); }
 #undef DIF_LAYER2
+#undef DIF_LAYER_HEAD
 #undef DIF_LAYER
     if (int rc = dif::launch_status("simple_layer_kernel")) return rc;
     if (next) return dif::launch_record_finalize(static_cast<float*>(workspace), P, rec, D * D + D, 0, next_record, st);
@@ -766,6 +815,20 @@ extern "C" int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows,
     return layer_entry<float>(x, ldx, n_rows, C, D, coef, ax, ldax, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha,
                               ln_weight, ln_bias, ln_eps, relu, out, ldo, next_record, rowptr, plan, next_ys, workspace,
                               workspace_bytes, stream);
+}
+
+// The LAST layer of a model with the output Linear of difformer.py:208 in the same pass: logits [n, Co] = out Wo^T + bo
+// (Co <= 128; Wo [Co, D], bo [Co] float32).  out may be NULL (the finished rows are then not stored at all).
+extern "C" int dif_simple_layer_head_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                         const float* ax, int64_t ldax, const float* Wv, const float* bv,
+                                         const float* row_sums, float gcn_scale, const float* x0, int64_t ldx0, int residual,
+                                         float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                                         float* out, int64_t ldo, const float* Wo, const float* bo, int Co, float* logits,
+                                         int64_t ldl, dif_stream_t stream) {
+    DIF_REQUIRE(Wo != nullptr, DIF_E_BADARG, "dif_simple_layer_head_f32: Wo is null");
+    return layer_entry<float>(x, ldx, n_rows, C, D, coef, ax, ldax, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha,
+                              ln_weight, ln_bias, ln_eps, relu, out, ldo, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream,
+                              Wo, bo, Co, logits, ldl);
 }
 
 // bfloat16 ACTIVATIONS (x, ax, x0, out); coefficients and parameters (Wv, bv, LayerNorm) float32 -- the host keeps exact

@@ -192,9 +192,15 @@ class DIFFormerConv(nn.Module):
                         self._narrow = (key, ops.NarrowFactors(self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias,
                                                                Wv, bv))
                 factors = self._narrow[1]
+            head = carry.get("head") if carry is not None else None
+            if head is not None and not (x.dtype == torch.float32 and head[0].dtype == torch.float32 and head[0].shape[0] <= 128
+                                         and head[1] is not None):
+                head = None
             out = ops.simple_layer_closed_form(x, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv, csr,
                                                a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps, carry=carry,
-                                               shard=shard, factors=factors)
+                                               shard=shard, factors=factors, head=head)
+            if head is not None:
+                carry["head_done"] = True          # `out` is already the model's logits (difformer.py:208)
             return out, None, None
         if not want_qk and self._fusable_projection(query_input, source_input):
             attn, v = ops.project_simple_attention(source_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,
@@ -298,6 +304,10 @@ class DIFFormer(nn.Module):
         for i, conv in enumerate(self.convs):
             bn = self.bns[i + 1] if self.use_bn else None
             carry["want_next"] = (not self.training) and i + 1 < len(self.convs)
+            # the last closed-form layer applies the output Linear (:208) to its rows in the same pass (inference)
+            last = i + 1 == len(self.convs)
+            fc = self.fcs[-1]
+            carry["head"] = (fc.weight, fc.bias) if (last and not self.training and not ag._needs_grad(x, fc.weight, fc.bias)) else None
             # head mean, + layer_[0] (use_source), alpha-residual, LayerNorm ride in the last kernel of the
             # layer (:137-140, :200-203)
             x, _, _ = conv._layer(x, x, edge_index, edge_weight, layer_[0] if conv.use_source else None,
@@ -307,6 +317,8 @@ class DIFFormer(nn.Module):
             if self.training:
                 x = F.dropout(x, p=self.dropout, training=True)
             layer_.append(x)
+        if carry.get("head_done"):
+            return x
         return ag.linear(x, self.fcs[-1].weight, self.fcs[-1].bias)   # :208
 
     def get_attentions(self, x):

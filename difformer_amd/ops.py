@@ -529,7 +529,7 @@ def f32_param(t):
 
 
 def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
-                             ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None, factors=None):
+                             ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None, factors=None, head=None):
     """One DIFFormer layer with the `simple` kernel, query == source == x [n, C] (this rank's rows), one head
     (csrc/simple_layer.hip): Gram record -> coefficients -> SpMM on x -> the layer kernel.  q, k, v and the attention
     output never reach memory.  csr = None: use_graph = False.  Wv = None: use_weight = False.
@@ -600,6 +600,9 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     want_rec = want_next and carry.get("next_record", False)
     if carry is not None:
         carry["products"] = None
+    if head is not None:                           # last layer: the model's output Linear rides in the same pass -> logits
+        return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu,
+                               head=head)
     if not (want_next and (sl is not None or want_rec)):
         return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu)
     out, ys2, record2 = be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps,

@@ -367,6 +367,15 @@ int dif_layer_tail_f32(const float* conv, int64_t ldc, int64_t n_rows, int H, in
  *   z = conv_scale * conv[row,:] / den[row * ldden] + add_scale * (add[row,:] + rs[row] * bv[:])      (:36-39, :75-78, :130-134)
  * then + x0, the alpha-residual with prev, LayerNorm, ReLU as dif_layer_tail_f32.  den / add / (rs, bv) may be NULL.
  * conv and den are typically the numerator columns and the denominator column of ONE row-GEMM output. */
+/* The LAST layer of a model with its output Linear (difformer.py:208) in the same pass: logits [n, Co] = out Wo^T + bo with
+ * Wo float[Co, D], bo float[Co], Co <= 128; the finished row piece is the B operand of one more transposed MFMA product.
+ * out may be NULL (the rows themselves are then not stored).  Other arguments as dif_simple_layer_f32. */
+int dif_simple_layer_head_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                              const float* ax, int64_t ldax, const float* Wv, const float* bv, const float* row_sums,
+                              float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,
+                              const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out,
+                              int64_t ldo, const float* Wo, const float* bo, int Co, float* logits, int64_t ldl,
+                              dif_stream_t stream);
 /* The coefficient chain of the closed form as BACKGROUND kernels (csrc/side_chain.hip): single-wave workgroups without LDS,
  * the footprint that fits beside a workgroup of the feature-sliced product, so that on a second stream the chain runs
  * under the product instead of in front of it (neither depends on the other).  Augmented formulation: X~ = [X | 1],

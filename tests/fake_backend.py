@@ -136,7 +136,7 @@ class OracleBackend:
 
     def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
                      alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, next_rowptr=None, next_plan=None,
-                     next_record=False):
+                     next_record=False, head=None):
         self.closed_form_calls = getattr(self, "closed_form_calls", 0) + 1
         xx, cf = _np(x).astype(np.float64), _np(coef).astype(np.float64)
         C = xx.shape[1]
@@ -158,6 +158,8 @@ class OracleBackend:
             z = orc.layer_norm(z, _np(ln_weight).astype(np.float64), _np(ln_bias).astype(np.float64), eps)
         if relu:
             z = np.maximum(z, 0.0)
+        if head is not None:                    # the model's output Linear in the same pass (difformer.py:208)
+            z = z @ _np(head[0]).astype(np.float64).T + _np(head[1]).astype(np.float64)
         out = torch.from_numpy(z.astype(np.float32))
         return out if (next_plan is None and not next_record) else (out, None, None)
 

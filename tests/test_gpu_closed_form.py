@@ -301,3 +301,38 @@ def test_background_coefficient_chain_matches_the_coefficient_kernel(n, c, d, us
             assert rel_err(got[part], want[part]) < 2e-5
         assert np.allclose(got[tail], want[tail], rtol=2e-5, atol=0)
     assert torch.equal(be.coeffs_bg(x, None, n, f, c, d, 0.7), be.coeffs_bg(x, None, n, f, c, d, 0.7))      # deterministic
+
+
+@pytest.mark.parametrize("n,deg,hidden,classes,f_in", [(20000, 60, 64, 112, 8), (3000, 8, 64, 7, 40), (5000, 0, 32, 10, 64),
+                                                        (4000, 6, 64, 128, 16), (2500, 5, 48, 2, 20)])
+def test_output_linear_rides_in_the_last_layer_kernel(n, deg, hidden, classes, f_in, dev):
+    """dif_simple_layer_head_f32: the model's output Linear (difformer.py:208) applied to the finished rows inside the last
+    closed-form layer kernel -- the whole model against the float64 oracle and against the two-kernel path."""
+    from difformer_amd import DIFFormer, ops
+    torch.manual_seed(n + classes)
+    use_graph = deg > 0
+    cfg = dict(hidden_channels=hidden, num_layers=2, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=True, use_graph=use_graph, graph_weight=-1, use_source=False)
+    model = DIFFormer(f_in, hidden, classes, num_layers=2, num_heads=1, kernel="simple", use_graph=use_graph).to(dev).eval()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, f_in, generator=g)
+    ei = torch.cat([torch.randint(0, n, (2, n * max(deg, 1)), generator=g), torch.arange(n).repeat(2, 1)], dim=1) if use_graph else None
+    be = ops.get_backend()
+    calls = []
+    orig = be.lib.dif_simple_layer_head_f32
+    with torch.no_grad():
+        out = model(x.to(dev), ei.to(dev) if use_graph else None)
+        # the same model with the head un-fused: the last layer leaves its rows, a separate Linear follows
+        x1 = model._input_layer(x.to(dev), False)
+        layer_ = [x1]
+        for i, conv in enumerate(model.convs):
+            bn = model.bns[i + 1]
+            x1, _, _ = conv._layer(x1, x1, ei.to(dev) if use_graph else None, None, None, layer_[i], model.alpha, bn.weight,
+                                   bn.bias, bn.eps)
+            layer_.append(x1)
+        two = torch.nn.functional.linear(x1, model.fcs[-1].weight, model.fcs[-1].bias)
+    p = {k: v.detach().cpu().double().numpy() for k, v in model.state_dict().items()}
+    ref = orc.difformer_forward(p, x.double().numpy(), ei.numpy() if use_graph else None, None, cfg)
+    assert out.shape == (n, classes)
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+    assert rel_err(out.cpu().numpy(), two.cpu().numpy()) < 1e-5
