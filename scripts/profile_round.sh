@@ -6,7 +6,7 @@ T=${1:-r02e}
 set -x
 ./scripts/profile_c4.sh $T > gpurun_out/${T}_c4.log 2>&1
 ./scripts/profile_configs.sh ${T}_cfg > gpurun_out/${T}_cfg.log 2>&1
-python bench.py --workload ogbn-proteins-zipf-s --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/$T/bench_zipf.json 2> gpurun_out/$T/bench_zipf.err
+python bench.py --workload ogbn-proteins-zipf-s --no-cpu-baseline > gpurun_out/$T/bench_zipf.json 2> gpurun_out/$T/bench_zipf.err
 (cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/zipf_stats -o z -- python $OLDPWD/bench.py --workload ogbn-proteins-zipf-s --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1; find /tmp/zipf_stats -name "*kernel_stats.csv" -exec cp {} $OLDPWD/gpurun_out/$T/zipf_kernel_stats.csv \;)
 python scripts/exp_pokec_epoch.py > gpurun_out/$T/pokec_epoch.log 2>&1
 python scripts/exp_train_step.py > gpurun_out/$T/train_step.log 2>&1
