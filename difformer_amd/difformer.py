@@ -295,6 +295,16 @@ class DIFFormer(nn.Module):
 
     def forward(self, x, edge_index, edge_weight=None):
         layer_ = []
+        # A graph with community structure (every row's entries in one or two source tiles) runs in a mixed node order:
+        # x is permuted once here, the logits once at the end, everything in between sees the relabelled graph
+        mix = None
+        conv0 = self.convs[0] if len(self.convs) else None
+        if (conv0 is not None and conv0.use_graph and edge_index is not None and edge_weight is None and conv0.row_shard is None
+                and x.dtype == torch.float32 and x.is_cuda and conv0.kernel == "simple" and conv0.num_heads == 1
+                and hasattr(ops, "mix_cache")):
+            mix = ops.mix_cache.get(edge_index, x.shape[0], self.fcs[0].out_features)
+        if mix is not None:
+            x, edge_index = x[mix.perm], mix.edge_index
         x = self._input_layer(x, self.training)                # difformer.py:188-192
         layer_.append(x)
         # closed-form layers write the slice-major copy of their output (the next layer's SpMM operand) from their
@@ -317,9 +327,8 @@ class DIFFormer(nn.Module):
             if self.training:
                 x = F.dropout(x, p=self.dropout, training=True)
             layer_.append(x)
-        if carry.get("head_done"):
-            return x
-        return ag.linear(x, self.fcs[-1].weight, self.fcs[-1].bias)   # :208
+        out = x if carry.get("head_done") else ag.linear(x, self.fcs[-1].weight, self.fcs[-1].bias)   # :208
+        return out[mix.inv] if mix is not None else out
 
     def get_attentions(self, x):
         """Dense per-layer attention [layers, N, N, H] (difformer.py:211-226; no graph term,

@@ -408,6 +408,66 @@ class _CSRCache:
 csr_cache = _CSRCache()
 
 
+# ------------------------------------------------------------------------------------------
+# graphs with community structure: the model runs in a MIXED node order
+# ------------------------------------------------------------------------------------------
+MIX_THRESHOLD = 2.5     # mean over rows of (largest per-tile share of the row's entries) x tiles: 1.3 on a uniform graph,
+                        # ~8 when every row's entries sit in one or two source tiles
+
+
+class MixedGraph:
+    """A graph relabelled by a fixed random permutation of its nodes.  The sliced product sweeps the SOURCE rows tile by
+    tile with all rows of a slot in lock step; when a row's entries sit in one or two tiles (the real ogbn-proteins: 8
+    species that interact almost only among themselves, node ids grouped by species) most rounds of a wave are empty in
+    any given tile and the rest are padded to them: 3.4-4.6 slots per entry instead of 1.56, 2-3x the time
+    (profiles/r02_experiments.md).  Every per-node operation of the model is equivariant under a relabelling, so the model
+    permutes x once on the way in and the logits once on the way out and runs everything else on `edge_index` = the
+    relabelled graph: perm[i] = original node at position i, inv[perm] = arange."""
+
+    def __init__(self, edge_index, num_nodes):
+        dev = edge_index.device
+        g = torch.Generator(device=dev).manual_seed(0x5EED)
+        self.perm = torch.randperm(num_nodes, generator=g, device=dev)
+        self.inv = torch.empty_like(self.perm)
+        self.inv[self.perm] = torch.arange(num_nodes, device=dev)
+        self.edge_index = self.inv[edge_index]              # same edges, same order, nodes renamed
+
+
+class _MixCache:
+    """MixedGraph (or the decision not to mix) per edge_index tensor, keyed like the CSR cache."""
+
+    def __init__(self, capacity=8):
+        self.capacity, self.entries = capacity, OrderedDict()
+
+    def get(self, edge_index, num_nodes, F):
+        key = (id(edge_index), edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes), int(F))
+        hit = self.entries.get(key)
+        if hit is not None and hit[0]() is edge_index:
+            self.entries.move_to_end(key)
+            return hit[1]
+        for k in [k for k, v in self.entries.items() if v[0]() is None]:
+            del self.entries[k]
+        mix = None
+        if sliced_tiling(num_nodes, F, edge_index.shape[1], None, None, 4) is not None:
+            csr = csr_cache.get(edge_index, None, num_nodes, F * 4)
+            if csr.n_blocks > 1 and csr.blkptr is not None:
+                cnt = csr.blkptr.view(csr.n_blocks + 1, num_nodes)
+                cnt = (cnt[1:] - cnt[:-1]).to(torch.float32)                    # entries per (tile, row)
+                share = float((cnt.max(dim=0).values.sum() * csr.n_blocks / max(csr.nnz, 1)).item())     # one sync, cold path
+                if share > MIX_THRESHOLD:
+                    mix = MixedGraph(edge_index, num_nodes)
+        self.entries[key] = (weakref.ref(edge_index), mix)
+        while len(self.entries) > self.capacity:
+            self.entries.popitem(last=False)
+        return mix
+
+    def clear(self):
+        self.entries.clear()
+
+
+mix_cache = _MixCache()
+
+
 def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard: Optional[RowShard] = None,
                   tail=None):
     """x [n,H,D] (this rank's rows of the value tensor) -> gcn_scale * A_hat x (+ attn_scale * attn).
