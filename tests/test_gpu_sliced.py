@@ -318,3 +318,24 @@ def test_model_runs_community_structured_graphs_in_a_mixed_node_order(dev):
     # a uniform graph keeps its order
     uni = _dense_graph(n, deg, seed=9).to(dev)
     assert ops.mix_cache.get(uni, n, hidden) is None
+    # training goes through the two permutations too (main.py:117-131): same parameter gradients as in the natural order
+    # (whose kernels are held to float64 autograd in test_gpu_parity.py)
+    model.train()
+    model.dropout = 0.0
+    xg = x.to(dev)
+
+    def grads():
+        model.zero_grad()
+        model(xg, eid).square().mean().backward()
+        return {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+    g_mixed = grads()
+    saved, ops.MIX_THRESHOLD = ops.MIX_THRESHOLD, 1e9
+    ops.mix_cache.clear()
+    try:
+        g_nat = grads()
+        assert ops.mix_cache.get(eid, n, hidden) is None
+    finally:
+        ops.MIX_THRESHOLD = saved
+        ops.mix_cache.clear()
+    for k in g_nat:
+        assert rel_err(g_mixed[k].cpu().numpy(), g_nat[k].cpu().numpy()) < 1e-4, k
