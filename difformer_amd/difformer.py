@@ -300,9 +300,10 @@ class DIFFormer(nn.Module):
         mix = None
         conv0 = self.convs[0] if len(self.convs) else None
         if (conv0 is not None and conv0.use_graph and edge_index is not None and edge_weight is None and conv0.row_shard is None
-                and x.dtype == torch.float32 and x.is_cuda and conv0.kernel == "simple" and conv0.num_heads == 1
-                and hasattr(ops, "mix_cache")):
-            mix = ops.mix_cache.get(edge_index, x.shape[0], self.fcs[0].out_features)
+                and x.dtype == torch.float32 and x.is_cuda and hasattr(ops, "mix_cache")):
+            # columns the aggregation runs on: the value tensor [n, H, D] (or the layer input itself without Wv)
+            width = conv0.out_channels * (conv0.num_heads if conv0.use_weight else 1)
+            mix = ops.mix_cache.get(edge_index, x.shape[0], width)
         if mix is not None:
             x, edge_index = x[mix.perm], mix.edge_index
         x = self._input_layer(x, self.training)                # difformer.py:188-192
