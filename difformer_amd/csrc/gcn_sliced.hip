@@ -156,35 +156,64 @@ __device__ __forceinline__ Counts load_counts(const uint4* __restrict__ cnt, int
     return c;
 }
 
+// One WAVE per row position: the entries of a (position, tile) group are contiguous in the CSR, so the wave reads them
+// as one coalesced chunk of up to 64 (the usual group has ~46), ranks every entry inside its bank quad with 16 ballots
+// (stable: original order inside a quad), and writes the 16-bit local ids + the 16 counters.  (The first version walked
+// one group per THREAD: 184-byte runs per lane, 19.8 GB through HBM for 0.5 GB of useful bytes, 3.2 ms at C4.)
 __global__ __launch_bounds__(256) void sliced_sort_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr,
                                                           const int32_t* __restrict__ src, int64_t n_src, int NT, int T,
                                                           int64_t row_begin, int64_t n_pos, const int32_t* __restrict__ order,
                                                           const uint16_t* __restrict__ parts,
                                                           uint16_t* __restrict__ srt, uint4* __restrict__ cnt,
                                                           int32_t* __restrict__ status) {
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= n_pos * NT) return;
-    const int64_t pos = idx / NT;
-    const int t = static_cast<int>(idx % NT);
-    int32_t e0, e1;
-    position_bounds(rowptr, blkptr, n_src, NT, row_begin, order, parts, pos, t, e0, e1);
-    const int32_t base = t * T;
-    Counts c = {{0, 0, 0, 0}};
-    if (e1 - e0 > kGroupCap) {       // 16-bit counters: such a graph takes the gather kernel
-        atomicOr(status, 1);
-        e1 = e0;
-    }
-    for (int32_t e = e0; e < e1; ++e) bump16(c, static_cast<uint32_t>(src[e] - base) & 15u);
-    cnt[idx * 2] = uint4{static_cast<uint32_t>(c.w[0]), static_cast<uint32_t>(c.w[0] >> 32), static_cast<uint32_t>(c.w[1]),
-                         static_cast<uint32_t>(c.w[1] >> 32)};
-    cnt[idx * 2 + 1] = uint4{static_cast<uint32_t>(c.w[2]), static_cast<uint32_t>(c.w[2] >> 32), static_cast<uint32_t>(c.w[3]),
-                             static_cast<uint32_t>(c.w[3] >> 32)};
-    Counts nx = bucket_starts(c);
-    for (int32_t e = e0; e < e1; ++e) {
-        const uint32_t loc = static_cast<uint32_t>(src[e] - base);
-        const uint32_t q = loc & 15u;
-        srt[e0 + lane16(nx, q)] = static_cast<uint16_t>(loc);
-        bump16(nx, q);
+    const int lane = threadIdx.x & 63;
+    const int64_t pos = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (pos >= n_pos) return;
+    const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t* cnt32 = reinterpret_cast<uint32_t*>(cnt);
+    for (int t = 0; t < NT; ++t) {
+        int32_t e0, e1;
+        position_bounds(rowptr, blkptr, n_src, NT, row_begin, order, parts, pos, t, e0, e1);
+        e0 = __builtin_amdgcn_readfirstlane(e0);
+        e1 = __builtin_amdgcn_readfirstlane(e1);
+        const int32_t base = t * T;
+        if (e1 - e0 > kGroupCap) {       // 16-bit counters: such a graph takes the gather kernel
+            if (lane == 0) atomicOr(status, 1);
+            e1 = e0;
+        }
+        uint32_t count[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) count[q] = 0;
+        for (int32_t c0 = e0; c0 < e1; c0 += 64) {
+            const int32_t e = c0 + lane;
+            const bool ok = e < e1;
+            const uint32_t q = ok ? (static_cast<uint32_t>(src[e] - base) & 15u) : 16u;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) count[qq] += static_cast<uint32_t>(__popcll(__ballot(q == static_cast<uint32_t>(qq))));
+        }
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (lane == j) word = count[2 * j] | (count[2 * j + 1] << 16);
+        if (lane < 8) cnt32[(pos * NT + t) * 8 + lane] = word;
+        uint32_t run[16];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { run[q] = acc; acc += count[q]; }
+        for (int32_t c0 = e0; c0 < e1; c0 += 64) {
+            const int32_t e = c0 + lane;
+            const bool ok = e < e1;
+            const uint32_t loc = ok ? static_cast<uint32_t>(src[e] - base) : 0u;
+            const uint32_t q = ok ? (loc & 15u) : 16u;
+            uint32_t dst = 0;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+                const uint64_t m = __ballot(q == static_cast<uint32_t>(qq));
+                if (q == static_cast<uint32_t>(qq)) dst = run[qq] + static_cast<uint32_t>(__popcll(m & below));
+                run[qq] += static_cast<uint32_t>(__popcll(m));
+            }
+            if (ok) srt[e0 + dst] = static_cast<uint16_t>(loc);
+        }
     }
 }
 
@@ -667,8 +696,7 @@ extern "C" int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t he = hipMemsetAsync(status, 0, 4, st);
     if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_sliced_measure: memset: %s", hipGetErrorString(he));
-    const int64_t n_groups = n_pos * pl.NT;
-    hipLaunchKernelGGL(sliced_sort_kernel, dim3(static_cast<unsigned>((n_groups + 255) / 256)), dim3(256), 0, st, rowptr,
+    hipLaunchKernelGGL(sliced_sort_kernel, dim3(static_cast<unsigned>((n_pos + 3) / 4)), dim3(256), 0, st, rowptr,
                        blkptr, src, n_src, pl.NT, pl.T, row_begin, n_pos, row_order, parts, sorted,
                        static_cast<uint4*>(counts), status);
     if (int rc = dif::launch_status("sliced_sort_kernel")) return rc;
