@@ -685,11 +685,13 @@ class HipBackend:
                 attn, lda = attn.contiguous(), F
         out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
         n_pos = int(n_rows) if sl.n_pos is None else int(sl.n_pos)
+        ws_bytes = self.lib.dif_sliced_spmm_workspace_bytes(int(n_src), n_pos, int(F))   # > 0: a row shard (source splits)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         with _Timed(self, "dif_sliced_spmm_f32", dev):
             rc = self.lib.dif_sliced_spmm_f32(_ptr(sl.entries), _ptr(sl.table), sl.plan, _ptr(ys), _ptr(rowptr), _ptr(dinv),
                                               _ptr(sl.order), _ptr(sl.parts), n_pos, int(n_src), int(row_begin), int(n_rows),
                                               int(F), _ptr(attn), lda, float(attn_scale), float(gcn_scale), _ptr(out), F,
-                                              _stream(dev))
+                                              _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_sliced_spmm_f32")
         return out
 

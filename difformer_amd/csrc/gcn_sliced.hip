@@ -47,7 +47,9 @@ __device__ const uint8_t kLaneOf[64] = {
 
 struct Plan {
     int slices, panels, G, PW, W, R, T, NT;      // G = 64-row slots, PW = panels * W (panel, wave) pairs, R = rounds
+    int S = 1;                                   // source splits (derived, not part of the int32[8] record): see make_plan
 };
+constexpr int kMaxSplits = 8;
 
 // slot of stratum j for pair index pw = wave * panels + panel (snake: odd strata run backwards)
 __host__ __device__ __forceinline__ int64_t slot_of(int j, int pw, int PW) {
@@ -63,6 +65,16 @@ int make_plan(int64_t n_src, int64_t n_rows, int F, Plan& p) {
     if (panels < 1) panels = 1;
     const int64_t cap = static_cast<int64_t>(kMaxWaves) * kMaxRounds;            // slots one workgroup can own
     if (panels * cap < G) panels = (G + cap - 1) / cap;
+    // A row shard (few destination rows, all the source rows): every workgroup would sweep ALL the source tiles for a
+    // few rounds of work, and the sweep does not shrink with the rows.  Fewer, fuller panels instead, and S workgroups
+    // per (panel, slice) that take 1/S of the source tiles each; their partial sums meet in a second pass
+    // (sliced_combine_kernel), in a fixed order.
+    const int64_t nt0 = (n_src + kTileRowsMax - 1) / kTileRowsMax;
+    const int64_t need = (G + (cap - kMaxWaves) - 1) / (cap - kMaxWaves);        // panels at kMaxRounds - 1 rounds
+    int S = 1;
+    while (S * 2 <= kMaxSplits && (n_src + n_rows - 1) / n_rows >= 2 * S && need * S * 2 <= panels && nt0 >= S * 2) S *= 2;
+    p.S = S;
+    panels /= S;
     if (panels > G) panels = G;
     if (panels * p.slices > (int64_t(1) << 20) || G >= (int64_t(1) << 30)) return DIF_E_RANGE;
     p.panels = static_cast<int>(panels);
@@ -81,7 +93,7 @@ int make_plan(int64_t n_src, int64_t n_rows, int F, Plan& p) {
     p.W = bestW;
     p.R = bestR;
     p.PW = p.panels * p.W;
-    const int64_t nt = (n_src + kTileRowsMax - 1) / kTileRowsMax;
+    const int64_t nt = (nt0 + S - 1) / S * S;                                    // every split takes NT / S tiles
     if (nt > 32767) return DIF_E_RANGE;
     p.NT = static_cast<int>(nt);
     p.T = static_cast<int>((((n_src + nt - 1) / nt) + 15) / 16 * 16);
@@ -437,6 +449,7 @@ struct Epilogue {
     float attn_scale, gcn_scale;
     float* out;
     int64_t ldo;
+    f32x4* partial;        // S > 1: [S][slices][G * 64] raw sums of the splits, finished by sliced_combine_kernel
 #ifdef DIF_SLICED_TRACE
     long long* trace;      // measurement build only (scripts/exp_sliced_trace.py): per-tile wall-clock stamps of the first and last wave
 #endif
@@ -503,18 +516,48 @@ struct Phases<0, NR> {
     static __device__ __forceinline__ void run(const f32x4*, int&, const uint4*&, uint4 (&)[NR], f32x4 (&)[NR], const int (&)[NR]) {}
 };
 
+// The sum of one row position (all 64 lanes of a slot call this together): parts of a split row are added up by
+// part 0, then the row is scaled, combined with the attention branch and stored.
+__device__ __forceinline__ void finish_position(const Epilogue& ep, int64_t pos, int slice, f32x4 acc) {
+    int64_t lrow = -1;
+    if (pos < ep.n_pos) lrow = ep.order ? ep.order[pos] : pos;
+    f32x4 sum = acc;
+    if (ep.parts) {
+        // the parts of a split row sit in consecutive lanes of this slot: part 0 adds them up in part order
+        const uint32_t pp = (pos < ep.n_pos && lrow >= 0) ? ep.parts[pos] : 0x0100u;
+        const int p = pp & 0xffu, P = pp >> 8;
+        for (int k = 1; __ballot(k < P) != 0ull; ++k) {
+            f32x4 o;
+            o.x = __shfl_down(acc.x, k);
+            o.y = __shfl_down(acc.y, k);
+            o.z = __shfl_down(acc.z, k);
+            o.w = __shfl_down(acc.w, k);
+            if (p == 0 && k < P) sum += o;
+        }
+        if (p != 0) lrow = -1;
+    }
+    if (lrow >= 0) {
+        const int64_t row = ep.row_begin + lrow;
+        f32x4 o = sum * (ep.gcn_scale * (ep.dinv ? ep.dinv[row] : dinv_of(ep.rowptr, row)));
+        if (ep.attn) o += ep.attn_scale * *reinterpret_cast<const f32x4*>(ep.attn + lrow * ep.lda + slice * 4);
+        *reinterpret_cast<f32x4*>(ep.out + lrow * ep.ldo + slice * 4) = o;
+    }
+}
+
 template <int NR>
 __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell, const int32_t* __restrict__ tabw,
                                       int64_t tab_stride, const f32x4* __restrict__ ysl, const Plan pl, const Epilogue ep,
-                                      int pw, int slice, int lane, int t0) {
+                                      int pw, int slice, int lane, int t0, int z) {
     constexpr int NA = NR > 0 ? NR : 1;
     const int T = pl.T;
     f32x4 acc[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int tt = 0; tt < pl.NT; ++tt) {
+    const int ntl = pl.NT / pl.S;                                             // this split's tiles: [z * ntl, (z + 1) * ntl)
+    for (int tt = 0; tt < ntl; ++tt) {
         int t = tt + t0;                                                      // XCDs start on different tiles (t0)
-        if (t >= pl.NT) t -= pl.NT;
+        if (t >= ntl) t -= ntl;
+        t += z * ntl;
 #ifdef DIF_SLICED_TRACE
         const int tw = (threadIdx.x >> 6) == 0 ? 0 : ((static_cast<int>(threadIdx.x >> 6) == pl.W - 1) ? 1 : -1);
         long long* tr4 = (tw >= 0 && lane == 0) ? ep.trace + ((static_cast<int64_t>(blockIdx.x) * 2 + tw) * pl.NT + tt) * 4 : nullptr;
@@ -583,29 +626,8 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int64_t pos = slot_of(j, pw, pl.PW) * 64 + lane;
-        int64_t lrow = -1;
-        if (pos < ep.n_pos) lrow = ep.order ? ep.order[pos] : pos;
-        f32x4 sum = acc[j];
-        if (ep.parts) {
-            // the parts of a split row sit in consecutive lanes of this slot: part 0 adds them up in part order
-            const uint32_t pp = (pos < ep.n_pos && lrow >= 0) ? ep.parts[pos] : 0x0100u;
-            const int p = pp & 0xffu, P = pp >> 8;
-            for (int k = 1; __ballot(k < P) != 0ull; ++k) {
-                f32x4 o;
-                o.x = __shfl_down(acc[j].x, k);
-                o.y = __shfl_down(acc[j].y, k);
-                o.z = __shfl_down(acc[j].z, k);
-                o.w = __shfl_down(acc[j].w, k);
-                if (p == 0 && k < P) sum += o;
-            }
-            if (p != 0) lrow = -1;
-        }
-        if (lrow >= 0) {
-            const int64_t row = ep.row_begin + lrow;
-            f32x4 o = sum * (ep.gcn_scale * (ep.dinv ? ep.dinv[row] : dinv_of(ep.rowptr, row)));
-            if (ep.attn) o += ep.attn_scale * *reinterpret_cast<const f32x4*>(ep.attn + lrow * ep.lda + slice * 4);
-            *reinterpret_cast<f32x4*>(ep.out + lrow * ep.ldo + slice * 4) = o;
-        }
+        if (pl.S > 1) ep.partial[(static_cast<int64_t>(z) * pl.slices + slice) * pl.G * 64 + pos] = acc[j];
+        else finish_position(ep, pos, slice, acc[j]);
     }
 }
 
@@ -615,17 +637,18 @@ __global__ __launch_bounds__(64 * kMaxWaves) void sliced_spmm_kernel(const uint4
                                                                      Epilogue ep) {
     __shared__ f32x4 tile[kLdsRows];
     const int b = blockIdx.x;
-    int panel, slice, t0 = 0;
+    int vp, slice, t0 = 0;                                   // vp = panel * S + split
     const int per = gridDim.x >> 3;
     if ((gridDim.x & 7) == 0 && per % pl.slices == 0) {      // the slices of a panel share an XCD (block b -> XCD b % 8)
         const int xcd = b & 7, k = b >> 3;
-        panel = xcd * (per / pl.slices) + k / pl.slices;
+        vp = xcd * (per / pl.slices) + k / pl.slices;
         slice = k % pl.slices;
-        t0 = (xcd * pl.NT) >> 3;                             // XCDs start on different tiles: their tile loads do not coincide
+        t0 = (xcd * (pl.NT / pl.S)) >> 3;                    // XCDs start on different tiles: their tile loads do not coincide
     } else {
-        panel = b / pl.slices;
+        vp = b / pl.slices;
         slice = b % pl.slices;
     }
+    const int panel = vp / pl.S, z = vp % pl.S;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < 16) tile[pl.T + threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -634,16 +657,39 @@ __global__ __launch_bounds__(64 * kMaxWaves) void sliced_spmm_kernel(const uint4
     const int64_t tab_stride = static_cast<int64_t>(pl.W) * (pl.R + 1);
     const int pw = w * pl.panels + panel;
     const bool full = slot_of(R - 1, pw, pl.PW) < pl.G;      // rounds of this wave: R or R - 1
-    if (full) sweep<R>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane, t0);
-    else sweep<R - 1>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane, t0);
+    if (full) sweep<R>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane, t0, z);
+    else sweep<R - 1>(tile, ell, tabw, tab_stride, ysl, pl, ep, pw, slice, lane, t0, z);
+}
+
+// second pass of a source-split product: the S partial sums of every (row position, slice), added in split order
+__global__ __launch_bounds__(256) void sliced_combine_kernel(Plan pl, Epilogue ep) {
+    const int64_t pair = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (pair >= static_cast<int64_t>(pl.G) * pl.slices) return;
+    const int slice = static_cast<int>(pair % pl.slices);
+    const int64_t pos = (pair / pl.slices) * 64 + (threadIdx.x & 63);
+    const int64_t plane = static_cast<int64_t>(pl.G) * 64;
+    const f32x4* src = ep.partial + slice * plane + pos;
+    f32x4 v[kMaxSplits];
+#pragma unroll
+    for (int z = 0; z < kMaxSplits; ++z)
+        if (z < pl.S) v[z] = src[static_cast<int64_t>(z) * pl.slices * plane];
+    f32x4 sum = v[0];
+#pragma unroll
+    for (int z = 1; z < kMaxSplits; ++z)
+        if (z < pl.S) sum += v[z];
+    finish_position(ep, pos, slice, sum);
 }
 
 template <int R>
 int launch_sweep(hipStream_t st, const uint4* ell, const int32_t* tab, const f32x4* ys, int64_t npad, const Plan& pl,
                  const Epilogue& ep) {
-    hipLaunchKernelGGL((sliced_spmm_kernel<R>), dim3(static_cast<unsigned>(pl.panels * pl.slices)), dim3(64 * pl.W), 0, st,
-                       ell, tab, ys, npad, pl, ep);
-    return dif::launch_status("sliced_spmm_kernel");
+    hipLaunchKernelGGL((sliced_spmm_kernel<R>), dim3(static_cast<unsigned>(pl.panels * pl.S * pl.slices)), dim3(64 * pl.W),
+                       0, st, ell, tab, ys, npad, pl, ep);
+    if (int rc = dif::launch_status("sliced_spmm_kernel")) return rc;
+    if (pl.S == 1) return 0;
+    const int64_t pairs = static_cast<int64_t>(pl.G) * pl.slices;            // one wave per (slot, slice)
+    hipLaunchKernelGGL(sliced_combine_kernel, dim3(static_cast<unsigned>((pairs + 3) / 4)), dim3(256), 0, st, pl, ep);
+    return dif::launch_status("sliced_combine_kernel");
 }
 
 // n_pos row positions: the n_rows rows themselves, or (parts != NULL) their parts plus padding
@@ -660,7 +706,7 @@ int check_plan(const int32_t* plan, int64_t n_src, int64_t n_rows, int F, Plan& 
     const int rc = make_plan(n_src, n_rows, F, want);
     if (rc) return dif::fail(rc, "dif_sliced: shape not covered (n_src=%lld, n_rows=%lld, F=%d)",
                              static_cast<long long>(n_src), static_cast<long long>(n_rows), F);
-    pl = Plan{plan[0], plan[1], plan[2], plan[3], plan[4], plan[5], plan[6], plan[7]};
+    pl = Plan{plan[0], plan[1], plan[2], plan[3], plan[4], plan[5], plan[6], plan[7], want.S};
     if (pl.slices != want.slices || pl.panels != want.panels || pl.G != want.G || pl.PW != want.PW || pl.W != want.W ||
         pl.R != want.R || pl.T != want.T || pl.NT != want.NT)
         return dif::fail(DIF_E_BADARG, "dif_sliced: plan does not match dif_sliced_plan(n_src, n_rows, F)");
@@ -678,6 +724,12 @@ extern "C" int dif_sliced_plan(int64_t n_src, int64_t n_rows, int F, int32_t* pl
     const int32_t v[8] = {p.slices, p.panels, p.G, p.PW, p.W, p.R, p.T, p.NT};
     for (int i = 0; i < 8; ++i) plan[i] = v[i];
     return 0;
+}
+
+extern "C" int64_t dif_sliced_spmm_workspace_bytes(int64_t n_src, int64_t n_rows, int F) {
+    Plan p;
+    if (make_plan(n_src, n_rows, F, p) != 0 || p.S == 1) return 0;
+    return static_cast<int64_t>(p.S) * p.slices * p.G * 64 * 16;
 }
 
 extern "C" int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, const int32_t* src, int64_t n_src,
@@ -746,11 +798,14 @@ extern "C" int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_
 extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table, const int32_t* plan, const float* ys,
                                    const int32_t* rowptr, const float* dinv, const int32_t* row_order, const uint16_t* parts,
                                    int64_t n_pos, int64_t n_src, int64_t row_begin, int64_t n_rows, int F, const float* attn,
-                                   int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo,
-                                   dif_stream_t stream) {
+                                   int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo, void* ws,
+                                   int64_t ws_bytes, dif_stream_t stream) {
     Plan pl;
     if (int rc = check_positions(row_order, parts, n_rows, n_pos, "dif_sliced_spmm")) return rc;
     if (int rc = check_plan(plan, n_src, n_pos, F, pl)) return rc;
+    const int64_t ws_need = pl.S > 1 ? static_cast<int64_t>(pl.S) * pl.slices * pl.G * 64 * 16 : 0;
+    DIF_REQUIRE(ws_need == 0 || (ws && ws_bytes >= ws_need && dif::aligned16(ws)), DIF_E_BADARG,
+                "dif_sliced_spmm: a row shard's product needs dif_sliced_spmm_workspace_bytes() of 16-byte aligned workspace");
     DIF_REQUIRE(entries && table && ys && rowptr && out, DIF_E_BADARG, "dif_sliced_spmm: null pointer");
     DIF_REQUIRE(row_begin >= 0 && row_begin + n_rows <= n_src, DIF_E_BADARG, "dif_sliced_spmm: row range exceeds n_src");
     DIF_REQUIRE(ldo >= F && ldo % 4 == 0 && dif::aligned16(out) && (!attn || (lda >= F && lda % 4 == 0 && dif::aligned16(attn))),
@@ -762,9 +817,10 @@ extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table
     const char* tp = getenv("DIF_SLICED_TRACE");
     DIF_REQUIRE(tp != nullptr, DIF_E_BADARG, "trace build: DIF_SLICED_TRACE = device address of int64[blocks * 2 * tiles * 4]");
     const Epilogue ep = {rowptr, dinv, row_order, parts, row_begin, n_pos, attn, lda, attn_scale, gcn_scale, out, ldo,
-                         reinterpret_cast<long long*>(strtoull(tp, nullptr, 0))};
+                         static_cast<f32x4*>(ws), reinterpret_cast<long long*>(strtoull(tp, nullptr, 0))};
 #else
-    const Epilogue ep = {rowptr, dinv, row_order, parts, row_begin, n_pos, attn, lda, attn_scale, gcn_scale, out, ldo};
+    const Epilogue ep = {rowptr, dinv, row_order, parts, row_begin, n_pos, attn, lda, attn_scale, gcn_scale, out, ldo,
+                         static_cast<f32x4*>(ws)};
 #endif
     const uint4* e4 = reinterpret_cast<const uint4*>(entries);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(ys);

@@ -152,14 +152,15 @@ SLICED_MIN_ROWS = 8192
 
 def sliced_tiling(num_nodes, F, nnz, edge_weight, shard, elem_size):
     """(n_tiles, tile_rows) the feature-sliced product would use for this graph, or None when it is not a candidate
-    (edge weights, non-fp32 rows, sparse or small graph).  csr_cache builds the CSR with that blocking; the tiling
-    depends on the number of SOURCE rows only, so row shards share it."""
+    (edge weights, non-fp32 rows, sparse or small graph).  csr_cache builds the CSR with that blocking.  A row shard
+    has its own tiling (source splits: a multiple of 2, 4 or 8 tiles, include/difformer_hip.h)."""
     if edge_weight is not None or elem_size != 4:
         return None
     if F % 4 or F > 256 or num_nodes < SLICED_MIN_ROWS or nnz < SLICED_MIN_DEGREE * num_nodes:
         return None
     be = get_backend()
-    plan = be.sliced_plan(num_nodes, num_nodes, F) if hasattr(be, "sliced_plan") else None
+    n_rows = shard.n_local if (shard is not None and shard.world > 1) else num_nodes
+    plan = be.sliced_plan(num_nodes, n_rows, F) if hasattr(be, "sliced_plan") else None
     return None if plan is None else (int(plan[7]), int(plan[6]))
 
 
@@ -171,7 +172,7 @@ class SlicedAdjacency:
     """Entry blocks + table + geometry of the feature-sliced product (include/difformer_hip.h, dif_sliced_*).
     order: rows by descending degree (skewed graphs); parts / n_pos: hub rows split into lock-step parts ("row
     positions" in the header) -- then order has n_pos entries (-1 = padding) and plan is the geometry of n_pos positions;
-    tile_plan is the geometry the slice-major source copy is written with (tiling only: the same for every shard)."""
+    The slice-major source copy is written with the same plan (its tiling)."""
 
     def __init__(self, plan, entries, table, order=None, parts=None, n_pos=None):
         self.plan, self.entries, self.table, self.order = plan, entries, table, order

@@ -237,6 +237,11 @@ int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int
  *   dif_sliced_spmm_f32 out[r,:] = gcn_scale * deg[r]^-1/2 * sum_e ys[src_e] (+ attn_scale * attn[r,:]) for the n_rows
  *                       rows the format was built for (out / attn hold only those rows; row_order as at build time).
  *                       Deterministic.
+ *   source splits       For a row shard (n_src >= 2 n_rows: one rank's destination rows over all the source rows) the
+ *                       plan has fewer, fuller panels and S = 2, 4 or 8 workgroups per (panel, slice), each sweeping
+ *                       NT / S of the source tiles (NT is a multiple of S); their partial sums meet in a second kernel,
+ *                       in split order.  The product then needs `ws` of dif_sliced_spmm_workspace_bytes(n_src, n_pos, F)
+ *                       bytes, 16-byte aligned (0 bytes and NULL for S = 1: every whole-graph product).
  *   row positions       Without `parts` (NULL) the n_pos = n_rows positions are the rows themselves (in row_order).  With
  *                       `parts` uint16[n_pos] a position is part p of P of row row_order[pos] (parts[pos] = p | P << 8,
  *                       1 <= P <= 64: in every tile part p takes the p-th of P equal shares of the row's entries) or empty
@@ -262,7 +267,9 @@ int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_t* rowptr, 
 int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table, const int32_t* plan, const float* ys,
                         const int32_t* rowptr, const float* dinv, const int32_t* row_order, const uint16_t* parts,
                         int64_t n_pos, int64_t n_src, int64_t row_begin, int64_t n_rows, int F, const float* attn,
-                        int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo, dif_stream_t stream);
+                        int64_t lda, float attn_scale, float gcn_scale, float* out, int64_t ldo, void* ws,
+                        int64_t ws_bytes, dif_stream_t stream);
+int64_t dif_sliced_spmm_workspace_bytes(int64_t n_src, int64_t n_rows, int F);
 
 /* Split product for row-sharded runs (one process per GPU): a rank owns the source rows of the blocks
  * [own_blk_begin, own_blk_end) before the all-gather of the value rows has delivered the others.

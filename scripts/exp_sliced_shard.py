@@ -28,11 +28,11 @@ def timeit(f, it=30):
     return (time.perf_counter() - t0) / it * 1e3
 
 
-csr = ops.csr_cache.get(ei, None, n, C * 4)
 base = None
 for world in (1, 2, 4, 8):
     for rank in sorted({0, world - 1}):
         s = RowShard(n, rank=rank, world=world)
+        csr = ops.csr_cache.get(ei, None, n, C * 4, s)          # a shard has its own tiling (source splits)
         lo, cnt = s.row_begin, s.n_local
         torch.cuda.synchronize(); t0 = time.perf_counter()
         sl = csr.sliced(lo, cnt, C)
@@ -51,6 +51,6 @@ for world in (1, 2, 4, 8):
         if base is None:
             base = t_sp
         plan = [int(v) for v in sl.plan]
-        print(f"world {world} rank {rank}: {cnt} rows  plan panels={plan[1]} W={plan[4]} R={plan[5]}  format build {t_build:.1f} ms | "
+        print(f"world {world} rank {rank}: {cnt} rows  plan panels={plan[1]} W={plan[4]} R={plan[5]} NT={plan[7]}  format build {t_build:.1f} ms | "
               f"sliced product {t_sp * 1e3:.0f} us ({t_sp / (base / world):.2f}x of 1/{world}), pre-scale of the gathered rows "
               f"{t_pre * 1e3:.0f} us, gram {t_gram * 1e3:.0f} us, layer kernel {t_layer * 1e3:.0f} us", flush=True)

@@ -25,7 +25,7 @@ def lib():
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and "dif_sliced_spmm_f32" in names and "dif_simple_layer_f32" in names and "dif_subgraph_batches_group" in names and "dif_graph_prepare" in names and len(names) == 66
+    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and "dif_sliced_spmm_f32" in names and "dif_simple_layer_f32" in names and "dif_subgraph_batches_group" in names and "dif_graph_prepare" in names and len(names) == 67
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -63,12 +63,21 @@ def test_sliced_plan_is_host_side_arithmetic(lib):
     assert plan[5] <= 10
     assert lib.dif_sliced_plan(1000, 1000, 30, plan) == -2 and b"F % 4" in lib.dif_last_error()
     assert lib.dif_sliced_plan(5000, 5000, 64, plan) == 0 and plan[7] == 1                     # one tile: plain CSR
-    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5000, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5000, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.dif_last_error()
-    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5000, 6000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5000, 6000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None, 0, None)
     assert rc == -1 and b"plan does not match" in lib.dif_last_error()
+    # a row shard (1/8 of the rows over all the sources): 2 full panels, 8 source splits of 2 tiles each, and a workspace
+    assert lib.dif_sliced_plan(132534, 16568, 64, plan) == 0
+    slices, panels, G, PW, W, R, T, NT = list(plan)
+    assert (slices, panels, R, NT) == (16, 2, 9, 16) and T * NT >= 132534 and R * PW >= G
+    assert lib.dif_sliced_spmm_workspace_bytes(132534, 16568, 64) == 8 * 16 * G * 64 * 16
+    assert lib.dif_sliced_spmm_workspace_bytes(132534, 132534, 64) == 0
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 16568, 132534, 0, 16568, 64, None, 0, 1.0, 1.0, None, 64, None, 0, None)
+    assert rc == -1 and b"workspace" in lib.dif_last_error()
+    assert lib.dif_sliced_plan(132534, 66272, 64, plan) == 0 and (plan[1], plan[7]) == (8, 14)   # world 2: 2 splits
     # row positions: without `parts` there are exactly n_rows of them; with `parts` the order is required
-    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5064, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None)
+    rc = lib.dif_sliced_spmm_f32(None, None, plan, None, None, None, None, None, 5064, 5000, 0, 5000, 64, None, 0, 1.0, 1.0, None, 64, None, 0, None)
     assert rc == -1 and b"n_pos" in lib.dif_last_error()
 
 

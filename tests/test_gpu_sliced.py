@@ -239,6 +239,38 @@ def test_sliced_product_on_skewed_degrees(n, deg, hubs, dev):
     assert torch.equal(gcn_conv(xd, eid, None), out)
 
 
+@pytest.mark.parametrize("n,deg,world,splits,skewed", [(90000, 60, 8, 8, False), (90000, 60, 4, 4, False),
+                                                         (50000, 60, 2, 2, False), (90000, 60, 8, 8, True)])
+def test_sliced_product_of_a_row_shard_splits_the_source_tiles(n, deg, world, splits, skewed, dev):
+    """One rank's destination rows over ALL the source rows: fewer, fuller panels and `splits` workgroups per
+    (panel, slice), each sweeping NT / splits source tiles; the partial sums meet in sliced_combine_kernel.  Every rank
+    reproduces its rows of the float64 oracle, bit for bit from run to run."""
+    from difformer_amd import ops
+    from difformer_amd.dist import RowShard
+    ei = _skewed_graph(n, deg, seed=11 * n, hubs=30) if skewed else _dense_graph(n, deg, seed=13 * n + world)
+    g = torch.Generator().manual_seed(world)
+    x = torch.randn(n, 64, generator=g)
+    eid, xd = ei.to(dev), x.to(dev)
+    be = ops.get_backend()
+    ref = orc.gcn_conv(x.double().numpy()[:, None, :], ei.numpy(), None)[:, 0, :]
+    for rank in sorted({0, world // 2, world - 1}):
+        sh = RowShard(n, rank=rank, world=world)
+        lo, cnt = sh.row_begin, sh.n_local
+        csr = ops.csr_cache.get(eid, None, n, 256, sh)
+        sl = csr.sliced(lo, cnt, 64)
+        assert sl is not None
+        n_pos = cnt if sl.n_pos is None else sl.n_pos
+        assert be.lib.dif_sliced_spmm_workspace_bytes(n, n_pos, 64) == splits * 16 * int(sl.plan[2]) * 64 * 16
+        assert int(sl.plan[7]) % splits == 0 and (sl.parts is not None) == skewed
+        ys = be.sliced_prescale(xd, csr.rowptr, n, sl.plan)
+        out = be.sliced_spmm(sl, ys, csr.rowptr, n, lo, cnt, 64)
+        assert rel_err(out.cpu().numpy(), ref[lo: lo + cnt]) < 1e-5, (world, rank)
+        assert torch.equal(be.sliced_spmm(sl, ys, csr.rowptr, n, lo, cnt, 64), out)
+        attn = torch.randn(cnt, 64, generator=g).to(dev)
+        mix = be.sliced_spmm(sl, ys, csr.rowptr, n, lo, cnt, 64, attn, 0.25, 0.75)
+        assert rel_err(mix.cpu().numpy(), 0.75 * ref[lo: lo + cnt] + 0.25 * attn.cpu().numpy()) < 1e-5
+
+
 def test_sliced_nodes_without_incoming_entries(dev):
     """deg = 0 -> infinite normaliser -> nan_to_num drops the entry (difformer.py:66-74)."""
     from difformer_amd import gcn_conv
