@@ -287,8 +287,11 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
         nbj = tb[1 + j];
     }
     int64_t rowbase = 0;            // blocks before block row k = step >> 3 of this (panel, tile, wave)
-    auto slot_addr = [&](int step, int lane) -> int64_t {
-        return ((blk0 + rowbase + j) * 64 + lane) * 8 + (step & 7);
+    // EMIT: the schedule of a step goes into the block it belongs to as one 16-byte record {bank quads of lanes 0-7,
+    // of lanes 8-15 (4 bits each), mask of lanes holding a real entry, 0} at uint4 grp * 8 + (step & 7);
+    // sliced_fill_kernel then turns the records of a block into its entries, in place.
+    auto record_at = [&](int step) -> uint4* {
+        return reinterpret_cast<uint4*>(ell) + (blk0 + rowbase + j) * 64 + grp * 8 + (step & 7);
     };
     auto new_row = [&](int step) {
         if (EMIT && (step & 7) == 0) {
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
     int step = 0;
     while (remaining > 0) {
         new_row(step);
-        uint32_t used = 0, picked = 0;
+        uint32_t used = 0, picked = 0, qlo = 0, qhi = 0;
         for (int ii = 0; ii < 16; ++ii) {
             const int i = (ii + step) & 15;
             int best = -1;
@@ -321,30 +324,145 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
             my[(i * 8 + (best >> 1)) * kColorThreads] -= 1u << (16 * (best & 1));
             --remaining;
             if (EMIT) {
-                // pop from the end of the lane's quad bucket: entry e0 + (entries of lower quads) + (left on this quad)
-                const int lane = kLaneOf[grp * 16 + i];
-                const Counts st = bucket_starts(load_counts(cnt, (g * 64 + lane) * pl.NT + t));
-                const uint32_t e0 = my[(128 + i) * kColorThreads];
-                ell[slot_addr(step, lane)] = srt[e0 + lane16(st, static_cast<uint32_t>(best)) + (bestv - 1)];
+                if (i < 8) qlo |= static_cast<uint32_t>(best) << (4 * i);
+                else qhi |= static_cast<uint32_t>(best) << (4 * (i - 8));
             }
         }
         if (EMIT) {             // idle lanes read a zero row on a quad nobody uses in this step
             for (int i = 0; i < 16; ++i) {
                 if ((picked >> i) & 1u) continue;
-                const int fq = __builtin_ctz(~used & 0xffffu);
+                const uint32_t fq = __builtin_ctz(~used & 0xffffu);
                 used |= 1u << fq;
-                ell[slot_addr(step, kLaneOf[grp * 16 + i])] = static_cast<uint16_t>(pl.T + fq);
+                if (i < 8) qlo |= fq << (4 * i);
+                else qhi |= fq << (4 * (i - 8));
             }
+            *record_at(step) = uint4{qlo, qhi, picked, 0u};
         }
         ++step;
     }
     if (!EMIT) {
         len[gid] = step;
     } else {
-        for (; step < nbj * 8; ++step) {
+        for (; step < nbj * 8; ++step) {            // padding steps: lane i reads zero row i
             new_row(step);
-            for (int i = 0; i < 16; ++i) ell[slot_addr(step, kLaneOf[grp * 16 + i])] = static_cast<uint16_t>(pl.T + i);
+            *record_at(step) = uint4{0x76543210u, 0xfedcba98u, 0u, 0u};
         }
+    }
+}
+
+// build, step 4: one wave per (slot, tile) walks the slot's blocks in step order and replaces the schedule records by
+// the entries -- lane L takes, from the bank-quad bucket the record names, the next entry of its (row position, tile)
+// group (16-bit tile-local source row), or the zero row T + quad where it idles; eight steps = one 16-byte store.
+// The 64 groups of the slot are first copied into LDS with coalesced loads (64 lanes picking single entries out of 64
+// different groups would cost one cache line per lane and load: 1.08 ms at C4 against 0.2 ms); slots whose groups do not
+// fit (hub rows) read global memory directly.
+constexpr int kFillStage = 4096;                 // entries of one slot in LDS (8 KiB per wave)
+
+template <bool STAGED>
+__device__ __forceinline__ void fill_blocks(const uint16_t* __restrict__ mine, const uint16_t* stage, Counts next,
+                                            const int32_t* __restrict__ tb, int R, int j, int nbj, int64_t blk0, int grp,
+                                            int i, int lane, uint32_t T, uint4* __restrict__ ell) {
+    uint64_t n0 = next.w[0], n1 = next.w[1], n2 = next.w[2], n3 = next.w[3];
+    const uint32_t himask = (i >= 8) ? ~0u : 0u, sh = 4u * (i & 7);
+    for (int k = 0; k < nbj; ++k) {
+        int64_t rowbase = 0;
+        for (int j2 = 0; j2 < R; ++j2) { const int v = tb[1 + j2]; rowbase += v < k ? v : k; }
+        uint4* blk = ell + (blk0 + rowbase + j) * 64;
+        uint4 rec[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) rec[s8] = blk[grp * 8 + s8];
+        uint32_t ent[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            // masks, not selects between array elements: those turn `rec` / `next` into indexed scratch arrays
+            const uint32_t q = ((((rec[s8].x & ~himask) | (rec[s8].y & himask)) >> sh)) & 15u;
+            const bool real = (rec[s8].z >> i) & 1u;
+            const uint32_t k = q >> 2;
+            const uint64_t m0 = k == 0u ? ~0ull : 0ull, m1 = k == 1u ? ~0ull : 0ull, m2 = k == 2u ? ~0ull : 0ull,
+                           m3 = k == 3u ? ~0ull : 0ull;
+            const uint64_t wsel = (n0 & m0) | (n1 & m1) | (n2 & m2) | (n3 & m3);
+            const uint32_t qs = (q & 3u) * 16u;
+            const uint32_t at = real ? (static_cast<uint32_t>(wsel >> qs) & 0xffffu) : 0u;   // idle lanes read entry 0 and drop it
+            const uint32_t v = STAGED ? stage[at] : mine[at];
+            const uint64_t one = real ? (1ull << qs) : 0ull;
+            n0 += one & m0; n1 += one & m1; n2 += one & m2; n3 += one & m3;
+            ent[s8] = real ? v : T + q;
+        }
+        // every lane has read its records (the loads above belong to instructions that completed for the whole wave
+        // before the first dependent use); now the block takes its final content
+        blk[lane] = uint4{ent[0] | (ent[1] << 16), ent[2] | (ent[3] << 16), ent[4] | (ent[5] << 16), ent[6] | (ent[7] << 16)};
+    }
+}
+
+__global__ __launch_bounds__(256) void sliced_fill_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr, int64_t n_src, int64_t row_begin,
+    int64_t n_pos, const int32_t* __restrict__ order, const uint16_t* __restrict__ parts, Plan pl,
+    const uint16_t* __restrict__ srt, const uint4* __restrict__ cnt, const int32_t* __restrict__ tab,
+    uint4* __restrict__ ell) {
+    __shared__ uint16_t stage_s[4][kFillStage + 8];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const int64_t g = gw / pl.NT;
+    const int t = static_cast<int>(gw % pl.NT);
+    if (g >= pl.G) return;
+    const int j = static_cast<int>(g / pl.PW);
+    const int idxp = static_cast<int>(g % pl.PW);
+    const int pw = (j & 1) ? pl.PW - 1 - idxp : idxp;
+    const int p = pw % pl.panels, w = pw / pl.panels;
+    const int32_t* tb = tab + ((static_cast<int64_t>(p) * pl.NT + t) * pl.W + w) * (pl.R + 1);
+    const int64_t blk0 = tb[0];
+    const int nbj = tb[1 + j];
+    if (nbj == 0) return;
+    int inv = 0;                                   // lane = kLaneOf[inv]: group inv >> 4, index inv & 15
+#pragma unroll
+    for (int k = 0; k < 64; ++k) inv = (kLaneOf[k] == lane) ? k : inv;
+    const int grp = inv >> 4, i = inv & 15;
+    const int64_t pos = g * 64 + lane;
+    Counts next = {{0, 0, 0, 0}};
+    int32_t e0 = 0, e1 = 0;
+    if (pos < n_pos) {
+        position_bounds(rowptr, blkptr, n_src, pl.NT, row_begin, order, parts, pos, t, e0, e1);
+        next = bucket_starts(load_counts(cnt, pos * pl.NT + t));     // next unread entry of each quad bucket
+    }
+    // where the groups of the 64 lanes go in LDS (exclusive scan of their sizes); entry 0 of `stage` / of the lane's
+    // group is what idle steps read, so an empty group must still point at readable memory
+    const int mycnt = e1 - e0;
+    int inc = mycnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    const int total = __shfl(inc, 63, 64);
+    uint16_t* stage = stage_s[wave];
+    if (total <= kFillStage) {
+        const int off = inc - mycnt;
+        for (int r0 = 0; r0 < 64; r0 += 16) {          // 16 groups per batch: all their loads in flight, then the LDS stores
+            uint16_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int n_r = __builtin_amdgcn_readlane(mycnt, r0 + u);
+                const int32_t e_r = __builtin_amdgcn_readlane(e0, r0 + u);
+                v[u] = (lane < n_r) ? srt[e_r + lane] : uint16_t(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int n_r = __builtin_amdgcn_readlane(mycnt, r0 + u), off_r = __builtin_amdgcn_readlane(off, r0 + u);
+                if (lane < n_r) stage[off_r + lane] = v[u];
+            }
+            for (int u = 0; u < 16; ++u) {              // groups beyond 64 entries: the rest
+                const int n_r = __builtin_amdgcn_readlane(mycnt, r0 + u), off_r = __builtin_amdgcn_readlane(off, r0 + u);
+                const int32_t e_r = __builtin_amdgcn_readlane(e0, r0 + u);
+                for (int x = lane + 64; x < n_r; x += 64) stage[off_r + x] = srt[e_r + x];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        fill_blocks<true>(nullptr, stage + off, next, tb, pl.R, j, nbj, blk0, grp, i, lane, static_cast<uint32_t>(pl.T),
+                          ell);
+    } else {
+        fill_blocks<false>(mycnt > 0 ? srt + e0 : srt, nullptr, next, tb, pl.R, j, nbj, blk0, grp, i, lane,
+                           static_cast<uint32_t>(pl.T), ell);
     }
 }
 
@@ -777,7 +895,12 @@ extern "C" int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int
     hipLaunchKernelGGL((sliced_color_kernel<true>), dim3(static_cast<unsigned>((n_hw + kColorThreads - 1) / kColorThreads)),
                        dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_pos, row_order, parts, pl, sorted,
                        static_cast<const uint4*>(counts), nullptr, table, entries);
-    return dif::launch_status("sliced_color_kernel");
+    if (int rc = dif::launch_status("sliced_color_kernel")) return rc;
+    const int64_t n_st = static_cast<int64_t>(pl.G) * pl.NT;                 // one wave per (slot, tile)
+    hipLaunchKernelGGL(sliced_fill_kernel, dim3(static_cast<unsigned>((n_st + 3) / 4)), dim3(256), 0, st, rowptr, blkptr,
+                       n_src, row_begin, n_pos, row_order, parts, pl, sorted, static_cast<const uint4*>(counts), table,
+                       reinterpret_cast<uint4*>(entries));
+    return dif::launch_status("sliced_fill_kernel");
 }
 
 extern "C" int dif_sliced_prescale_f32(const float* x, int64_t ldx, const int32_t* rowptr, const float* dinv, int64_t n_src,
