@@ -233,45 +233,42 @@ __global__ __launch_bounds__(256) void sliced_sort_kernel(const int32_t* __restr
 // build, step 2: greedy edge colouring, one THREAD per (slot, tile, hardware lane group).  A step serves the 16 lanes
 // in rotating order; a lane takes the bank quad it still has the most entries on among the quads no earlier lane of the
 // step took (within ~0.2 % of the lower bound max(longest lane, fullest quad)).  EMIT = false only counts the steps;
-// EMIT = true writes the schedule (and zero-row reads on the free quads for idle lanes) into the blocks.
+// EMIT = true writes the schedule of every step as a 16-byte record into the block it belongs to.
+// The 16 x 16 remaining counts (16-bit, two per dword) live in 128 REGISTERS: the lane loop is unrolled twice (lanes
+// >= start, then lanes < start; start = step & 15 is wave-uniform, the skipped bodies cost a scalar branch) so that every
+// register index is static.  There are only ~1,700 waves of this work at C4, so occupancy does not matter and the
+// latency of the former LDS copy of the counts (74 KB per 128 threads, one wave per SIMD) was the whole run time:
+// 1.16 -> 0.3 ms per pass.
 // Table row of (panel, tile, wave): {first block, nb_0 >= nb_1 >= ... >= nb_{R-1}} (blocks per round, padded to a
 // non-increasing sequence); block row k holds the rounds j with nb_j > k: block (k, j) = first + sum_j' min(nb_j', k) + j.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kColorThreads = 128;
-constexpr int kColorWords = 128 + 16;        // per thread in LDS: rem[16 lanes][16 quads] 16-bit + first entry of each lane
+constexpr int kColorThreads = 64;
 
 template <bool EMIT>
-__global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ blkptr, int64_t n_src, int64_t row_begin,
-    int64_t n_pos, const int32_t* __restrict__ order, const uint16_t* __restrict__ parts, Plan pl,
-    const uint16_t* __restrict__ srt, const uint4* __restrict__ cnt, int32_t* __restrict__ len,
-    const int32_t* __restrict__ tab, uint16_t* __restrict__ ell) {
-    __shared__ uint32_t sm[kColorWords * kColorThreads];
+__global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(int64_t n_pos, Plan pl, const uint4* __restrict__ cnt,
+                                                                     int32_t* __restrict__ len,
+                                                                     const int32_t* __restrict__ tab,
+                                                                     uint16_t* __restrict__ ell) {
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kColorThreads + threadIdx.x;
     const int64_t n_groups = static_cast<int64_t>(pl.G) * pl.NT * 4;
     if (gid >= n_groups) return;
     const int grp = static_cast<int>(gid & 3);
     const int t = static_cast<int>((gid >> 2) % pl.NT);
     const int64_t g = (gid >> 2) / pl.NT;                     // slot
-    uint32_t* my = sm + threadIdx.x;             // word k of this thread: my[k * kColorThreads]
+    uint32_t c[16][8];                           // c[lane][k]: entries left on quads 2k (low half) and 2k + 1 (high half)
     int remaining = 0;
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int64_t pos = g * 64 + kLaneOf[grp * 16 + i];
-        Counts c = {{0, 0, 0, 0}};
-        int32_t e0 = 0;
-        if (pos < n_pos) {
-            c = load_counts(cnt, pos * pl.NT + t);
-            int32_t e1;
-            position_bounds(rowptr, blkptr, n_src, pl.NT, row_begin, order, parts, pos, t, e0, e1);
-        }
+        Counts cc = {{0, 0, 0, 0}};
+        if (pos < n_pos) cc = load_counts(cnt, pos * pl.NT + t);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            my[(i * 8 + 2 * k) * kColorThreads] = static_cast<uint32_t>(c.w[k]);
-            my[(i * 8 + 2 * k + 1) * kColorThreads] = static_cast<uint32_t>(c.w[k] >> 32);
-            remaining += static_cast<int>((c.w[k] & 0xffffu) + ((c.w[k] >> 16) & 0xffffu) + ((c.w[k] >> 32) & 0xffffu) +
-                                          (c.w[k] >> 48));
+            c[i][2 * k] = static_cast<uint32_t>(cc.w[k]);
+            c[i][2 * k + 1] = static_cast<uint32_t>(cc.w[k] >> 32);
+            remaining += static_cast<int>((cc.w[k] & 0xffffu) + ((cc.w[k] >> 16) & 0xffffu) + ((cc.w[k] >> 32) & 0xffffu) +
+                                          (cc.w[k] >> 48));
         }
-        my[(128 + i) * kColorThreads] = static_cast<uint32_t>(e0);
     }
     // where this slot's blocks go
     const int j = static_cast<int>(g / pl.PW);
@@ -304,31 +301,38 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(
     while (remaining > 0) {
         new_row(step);
         uint32_t used = 0, picked = 0, qlo = 0, qhi = 0;
-        for (int ii = 0; ii < 16; ++ii) {
-            const int i = (ii + step) & 15;
-            int best = -1;
-            uint32_t bestv = 0;
+        const int start = step & 15;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t wd = my[(i * 8 + k) * kColorThreads];
+        for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const uint32_t v = (wd >> (16 * b)) & 0xffffu;
-                    const int q = k * 2 + b;
-                    if (v > bestv && !((used >> q) & 1u)) { bestv = v; best = q; }
+            for (int i = 0; i < 16; ++i) {
+                if ((i >= start) != (pass == 0)) continue;
+                // most entries left among the free quads; ties go to the lower quad (key = count << 4 | 15 - quad)
+                uint32_t key = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t lo = ((c[i][k] & 0xffffu) << 4) | static_cast<uint32_t>(15 - 2 * k);
+                    const uint32_t hi = ((c[i][k] >> 16) << 4) | static_cast<uint32_t>(14 - 2 * k);
+                    const uint32_t flo = ((used >> (2 * k)) & 1u) ? 0u : lo;
+                    const uint32_t fhi = ((used >> (2 * k + 1)) & 1u) ? 0u : hi;
+                    key = max(key, max(flo, fhi));
                 }
-            }
-            if (best < 0) continue;
-            used |= 1u << best;
-            picked |= 1u << i;
-            my[(i * 8 + (best >> 1)) * kColorThreads] -= 1u << (16 * (best & 1));
-            --remaining;
-            if (EMIT) {
-                if (i < 8) qlo |= static_cast<uint32_t>(best) << (4 * i);
-                else qhi |= static_cast<uint32_t>(best) << (4 * (i - 8));
+                if (key < 16u) continue;                       // nothing left on a free quad
+                const uint32_t best = 15u - (key & 15u);
+                used |= 1u << best;
+                picked |= 1u << i;
+                const uint32_t dec = 1u << (16u * (best & 1u)), wsel = best >> 1;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[i][k] -= (wsel == static_cast<uint32_t>(k)) ? dec : 0u;
+                --remaining;
+                if (EMIT) {
+                    if (i < 8) qlo |= best << (4 * i);
+                    else qhi |= best << (4 * (i - 8));
+                }
             }
         }
         if (EMIT) {             // idle lanes read a zero row on a quad nobody uses in this step
+#pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if ((picked >> i) & 1u) continue;
                 const uint32_t fq = __builtin_ctz(~used & 0xffffu);
@@ -872,8 +876,7 @@ extern "C" int dif_sliced_measure(const int32_t* rowptr, const int32_t* blkptr, 
     if (int rc = dif::launch_status("sliced_sort_kernel")) return rc;
     const int64_t n_hw = static_cast<int64_t>(pl.G) * pl.NT * 4;
     hipLaunchKernelGGL((sliced_color_kernel<false>), dim3(static_cast<unsigned>((n_hw + kColorThreads - 1) / kColorThreads)),
-                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_pos, row_order, parts, pl, sorted,
-                       static_cast<const uint4*>(counts), lengths, nullptr, nullptr);
+                       dim3(kColorThreads), 0, st, n_pos, pl, static_cast<const uint4*>(counts), lengths, nullptr, nullptr);
     if (int rc = dif::launch_status("sliced_color_kernel")) return rc;
     hipLaunchKernelGGL(sliced_table_kernel, dim3(1), dim3(1024), 0, st, lengths, pl, table);
     return dif::launch_status("sliced_table_kernel");
@@ -893,8 +896,7 @@ extern "C" int dif_sliced_emit(const int32_t* rowptr, const int32_t* blkptr, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n_hw = static_cast<int64_t>(pl.G) * pl.NT * 4;
     hipLaunchKernelGGL((sliced_color_kernel<true>), dim3(static_cast<unsigned>((n_hw + kColorThreads - 1) / kColorThreads)),
-                       dim3(kColorThreads), 0, st, rowptr, blkptr, n_src, row_begin, n_pos, row_order, parts, pl, sorted,
-                       static_cast<const uint4*>(counts), nullptr, table, entries);
+                       dim3(kColorThreads), 0, st, n_pos, pl, static_cast<const uint4*>(counts), nullptr, table, entries);
     if (int rc = dif::launch_status("sliced_color_kernel")) return rc;
     const int64_t n_st = static_cast<int64_t>(pl.G) * pl.NT;                 // one wave per (slot, tile)
     hipLaunchKernelGGL(sliced_fill_kernel, dim3(static_cast<unsigned>((n_st + 3) / 4)), dim3(256), 0, st, rowptr, blkptr,
