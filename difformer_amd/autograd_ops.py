@@ -16,10 +16,28 @@ def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and getattr(t, "requires_grad", False) for t in tensors)
 
 
-def _no_sharded_training(shard):
-    if shard is not None and shard.world > 1:
-        raise NotImplementedError("difformer_amd: row-sharded execution is forward-only; train with one GPU per "
-                                  "replica (batches are independent, main-batch.py:126-142)")
+def _sharded(shard):
+    return shard if (shard is not None and shard.world > 1) else None
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x, every rank gets y.  With L = sum over ranks of the local losses, dL/dx on a rank is the
+    sum over ranks of their dL_r/dy: the backward is the same collective on the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, shard):
+        ctx.shard = shard
+        return shard.all_reduce_sum(x.detach().clone().contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.shard.all_reduce_sum(g.contiguous().clone()), None
+
+
+def _own_rows_of_sum(shard, t):
+    """Every rank holds a partial [n_global, ...] gradient of gathered rows: sum over ranks, keep this rank's rows.
+    (all-reduce + slice rather than reduce-scatter: the blocks may be uneven, and gloo has no reduce-scatter.)"""
+    return shard.local_rows(shard.all_reduce_sum(t.contiguous())).contiguous()
 
 
 def _grad_by_recompute(fn, inputs, grad_out):
@@ -40,6 +58,23 @@ def _simple_expr(q, k, v):
     num = s * torch.einsum("nhm,hmd->nhd", q, ktv) + v.sum(dim=0)
     den = s * torch.einsum("nhm,hm->nh", q, k.sum(dim=0)) + q.shape[0]
     return num / den.unsqueeze(-1)
+
+
+def _simple_expr_sharded(shard):
+    """_simple_expr over a rank's rows: the sums over nodes are all-reduced (one record), N is the global count."""
+    def fn(q, k, v):
+        H, M, D = k.shape[1], k.shape[2], v.shape[2]
+        rec = torch.cat([torch.einsum("lhm,lhd->hmd", k, v).reshape(-1), k.sum(dim=0).reshape(-1), v.sum(dim=0).reshape(-1),
+                         (q * q).sum().reshape(1), (k * k).sum().reshape(1)])
+        rec = _AllReduceSum.apply(rec, shard)
+        ktv = rec[: H * M * D].reshape(H, M, D)
+        ksum = rec[H * M * D: H * M * D + H * M].reshape(H, M)
+        vsum = rec[H * M * D + H * M: H * M * D + H * M + H * D].reshape(H, D)
+        s = 1.0 / (torch.sqrt(rec[-2]) * torch.sqrt(rec[-1]))
+        num = s * torch.einsum("nhm,hmd->nhd", q, ktv) + vsum
+        den = s * torch.einsum("nhm,hm->nh", q, ksum) + shard.n_global
+        return num / den.unsqueeze(-1)
+    return fn
 
 
 def _sigmoid_expr(q, k, v):
@@ -65,14 +100,17 @@ class _SimpleAttention(torch.autograd.Function):
     differentiable device ops."""
 
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, q, k, v, shard=None):
         if q.shape[0] != v.shape[0] or k.shape[0] != v.shape[0]:
             # the kernels take the row count from q: L < N would read past the end of k / v (difformer.py:29 raises too)
             raise RuntimeError(f"simple kernel needs as many queries as sources (N={q.shape[0]}, L={v.shape[0]}; "
                                "difformer.py:29)")
         be = ops.get_backend()
+        ctx.shard = shard = _sharded(shard)
         reduced = be.simple_reduce(q, k, v)
-        out = be.simple_apply(q, reduced, q.shape[0], v.shape[2])
+        if shard is not None:
+            shard.all_reduce_sum(reduced)                      # the one exchange step of the forward (SURVEY 8e)
+        out = be.simple_apply(q, reduced, shard.n_global if shard is not None else q.shape[0], v.shape[2])
         ctx.save_for_backward(q, k, v, reduced, out)
         return out
 
@@ -82,17 +120,24 @@ class _SimpleAttention(torch.autograd.Function):
         hip_ok = (q.dtype == torch.float32 and q.shape[2] <= 64 and v.shape[2] <= 64 and
                   hasattr(ops.get_backend(), "simple_backward"))
         if hip_ok:
-            return ops.get_backend().simple_backward(q, k, v, reduced, out, g)
-        return _grad_by_recompute(_simple_expr, (q, k, v), g.contiguous())
+            # row-sharded: two small all-reduces inside (the sums over nodes of the backward, then the scalar T)
+            return ops.get_backend().simple_backward(q, k, v, reduced, out, g, ctx.shard) + (None,)
+        expr = _simple_expr if ctx.shard is None else _simple_expr_sharded(ctx.shard)
+        return _grad_by_recompute(expr, (q, k, v), g.contiguous()) + (None,)
 
 
 class _SigmoidAttention(torch.autograd.Function):
     """Forward and (fp32, M, D <= 64) backward on the HIP kernels: the forward leaves the row sums, the backward
-    recomputes sigma tile by tile (csrc/sigmoid_attn_bwd.hip).  Other shapes re-derive the gradient with tensor ops."""
+    recomputes sigma tile by tile (csrc/sigmoid_attn_bwd.hip).  Other shapes re-derive the gradient with tensor ops.
+    Row-sharded: the key / value rows are all-gathered (queries stay local); their gradients are partial sums over the
+    ranks' queries and come back as the sum over ranks of this rank's rows."""
 
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, q, k, v, shard=None):
         be = ops.get_backend()
+        ctx.shard = shard = _sharded(shard)
+        if shard is not None:
+            k, v = shard.all_gather_rows(k), shard.all_gather_rows(v)
         ctx.hip = (q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32 and
                    q.shape[2] <= 64 and v.shape[2] <= 64 and hasattr(be, "sigmoid_backward"))
         if ctx.hip:
@@ -100,28 +145,34 @@ class _SigmoidAttention(torch.autograd.Function):
             ctx.save_for_backward(q, k, v, out, den)
             return out
         ctx.save_for_backward(q, k, v)
-        return ops.sigmoid_attention(q, k, v)
+        return be.sigmoid_attention(q, k, v)
 
     @staticmethod
     def backward(ctx, g):
         if ctx.hip:
             q, k, v, out, den = ctx.saved_tensors
-            return ops.get_backend().sigmoid_backward(q, k, v, out, den, g)
-        return _grad_by_recompute(_sigmoid_expr, ctx.saved_tensors, g.contiguous())
+            dq, dk, dv = ops.get_backend().sigmoid_backward(q, k, v, out, den, g)
+        else:
+            dq, dk, dv = _grad_by_recompute(_sigmoid_expr, ctx.saved_tensors, g.contiguous())
+        if ctx.shard is not None:
+            dk, dv = _own_rows_of_sum(ctx.shard, dk), _own_rows_of_sum(ctx.shard, dv)
+        return dq, dk, dv, None
 
 
 class _GcnAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, csr, x, attn, attn_scale, gcn_scale):
+    def forward(ctx, csr, x, attn, attn_scale, gcn_scale, shard=None):
         ctx.csr, ctx.attn_scale, ctx.gcn_scale, ctx.has_attn = csr, attn_scale, gcn_scale, attn is not None
         ctx.edges = csr.hold_edges() if csr._adjoint is None else None    # the adjoint CSR is built from them in backward
-        return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale)
+        ctx.shard = _sharded(shard)
+        return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, ctx.shard)
 
     @staticmethod
     def backward(ctx, g):
-        # adjoint product on the same blocked SpMM kernel: grad_x = gcn_scale * A_hat^T g
-        gx = ops.gcn_aggregate(ctx.csr.adjoint(), g.contiguous(), None, 1.0, ctx.gcn_scale)
-        return None, gx, (ctx.attn_scale * g if ctx.has_attn else None), None, None
+        # adjoint product on the same SpMM kernels: grad_x = gcn_scale * A_hat^T g.  Row-sharded it is the forward
+        # pattern again on the transposed CSR: all-gather the rows of g, product over this rank's (source) rows.
+        gx = ops.gcn_aggregate(ctx.csr.adjoint(), g.contiguous(), None, 1.0, ctx.gcn_scale, ctx.shard)
+        return None, gx, (ctx.attn_scale * g if ctx.has_attn else None), None, None, None
 
 
 class _LayerTail(torch.autograd.Function):
@@ -183,15 +234,13 @@ def _row_linear(x, weight, bias):
 # ---- public wrappers -----------------------------------------------------------------------------
 def simple_attention(q, k, v, shard=None):
     if _needs_grad(q, k, v):
-        _no_sharded_training(shard)
-        return _SimpleAttention.apply(q, k, v)
+        return _SimpleAttention.apply(q, k, v, shard)
     return ops.simple_attention(q, k, v, shard)
 
 
 def sigmoid_attention(q, k, v, shard=None):
     if _needs_grad(q, k, v):
-        _no_sharded_training(shard)
-        return _SigmoidAttention.apply(q, k, v)
+        return _SigmoidAttention.apply(q, k, v, shard)
     return ops.sigmoid_attention(q, k, v, shard)
 
 
@@ -256,8 +305,7 @@ def batched_attention(q, k, v, layout, kernel):
 
 def gcn_aggregate(csr, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard=None):
     if _needs_grad(x, attn):
-        _no_sharded_training(shard)
-        return _GcnAggregate.apply(csr, x, attn, attn_scale, gcn_scale)
+        return _GcnAggregate.apply(csr, x, attn, attn_scale, gcn_scale, shard)
     return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard)
 
 

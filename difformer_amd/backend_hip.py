@@ -180,10 +180,14 @@ class HipBackend:
         return out
 
     # ---- a1 backward ------------------------------------------------------------------------
-    def simple_backward(self, q, k, v, reduced, out, g):
-        """(dq, dk, dv) of the simple kernel for fp32 q,k [n,H,M], v/out/g [n,H,D] with M, D <= 64 (single GPU)."""
+    def simple_backward(self, q, k, v, reduced, out, g, shard=None):
+        """(dq, dk, dv) of the simple kernel for fp32 q,k [n,H,M], v/out/g [n,H,D] with M, D <= 64.  Row-sharded
+        (`shard`, `reduced` already summed over the ranks): the sums over nodes of the backward -- q^T gn, sum gn, the
+        ks-gradient -- are all-reduced in one buffer, then the scalar T: two small exchange steps."""
         dev = _require_device(q, k, v, reduced, out, g)
         n, H, M = q.shape
+        sharded = shard is not None and shard.world > 1
+        n_global = shard.n_global if sharded else n
         D = v.shape[2]
         for t_, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (g, "grad")):
             _f32(t_, nm)
@@ -194,11 +198,15 @@ class HipBackend:
         ws_bytes = self.lib.dif_simple_bwd_workspace_bytes(n, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _Timed(self, "dif_simple_bwd_prep_f32", dev):
-            rc = self.lib.dif_simple_bwd_prep_f32(_ptr(q), H * M, _ptr(g), H * D, _ptr(out), H * D, _ptr(reduced), n, n,
-                                                  H, M, D, _ptr(gn), _ptr(gd), _ptr(sums), _ptr(ws), ws_bytes,
-                                                  _stream(dev))
+            rc = self.lib.dif_simple_bwd_prep_f32(_ptr(q), H * M, _ptr(g), H * D, _ptr(out), H * D, _ptr(reduced), n,
+                                                  int(n_global), H, M, D, _ptr(gn), _ptr(gd), _ptr(sums), _ptr(ws),
+                                                  ws_bytes, _stream(dev))
         _lib.check(rc, "dif_simple_bwd_prep_f32")
         rec2 = self.simple_reduce(q, q, gn)                      # q^T gn, (sum q), sum gn
+        if sharded:
+            both = torch.cat([rec2, sums])
+            shard.all_reduce_sum(both)
+            rec2, sums = both[: rec2.numel()], both[rec2.numel():]
         # small per-head coefficient tensors, all on the device (no host synchronisation)
         hmd = H * M * D
         s = torch.rsqrt(reduced[-2]) * torch.rsqrt(reduced[-1])
@@ -220,6 +228,8 @@ class HipBackend:
         # T = s * dL/ds = sum q . dq_main.  (Algebraically also -(vs . dvs) - N sum gd, but those two terms cancel to
         # ~1e-4 of their size at N ~ 1e5; this form has no cancellation.)
         T = (q * dq).sum()
+        if sharded:
+            T = shard.all_reduce_sum(T.reshape(1))[0]
         dq.addcmul_(q, (-T / reduced[-2]).expand_as(q))               # - (T/|Q|^2) q
         beta_k = (-T / reduced[-1]).reshape(1).contiguous()
         rowgemm(v, D, dktv, 1, dks, None, None, k, beta_k, M, dk)     # v dKtV^T + dks - (T/|K|^2) k

@@ -100,6 +100,20 @@ class RowShard:
                             group=self.side_group if self.side_group is not None else self.group)
         return buf
 
+    def all_reduce_gradients(self, params) -> None:
+        """Training on row shards: every rank holds the parameter gradients of ITS rows' share of the loss; the
+        gradient of the summed loss is their sum over ranks (one flat all-reduce; call it between backward() and
+        optimizer.step(); divide the loss or the learning rate yourself if the reference's loss is a mean)."""
+        grads = [p.grad for p in params if p is not None and p.grad is not None]
+        if self.world <= 1 or not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self.all_reduce_sum(flat)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off: off + g.numel()].view_as(g))
+            off += g.numel()
+
     def all_reduce_sum_async(self, buf: torch.Tensor):
         """Start the in-place sum of the record and return the work handle (None when there is nothing to wait for)."""
         if self.world <= 1:

@@ -144,3 +144,62 @@ def test_bench_sharding_arithmetic_dry_run(world):
         assert abs(value - world * n * 10 / (0.1 * world)) < 1e-3
     one = bench.shard_plan("ogbn-proteins-s", 1, 0)
     assert one["parallelism"] == "single GPU" and one["n_local"] == 132534
+
+
+def _train_worker(rank, world, port, kernel, n, heads, use_graph, out_q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from difformer_amd import DIFFormer, RowShard, ops
+        from fake_backend import OracleBackend
+        ops._BACKEND = OracleBackend()
+        torch.manual_seed(11)
+        model = DIFFormer(12, 16, 5, num_layers=2, num_heads=heads, kernel=kernel, dropout=0.0, use_source=True,
+                          use_graph=use_graph).train()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(n, 12, generator=g)
+        ei = torch.cat([torch.randint(0, n, (2, 6 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+        target = torch.randn(n, 5, generator=g)
+        # one process, all rows: loss = sum over nodes
+        xf = x.clone().requires_grad_(True)
+        ((model(xf, ei) - target) ** 2).sum().backward()
+        ref = [p.grad.clone() for p in model.parameters()]
+        ref_x = xf.grad.clone()
+        model.zero_grad()
+        # row-sharded: this rank's rows of the loss; parameter gradients summed over the ranks afterwards
+        shard = RowShard.from_process_group(n)
+        model.set_row_shard(shard)
+        xl = shard.local_rows(x).contiguous().requires_grad_(True)
+        out = model(xl, ei)
+        ((out - shard.local_rows(target)) ** 2).sum().backward()
+        shard.all_reduce_gradients(model.parameters())
+        scale = max(float(r.abs().max()) for r in ref)
+        err_p = max(float((p.grad - r).abs().max()) for p, r in zip(model.parameters(), ref)) / scale
+        err_x = float((xl.grad - shard.local_rows(ref_x)).abs().max() / ref_x.abs().max())
+        out_q.put((rank, err_p, err_x))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kernel,world,n,heads,use_graph", [("simple", 2, 64, 2, True), ("simple", 3, 50, 1, True),
+                                                            ("sigmoid", 2, 41, 2, True), ("simple", 2, 300, 2, True),
+                                                            ("simple", 2, 40, 1, False)])
+def test_row_sharded_training_step_matches_single_process(kernel, world, n, heads, use_graph):
+    """loss.backward() on row shards (main.py:130): the attention's sums over nodes and the aggregation's gathered rows
+    carry their gradients back through the same collectives; parameter gradients summed over ranks and the gradient
+    of the local input rows equal the single-process ones."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, kernel, n, heads, use_graph, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err_p, err_x in sorted(results):
+        assert err_p < 2e-4 and err_x < 2e-4, (rank, err_p, err_x)
