@@ -157,10 +157,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local_rank)
+    # Dry run of the N > 1 path on a one-GPU box (tests/test_gpu_dist.py): every rank on cuda:0, collectives over gloo
+    # (RCCL refuses two ranks per device).  Exercises the code the driver launches; its timings mean nothing.
+    one_gpu = os.environ.get("DIFFORMER_BENCH_ONE_GPU", "0") == "1"
+    dev = torch.device("cuda", 0 if one_gpu else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from difformer_amd import DIFFormer, GraphedForward, RowShard, ops
 

@@ -91,3 +91,27 @@ def test_two_ranks_on_one_gpu_forward_and_training_step(kernel, n, deg, heads):
         assert err_p < 1e-4 and err_x < 1e-4, (rank, err_p, err_x)
         if deg >= 48:                        # the shard ran the feature-sliced product, with its source tiles split
             assert n_sliced >= 1 and splits == 1
+
+
+@pytest.mark.parametrize("workload", ["ogbn-proteins-s", "pokec-batch-s-bf16"])
+def test_bench_with_two_ranks_runs_end_to_end(workload):
+    """The command the driver launches for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), with both ranks
+    on this box's one GPU and the collectives over gloo: the row-sharded headline workload (closed-form layers, the
+    shard's sliced product) and the replica workload print one well-formed JSON line from rank 0."""
+    import json
+    import subprocess
+    env = dict(os.environ, DIFFORMER_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", workload]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["unit"] == "nodes/s"
+    if workload == "ogbn-proteins-s":
+        assert d["scaling"] == "strong" and d["config"]["parallelism"] == "row-shard x2"
+        assert d["roofline"]["kernel"].startswith("sliced_spmm_kernel") and d["roofline"]["avg_launch_ms"] > 0
+    else:
+        assert d["scaling"] == "weak" and d["config"]["parallelism"] == "replicas x2"
