@@ -80,6 +80,9 @@ SIGNATURES = {
     "dif_sliced_spmm_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp,
                                     c_i64, c_f32, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dif_sliced_spmm_workspace_bytes": (c_i64, [c_i64, c_i64, c_int]),
+    "dif_wide_partials": (c_i64, [c_int]),
+    "dif_wide_gram_f64": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "dif_wide_scale_f64": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "dif_row_order_workspace_bytes": (c_sz, [c_i64]),
     "dif_row_order": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_simple_layer_head_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64,

@@ -820,6 +820,28 @@ class HipBackend:
         _lib.check(rc, "dif_gram_sym_f32")
         return rec
 
+    def wide_gram(self, rec, C, n_global, S):
+        """Record of gram_sym -> (G~ float64 [(C+1), (C+1)], partial sums of the two norm products) -- dif_wide_gram_f64."""
+        dev = _require_device(rec, S)
+        Gt = torch.empty((C + 1, C + 1), dtype=torch.float64, device=dev)
+        partial = torch.empty(2 * self.lib.dif_wide_partials(C), dtype=torch.float64, device=dev)
+        with _Timed(self, "dif_wide_gram_f64", dev):
+            rc = self.lib.dif_wide_gram_f64(_ptr(rec), C, int(n_global), _ptr(S), _ptr(Gt), _ptr(partial), _stream(dev))
+        _lib.check(rc, "dif_wide_gram_f64")
+        return Gt, partial
+
+    def wide_scale(self, R, T, partial, C):
+        """R, T float64 [(C+1), DV] -> (B float32 [C, DV], bias float32 [DV]) = (s R[:C], s R[C] + T[C]) -- dif_wide_scale_f64."""
+        dev = _require_device(R, T, partial)
+        DV = R.shape[1]
+        R, T = R.contiguous(), T.contiguous()
+        B = torch.empty((C, DV), dtype=torch.float32, device=dev)
+        bias = torch.empty(DV, dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_wide_scale_f64", dev):
+            rc = self.lib.dif_wide_scale_f64(_ptr(R), _ptr(T), _ptr(partial), C, DV, _ptr(B), _ptr(bias), _stream(dev))
+        _lib.check(rc, "dif_wide_scale_f64")
+        return B, bias
+
     def layer_tail_mix(self, Z, D, den_col, conv_scale, add, add_scale, rs, bv, x0, prev, alpha, ln_weight, ln_bias, eps,
                        relu=False):
         """Tail of the closed form at the scripts' widths (dif_layer_tail_mix_f32): Z [n, >= D + 1] fp32 holds the

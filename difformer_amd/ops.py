@@ -702,8 +702,6 @@ class WideCoefficients:
         V[:, : self.D] = Wv_.t()
         V[C1 - 1, self.D] = 1.0
         self.V = V
-        blk = torch.arange(C1 - 1, device=Wq.device) // 64
-        self.upper = blk[:, None] <= blk[None, :]                       # the blocks of X^T X that dif_gram_sym_f32 writes
 
 
 def simple_layer_closed_form_wide(x, coeffs: WideCoefficients, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha,
@@ -722,19 +720,10 @@ def simple_layer_closed_form_wide(x, coeffs: WideCoefficients, Wv, bv, csr, attn
     D = coeffs.D
     x3 = x.reshape(n, 1, C)
     rec = be.gram_sym(x)                                                # [X^T X (upper blocks) | sum x | ...]
-    f64 = torch.float64
-    Gt = torch.empty((C + 1, C + 1), dtype=f64, device=x.device)
-    Graw = rec[: C * C].view(C, C)
-    Gt[:C, :C] = torch.where(coeffs.upper, Graw, Graw.t())
-    Gt[:C, C] = rec[C * C: C * C + C]
-    Gt[C, :C] = rec[C * C: C * C + C]
-    Gt[C, C].fill_(float(n))                                            # (a fill kernel: capturable, no host copy)
-    norms = coeffs.S @ Gt.reshape(-1)                                   # |Q|^2, |K|^2
-    s = torch.rsqrt(norms[0] * norms[1])
+    Gt, partial = be.wide_gram(rec, C, n, coeffs.S)                     # G~ (float64) and the partial sums of |Q|^2, |K|^2
     T = Gt @ coeffs.V                                                   # [(C+1), D+4]
     R = coeffs.P @ T
-    B = (s * R[:C]).to(torch.float32)                                   # [Mn | u | 0 0 0]
-    bias = (s * R[C] + T[C]).to(torch.float32)                          # [cn | cd | 0 0 0]
+    B, bias = be.wide_scale(R, T, partial, C)                           # [Mn | u | 0 0 0], [cn | cd | 0 0 0] (float32)
     Z = torch.addmm(bias, x, B)                                         # [n, D + 4]: numerator | denominator
     gcn = rs = None
     if csr is not None:

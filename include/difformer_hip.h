@@ -402,6 +402,17 @@ int dif_simple_coeffs_bg_f32(const float* gt, const float* pt, const float* vtt,
  * One streaming pass on the fp32 MFMA; workspace: dif_simple_workspace_bytes(n_rows, 1, C, C), 16-byte aligned. */
 int dif_gram_sym_f32(const float* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
                      size_t workspace_bytes, dif_stream_t stream);
+/* Float64 bookkeeping of that closed form around its two library GEMMs (csrc/wide_coeffs.hip):
+ *   dif_wide_gram_f64   Gt double[(C+1)^2] = [[X^T X, sx], [sx^T, n_global]] from the record of dif_gram_sym_f32 (lower
+ *                       blocks mirrored), and partial double[2 * dif_wide_partials(C)]: per-workgroup sums of
+ *                       <S[0], Gt> = |Q|^2 and <S[1], Gt> = |K|^2 with S double[2][(C+1)^2] = {W~q^T W~q, W~k^T W~k}
+ *   dif_wide_scale_f64  s = 1 / (|Q| |K|) from the partial sums; B float[C][DV] = s R[0..C), bias float[DV] = s R[C] + T[C]
+ *                       for R, T double[(C+1)][DV] (R = P~ T, T = Gt V~): the operands of the row GEMM x B + bias. */
+int64_t dif_wide_partials(int C);
+int dif_wide_gram_f64(const float* record, int C, int64_t n_global, const double* S, double* Gt, double* partial,
+                      dif_stream_t stream);
+int dif_wide_scale_f64(const double* R, const double* T, const double* partial, int C, int DV, float* B, float* bias,
+                       dif_stream_t stream);
 int dif_layer_tail_mix_f32(const float* conv, int64_t ldc, const float* den, int64_t ldden, float conv_scale,
                            const float* add, int64_t lda, float add_scale, const float* rs, const float* bv,
                            int64_t n_rows, int D, const float* x0, int64_t ldx0, const float* prev, int64_t ldp,

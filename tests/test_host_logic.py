@@ -371,7 +371,6 @@ def test_wide_coefficients_algebra_matches_the_oracle(use_weight):
     assert abs(float(norms[0]) - (q * q).sum()) < 1e-9 * (q * q).sum() and abs(float(norms[1]) - (k * k).sum()) < 1e-9 * (k * k).sum()
     ref = orc.simple_attention(q[:, None, :], k[:, None, :], v[:, None, :])[:, 0, :]
     assert np.abs(out - ref).max() < 1e-10 * np.abs(ref).max()
-    assert co.upper.shape == (C, C) and bool(co.upper.all())          # one 64-block at this width: everything is "upper"
 
 
 @pytest.mark.parametrize("C,D,use_weight", [(64, 64, True), (32, 48, True), (24, 24, False)])
