@@ -246,6 +246,21 @@ def main():
     be.kernel_events = None
     elapsed = max_over_ranks(elapsed, dev)
 
+    def dominant_alone(entry):
+        # Second event pass with ONLY the dominant entry point bracketed: two events around every C-ABI call cost the
+        # host enough that, on a slow host, the GPU queue runs dry in the pass above and the brackets then include the
+        # wait for the launch (0.375 ms against rocprofv3's 0.333 ms for the same kernel on one box).  With one bracket
+        # per layer the forward stays GPU-bound and the bracket is the kernel.
+        be.kernel_events, be.kernel_events_only = {}, {entry}
+        with torch.no_grad():
+            for i in range(2 + min(args.steps, 5)):
+                if i == 2:
+                    be.kernel_events = {}          # the first forwards refill the queue; their brackets are dropped
+                model(x, edge_index)
+        got = be.kernel_times_ms().get(entry)
+        be.kernel_events, be.kernel_events_only = None, None
+        return got
+
     ms_per_step = elapsed / args.steps * 1e3
     value = job_value(n, args.steps, elapsed, world, replicas)
 
@@ -269,7 +284,8 @@ def main():
     else:
         dom, alg_bytes, dom_key = "dif_sigmoid_attn_f32", 4.0 * n_local * hidden * 4, "sigmoid_attn_kernel"
         dom_name = "sigmoid_attn_kernel"
-    dom_ms = float(np.mean(ktimes[dom])) if ktimes.get(dom) else None
+    alone = dominant_alone(dom) if ktimes.get(dom) else None
+    dom_ms = float(np.mean(alone)) if alone else (float(np.mean(ktimes[dom])) if ktimes.get(dom) else None)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
     # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE, calibrated; scripts/pmc_traffic.sh) stored under profiles/ -- a counter run cannot

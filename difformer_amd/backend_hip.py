@@ -94,7 +94,8 @@ class _Timed:
     """Optional HIP-event bracket around one C-ABI call (events on the launching stream)."""
 
     def __init__(self, backend, name, dev):
-        self.rec = backend.kernel_events
+        only = backend.kernel_events_only          # bracket just these entry points (keeps the host ahead of the GPU)
+        self.rec = backend.kernel_events if (only is None or name in only) else None
         self.name, self.dev = name, dev
 
     def __enter__(self):
@@ -123,6 +124,7 @@ class HipBackend:
         self.lib = _lib.load()
         # bench.py sets this to a dict to collect (start, end) HIP events per entry point
         self.kernel_events = None
+        self.kernel_events_only = None
 
     def kernel_times_ms(self):
         """{entry point: [ms per call]} from the collected events (synchronises)."""
