@@ -284,7 +284,7 @@ def main():
     else:
         dom, alg_bytes, dom_key = "dif_sigmoid_attn_f32", 4.0 * n_local * hidden * 4, "sigmoid_attn_kernel"
         dom_name = "sigmoid_attn_kernel"
-    alone = dominant_alone(dom) if ktimes.get(dom) else None
+    alone = dominant_alone(dom)        # unconditional: every rank runs the same number of forwards (collectives inside)
     dom_ms = float(np.mean(alone)) if alone else (float(np.mean(ktimes[dom])) if ktimes.get(dom) else None)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
     # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
