@@ -27,9 +27,14 @@ for it in range(cases):
         dst = (torch.rand(e, generator=g) ** 2.5 * n).long().clamp_(max=n - 1)
     dst[: n // 7] = n - 1 - torch.arange(n // 7)                 # some rows get at least one entry, rest may be empty
     ei = torch.stack([src, dst]).to(dev)
-    csr = ops.csr_cache.get(ei, None, n, F * 4)
     lo = int(torch.randint(0, n // 2, (1,), generator=g)) if it % 3 == 0 else 0
     cnt = int(torch.randint(1000, n - lo, (1,), generator=g)) if it % 3 == 0 else n
+    if it % 6 == 3:                                              # a thin shard: the plan splits the source tiles
+        cnt = max(1000, cnt // int(torch.randint(3, 9, (1,), generator=g)))
+
+    class _Rows:                                                 # what csr_cache.get reads of a RowShard: the tiling of a shard
+        world, n_local, counts, offsets = 2, cnt, [cnt, n - cnt], [0, cnt, n]
+    csr = ops.csr_cache.get(ei, None, n, F * 4, _Rows() if cnt < n else None)
     sl = csr.sliced(lo, cnt, F)
     x = torch.randn(n, F, generator=g).to(dev)
     a = torch.randn(cnt, F, generator=g).to(dev) if it % 2 else None
@@ -44,7 +49,7 @@ for it in range(cases):
     out2 = be.sliced_spmm(sl, ys, csr.rowptr, n, lo, cnt, F, a, 0.7, 1.3)
     err = float((out - ref).abs().max() / ref.abs().max())
     worst = max(worst, err)
-    plan = [int(v) for v in sl.plan]
+    plan = [int(v) for v in sl.plan] + [int(be.lib.dif_sliced_spmm_workspace_bytes(n, cnt if sl.n_pos is None else sl.n_pos, F) > 0)]
     print(f"case {it}: n={n} deg={deg} F={F} mode={mode} rows=[{lo},{lo + cnt}) order={'yes' if sl.order is not None else 'no'} "
           f"plan={plan} err={err:.2e} bitwise={bool(torch.equal(out, out2))}", flush=True)
     assert err < 2e-5 and torch.equal(out, out2), "MISMATCH"
