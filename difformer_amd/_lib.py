@@ -43,6 +43,10 @@ SIGNATURES = {
     "dif_batched_simple_workspace_bytes": (c_sz, []),
     "dif_batched_simple_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int,
                                             c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "dif_batched_simple_attn_fwd_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int,
+                                                c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "dif_batched_simple_raw_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int,
+                                           c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp]),
     "dif_batched_sigmoid_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                              c_int, c_vp, c_i64, c_vp]),
     "dif_csr_workspace_bytes": (c_sz, [c_i64, c_i64, c_int]),

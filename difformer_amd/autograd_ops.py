@@ -281,15 +281,30 @@ def _batched_sigmoid_expr(layout):
 
 
 class _BatchedAttention(torch.autograd.Function):
+    """'simple' (fp32, widths up to 256, more than one graph): forward with the row denominators kept, backward as three
+    launches of the forward kernel's raw mode (csrc/batched_attn.hip).  'sigmoid' and the other shapes re-derive the
+    gradient with tensor ops on the padded batch."""
+
     @staticmethod
     def forward(ctx, q, k, v, layout, kernel):
-        ctx.save_for_backward(q, k, v)
         ctx.layout, ctx.kernel = layout, kernel
+        be = ops.get_backend()
+        ctx.hip = (kernel == "simple" and layout.n_graphs > 1 and hasattr(be, "batched_simple_backward") and
+                   all(t.dtype == torch.float32 for t in (q, k, v)) and q.shape[2] <= 256 and v.shape[2] <= 256)
+        if ctx.hip:
+            ops._check_batch(q, k, v, layout)
+            out, den, sumsq = be.batched_simple_attention(q, k, v, layout.graph_ptr, want_den=True)
+            ctx.save_for_backward(q, k, v, out, den, sumsq)
+            return out
+        ctx.save_for_backward(q, k, v)
         fwd = ops.batched_simple_attention if kernel == "simple" else ops.batched_sigmoid_attention
         return fwd(q, k, v, layout)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.hip:
+            q, k, v, out, den, sumsq = ctx.saved_tensors
+            return ops.get_backend().batched_simple_backward(q, k, v, out, den, sumsq, g, ctx.layout.graph_ptr) + (None, None)
         expr = _batched_simple_expr if ctx.kernel == "simple" else _batched_sigmoid_expr
         return _grad_by_recompute(expr(ctx.layout), ctx.saved_tensors, g.contiguous()) + (None, None)
 

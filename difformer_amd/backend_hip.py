@@ -291,8 +291,9 @@ class HipBackend:
         return dq, dk, dv
 
     # ---- f4: batch of graphs (physical particle/difformer-v2.py:71-137) ---------------------
-    def batched_simple_attention(self, q, k, v, graph_ptr):
-        """graph_ptr: int32 [B+1] device tensor, graph b = rows [graph_ptr[b], graph_ptr[b+1])."""
+    def batched_simple_attention(self, q, k, v, graph_ptr, want_den=False):
+        """graph_ptr: int32 [B+1] device tensor, graph b = rows [graph_ptr[b], graph_ptr[b+1]).
+        want_den (training): -> (out, den float32 [N,H], sumsq float32 [2] = |Q|^2, |K|^2) for batched_simple_backward."""
         dev = _require_device(q, k, v, graph_ptr)
         N, H, M = q.shape
         D = v.shape[2]
@@ -306,12 +307,52 @@ class HipBackend:
         out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
         ws_bytes = self.lib.dif_batched_simple_workspace_bytes()
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        if want_den:
+            den = torch.empty((N, H), dtype=torch.float32, device=dev)
+            with _Timed(self, "dif_batched_simple_attn_fwd_f32", dev):
+                rc = self.lib.dif_batched_simple_attn_fwd_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(graph_ptr),
+                                                              graph_ptr.numel() - 1, N, H, M, D, _ptr(out), H * D, _ptr(den),
+                                                              _ptr(ws), ws_bytes, _stream(dev))
+            _lib.check(rc, "dif_batched_simple_attn_fwd_f32")
+            return out, den, ws.view(torch.float32)[-2:].clone()
         with _Timed(self, "dif_batched_simple_attn_f32", dev):
             rc = self.lib.dif_batched_simple_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(graph_ptr),
                                                       graph_ptr.numel() - 1, N, H, M, D, _ptr(out), H * D, _ptr(ws),
                                                       ws_bytes, _stream(dev))
         _lib.check(rc, "dif_batched_simple_attn_f32")
         return out
+
+    def batched_simple_backward(self, q, k, v, out, den, sumsq, g, graph_ptr):
+        """(dq, dk, dv) of batched_simple_attention: three launches of the forward kernel's raw mode
+        (dif_batched_simple_raw_f32: per-graph sum of outer products applied to the graph's own rows) plus row-wise
+        tensor arithmetic; formulas in include/difformer_hip.h."""
+        dev = _require_device(q, k, v, out, den, sumsq, g, graph_ptr)
+        N, H, M = q.shape
+        D = v.shape[2]
+        for t_, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (den, "den"), (g, "grad")):
+            _f32(t_, nm)
+        q, k, v, g = (t_.contiguous() for t_ in (q, k, v, g))
+        gn = (g / den.unsqueeze(-1)).contiguous()
+        gd = (-(g * out).sum(dim=-1) / den).contiguous()
+        B = graph_ptr.numel() - 1
+
+        def raw(a, b, c, rs, vw, vs_is_s):
+            Ma, Dc = a.shape[2], c.shape[2]
+            dst = torch.empty((N, H, Dc), dtype=torch.float32, device=dev)
+            with _Timed(self, "dif_batched_simple_raw_f32", dev):
+                rc = self.lib.dif_batched_simple_raw_f32(_ptr(a), H * Ma, _ptr(b), H * Ma, _ptr(c), H * Dc, _ptr(graph_ptr), B, N,
+                                                         H, Ma, Dc, _ptr(sumsq), _ptr(rs), _ptr(vw), int(vs_is_s), _ptr(dst),
+                                                         H * Dc, _stream(dev))
+            _lib.check(rc, "dif_batched_simple_raw_f32")
+            return dst
+
+        dq = raw(gn, v, k, gd, None, 1)                 # s gn (sum v (x) k) + s gd ksum_b
+        T = (q * dq).sum()                              # s dL/ds (no cancellation: as in simple_backward)
+        dk = raw(v, gn, q, None, gd, 1)                 # s v (sum gn (x) q) + s sum gd q
+        dv = raw(k, q, gn, None, None, 0)               # s k (sum q (x) gn) + sum gn
+        dq.addcmul_(q, (-T / sumsq[0]).expand_as(q))
+        dk.addcmul_(k, (-T / sumsq[1]).expand_as(k))
+        return dq, dk, dv
 
     def batched_sigmoid_attention(self, q, k, v, ranked_first, pos_count):
         """ranked_first: int32 [B] first row of the r-th largest graph; pos_count: int32 [max_nodes]."""

@@ -86,13 +86,22 @@ __global__ __launch_bounds__(64) void sumsq_fold_kernel(const float* __restrict_
 // ---- one wave (WAVES == 1) or one 4-wave workgroup (WAVES == 4) per (graph, head, 64-column tile) ------------------
 // WAVES == 4 serves batches of few, larger graphs (not enough items to fill the chip with one wave each): the four
 // waves split the graph's rows in both phases and fold their K^T V accumulators through LDS in a fixed order.
-template <int MT, bool VEC, int WAVES>
+// RAW (the three products of the backward, dif_batched_simple_raw_f32): no "+ n_b", no division --
+//   out_i = s q_i KtV_b + coef_i vsum_b,  coef_i = (rs ? rs[i, h] : 1) (vs_is_s ? s : 1),  vsum_b = sum_l (vw ? vw[l, h] : 1) v_l
+struct BatchedExtra {
+    const float* rs;       // RAW: per (row, head) factor of the vsum term
+    const float* vw;       // RAW: per (row, head) weight inside vsum
+    int vs_is_s;           // RAW: the vsum term carries the scale s
+    float* den_out;        // !RAW: s q.ksum_b + n_b per (row, head), for the backward
+};
+
+template <int MT, bool VEC, int WAVES, bool RAW>
 __global__ __launch_bounds__(256) void batched_simple_kernel(const float* __restrict__ q, int64_t ldq,
                                                              const float* __restrict__ k, int64_t ldk,
                                                              const float* __restrict__ v, int64_t ldv,
                                                              const int32_t* __restrict__ graph_ptr, int n_graphs, int H,
                                                              int M, int D, const float* __restrict__ sumsq,
-                                                             float* __restrict__ out, int64_t ldo) {
+                                                             float* __restrict__ out, int64_t ldo, BatchedExtra ex) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15;
     const int lg = lane >> 4;
@@ -143,7 +152,12 @@ __global__ __launch_bounds__(256) void batched_simple_kernel(const float* __rest
                         acc[mt][t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[st][mt][t], vx[st][u], acc[mt][t][u], 0, 0, 0);
                     acck[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[st][mt][t], 1.0f, acck[mt][t], 0, 0, 0);
                 }
-            vs += vx[st];
+            if (RAW && ex.vw) {
+                const int64_t r = rb + 4 * st + lg;
+                vs += (r < r1 ? ex.vw[r * H + h] : 0.f) * vx[st];
+            } else {
+                vs += vx[st];
+            }
         }
     }
     // vsum: fold the four row groups; every lane then holds vsum[64 dt + 4 l15 + u], the columns it will write
@@ -215,10 +229,18 @@ __global__ __launch_bounds__(256) void batched_simple_kernel(const float* __rest
         for (int r = 0; r < 4; ++r) {
             const int64_t row = rb + 4 * lg + r;
             if (row >= r1) continue;
-            const float inv = 1.0f / (s * den[r] + n_b);
             f32x4 y;
+            if (RAW) {
+                const float coef = (ex.rs ? ex.rs[row * H + h] : 1.0f) * (ex.vs_is_s ? s : 1.0f);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) y[u] = (s * o[u][r] + vs[u]) * inv;
+                for (int u = 0; u < 4; ++u) y[u] = s * o[u][r] + coef * vs[u];
+            } else {
+                const float dn = s * den[r] + n_b;
+                const float inv = 1.0f / dn;
+                if (ex.den_out && dt == 0 && l15 == 0) ex.den_out[row * H + h] = dn;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) y[u] = (s * o[u][r] + vs[u]) * inv;
+            }
             float* dst = out + row * ldo + h * D + dt * 64 + 4 * l15;
             const int c0 = dt * 64 + 4 * l15;
             if (VEC) {
@@ -236,10 +258,39 @@ __global__ __launch_bounds__(256) void batched_simple_kernel(const float* __rest
 
 extern "C" size_t dif_batched_simple_workspace_bytes(void) { return static_cast<size_t>(2 * kNormWG + 2) * sizeof(float); }
 
-extern "C" int dif_batched_simple_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
-                                           int64_t ldv, const int32_t* graph_ptr, int n_graphs, int64_t n_rows, int H,
-                                           int M, int D, float* out, int64_t ldo, void* workspace,
-                                           size_t workspace_bytes, dif_stream_t stream) {
+namespace {
+
+int launch_batched(hipStream_t st, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                   const int32_t* graph_ptr, int n_graphs, int64_t n_rows, int H, int M, int D, const float* sumsq,
+                   float* out, int64_t ldo, bool raw, const BatchedExtra& ex) {
+    const int DT = (D + 63) / 64;
+    const int64_t items = static_cast<int64_t>(n_graphs) * H * DT;
+    // few items of many rows: a 4-wave workgroup per item (>= ~16 rows per wave and phase to be worth the fold)
+    const bool wide = items < 8 * dif::kCUs && n_rows >= 64 * static_cast<int64_t>(n_graphs);
+    const int64_t grid = wide ? items : (items + 3) / 4;
+    DIF_REQUIRE(grid < (1ll << 31), DIF_E_RANGE, "dif_batched_simple: grid too large");
+    const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) && (ldo % 4 == 0) &&
+                     dif::aligned16(q) && dif::aligned16(k) && dif::aligned16(v) && dif::aligned16(out);
+    const int MT = (M + 63) / 64;
+#define DIF_LAUNCH_BS2(MTV, V, W, R) \
+    hipLaunchKernelGGL((batched_simple_kernel<MTV, V, W, R>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, q, ldq, k, ldk, \
+                       v, ldv, graph_ptr, n_graphs, H, M, D, sumsq, out, ldo, ex)
+#define DIF_LAUNCH_BS(MTV, V) \
+    do { \
+        if (wide) { if (raw) DIF_LAUNCH_BS2(MTV, V, 4, true); else DIF_LAUNCH_BS2(MTV, V, 4, false); } \
+        else { if (raw) DIF_LAUNCH_BS2(MTV, V, 1, true); else DIF_LAUNCH_BS2(MTV, V, 1, false); } \
+    } while (0)
+    if (MT == 1) { if (vec) DIF_LAUNCH_BS(1, true); else DIF_LAUNCH_BS(1, false); }
+    else if (MT == 2) { if (vec) DIF_LAUNCH_BS(2, true); else DIF_LAUNCH_BS(2, false); }
+    else { if (vec) DIF_LAUNCH_BS(4, true); else DIF_LAUNCH_BS(4, false); }
+#undef DIF_LAUNCH_BS
+#undef DIF_LAUNCH_BS2
+    return dif::launch_status("batched_simple_kernel");
+}
+
+int batched_forward(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                    const int32_t* graph_ptr, int n_graphs, int64_t n_rows, int H, int M, int D, float* out, int64_t ldo,
+                    float* den, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
     DIF_REQUIRE(n_graphs > 0 && n_rows > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG,
                 "dif_batched_simple_attn_f32: n_graphs, n_rows, H, M, D must be positive");
     DIF_REQUIRE(q && k && v && out && graph_ptr, DIF_E_BADARG, "dif_batched_simple_attn_f32: null pointer");
@@ -263,26 +314,43 @@ extern "C" int dif_batched_simple_attn_f32(const float* q, int64_t ldq, const fl
     if (int rc = dif::launch_status("sumsq_pair_kernel")) return rc;
     hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(64), 0, st, part, static_cast<int>(ng), sumsq);
     if (int rc = dif::launch_status("sumsq_fold_kernel")) return rc;
+    const BatchedExtra ex = {nullptr, nullptr, 0, den};
+    return launch_batched(st, q, ldq, k, ldk, v, ldv, graph_ptr, n_graphs, n_rows, H, M, D, sumsq, out, ldo, false, ex);
+}
 
-    const int DT = (D + 63) / 64;
-    const int64_t items = static_cast<int64_t>(n_graphs) * H * DT;
-    // few items of many rows: a 4-wave workgroup per item (>= ~16 rows per wave and phase to be worth the fold)
-    const bool wide = items < 8 * dif::kCUs && n_rows >= 64 * static_cast<int64_t>(n_graphs);
-    const int64_t grid = wide ? items : (items + 3) / 4;
-    DIF_REQUIRE(grid < (1ll << 31), DIF_E_RANGE, "dif_batched_simple_attn_f32: grid too large");
-    const bool vec = (M % 4 == 0) && (D % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) && (ldo % 4 == 0) &&
-                     dif::aligned16(q) && dif::aligned16(k) && dif::aligned16(v) && dif::aligned16(out);
-    const int MT = (M + 63) / 64;
-#define DIF_LAUNCH_BS(MTV, V) \
-    do { \
-        if (wide) hipLaunchKernelGGL((batched_simple_kernel<MTV, V, 4>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, q, \
-                                     ldq, k, ldk, v, ldv, graph_ptr, n_graphs, H, M, D, sumsq, out, ldo); \
-        else hipLaunchKernelGGL((batched_simple_kernel<MTV, V, 1>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, q, \
-                                ldq, k, ldk, v, ldv, graph_ptr, n_graphs, H, M, D, sumsq, out, ldo); \
-    } while (0)
-    if (MT == 1) { if (vec) DIF_LAUNCH_BS(1, true); else DIF_LAUNCH_BS(1, false); }
-    else if (MT == 2) { if (vec) DIF_LAUNCH_BS(2, true); else DIF_LAUNCH_BS(2, false); }
-    else { if (vec) DIF_LAUNCH_BS(4, true); else DIF_LAUNCH_BS(4, false); }
-#undef DIF_LAUNCH_BS
-    return dif::launch_status("batched_simple_kernel");
+}  // namespace
+
+extern "C" int dif_batched_simple_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                           int64_t ldv, const int32_t* graph_ptr, int n_graphs, int64_t n_rows, int H,
+                                           int M, int D, float* out, int64_t ldo, void* workspace,
+                                           size_t workspace_bytes, dif_stream_t stream) {
+    return batched_forward(q, ldq, k, ldk, v, ldv, graph_ptr, n_graphs, n_rows, H, M, D, out, ldo, nullptr, workspace,
+                           workspace_bytes, stream);
+}
+
+// training: also den float[n_rows * H] (= s q.ksum_b + n_b); the two squared norms stay in the LAST two floats of the
+// workspace for dif_batched_simple_raw_f32
+extern "C" int dif_batched_simple_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                               int64_t ldv, const int32_t* graph_ptr, int n_graphs, int64_t n_rows, int H,
+                                               int M, int D, float* out, int64_t ldo, float* den, void* workspace,
+                                               size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(den != nullptr, DIF_E_BADARG, "dif_batched_simple_attn_fwd_f32: den is null");
+    return batched_forward(q, ldq, k, ldk, v, ldv, graph_ptr, n_graphs, n_rows, H, M, D, out, ldo, den, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" int dif_batched_simple_raw_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* c,
+                                          int64_t ldc, const int32_t* graph_ptr, int n_graphs, int64_t n_rows, int H, int M,
+                                          int D, const float* sumsq, const float* rs, const float* vw, int vs_is_s,
+                                          float* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_graphs > 0 && n_rows > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG,
+                "dif_batched_simple_raw_f32: n_graphs, n_rows, H, M, D must be positive");
+    DIF_REQUIRE(a && b && c && out && graph_ptr && sumsq, DIF_E_BADARG, "dif_batched_simple_raw_f32: null pointer");
+    DIF_REQUIRE(lda >= H * M && ldb >= H * M && ldc >= H * D && ldo >= H * D, DIF_E_BADARG,
+                "dif_batched_simple_raw_f32: leading dimension smaller than a row");
+    DIF_REQUIRE(M <= 256, DIF_E_SHAPE, "dif_batched_simple_raw_f32: width of a / b = %d; covered up to 256", M);
+    DIF_REQUIRE(n_rows < (1ll << 31), DIF_E_RANGE, "dif_batched_simple_raw_f32: graph_ptr is int32");
+    const BatchedExtra ex = {rs, vw, vs_is_s, nullptr};
+    return launch_batched(static_cast<hipStream_t>(stream), a, lda, b, ldb, c, ldc, graph_ptr, n_graphs, n_rows, H, M, D, sumsq,
+                          out, ldo, true, ex);
 }

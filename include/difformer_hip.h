@@ -121,6 +121,21 @@ int dif_batched_simple_attn_f32(const float* q, int64_t ldq, const float* k, int
                                 const float* v, int64_t ldv, const int32_t* graph_ptr, int n_graphs,
                                 int64_t n_rows, int H, int M, int D, float* out, int64_t ldo,
                                 void* workspace, size_t workspace_bytes, dif_stream_t stream);
+/* Training (csrc/batched_attn.hip):  dif_batched_simple_attn_fwd_f32 also writes den float[n_rows * H] = s q_i.ksum_b + n_b
+ * and leaves {|Q|^2, |K|^2} in the LAST two floats of `workspace`.  The backward is three launches of
+ *   dif_batched_simple_raw_f32:  out_i = s a_i (sum_{l in graph(i)} b_l (x) c_l) + coef_i sum_l w_l c_l
+ *       a, b [n_rows, H, M], c / out [n_rows, H, D];  coef_i = (rs ? rs[i, h] : 1) (vs_is_s ? s : 1),  w_l = vw ? vw[l, h] : 1;
+ *       s from sumsq = float[2] {|Q|^2, |K|^2} of the forward;  rs, vw float[n_rows * H] or NULL
+ * with gn = g / den, gd = -(g . out) / den:   dq = raw(gn, v, k; rs = gd, s)  - (T / |Q|^2) q,  T = sum q . dq_direct
+ *                                             dk = raw(v, gn, q; vw = gd, s) - (T / |K|^2) k
+ *                                             dv = raw(k, q, gn)  (vsum term unscaled). */
+int dif_batched_simple_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                    const int32_t* graph_ptr, int n_graphs, int64_t n_rows, int H, int M, int D, float* out,
+                                    int64_t ldo, float* den, void* workspace, size_t workspace_bytes, dif_stream_t stream);
+int dif_batched_simple_raw_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* c, int64_t ldc,
+                               const int32_t* graph_ptr, int n_graphs, int64_t n_rows, int H, int M, int D,
+                               const float* sumsq, const float* rs, const float* vw, int vs_is_s, float* out, int64_t ldo,
+                               dif_stream_t stream);
 int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
                                  const float* v, int64_t ldv, const int32_t* ranked_first,
                                  const int32_t* pos_count, int n_graphs, int max_nodes, int H, int M, int D,

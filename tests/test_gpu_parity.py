@@ -1114,6 +1114,41 @@ def test_v2_attention_random_batches(B, mx, H, D, kernel, dev):
     assert rel_err(out.cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("B,mx,H,M,D", [(40, 12, 1, 64, 64), (300, 30, 2, 16, 24), (9, 700, 1, 64, 64), (64, 20, 1, 100, 36),
+                                        (2000, 6, 4, 8, 8)])
+def test_v2_simple_attention_backward_kernels(B, mx, H, M, D, dev):
+    """dq, dk, dv of the batched simple attention (three raw launches of the forward kernel + row arithmetic) against
+    float64 autograd of the graph-by-graph expression (difformer-v2.py:80-111), on ragged batches with empty graphs."""
+    from difformer_amd import autograd_ops as ag, ops
+    rng = np.random.default_rng(B + M)
+    n_nodes = rng.integers(1, mx + 1, size=B)
+    n_nodes[rng.integers(0, B, size=max(B // 20, 1))] = 0
+    n = int(n_nodes.sum())
+    offs = np.concatenate([[0], np.cumsum(n_nodes)])
+    mk = lambda w: torch.from_numpy(rng.standard_normal((n, H, w)).astype(np.float32))
+    q, k, v, g = mk(M), mk(M), mk(D), mk(D)
+    layout = ops.BatchLayout(torch.from_numpy(n_nodes), dev)
+    leaves = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    out = ag.batched_attention(*leaves, layout, "simple")
+    out.backward(g.to(dev))
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    qn, kn = q64 / q64.norm(), k64 / k64.norm()
+    ref = torch.zeros(n, H, D, dtype=torch.float64)
+    pieces = []
+    for b in range(B):
+        sl = slice(int(offs[b]), int(offs[b + 1]))
+        if offs[b + 1] == offs[b]:
+            continue
+        num = torch.einsum("nhm,hmd->nhd", qn[sl], torch.einsum("lhm,lhd->hmd", kn[sl], v64[sl])) + v64[sl].sum(0)
+        den = torch.einsum("nhm,hm->nh", qn[sl], kn[sl].sum(0)) + float(n_nodes[b])
+        pieces.append((sl, num / den[..., None]))
+    ref = torch.cat([p for _, p in pieces], dim=0)
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL
+    ref.backward(g.double())
+    for got, want, nm in zip(leaves, (q64, k64, v64), "qkv"):
+        assert rel_err(got.grad.cpu().numpy(), want.grad.numpy()) < 2e-5, nm
+
+
 def test_v2_single_graph_equals_a1(dev):
     """B = 1: difformer-v2.py:80-111 is difformer.py:18-39."""
     from difformer_amd import full_attention_conv
