@@ -72,7 +72,7 @@ int make_plan(int64_t n_src, int64_t n_rows, int F, Plan& p) {
     const int64_t nt0 = (n_src + kTileRowsMax - 1) / kTileRowsMax;
     const int64_t need = (G + (cap - kMaxWaves) - 1) / (cap - kMaxWaves);        // panels at kMaxRounds - 1 rounds
     int S = 1;
-    while (S * 2 <= kMaxSplits && (n_src + n_rows - 1) / n_rows >= 2 * S && need * S * 2 <= panels && nt0 >= S * 2) S *= 2;
+    while (S * 2 <= kMaxSplits && n_src + (n_src >> 4) >= int64_t(2) * S * n_rows && need * S * 2 <= panels && nt0 >= S * 2) S *= 2;   // (1/16 slack: ranks' row counts are rounded up)
     p.S = S;
     panels /= S;
     if (panels > G) panels = G;

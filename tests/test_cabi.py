@@ -81,6 +81,33 @@ def test_sliced_plan_is_host_side_arithmetic(lib):
     assert rc == -1 and b"n_pos" in lib.dif_last_error()
 
 
+def test_sliced_plan_invariants_over_random_shapes(lib):
+    """Every plan dif_sliced_plan hands out is self-consistent: the (panel, wave, round) slots cover the 64-row slots, the
+    tiles cover the source rows and fit the LDS, a row shard's tiles divide evenly among its source splits, and the
+    workspace is what the splits write."""
+    import random
+    rnd = random.Random(5)
+    plan = (ctypes.c_int32 * 8)()
+    for _ in range(3000):
+        n_src = rnd.choice([rnd.randint(1, 5000), rnd.randint(5000, 300000), rnd.randint(300000, 4000000)])
+        n_rows = n_src if rnd.random() < 0.4 else rnd.randint(1, n_src)
+        F = 4 * rnd.choice([1, 2, 4, 8, 16, 16, 16, 32, 64, 75, 100])
+        rc = lib.dif_sliced_plan(n_src, n_rows, F, plan)
+        slices, panels, G, PW, W, R, T, NT = list(plan)
+        if rc != 0:
+            continue
+        assert slices == F // 4 and G == -(-n_rows // 64) and PW == panels * W and 1 <= W <= 16 and 1 <= R <= 10
+        assert (R - 1) * PW < G <= R * PW, (n_src, n_rows, F, list(plan))
+        assert T % 16 == 0 and 16 <= T <= 10208 and T * NT >= n_src and (NT - 1) * T < n_src + 16 * NT
+        ws = lib.dif_sliced_spmm_workspace_bytes(n_src, n_rows, F)
+        if ws:
+            S = ws // (slices * G * 64 * 16)
+            assert S in (2, 4, 8) and ws == S * slices * G * 64 * 16 and NT % S == 0 and n_src + n_src // 16 >= S * n_rows
+            assert panels * S * slices <= 256 or panels == 1
+        elif n_src == n_rows:
+            assert True                                     # a whole-graph product never splits
+
+
 def test_argument_checks_reject_before_touching_the_device(lib):
     """Bad arguments return a negative DIF_E_* code and set dif_last_error; nothing is launched."""
     rc = lib.dif_simple_reduce_f32(None, 64, None, 64, None, 64, 10, 1, 64, 64, None, None, 0, None)
