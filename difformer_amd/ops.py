@@ -504,8 +504,21 @@ def gcn_aggregate(csr: GraphCSR, x, attn=None, attn_scale=1.0, gcn_scale=1.0, sh
         local = x.reshape(n, H * D)
         handle = shard.all_gather_rows_async(local)
     row_begin, n_rows = shard.row_begin, shard.n_local
-    order = csr.row_order(row_begin, n_rows)
     F = H * D
+    sl = csr.sliced(row_begin, n_rows, F) if local.dtype == torch.float32 else None
+    if sl is not None:
+        # dense unweighted graph: the shard's feature-sliced product (source tiles split over the workgroups of a panel)
+        # over the gathered rows, as in the single-GPU branch above
+        a2 = flat(attn)                        # waits for the record all-reduce, runs `apply` under the all-gather
+        x2 = handle.wait()
+        ys = be.sliced_prescale(x2, csr.rowptr, csr.num_nodes, sl.plan, csr.dinv)
+        out = be.sliced_spmm(sl, ys, csr.rowptr, csr.num_nodes, row_begin, n_rows, F, a2, attn_scale, gcn_scale, csr.dinv)
+        if tail is not None:
+            out = be.layer_tail(out.reshape(n_rows, H, D), tail.get("x0"), tail.get("prev"), tail.get("alpha", 0.5),
+                                tail.get("ln_weight"), tail.get("ln_bias"), tail.get("eps", 1e-5), tail.get("relu", False))
+            return out.reshape(n_rows, 1, D)
+        return out.reshape(n_rows, H, D)
+    order = csr.row_order(row_begin, n_rows)
     rows = csr.block_rows
     split = (csr.n_blocks > 1 and csr.nnz > 0 and F % 4 == 0 and F <= 256 and row_begin % rows == 0 and
              (row_begin + n_rows == csr.num_nodes or (row_begin + n_rows) % rows == 0))

@@ -64,17 +64,19 @@ def _worker(rank, world, port, kernel, n, deg, heads, out_q):
         torch.cuda.synchronize()
         from difformer_amd import ops
         sliced = [sl for _, _, csr in ops.csr_cache.entries.values() for sl in csr._sliced.values() if sl is not None]
-        splits = max([int(ops.get_backend().lib.dif_sliced_spmm_workspace_bytes(n, shard.n_local, 64) > 0)] if sliced else [0])
+        splits = max([int(ops.get_backend().lib.dif_sliced_spmm_workspace_bytes(n, shard.n_local, 64 * heads) > 0)] if sliced else [0])
         out_q.put((rank, err_f, err_p, err_x, len(sliced), splits))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kernel,n,deg,heads", [("simple", 20000, 60, 1), ("simple", 6000, 8, 2), ("sigmoid", 3000, 6, 1)])
+@pytest.mark.parametrize("kernel,n,deg,heads", [("simple", 20000, 60, 1), ("simple", 6000, 8, 2), ("sigmoid", 3000, 6, 1),
+                                                ("simple", 18000, 64, 2)])
 def test_two_ranks_on_one_gpu_forward_and_training_step(kernel, n, deg, heads):
     """simple / one head / dense graph: closed-form layers with the sliced product of a shard (source splits) in
     inference, the operator kernels and their backward kernels (two all-reduces inside the attention backward, the
-    adjoint product over all-gathered gradient rows) in training; several heads and sigmoid: the operator path."""
+    adjoint product over all-gathered gradient rows) in training; several heads and sigmoid: the operator path -- on a
+    dense graph with the shard's sliced product there too (forward and adjoint)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
