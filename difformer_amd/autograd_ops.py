@@ -160,19 +160,35 @@ class _SigmoidAttention(torch.autograd.Function):
 
 
 class _GcnAggregate(torch.autograd.Function):
+    """edge_weight is an input only when the caller wants its gradient (the CSR values are built from it outside
+    autograd); the product itself always runs on the cached CSR."""
+
     @staticmethod
-    def forward(ctx, csr, x, attn, attn_scale, gcn_scale, shard=None):
+    def forward(ctx, csr, x, attn, attn_scale, gcn_scale, shard=None, edge_weight=None):
         ctx.csr, ctx.attn_scale, ctx.gcn_scale, ctx.has_attn = csr, attn_scale, gcn_scale, attn is not None
-        ctx.edges = csr.hold_edges() if csr._adjoint is None else None    # the adjoint CSR is built from them in backward
+        ctx.edges = csr.hold_edges() if (csr._adjoint is None or edge_weight is not None) else None
         ctx.shard = _sharded(shard)
+        if edge_weight is not None:
+            if ctx.shard is not None:
+                raise NotImplementedError("difformer_amd: edge_weight gradients are single-GPU only")
+            ctx.save_for_backward(x)
         return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, ctx.shard)
 
     @staticmethod
     def backward(ctx, g):
         # adjoint product on the same SpMM kernels: grad_x = gcn_scale * A_hat^T g.  Row-sharded it is the forward
         # pattern again on the transposed CSR: all-gather the rows of g, product over this rank's (source) rows.
-        gx = ops.gcn_aggregate(ctx.csr.adjoint(), g.contiguous(), None, 1.0, ctx.gcn_scale, ctx.shard)
-        return None, gx, (ctx.attn_scale * g if ctx.has_attn else None), None, None, None
+        g = g.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            gx = ops.gcn_aggregate(ctx.csr.adjoint(), g, None, 1.0, ctx.gcn_scale, ctx.shard)
+        if ctx.needs_input_grad[6]:
+            # d value_e = <g[col_e], x[row_e]>, chained through value = w * d_in * d_out and nan_to_num (difformer.py:73-74)
+            (x,) = ctx.saved_tensors
+            n = x.shape[0]
+            gw = ops.get_backend().edge_weight_grad(ctx.edges[0], ctx.edges[1], ctx.csr.rowptr, n, g.reshape(n, -1),
+                                                    x.reshape(n, -1), ctx.gcn_scale)
+        return None, gx, (ctx.attn_scale * g if ctx.has_attn else None), None, None, None, gw
 
 
 class _LayerTail(torch.autograd.Function):
@@ -319,8 +335,9 @@ def batched_attention(q, k, v, layout, kernel):
 
 
 def gcn_aggregate(csr, x, attn=None, attn_scale=1.0, gcn_scale=1.0, shard=None):
-    if _needs_grad(x, attn):
-        return _GcnAggregate.apply(csr, x, attn, attn_scale, gcn_scale, shard)
+    w = csr.weight_leaf()
+    if w is not None or _needs_grad(x, attn):
+        return _GcnAggregate.apply(csr, x, attn, attn_scale, gcn_scale, shard, w)
     return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard)
 
 
@@ -330,7 +347,7 @@ def gcn_aggregate_tail(csr, x, attn, attn_scale, gcn_scale, shard, x0, prev, alp
     layer has a single head; otherwise the two operators run back to back."""
     d = x.shape[2]
     fused = (x.shape[1] == 1 and (d <= 64 or (d % 4 == 0 and d <= 256)) and
-             not _needs_grad(x, attn, x0, prev, ln_weight, ln_bias))
+             not _needs_grad(x, attn, x0, prev, ln_weight, ln_bias) and csr.weight_leaf() is None)
     if fused:
         tail = dict(x0=x0, prev=prev, alpha=alpha, ln_weight=ln_weight, ln_bias=ln_bias, eps=eps, relu=relu)
         return ops.gcn_aggregate(csr, x, attn, attn_scale, gcn_scale, shard, tail)[:, 0, :]

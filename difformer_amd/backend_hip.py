@@ -501,6 +501,26 @@ class HipBackend:
             csr = (rowptr, src, val)
         return out_ei[:, :kept], (None if out_w is None else out_w[:kept]), ptr, csr
 
+    def edge_weight_grad(self, edge_index, edge_weight, rowptr, n_nodes, g, x, scale=1.0):
+        """d loss / d edge_weight of the aggregation (difformer.py:73 under autograd): g, x [n_nodes, F] -> [E]."""
+        dev = _require_device(edge_index, edge_weight, rowptr, g, x)
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise TypeError("difformer_amd: edge_index must be int64 [2, E]")
+        E, F = edge_index.shape[1], x.shape[1]
+        if g.shape != x.shape or x.shape[0] != n_nodes:
+            raise ValueError(f"difformer_amd: edge_weight_grad needs g and x as [{n_nodes}, F] (got {tuple(g.shape)}, {tuple(x.shape)})")
+        _f32(g, "g"), _f32(x, "x")
+        w = _f32(edge_weight, "edge_weight").detach().contiguous()
+        ei = edge_index.contiguous()
+        g, ldg = _row_major(g, F)
+        x, ldx = _row_major(x, F)
+        dw = torch.empty(E, dtype=torch.float32, device=dev)
+        with _Timed(self, "dif_gcn_edge_weight_grad_f32", dev):
+            rc = self.lib.dif_gcn_edge_weight_grad_f32(_ptr(ei), E, n_nodes, _ptr(w), _ptr(rowptr), _ptr(g), ldg, _ptr(x), ldx,
+                                                       F, float(scale), _ptr(dw), _stream(dev))
+        _lib.check(rc, "dif_gcn_edge_weight_grad_f32")
+        return dw
+
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
              gcn_scale=1.0, tail=None, order=None, part=None):
         """tail = None | dict(x0, prev, alpha, ln_weight, ln_bias, eps[, relu]): fuse the layer tail (H == 1).

@@ -160,7 +160,8 @@ class DIFFormerConv(nn.Module):
         H = self.num_heads
         shard = self.row_shard
         q = k = None
-        if self._closed_form(query_input, source_input, prev, want_qk):
+        w_grad = ag._needs_grad(edge_weight)     # difformer.py:73 is differentiable in edge_weight: operator path then
+        if not w_grad and self._closed_form(query_input, source_input, prev, want_qk):
             if self.use_graph and edge_index is None:
                 raise ValueError("use_graph=True needs an edge_index")
             x = source_input
@@ -202,7 +203,7 @@ class DIFFormerConv(nn.Module):
             if head is not None:
                 carry["head_done"] = True          # `out` is already the model's logits (difformer.py:208)
             return out, None, None
-        if not want_qk and self._fusable_projection(query_input, source_input):
+        if not want_qk and not w_grad and self._fusable_projection(query_input, source_input):
             attn, v = ops.project_simple_attention(source_input, self.Wq.weight, self.Wq.bias, self.Wk.weight,
                                                    self.Wk.bias, self.Wv.weight, self.Wv.bias, H,
                                                    self.out_channels, shard, gather_values=self.use_graph)

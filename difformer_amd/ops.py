@@ -305,6 +305,14 @@ class GraphCSR:
             self._row_sums = out[:, 0].contiguous()
         return self._row_sums
 
+    def weight_leaf(self):
+        """The edge_weight tensor this CSR was built from when the caller wants its gradient (difformer.py:73 is
+        differentiable in it), else None."""
+        if not self.weighted or not self._edges or self._edges[1] is None or not torch.is_grad_enabled():
+            return None
+        w = self._edges[1]()
+        return w if (w is not None and w.requires_grad) else None
+
     def hold_edges(self):
         """Strong references to the tensors this CSR was built from (None if already freed).  The autograd node of the
         aggregation keeps them until backward(), so callers may pass temporaries (`model(x, ei.to(dev))`)."""
@@ -353,11 +361,13 @@ class _CSRCache:
         """`row_bytes` = bytes of one feature row the SpMM will gather (H*D*elem_size); picks the blocking -- the
         tiling of the feature-sliced product for dense unweighted fp32 graphs, else ~2.5 MiB source blocks, aligned
         with the rank boundaries of `shard` when the run is row-sharded."""
-        if edge_weight is not None and edge_weight.requires_grad and torch.is_grad_enabled():
+        if edge_weight is not None and edge_weight.requires_grad and torch.is_grad_enabled() and shard is not None \
+                and shard.world > 1:
             # the reference's gcn_conv is differentiable in edge_weight (value = w * d_in * d_out through
-            # torch_sparse.matmul); the CSR values here are built outside autograd
-            raise NotImplementedError("difformer_amd: gradients with respect to edge_weight are not implemented; "
-                                      "detach() it or keep it a constant of the graph")
+            # torch_sparse.matmul).  One GPU: autograd_ops._GcnAggregate returns that gradient (csrc/gcn_edge_grad.hip);
+            # row-sharded it would need the gathered rows of both operands on every rank
+            raise NotImplementedError("difformer_amd: gradients with respect to edge_weight are not implemented for "
+                                      "row-sharded runs; detach() it or keep it a constant of the graph")
         self._purge()
         tiling = sliced_tiling(num_nodes, row_bytes // elem_size, edge_index.shape[1], edge_weight, shard, elem_size)
         aligned = choose_shard_blocks(num_nodes, row_bytes, edge_index.shape[1], shard)

@@ -184,6 +184,16 @@ int dif_gcn_spmm_f32(const int32_t* rowptr, const int32_t* blkptr, int n_blocks,
  * degree > 4x the mean) are each split over the wave's four lane groups, whose partial rows are added in a fixed order;
  * every other row is summed exactly as without the order.  Ignored by the unblocked kernels.
  * dif_row_order: order int32 [n_rows]; stats int32 [2] (device) = {rows with degree > 4x mean, max degree}. */
+/* dif_gcn_edge_weight_grad_f32: gradient of gcn_conv with respect to edge_weight, in the ORIGINAL edge order
+ * (the reference's value = edge_weight * d_in * d_out, :73, feeds torch_sparse.matmul, which autograd differentiates in
+ * the values; reached by loss.backward(), main.py:130, whenever edge_weight requires a gradient):
+ *     dw[e] = [value_e finite] * scale * <g[col_e, :], x[row_e, :]> * deg[row_e]^-1/2 * deg[col_e]^-1/2
+ * with deg from `rowptr` of the destination-row CSR (full graph).  An edge leaving a node without incoming entries has
+ * deg^-1/2 = inf and the reference's gradient is 0 * inf = NaN; so it is here.  g: upstream gradient of the aggregation's
+ * output rows [N, F]; x: its input rows [N, F]; scale = gcn_scale of the combine (:130-134). */
+int dif_gcn_edge_weight_grad_f32(const int64_t* edge_index, int64_t E, int64_t N, const float* edge_weight,
+                                 const int32_t* rowptr, const float* g, int64_t ldg, const float* x, int64_t ldx, int F,
+                                 float scale, float* dw, dif_stream_t stream);
 size_t dif_row_order_workspace_bytes(int64_t n_rows);
 int dif_row_order(const int32_t* rowptr, int64_t row_begin, int64_t n_rows, int32_t* order, int32_t* stats,
                   void* workspace, size_t workspace_bytes, dif_stream_t stream);

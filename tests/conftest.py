@@ -47,6 +47,24 @@ def rel_err(y, ref):
     return float(np.max(np.abs(y - ref)) / denom) if ref.size else 0.0
 
 
+def grad_err(got, ref, gmax):
+    """Parity metric for ONE gradient tensor of a training step: max|got - ref| / max(max|ref|, 1e-6 * gmax), gmax = the
+    largest |entry| over all gradients of the step.  Per-tensor norm-wise as rel_err, with a floor: the Wq / Wk gradients
+    of the `simple` kernel are 1e-5..1e-7 of the others (its attention is close to uniform), and a float32 backward pass
+    cannot resolve a tensor that small to 1e-4 of ITSELF -- the float32 run of the reference does not either."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    if not ref.size:
+        return 0.0
+    denom = max(float(np.max(np.abs(ref))), 1e-6 * float(gmax))
+    return float(np.max(np.abs(got - ref)) / (denom if denom > 0 else 1.0))
+
+
+def grad_scale(case, sfx="f64"):
+    """Largest |entry| over the parameter gradients of a golden 'grad' model case."""
+    return max(float(np.max(np.abs(v))) for k, v in case.items() if k.startswith(f"grad_{sfx}/") and v.size)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return {fam: load_golden(fam) for fam in ("attn", "attnw", "gcn", "model")}

@@ -74,6 +74,16 @@ class OracleBackend:
         return (torch.from_numpy(rowptr), blk, torch.from_numpy(row[order].astype(np.int32)),
                 torch.from_numpy(val[order]))
 
+    def edge_weight_grad(self, edge_index, edge_weight, rowptr, n_nodes, g, x, scale=1.0):
+        """difformer.py:73-74 under autograd, restated term by term in float32 (NaN where the source has no incoming entry)."""
+        ei, w = _np(edge_index), _np(edge_weight).astype(np.float32)
+        deg = np.diff(_np(rowptr).astype(np.int64)).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            d_in, d_out = np.sqrt(np.float32(1) / deg[ei[1]]), np.sqrt(np.float32(1) / deg[ei[0]])
+            dot = np.einsum("ef,ef->e", _np(g).astype(np.float64)[ei[1]], _np(x).astype(np.float64)[ei[0]])
+            gv = np.where(np.isfinite(w * d_in * d_out), scale * dot, 0.0).astype(np.float32)
+            return torch.from_numpy(((gv * d_out) * d_in).astype(np.float32))
+
     def spmm(self, rowptr, blkptr, n_blocks, src, val, n_nodes, nnz, x, row_begin, n_rows, attn=None, attn_scale=1.0,
              gcn_scale=1.0, tail=None, order=None, part=None):
         rp, s, w, xx = _np(rowptr), _np(src)[:nnz], _np(val)[:nnz].astype(np.float64), _np(x).astype(np.float64)

@@ -1,0 +1,268 @@
+"""Backward parity of the HIP path (training step, loss / gradients).
+
+Two yardsticks, both derived from the reference:
+  * tests/golden/golden_grad.npz -- gradients of the reference itself (float64 run), small cases;
+  * oracle/difformer_oracle_grad.py -- float64 CPU restatement pinned to those fixtures (tests/test_oracle_grad_golden.py),
+    for sizes the fixtures cannot hold: a graph that takes the feature-sliced product and its adjoint inside a training
+    step, and Cora size.
+Tolerance: 1e-4 norm-wise per tensor (conftest.grad_err: relative to the tensor's own largest entry, floored at 1e-6 of the
+step's largest gradient entry).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import grad_err, grad_scale, load_golden, rel_err, split_model_case
+from oracle import difformer_oracle_grad as og
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+GRAD = load_golden("grad")
+
+
+def cases(prefix):
+    return sorted(n for n in GRAD if n.startswith(prefix + "/"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def t(a, dev, grad=False):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return x.requires_grad_(True) if grad else x
+
+
+def nan_err(got, ref, gmax=None):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), "NaN positions differ from the reference's"
+    got, ref = np.nan_to_num(got), np.nan_to_num(ref)
+    return rel_err(got, ref) if gmax is None else grad_err(got, ref, gmax)
+
+
+# ------------------------------------------------------------------ a1 / a2
+@pytest.mark.parametrize("name", cases("attn"))
+def test_full_attention_conv_gradients_golden(name, dev):
+    from difformer_amd import full_attention_conv
+    c = GRAD[name]
+    q, k, v = (t(c[a], dev, True) for a in "qkv")
+    out = full_attention_conv(q, k, v, str(c["kernel"]))
+    out.backward(t(c["g"], dev))
+    assert rel_err(out.detach().cpu().numpy(), c["out_f64"]) < TOL
+    gmax = max(np.abs(c[f"d{a}_f64"]).max() for a in "qkv")
+    for x, a in ((q, "dq"), (k, "dk"), (v, "dv")):
+        assert grad_err(x.grad.cpu().numpy(), c[a + "_f64"], gmax) < TOL, a
+
+
+# ------------------------------------------------------------------ a3
+@pytest.mark.parametrize("name", cases("gcn"))
+def test_gcn_conv_gradients_golden(name, dev):
+    """dx through the adjoint product, d edge_weight through csrc/gcn_edge_grad.hip (NaN exactly where the reference's is)."""
+    from difformer_amd import gcn_conv
+    c = GRAD[name]
+    x = t(c["x"], dev, True)
+    ei = t(c["edge_index"], dev)
+    w = t(c["edge_weight"], dev, True) if "edge_weight" in c else None
+    out = gcn_conv(x, ei, w)
+    out.backward(t(c["g"], dev))
+    assert rel_err(out.detach().cpu().numpy(), c["out_f64"]) < TOL
+    assert rel_err(x.grad.cpu().numpy(), c["dx_f64"]) < TOL
+    if w is not None:
+        assert nan_err(w.grad.cpu().numpy(), c["dw_f64"]) < TOL
+
+
+@pytest.mark.parametrize("n,e,f,iso", [(5000, 200000, 64, 7), (3000, 40000, 10, 0), (20000, 900000, 128, 50)])
+def test_edge_weight_gradient_vs_oracle(n, e, f, iso, dev):
+    """Bigger graphs (vector and scalar loads, several heads' worth of columns) against float64 autograd of the oracle."""
+    from difformer_amd import gcn_conv
+    g = torch.Generator().manual_seed(n)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n - iso, (e,), generator=g)])
+    h = 2 if f % 2 == 0 else 1
+    x = torch.randn(n, h, f // h, generator=g)
+    w = torch.rand(e, generator=g) + 0.1
+    go = torch.randn(n, h, f // h, generator=g)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    og.gcn_conv(x64, ei, w64).backward(go.double())
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    gcn_conv(xd, ei.to(dev), wd).backward(go.to(dev))
+    assert rel_err(xd.grad.cpu().numpy(), x64.grad.numpy()) < TOL
+    assert nan_err(wd.grad.cpu().numpy(), w64.grad.numpy()) < TOL
+
+
+# ------------------------------------------------------------------ a4 / a5: training step of main.py:117-131
+def _build(c, dev):
+    from difformer_amd import DIFFormer
+    cfg, sd = split_model_case(c)
+    kw = {k: cfg[k] for k in ("num_layers", "num_heads", "kernel", "alpha", "use_bn", "use_residual", "use_weight",
+                              "use_graph", "graph_weight", "use_source")}
+    kw["kernel"] = str(kw["kernel"])
+    model = DIFFormer(int(cfg["in_channels"]), int(cfg["hidden_channels"]), int(cfg["out_channels"]), dropout=0.0, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return model.to(dev).train(), cfg
+
+
+def _loss(out, y, idx, kind):
+    if kind == "bce":
+        return F.binary_cross_entropy_with_logits(out[idx], y[idx].to(out.dtype))
+    return F.nll_loss(F.log_softmax(out, dim=1)[idx], y[idx])
+
+
+@pytest.mark.parametrize("name", cases("model"))
+def test_training_step_gradients_golden(name, dev):
+    """loss, every parameter gradient, dx (and d edge_weight) of one training step against the reference's own."""
+    c = GRAD[name]
+    model, cfg = _build(c, dev)
+    x = t(c["x"], dev, True)
+    ei = t(c["edge_index"], dev) if cfg["use_graph"] else None
+    w = t(c["edge_weight"], dev, True) if "edge_weight" in c else None
+    out = model(x, ei, w)
+    loss = _loss(out, t(c["y"], dev), t(c["train_idx"], dev), str(c["loss_kind"]))
+    loss.backward()
+    assert rel_err(out.detach().cpu().numpy(), c["out_f64"]) < TOL
+    assert abs(float(loss.detach()) - float(c["loss_f64"])) < TOL * abs(float(c["loss_f64"]))
+    gmax = grad_scale(c)
+    assert grad_err(x.grad.cpu().numpy(), c["dx_f64"], gmax) < TOL
+    if w is not None:
+        assert nan_err(w.grad.cpu().numpy(), c["dw_f64"], gmax) < TOL
+    for k, p in model.named_parameters():
+        ref = c["grad_f64/" + k]
+        got = np.zeros_like(ref) if p.grad is None else p.grad.cpu().numpy()
+        assert np.isfinite(got).all(), k
+        assert grad_err(got, ref, gmax) < TOL, k
+
+
+def _oracle_step(model, x, ei, cfg, y, idx, kind="nll", w=None):
+    """float64 CPU oracle of the same step -> (out, loss, {param: grad}, dx)."""
+    p = og.leaves({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    x64 = x.detach().cpu().double().requires_grad_(True)
+    out = og.difformer_forward(p, x64, None if ei is None else ei.cpu(), w, cfg)
+    loss = og.training_loss(out, y.cpu(), idx.cpu(), kind)
+    loss.backward()
+    return out.detach().numpy(), float(loss.detach()), {k: v.grad.numpy() for k, v in p.items()}, x64.grad.numpy()
+
+
+def _check_step(model, x, ei, cfg, y, idx, launched=None, kind="nll"):
+    out = model(x, ei)
+    loss = _loss(out, y, idx, kind)
+    loss.backward()
+    r_out, r_loss, r_grads, r_dx = _oracle_step(model, x, ei, cfg, y, idx, kind)
+    assert rel_err(out.detach().cpu().numpy(), r_out) < TOL
+    assert abs(float(loss.detach()) - r_loss) < TOL * abs(r_loss)
+    gmax = max(float(np.abs(v).max()) for v in r_grads.values())
+    if x.grad is not None:
+        assert grad_err(x.grad.cpu().numpy(), r_dx, gmax) < TOL
+    for k, prm in model.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+        assert grad_err(prm.grad.cpu().numpy(), r_grads[k], gmax) < TOL, k
+
+
+@pytest.mark.parametrize("layers,heads,skew", [(2, 1, False), (3, 1, True), (2, 2, False)])
+def test_training_step_on_a_graph_that_takes_the_sliced_product(layers, heads, skew, dev):
+    """>= 8,192 nodes and >= 48 entries per row: the forward aggregation is the feature-sliced product and its gradient the
+    same kernel over the transposed CSR (the headline kernels inside loss.backward()).  skew: hub rows (split positions)."""
+    from difformer_amd import DIFFormer, ops
+    n, per = 9000, 56
+    g = torch.Generator().manual_seed(11 + layers)
+    if skew:
+        wgt = 1.0 / torch.arange(1, n + 1, dtype=torch.float64) ** 0.8
+        dst = torch.multinomial(wgt, n * per // 2, replacement=True, generator=g)
+    else:
+        dst = torch.randint(0, n, (n * per // 2,), generator=g)
+    src = torch.randint(0, n, (n * per // 2,), generator=g)
+    ei = torch.cat([torch.stack([src, dst]), torch.stack([dst, src]), torch.arange(n).repeat(2, 1)], dim=1)
+    torch.manual_seed(5)
+    model = DIFFormer(12, 64 // heads, 9, num_layers=layers, num_heads=heads, kernel="simple", dropout=0.0).to(dev).train()
+    cfg = dict(hidden_channels=64 // heads, num_layers=layers, num_heads=heads, kernel="simple", alpha=0.5, use_bn=True,
+               use_residual=True, use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    x = torch.randn(n, 12, generator=g).to(dev).requires_grad_(True)
+    y = torch.randint(0, 9, (n,), generator=g).to(dev)
+    idx = torch.randperm(n, generator=g)[: n // 2].to(dev)
+    be = ops.get_backend()
+    be.kernel_events = {}
+    try:
+        _check_step(model, x, ei.to(dev), cfg, y, idx)
+        launched = set(be.kernel_events)
+    finally:
+        be.kernel_events = None
+    assert "dif_sliced_spmm_f32" in launched, launched
+
+
+def test_training_step_at_cora_size(dev):
+    """BASELINE config C1 as a training step (main.py:117-131 on Cora: 2,708 nodes, 1,433 features, 7 classes)."""
+    from difformer_amd import DIFFormer
+    n, f_in = 2708, 1433
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(n, f_in, generator=g)
+    x = (x / x.sum(dim=1, keepdim=True))
+    pairs = torch.randint(0, n, (2, 5278), generator=g)
+    ei = torch.cat([pairs, pairs.flip(0), torch.arange(n).repeat(2, 1)], dim=1)
+    torch.manual_seed(123)
+    model = DIFFormer(f_in, 64, 7, num_layers=2, kernel="simple", dropout=0.0).to(dev).train()
+    cfg = dict(hidden_channels=64, num_layers=2, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    y = torch.randint(0, 7, (n,), generator=g).to(dev)
+    idx = torch.randperm(n, generator=g)[:140].to(dev)
+    _check_step(model, x.to(dev), ei.to(dev), cfg, y, idx)
+
+
+def test_training_step_sigmoid_at_cora_size(dev):
+    """BASELINE config C2 (DIFFormer-a) as a training step: the sigmoid backward kernels at N = 2,708."""
+    from difformer_amd import DIFFormer
+    n, f_in = 2708, 200
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, f_in, generator=g)
+    pairs = torch.randint(0, n, (2, 5278), generator=g)
+    ei = torch.cat([pairs, pairs.flip(0), torch.arange(n).repeat(2, 1)], dim=1)
+    torch.manual_seed(124)
+    model = DIFFormer(f_in, 64, 7, num_layers=2, kernel="sigmoid", dropout=0.0).to(dev).train()
+    cfg = dict(hidden_channels=64, num_layers=2, num_heads=1, kernel="sigmoid", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    y = torch.randint(0, 7, (n,), generator=g).to(dev)
+    idx = torch.randperm(n, generator=g)[:140].to(dev)
+    _check_step(model, x.to(dev), ei.to(dev), cfg, y, idx)
+
+
+# ------------------------------------------------------------------ f4: physical particle/difformer-v2.py
+@pytest.mark.parametrize("name", cases("v2attn"))
+def test_v2_attention_gradients_golden(name, dev):
+    from difformer_amd.difformer_v2 import TransConv
+    c = GRAD[name]
+    h, d = c["q"].shape[1:]
+    conv = TransConv(d, d, num_heads=h, kernel=str(c["kernel"])).to(dev)
+    q, k, v = (t(c[a], dev, True) for a in "qkv")
+    out = conv.full_attention(q, k, v, str(c["kernel"]), torch.from_numpy(c["n_nodes"]))
+    out.backward(t(c["g"], dev))
+    assert rel_err(out.detach().cpu().numpy(), c["out_f64"]) < TOL
+    gmax = max(np.abs(c[f"d{a}_f64"]).max() for a in "qkv")
+    for x, a in ((q, "dq"), (k, "dk"), (v, "dv")):
+        assert grad_err(x.grad.cpu().numpy(), c[a + "_f64"], gmax) < TOL, a
+
+
+@pytest.mark.parametrize("name", cases("v2model"))
+def test_v2_training_step_gradients_golden(name, dev):
+    from difformer_amd.difformer_v2 import DIFFormer_v2
+    c = GRAD[name]
+    cfg, sd = split_model_case(c)
+    kw = {k: cfg[k] for k in ("num_layers", "kernel", "alpha", "use_bn", "use_residual", "use_weight", "use_graph",
+                              "graph_weight")}
+    kw["kernel"] = str(kw["kernel"])
+    hid = int(cfg["hidden_channels"])
+    model = DIFFormer_v2(int(cfg["in_channels"]), hid, hid, dropout=0.0, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).train()
+    x = t(c["x"], dev, True)
+    out = model(x, t(c["edge_index"], dev) if cfg["use_graph"] else None, torch.from_numpy(c["n_nodes"]))
+    loss = F.mse_loss(out, t(c["target"], dev))
+    loss.backward()
+    assert rel_err(out.detach().cpu().numpy(), c["out_f64"]) < TOL
+    assert abs(float(loss.detach()) - float(c["loss_f64"])) < TOL * abs(float(c["loss_f64"]))
+    gmax = grad_scale(c)
+    assert grad_err(x.grad.cpu().numpy(), c["dx_f64"], gmax) < TOL
+    for k, p in model.named_parameters():
+        ref = c["grad_f64/" + k]
+        got = np.zeros_like(ref) if p.grad is None else p.grad.cpu().numpy()
+        assert grad_err(got, ref, gmax) < TOL, k

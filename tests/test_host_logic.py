@@ -147,10 +147,14 @@ def test_csr_cache_identity_version_and_eviction(fake_backend):
     ops.csr_cache.get(keep, None, 50)
     assert len(ops.csr_cache.entries) == 1
     wg = torch.rand(40, requires_grad=True)
-    with pytest.raises(NotImplementedError, match="edge_weight"):     # the reference differentiates through the values
-        ops.csr_cache.get(keep, wg, 50)
+    # the reference differentiates through the values (difformer.py:73): one GPU returns that gradient
+    # (autograd_ops._GcnAggregate), a row-sharded run refuses instead of dropping it silently
+    assert ops.csr_cache.get(keep, wg, 50).weight_leaf() is wg
     with torch.no_grad():
-        ops.csr_cache.get(keep, wg, 50)
+        assert ops.csr_cache.get(keep, wg, 50).weight_leaf() is None
+    from difformer_amd.dist import RowShard
+    with pytest.raises(NotImplementedError, match="edge_weight"):
+        ops.csr_cache.get(keep, wg, 50, shard=RowShard(50, 0, 2))
 
 
 def test_simple_attention_under_grad_checks_the_lengths(fake_backend):
@@ -404,3 +408,47 @@ def test_narrow_factors_algebra_matches_the_oracle(C, D, use_weight):
     ref = orc.simple_attention(q[:, None, :], k[:, None, :], v[:, None, :])[:, 0, :]
     assert abs(q2 - (q * q).sum()) < 1e-5 * (q * q).sum()           # the factors are stored in float32
     assert np.abs(out - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+# ---- training step through the autograd glue against GRADIENTS of the reference (tests/golden/golden_grad.npz) -----------
+GRAD = load_golden("grad")
+
+
+@pytest.mark.parametrize("name", sorted(n for n in GRAD if n.startswith("model/")))
+def test_training_step_plumbing_against_reference_gradients(name, fake_backend):
+    """main.py:117-131 on the package's modules with the arithmetic on the fake backend: what is checked here is the
+    autograd glue (which operator sees which tensor, the scales of the combine, the edge_weight gradient), against the
+    reference's own loss / parameter gradients / dx / d edge_weight.  float32 operators: 1e-4 norm-wise."""
+    import torch.nn.functional as F
+    from conftest import grad_err, grad_scale
+    from difformer_amd import DIFFormer
+    c = GRAD[name]
+    cfg, sd = split_model_case(c)
+    kw = {k: cfg[k] for k in ("num_layers", "num_heads", "kernel", "alpha", "use_bn", "use_residual", "use_weight",
+                              "use_graph", "graph_weight", "use_source")}
+    kw["kernel"] = str(kw["kernel"])
+    model = DIFFormer(int(cfg["in_channels"]), int(cfg["hidden_channels"]), int(cfg["out_channels"]), dropout=0.0, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.train()
+    x = torch.from_numpy(c["x"]).requires_grad_(True)
+    ei = torch.from_numpy(c["edge_index"]) if cfg["use_graph"] else None
+    w = torch.from_numpy(c["edge_weight"]).requires_grad_(True) if "edge_weight" in c else None
+    out = model(x, ei, w)
+    idx, y = torch.from_numpy(c["train_idx"]), torch.from_numpy(c["y"])
+    if str(c["loss_kind"]) == "bce":
+        loss = F.binary_cross_entropy_with_logits(out[idx], y[idx])
+    else:
+        loss = F.nll_loss(F.log_softmax(out, dim=1)[idx], y[idx])
+    loss.backward()
+    assert rel_err(out.detach().numpy(), c["out_f64"]) < 1e-4
+    assert abs(float(loss.detach()) - float(c["loss_f64"])) < 1e-4 * abs(float(c["loss_f64"]))
+    gmax = grad_scale(c)
+    assert grad_err(x.grad.numpy(), c["dx_f64"], gmax) < 1e-4
+    if w is not None:
+        got, ref = w.grad.numpy(), c["dw_f64"]
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert grad_err(np.nan_to_num(got), np.nan_to_num(ref), gmax) < 1e-4
+    for k, p in model.named_parameters():
+        ref = c["grad_f64/" + k]
+        got = np.zeros_like(ref) if p.grad is None else p.grad.numpy()
+        assert grad_err(got, ref, gmax) < 1e-4, k
