@@ -32,10 +32,23 @@ namespace {
 
 using dif::f32x4;
 
-constexpr int kTileRowsMax = 10208;              // + 16 zero rows = 10,224 rows x 16 B = 163,584 B of LDS
+// Geometry knobs of measurement builds (profiles/r03_experiments.md): the default is one 16-wave workgroup per CU with the
+// whole LDS; -DDIF_SLICED_TILE_ROWS=5104 -DDIF_SLICED_MAX_WAVES=8 -DDIF_SLICED_WG_PER_CU=2 builds two 8-wave workgroups
+// per CU with 80 KiB each (one drains / loads its tile while the other computes; half-length lists).
+#ifndef DIF_SLICED_TILE_ROWS
+#define DIF_SLICED_TILE_ROWS 10208
+#endif
+#ifndef DIF_SLICED_MAX_WAVES
+#define DIF_SLICED_MAX_WAVES 16
+#endif
+#ifndef DIF_SLICED_WG_PER_CU
+#define DIF_SLICED_WG_PER_CU 1
+#endif
+constexpr int kTileRowsMax = DIF_SLICED_TILE_ROWS;   // + 16 zero rows = 10,224 rows x 16 B = 163,584 B of LDS
 constexpr int kLdsRows = kTileRowsMax + 16;
+constexpr int kWgPerCU = DIF_SLICED_WG_PER_CU;
 constexpr int kMaxRounds = 10;                   // destination rows per lane (float4 accumulator + entry registers each)
-constexpr int kMaxWaves = 16;
+constexpr int kMaxWaves = DIF_SLICED_MAX_WAVES;
 constexpr int kGroupCap = 65535;                 // entries of one (row, tile) group (16-bit counters)
 
 // lane sets that share one LDS cycle of a ds_read_b128 (MI355X_MICROARCH.md, LDS table): position -> lane
@@ -61,7 +74,7 @@ int make_plan(int64_t n_src, int64_t n_rows, int F, Plan& p) {
     if (n_src <= 0 || n_rows <= 0 || F <= 0 || F % 4 != 0 || F / 4 > 256) return DIF_E_SHAPE;
     p.slices = F / 4;
     const int64_t G = (n_rows + 63) / 64;
-    int64_t panels = dif::kCUs / p.slices;
+    int64_t panels = dif::kCUs * kWgPerCU / p.slices;
     if (panels < 1) panels = 1;
     const int64_t cap = static_cast<int64_t>(kMaxWaves) * kMaxRounds;            // slots one workgroup can own
     if (panels * cap < G) panels = (G + cap - 1) / cap;
@@ -754,7 +767,7 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
 }
 
 template <int R>
-__global__ __launch_bounds__(64 * kMaxWaves) void sliced_spmm_kernel(const uint4* __restrict__ ell, const int32_t* __restrict__ tab,
+__global__ __launch_bounds__(64 * kMaxWaves, (kWgPerCU * kMaxWaves + 3) / 4) void sliced_spmm_kernel(const uint4* __restrict__ ell, const int32_t* __restrict__ tab,
                                                                      const f32x4* __restrict__ ys, int64_t npad, Plan pl,
                                                                      Epilogue ep) {
     __shared__ f32x4 tile[kLdsRows];
