@@ -1,0 +1,221 @@
+"""The reference's own CALLERS executed against the drop-in: `parse.py` of every task folder is
+loaded verbatim with `difformer` resolving to `dropin/difformer.py` (or `dropin/physical_particle/difformer.py`), every
+`--method difformer` command line of the folder's `run.sh` goes through the reference's own `parser_add_main_args`, and
+`parse_method(...)` builds the model exactly as `main.py` does (node classification/main.py:30-31,82; image and
+text/main.py:31-32,77; spatial-temporal/main.py:24-25,70; physical particle/main.py:27-28,53).  Then what the scripts do with
+it: `reset_parameters()` (main.py:110), one forward with the script's call shape (main.py:118; spatial-temporal/main.py:105
+passes `edge_attr` positionally; physical particle/main.py:85 passes `n_nodes`), and a strict `state_dict` round trip
+(test_large_dataset.py:88).
+
+CPU test: the arithmetic runs on tests/fake_backend.OracleBackend; skipped where /root/reference is absent (GPU box).
+The baseline-GNN zoo the reference's `gnns.py` / `models.py` import (torch_geometric.nn, torch_sparse) is out of scope
+and absent from this image: those imports resolve to inert stubs -- only the `difformer` branch of parse_method is run.
+"""
+import argparse
+import importlib.util
+import os
+import re
+import shlex
+import sys
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+
+from fake_backend import OracleBackend
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
+
+
+@pytest.fixture()
+def fake_backend(monkeypatch):
+    from difformer_amd import ops
+    be = OracleBackend()
+    monkeypatch.setattr(ops, "_BACKEND", be)
+    ops.csr_cache.clear()
+    yield be
+    ops.csr_cache.clear()
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m
+
+
+class _Inert(nn.Module):
+    """Stands in for the torch_geometric layers of the baseline zoo (never instantiated here)."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+def _load(folder, dropin_file, extra=()):
+    """-> the folder's `parse` module, loaded from the reference source with `difformer` = the drop-in."""
+    saved = {k: sys.modules.get(k) for k in ("difformer", "gnns", "models", "parse", "data_utils", "torch_sparse",
+                                              "torch_geometric", "torch_geometric.nn", "torch_geometric.nn.conv",
+                                              "torch_geometric.nn.conv.gcn_conv", "torch_geometric.utils")}
+    layers = {n: _Inert for n in ("GCNConv", "SGConv", "GATConv", "JumpingKnowledge", "APPNP", "MessagePassing", "GINConv",
+                                  "global_mean_pool", "global_add_pool", "global_max_pool", "InstanceNorm", "SAGEConv")}
+    tg_nn = _stub("torch_geometric.nn", **layers)
+    tg_nn.__getattr__ = lambda name: _Inert                           # whatever else the zoo imports
+    tg_conv = _stub("torch_geometric.nn.conv", MessagePassing=_Inert)
+    tg_gcn = _stub("torch_geometric.nn.conv.gcn_conv", gcn_norm=lambda *a, **k: None)
+    tg_utils = _stub("torch_geometric.utils", to_dense_adj=None, dense_to_sparse=None, degree=None)
+    tg = _stub("torch_geometric", nn=tg_nn, utils=tg_utils)
+    ts = _stub("torch_sparse", SparseTensor=object, matmul=None)
+    sys.modules.update({"torch_sparse": ts, "torch_geometric": tg, "torch_geometric.nn": tg_nn,
+                        "torch_geometric.nn.conv": tg_conv, "torch_geometric.nn.conv.gcn_conv": tg_gcn,
+                        "torch_geometric.utils": tg_utils})
+    spec = importlib.util.spec_from_file_location("difformer", os.path.join(ROOT, "dropin", dropin_file))
+    dropin = importlib.util.module_from_spec(spec)
+    sys.modules["difformer"] = dropin                                   # what `from difformer import *` finds
+    spec.loader.exec_module(dropin)
+    path = os.path.join(REF, folder)
+    sys.path.insert(0, path)
+    try:
+        for dep in extra + ("parse",):
+            sys.modules.pop(dep, None)
+            sp = importlib.util.spec_from_file_location(dep, os.path.join(path, dep + ".py"))
+            mod = importlib.util.module_from_spec(sp)
+            sys.modules[dep] = mod
+            sp.loader.exec_module(mod)
+        return sys.modules["parse"], dropin
+    finally:
+        sys.path.remove(path)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _difformer_commands(folder, script="run.sh"):
+    """The `--method difformer` command lines of a run script -> list of argv lists (shell variables -> '1')."""
+    text = open(os.path.join(REF, folder, script)).read().replace("\\\n", " ")
+    out = []
+    for line in text.splitlines():
+        line = line.strip()
+        m = re.match(r"python\s+(main(?:-batch)?\.py|test_large_dataset\.py)\s+(.*)", line)
+        if not m or "--method difformer" not in line:
+            continue
+        args = re.sub(r"\$\{?\w+\}?", "1", m.group(2))
+        out.append(shlex.split(args))
+    return out
+
+
+def _args(parse, argv):
+    parser = argparse.ArgumentParser()
+    parse.parser_add_main_args(parser)
+    return parser.parse_args(argv)
+
+
+def _graph(n, e, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.cat([torch.randint(0, n, (2, e), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+
+
+def _roundtrip(model, rebuild):
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    other = rebuild()
+    missing = other.load_state_dict(sd, strict=True)                    # test_large_dataset.py:88
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return other
+
+
+NODE_CMDS = _difformer_commands("node classification") if os.path.isdir(REF) else []
+
+
+def test_run_scripts_were_found():
+    assert len(NODE_CMDS) >= 14                                         # run.sh: cora ... chameleon
+    assert len(_difformer_commands("image and text")) >= 7
+    assert len(_difformer_commands("spatial-temporal")) >= 12
+    assert len(_difformer_commands("physical particle")) >= 6
+    assert len(_difformer_commands("node classification", "run_test_large.sh")) == 2
+
+
+@pytest.mark.parametrize("script", ["run.sh", "run_test_large.sh"])
+def test_node_classification_callers(script, fake_backend):
+    parse, dropin = _load("node classification", "difformer.py", extra=("gnns",))
+    assert parse.DIFFormer is dropin.DIFFormer                          # `from difformer import *` (parse.py:2)
+    n, c, d = 60, 5, 12
+    x, ei = torch.randn(n, d), _graph(n, 200)
+    for argv in _difformer_commands("node classification", script):
+        args = _args(parse, argv)
+        model = parse.parse_method(args, n, c, d, torch.device("cpu"))   # parse.py:4-8
+        assert isinstance(model, dropin.DIFFormer) and len(model.convs) == args.num_layers
+        assert model.convs[0].use_graph == args.use_graph and model.convs[0].use_weight == args.use_weight
+        assert model.convs[0].kernel == args.kernel and model.convs[0].num_heads == args.num_heads
+        model.reset_parameters()                                         # main.py:110
+        model.eval()
+        xin = x
+        with torch.no_grad():
+            out = model(xin, ei)                                         # main.py:118 / eval.py:10
+        assert out.shape == (n, c) and torch.isfinite(out).all()
+        other = _roundtrip(model, lambda: parse.parse_method(args, n, c, d, torch.device("cpu")))
+        with torch.no_grad():
+            assert torch.equal(other.eval()(xin, ei), out)
+
+
+def test_image_and_text_callers(fake_backend):
+    parse, dropin = _load("image and text", "difformer.py", extra=("gnns", "data_utils"))
+    n, c, d = 48, 10, 20
+    x = torch.randn(n, d)
+    for argv in _difformer_commands("image and text"):
+        args = _args(parse, argv)
+        model = parse.parse_method(args, None, n, c, d, torch.device("cpu"))     # parse.py:5, :64-65
+        assert isinstance(model, dropin.DIFFormer)
+        model.reset_parameters()
+        model.eval()
+        ei = _graph(n, 150) if args.use_graph else None                  # Readme.md:54-55: no graph -> edge_index None
+        with torch.no_grad():
+            out = model(x, ei)                                           # main.py:101
+        assert out.shape == (n, c) and torch.isfinite(out).all()
+        _roundtrip(model, lambda: parse.parse_method(args, None, n, c, d, torch.device("cpu")))
+
+
+def test_spatial_temporal_callers(fake_backend):
+    parse, dropin = _load("spatial-temporal", "difformer.py", extra=("gnns",))
+    assert parse.DIFFormer is dropin.DIFFormer                          # `from difformer import DIFFormer` (parse.py:2)
+    n, c, d = 20, 1, 4
+    x, ei = torch.randn(n, d), _graph(n, 60)
+    edge_attr = torch.rand(ei.shape[1]) + 0.1
+    for script in ("run.sh", "run_hyper_search.sh"):
+        for argv in _difformer_commands("spatial-temporal", script):
+            args = _args(parse, argv)
+            model, suffix = parse.parse_method(args, n, c, d, torch.device("cpu"))   # parse.py:54-57
+            assert isinstance(model, dropin.DIFFormer) and "kernel" + args.kernel in suffix
+            model.reset_parameters()
+            model.eval()
+            with torch.no_grad():
+                out = model(x, ei, edge_attr)                            # main.py:105: edge_attr positional
+            assert out.shape == (n, c) and torch.isfinite(out).all()
+            _roundtrip(model, lambda: parse.parse_method(args, n, c, d, torch.device("cpu"))[0])
+
+
+def test_physical_particle_callers(fake_backend):
+    parse, dropin = _load("physical particle", os.path.join("physical_particle", "difformer.py"), extra=("models",))
+    assert parse.DIFFormer_v2 is dropin.DIFFormer_v2                    # parse.py:3
+    n_nodes = torch.tensor([7, 3, 12, 5])
+    n, d = int(n_nodes.sum()), 6
+    x = torch.randn(n, d)
+    parts, off = [], 0
+    for nb in n_nodes.tolist():
+        parts.append(_graph(nb, 3 * nb, seed=nb) + off)
+        off += nb
+    ei = torch.cat(parts, dim=1)
+    for argv in _difformer_commands("physical particle"):
+        args = _args(parse, argv)
+        model = parse.parse_method(args, 1, d, torch.device("cpu"))      # parse.py:5, :20-32
+        assert isinstance(model, dropin.DIFFormer_v2)
+        model.reset_parameters()
+        model.eval()
+        with torch.no_grad():
+            out = model(x, ei, n_nodes)                                  # main.py:85 (through models.GraphModel)
+        assert out.shape == (n, args.hidden_channels) and torch.isfinite(out).all()
+        _roundtrip(model, lambda: parse.parse_method(args, 1, d, torch.device("cpu")))
