@@ -232,18 +232,21 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = g @ weight
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[1] or (len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]):
             n, co = g.shape
             ci = x.shape[1]
             g3 = g.reshape(n, 1, co)
-            red = ops.get_backend().simple_reduce(g3, g3, x.detach().reshape(n, 1, ci))
-            gw, gb = red[: co * ci].view(co, ci), red[co * ci: co * ci + co]
+            red = ops.get_backend().simple_reduce(g3, g3, x.detach().reshape(n, 1, ci))     # one pass yields both
+            if ctx.needs_input_grad[1]:
+                gw = red[: co * ci].view(co, ci)
+            if ctx.needs_input_grad[2]:
+                gb = red[co * ci: co * ci + co]
         return gx, gw, gb
 
 
 def _row_linear(x, weight, bias):
     ok = (x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[0] >= 1024
-          and x.shape[1] <= 256 and weight.shape[0] <= 256)
+          and x.shape[1] <= 256 and weight.shape[0] <= 256 and bias is not None)
     return _Linear.apply(x, weight, bias) if ok else torch.nn.functional.linear(x, weight, bias)
 
 

@@ -86,6 +86,24 @@ class DIFFormerConv(nn.Module):
         self.Wq.reset_parameters()
         if self.use_weight:
             self.Wv.reset_parameters()
+        self.invalidate_caches()
+
+    def invalidate_caches(self):
+        """Drop the inference-time caches derived from the parameters (concatenated projections, weight-only factors of
+        the closed form).  They are keyed on (data_ptr, _version) of the parameters, which in-place optimiser steps,
+        `copy_` and `load_state_dict` bump -- but writes through `.data` (EMA, weight averaging, manual loading) do not:
+        call this (or `DIFFormer.invalidate_caches()`) after such an update."""
+        self._fused_wb = self._wide = self._narrow = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_caches()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_caches()
+        return out
 
     # -- projections: one fused GEMM when query and source are the same tensor -----------------
     def _project(self, query_input, source_input):
@@ -99,8 +117,8 @@ class DIFFormerConv(nn.Module):
             else:
                 # inference: the concatenation is rebuilt only when a parameter changes (in-place optimiser steps and
                 # load_state_dict bump _version; .to() replaces the tensors) -- two concat kernels per layer otherwise
-                key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in params)
-                if self._fused_wb is None or self._fused_wb[0] != key:
+                key = ops.param_key(params)
+                if key is None or self._fused_wb is None or self._fused_wb[0] != key:
                     with torch.no_grad():
                         self._fused_wb = (key, torch.cat([m.weight for m in mods], dim=0),
                                           torch.cat([m.bias for m in mods], dim=0))
@@ -176,8 +194,8 @@ class DIFFormerConv(nn.Module):
             Wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
             if x.shape[1] > 64 or self.out_channels > 64:          # the scripts' widths (hidden 128 / 300 / 400)
                 params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias] + ([Wv, bv] if self.use_weight else [])
-                key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in params)
-                if self._wide is None or self._wide[0] != key:      # weight-only factors: rebuilt when a parameter changes
+                key = ops.param_key(params)
+                if key is None or self._wide is None or self._wide[0] != key:      # weight-only factors: rebuilt when a parameter changes
                     with torch.no_grad():
                         self._wide = (key, ops.WideCoefficients(self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias,
                                                                 Wv, bv))
@@ -187,8 +205,8 @@ class DIFFormerConv(nn.Module):
             factors = None
             if csr is not None and shard is None and x.dtype == torch.float32 and hasattr(ops.get_backend(), "coeffs_bg"):
                 params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias] + ([Wv, bv] if self.use_weight else [])
-                key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in params)
-                if self._narrow is None or self._narrow[0] != key:   # weight-only factors of the background coefficient chain
+                key = ops.param_key(params)
+                if key is None or self._narrow is None or self._narrow[0] != key:   # weight-only factors of the background coefficient chain
                     with torch.no_grad():
                         self._narrow = (key, ops.NarrowFactors(self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias,
                                                                Wv, bv))
@@ -282,6 +300,23 @@ class DIFFormer(nn.Module):
             bn.reset_parameters()
         for fc in self.fcs:
             fc.reset_parameters()
+
+    def invalidate_caches(self):
+        """Forget everything cached from the parameters (see DIFFormerConv.invalidate_caches): needed only after
+        updates that bypass the version counter (`p.data.copy_()`, `p.data.mul_()`, ...)."""
+        for conv in self.convs:
+            conv.invalidate_caches()
+        ops.invalidate_param_caches()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_caches()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_caches()
+        return out
 
     def set_row_shard(self, shard):
         """Multi-GPU: `shard` (dist.RowShard) says which contiguous block of node rows this rank

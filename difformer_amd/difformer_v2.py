@@ -63,14 +63,29 @@ class TransConv(nn.Module):
         if self.use_weight:
             self.Wv.reset_parameters()
 
+    def invalidate_caches(self):
+        """Drop the cached concatenation of the projections (needed after parameter writes through `.data`, which do not
+        bump the version counter the cache is keyed on)."""
+        self._cat_key = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_caches()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_caches()
+        return out
+
     def _project(self, query_input, source_input):
         """Wq / Wk / Wv (:143-146).  Same input and nothing to differentiate: ONE narrow-Linear launch over the
         concatenated weights (x read once); q, k, v are then column slices of its [n, 3*H*D] result."""
         H, D = self.num_heads, self.out_channels
         params = (self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, self.Wv.weight, self.Wv.bias)
         if query_input is source_input and source_input.shape[1] <= 64 and not ag._needs_grad(source_input, *params):
-            key = tuple((p.data_ptr(), p._version) for p in params)
-            if getattr(self, "_cat_key", None) != key:
+            key = ops.param_key(params)
+            if key is None or getattr(self, "_cat_key", None) != key:
                 self._cat_w = torch.cat([self.Wq.weight, self.Wk.weight, self.Wv.weight], dim=0).detach().contiguous()
                 self._cat_b = torch.cat([self.Wq.bias, self.Wk.bias, self.Wv.bias], dim=0).detach().contiguous()
                 self._cat_key = key
@@ -140,6 +155,10 @@ class DIFFormer_v2(nn.Module):
             bn.reset_parameters()
         for fc in self.fcs:
             fc.reset_parameters()
+
+    def invalidate_caches(self):
+        for conv in self.convs:
+            conv.invalidate_caches()
 
     def forward(self, x, edge_index, n_nodes):
         layer_ = []

@@ -51,6 +51,8 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
         ops.csr_cache.reserve(nb + ops.csr_cache.capacity)
         for b, (eb, wb) in enumerate(out):
             lo, hi = b * bs, min((b + 1) * bs, m)
+            if ops.csr_cache.blocking(eb, wb, hi - lo) != (1, 0):
+                continue        # a dense batch: `get` builds the tiled CSR of the sliced product itself (different key)
             rp = (rowptr[lo: hi + 1] - ptr[b]).contiguous()
             e0, e1 = ptr[b], ptr[b + 1]
             g = ops.GraphCSR(rp, None, 1, src[e0: max(e1, e0 + 1)], val[e0: max(e1, e0 + 1)], hi - lo, e1 - e0)
@@ -61,7 +63,10 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
 
 
 def _n(edge_index, num_nodes):
-    return int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
+    """Node count: the caller's, else max id + 1 (one host sync, as torch_geometric's maybe_num_nodes; 0 for no edges)."""
+    if num_nodes is not None:
+        return int(num_nodes)
+    return int(edge_index.max().item()) + 1 if edge_index.numel() else 0
 
 
 def add_self_loops(edge_index, edge_weight=None, fill_value=1.0, num_nodes=None):
@@ -69,20 +74,26 @@ def add_self_loops(edge_index, edge_weight=None, fill_value=1.0, num_nodes=None)
     n = _n(edge_index, num_nodes)
     if edge_weight is not None:
         edge_weight = torch.cat([edge_weight, edge_weight.new_full((n,), fill_value)])
+    if edge_index.numel() == 0:
+        loops = torch.arange(n, device=edge_index.device, dtype=edge_index.dtype)
+        return torch.stack([loops, loops]), edge_weight
     return ops.get_backend().graph_prepare(edge_index, n, add_loops=True), edge_weight
 
 
 def remove_self_loops(edge_index, edge_attr=None):
     """main.py:75, main-batch.py:97: edges (v, v) dropped, order kept (HIP: dif_graph_prepare).  With attributes the
     filter is a mask (the attributes have to follow the same selection)."""
-    if edge_attr is not None:
+    if edge_attr is not None or edge_index.numel() == 0:
+        # a mask needs no node count (no host sync) and handles the empty edge list
         keep = edge_index[0] != edge_index[1]
-        return edge_index[:, keep], edge_attr[keep]
+        return edge_index[:, keep], (None if edge_attr is None else edge_attr[keep])
     return ops.get_backend().graph_prepare(edge_index, _n(edge_index, None), remove_loops=True), None
 
 
 def to_undirected(edge_index, num_nodes=None):
     """main.py:73: both directions of every edge, duplicates removed, sorted by (row, col) (HIP: dif_graph_prepare)."""
+    if edge_index.numel() == 0:
+        return edge_index
     return ops.get_backend().graph_prepare(edge_index, _n(edge_index, num_nodes), undirected=True)
 
 

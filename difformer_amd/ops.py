@@ -22,6 +22,29 @@ from .dist import RowShard
 _BACKEND = None
 
 
+def tensor_version(t):
+    """`t._version`, or -1 for tensors that do not track one (created under torch.inference_mode())."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
+def param_key(params):
+    """Identity + version key of a list of parameters for the inference-time caches (concatenated projections,
+    weight-only factors of the closed form, float32 copies), or None when a version cannot be read (inference tensors):
+    the caller then rebuilds instead of caching.  NOTE: writes through `.data` (`p.data.copy_()`, EMA / weight averaging
+    done on `.data`) do NOT bump the version counter -- call `model.invalidate_caches()` after such an update
+    (`load_state_dict` and `.to()` / `.half()` / ... do it themselves)."""
+    key = []
+    for t in params:
+        v = tensor_version(t)
+        if v < 0:
+            return None
+        key.append((t.data_ptr(), v, t.dtype, t.device))
+    return tuple(key)
+
+
 def get_backend():
     """The HIP backend (created on first use; import fails loudly if the .so is missing)."""
     global _BACKEND
@@ -351,13 +374,13 @@ class _CSRCache:
 
     @staticmethod
     def _key(edge_index, edge_weight, num_nodes, n_blocks, block_rows=0):
-        k = (id(edge_index), edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes),
+        k = (id(edge_index), edge_index.data_ptr(), tuple(edge_index.shape), tensor_version(edge_index), int(num_nodes),
              int(n_blocks), int(block_rows), str(edge_index.device))
         if edge_weight is not None:
-            k += (id(edge_weight), edge_weight.data_ptr(), edge_weight._version)
+            k += (id(edge_weight), edge_weight.data_ptr(), tensor_version(edge_weight))
         return k
 
-    def get(self, edge_index, edge_weight, num_nodes, row_bytes=256, shard=None, elem_size=4):
+    def get(self, edge_index, edge_weight, num_nodes, row_bytes=256, shard=None, elem_size=4, build_format=True):
         """`row_bytes` = bytes of one feature row the SpMM will gather (H*D*elem_size); picks the blocking -- the
         tiling of the feature-sliced product for dense unweighted fp32 graphs, else ~2.5 MiB source blocks, aligned
         with the rank boundaries of `shard` when the run is row-sharded."""
@@ -369,12 +392,7 @@ class _CSRCache:
             raise NotImplementedError("difformer_amd: gradients with respect to edge_weight are not implemented for "
                                       "row-sharded runs; detach() it or keep it a constant of the graph")
         self._purge()
-        tiling = sliced_tiling(num_nodes, row_bytes // elem_size, edge_index.shape[1], edge_weight, shard, elem_size)
-        aligned = choose_shard_blocks(num_nodes, row_bytes, edge_index.shape[1], shard)
-        if tiling is not None:
-            n_blocks, block_rows = tiling if tiling[0] > 1 else (1, 0)
-        else:
-            n_blocks, block_rows = aligned if aligned else (choose_source_blocks(num_nodes, row_bytes, edge_index.shape[1]), 0)
+        n_blocks, block_rows = self.blocking(edge_index, edge_weight, num_nodes, row_bytes, shard, elem_size)
         key = self._key(edge_index, edge_weight, num_nodes, n_blocks, block_rows)
         hit = self.entries.get(key)
         if hit is not None:
@@ -384,11 +402,39 @@ class _CSRCache:
                 return csr
             del self.entries[key]
         csr = GraphCSR.build(edge_index, edge_weight, num_nodes, n_blocks, block_rows=block_rows)
+        F = row_bytes // elem_size
+        if build_format and sliced_tiling(num_nodes, F, edge_index.shape[1], edge_weight, shard, elem_size) is not None:
+            # the blocking above is the tiling of the sliced product: build its format now, and if the graph turns out not
+            # to fit it (a (row, tile) group beyond the 16-bit counters, a split plan with another tiling), fall back to a
+            # CSR blocked for the gather kernels instead of running them on a blocking that was never tuned for them
+            sharded = shard is not None and shard.world > 1
+            rb, nr = (shard.row_begin, shard.n_local) if sharded else (0, num_nodes)
+            if csr.sliced(rb, nr, F) is None:
+                aligned = choose_shard_blocks(num_nodes, row_bytes, edge_index.shape[1], shard)
+                nb2, br2 = aligned if aligned else (choose_source_blocks(num_nodes, row_bytes, edge_index.shape[1]), 0)
+                if (nb2, br2 or -(-int(num_nodes) // nb2)) != (csr.n_blocks, csr.block_rows):
+                    global _SLICED_FALLBACK_WARNED
+                    if not _SLICED_FALLBACK_WARNED:
+                        _SLICED_FALLBACK_WARNED = True
+                        import warnings
+                        warnings.warn("difformer_amd: this graph does not fit the feature-sliced product (see "
+                                      "GraphCSR._build_sliced); using the gather kernels on their own blocking")
+                    csr = GraphCSR.build(edge_index, edge_weight, num_nodes, nb2, block_rows=br2)
         self.entries[key] = (weakref.ref(edge_index), weakref.ref(edge_weight) if edge_weight is not None else None,
                              csr)
         while len(self.entries) > max(self.capacity, getattr(self, "_floor", 0)):
             self.entries.popitem(last=False)
         return csr
+
+    @staticmethod
+    def blocking(edge_index, edge_weight, num_nodes, row_bytes=256, shard=None, elem_size=4):
+        """(n_blocks, block_rows) of the CSR `get` builds for this graph: the tiling of the feature-sliced product for
+        dense unweighted fp32 graphs, else ~2.5 MiB source blocks (aligned with the rank boundaries of a row shard)."""
+        tiling = sliced_tiling(num_nodes, row_bytes // elem_size, edge_index.shape[1], edge_weight, shard, elem_size)
+        if tiling is not None:
+            return tiling if tiling[0] > 1 else (1, 0)
+        aligned = choose_shard_blocks(num_nodes, row_bytes, edge_index.shape[1], shard)
+        return aligned if aligned else (choose_source_blocks(num_nodes, row_bytes, edge_index.shape[1]), 0)
 
     def put(self, edge_index, edge_weight, num_nodes, csr):
         """Register a CSR built elsewhere (graph_utils.subgraph_batches: all batches of an epoch from one sort) under the
@@ -398,6 +444,11 @@ class _CSRCache:
         self.entries.move_to_end(key)
         while len(self.entries) > max(self.capacity, getattr(self, "_floor", 0)):
             self.entries.popitem(last=False)
+
+    def drop(self, edge_index):
+        """Forget every CSR built from this edge_index tensor (frees its HBM once no autograd node holds it)."""
+        for k in [k for k, (ei_ref, _, _) in self.entries.items() if ei_ref() is edge_index]:
+            del self.entries[k]
 
     def reserve(self, n):
         """Keep room for at least n entries (an epoch's worth of registered batches must not evict one another)."""
@@ -416,6 +467,7 @@ class _CSRCache:
         self.entries.clear()
 
 
+_SLICED_FALLBACK_WARNED = False
 csr_cache = _CSRCache()
 
 
@@ -451,7 +503,7 @@ class _MixCache:
         self.capacity, self.entries = capacity, OrderedDict()
 
     def get(self, edge_index, num_nodes, F):
-        key = (id(edge_index), edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes), int(F))
+        key = (id(edge_index), edge_index.data_ptr(), tuple(edge_index.shape), tensor_version(edge_index), int(num_nodes), int(F))
         hit = self.entries.get(key)
         if hit is not None and hit[0]() is edge_index:
             self.entries.move_to_end(key)
@@ -460,13 +512,14 @@ class _MixCache:
             del self.entries[k]
         mix = None
         if sliced_tiling(num_nodes, F, edge_index.shape[1], None, None, 4) is not None:
-            csr = csr_cache.get(edge_index, None, num_nodes, F * 4)
+            csr = csr_cache.get(edge_index, None, num_nodes, F * 4, build_format=False)     # probe: pointers only
             if csr.n_blocks > 1 and csr.blkptr is not None:
                 cnt = csr.blkptr.view(csr.n_blocks + 1, num_nodes)
                 cnt = (cnt[1:] - cnt[:-1]).to(torch.float32)                    # entries per (tile, row)
                 share = float((cnt.max(dim=0).values.sum() * csr.n_blocks / max(csr.nnz, 1)).item())     # one sync, cold path
                 if share > MIX_THRESHOLD:
                     mix = MixedGraph(edge_index, num_nodes)
+                    csr_cache.drop(edge_index)      # the forward runs on the relabelled graph: the probe CSR is dead weight
         self.entries[key] = (weakref.ref(edge_index), mix)
         while len(self.entries) > self.capacity:
             self.entries.popitem(last=False)
@@ -600,7 +653,10 @@ def f32_param(t):
     the CSR cache); float32 tensors pass through.  The closed-form kernels take their coefficients in float32."""
     if t is None or t.dtype == torch.float32:
         return t
-    key = (id(t), t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+    ver = tensor_version(t)
+    if ver < 0:
+        return t.detach().to(torch.float32).contiguous()       # version unreadable (inference tensor): never cached
+    key = (id(t), t.data_ptr(), ver, tuple(t.shape), str(t.device))
     hit = _F32_PARAMS.get(key)
     if hit is not None and hit[0]() is t:
         _F32_PARAMS.move_to_end(key)
@@ -610,6 +666,11 @@ def f32_param(t):
     while len(_F32_PARAMS) > 256:
         _F32_PARAMS.popitem(last=False)
     return c
+
+
+def invalidate_param_caches():
+    """Forget the cached float32 copies of bfloat16 parameters (see param_key for when this is needed)."""
+    _F32_PARAMS.clear()
 
 
 def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
@@ -802,7 +863,7 @@ class _LayoutCache:
         if not torch.is_tensor(n_nodes):
             n_nodes = torch.as_tensor(n_nodes)
             return BatchLayout(n_nodes, device)
-        key = (id(n_nodes), n_nodes.data_ptr(), tuple(n_nodes.shape), n_nodes._version, str(device))
+        key = (id(n_nodes), n_nodes.data_ptr(), tuple(n_nodes.shape), tensor_version(n_nodes), str(device))
         hit = self.entries.get(key)
         if hit is not None:
             ref, lay = hit

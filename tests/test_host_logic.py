@@ -452,3 +452,33 @@ def test_training_step_plumbing_against_reference_gradients(name, fake_backend):
         ref = c["grad_f64/" + k]
         got = np.zeros_like(ref) if p.grad is None else p.grad.numpy()
         assert grad_err(got, ref, gmax) < 1e-4, k
+
+
+def test_parameter_caches_invalidate(fake_backend):
+    """the inference caches are keyed on (data_ptr, _version); `.data` writes bypass the version counter, so
+    there is an explicit hook, and load_state_dict / _apply / reset_parameters call it.  Parameters made under
+    inference_mode (no version counter) are never cached."""
+    from difformer_amd import DIFFormer, ops
+    torch.manual_seed(0)
+    model = DIFFormer(8, 16, 3, num_layers=2, num_heads=2, kernel="sigmoid", use_graph=False).eval()
+    x = torch.randn(30, 8)
+    with torch.no_grad():
+        a = model(x, None)
+        assert model.convs[0]._fused_wb is not None
+        model.convs[0].Wq.weight.data.mul_(2.0)                 # bypasses _version: stale cache until invalidated
+        model.invalidate_caches()
+        assert model.convs[0]._fused_wb is None
+        b = model(x, None)
+        assert not torch.allclose(a, b)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        model(x, None)
+        model.load_state_dict(sd)
+        assert model.convs[0]._fused_wb is None
+        model(x, None)
+        model.double().float()
+        assert model.convs[1]._fused_wb is None
+    with torch.inference_mode():
+        w = torch.randn(4, 4)
+        ei = torch.randint(0, 30, (2, 50))
+    assert ops.tensor_version(w) == -1 and ops.param_key([w]) is None
+    assert ops.csr_cache.get(ei, None, 30) is ops.csr_cache.get(ei, None, 30)      # keyed without a version, no raise
