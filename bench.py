@@ -35,6 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.0   # fp32-input MFMA, dense (same guide)
+LDS_PEAK_TBS = 256 * 256 * 2.4e9 / 1e12   # 256 CUs x 256 B/clk (ds_read_b128 / b64) at 2.4 GHz = 157 TB/s (same guide, LDS table)
 
 WORKLOADS = {
     # name: (N, undirected pairs, F_in, classes, hidden, layers, kernel, use_graph)
@@ -54,9 +56,16 @@ WORKLOADS = {
     # node ids grouped by species): 8 contiguous blocks, 95 % of the edges inside a block; the model runs it in a mixed
     # node order (ops.MixedGraph); not the headline line
     "ogbn-proteins-blocks-s": (132534, 39561252, 8, 112, 64, 4, "simple", True),
+    # ... and with BOTH: Zipf degrees inside 8 communities (mixing + hub splitting together); not the headline line
+    "ogbn-proteins-zipf-blocks-s": (132534, 39561252, 8, 112, 64, 4, "simple", True),
+    # the full-graph Pokec forward of the evaluation path (node classification/eval.py:40-43, main-batch.py:144-145: after
+    # mini-batch training the model runs ONCE over the whole graph): N = 1,632,803, 15.4 M undirected pairs + loops =
+    # 32.4 M entries (mean degree ~19: gather kernel), F_in = 65, C = 2, 3 layers, hidden 64 / 128 (run.sh:42-44)
+    "pokec-full-s": (1632803, 15400000, 65, 2, 64, 3, "simple", True),
+    "pokec-full-h128": (1632803, 15400000, 65, 2, 128, 3, "simple", True),
     # the widths the reference's scripts train with (node classification/run.sh:42-44 hidden 128 on Pokec batches;
-    # image and text/run.sh:27 hidden 300): wider than the closed-form / fused-projection kernels (<= 64), so the
-    # projections run on the vendor GEMM and the attention on the stand-alone reduce / apply kernels
+    # image and text/run.sh:27 hidden 300): hidden 128 takes the operator path (projections on the vendor GEMM, stand-alone
+    # reduce / wide apply kernels), hidden 300 the closed form on library GEMMs around the hand-written Gram / tail passes
     "pokec-batch-h128": (100000, 115000, 65, 2, 128, 3, "simple", True),
     "cifar50k-h300": (50000, 0, 512, 10, 300, 4, "simple", False),
 }
@@ -64,7 +73,24 @@ WORKLOADS = {
 
 def make_graph(n, pairs, dev, zipf=False, blocks=0):
     g = torch.Generator(device=dev).manual_seed(0)
-    if blocks:
+    if blocks and zipf:
+        # both properties of the real ogbn-proteins at once: `blocks` contiguous groups of nodes (species) with 95 % of the
+        # pairs inside the group of their first endpoint, AND skewed degrees (endpoint probability ~ (rank + 1100)^-0.75,
+        # ranks scattered over the ids: max / mean degree ~ 13) inside every group
+        size = -(-n // blocks)
+        rank_of = torch.randperm(n, generator=g, device=dev)
+        w = (rank_of.to(torch.float64) + 1100.0) ** -0.75                       # weight of node id v
+        cdf = torch.cumsum(w, 0)
+        draw = lambda lo, hi: torch.searchsorted(cdf, lo + torch.rand(pairs, generator=g, device=dev, dtype=torch.float64)
+                                                 * (hi - lo)).clamp_(max=n - 1)
+        zero = torch.zeros(pairs, device=dev, dtype=torch.float64)
+        a = draw(zero, cdf[-1].expand(pairs))
+        first = (a // size) * size
+        last = (first + size).clamp_(max=n) - 1
+        lo = torch.where(first > 0, cdf[(first - 1).clamp_(min=0)], zero)
+        inside = torch.rand(pairs, generator=g, device=dev) < 0.95
+        b = torch.where(inside, draw(lo, cdf[last]), draw(zero, cdf[-1].expand(pairs)))
+    elif blocks:
         # `blocks` contiguous groups of nodes; 95 % of the pairs stay inside the group of their first endpoint
         size = -(-n // blocks)
         a = torch.randint(0, n, (pairs,), generator=g, device=dev)
@@ -150,6 +176,9 @@ def main():
                     help="replay the whole forward as one hipGraph (single GPU); per-kernel events then come from a "
                          "short eager pass after the timed region instead of from the timed region itself")
     ap.add_argument("--per-kernel", action="store_true", help="also print mean ms per C-ABI entry point (stderr)")
+    ap.add_argument("--shard-product", choices=["row", "slice"], default=os.environ.get("DIFFORMER_SHARD_PRODUCT", "row"),
+                    help="N > 1: how closed-form layers split the aggregation -- by destination rows (all-gather of the "
+                         "layer input; default) or by feature slices (two all-to-alls of 1/N of it; difformer_amd/dist.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,6 +219,7 @@ def main():
     assert shard is None or (shard.row_begin, shard.n_local) == (plan["row_begin"], plan["n_local"])
     x = x_full if shard is None else shard.local_rows(x_full).contiguous()
     if shard is not None:
+        shard.product = args.shard_product
         model.set_row_shard(shard)
     n_local = x.shape[0]
 
@@ -272,6 +302,13 @@ def main():
             dom, dom_name, dom_key = "dif_sliced_spmm_f32", "sliced_spmm_kernel (gcn_conv)", "sliced_spmm_kernel"
         else:
             dom, dom_name, dom_key = "dif_gcn_spmm_f32", "spmm_blocked_kernel (gcn_conv)", "spmm_blocked_kernel"
+    elif kernel == "simple" and ktimes.get("dif_gram_sym_f32"):
+        # closed form beyond 128 columns (hidden 300 / 400): the Gram pass X~^T X~ on the fp32 MFMA is the largest kernel;
+        # its bound is the matrix core, not HBM: N * C * (C + 1) FLOP for the tiles on and above the diagonal
+        dom, dom_key = "dif_gram_sym_f32", "simple_reduce_kernel"
+        dom_name = "simple_reduce_kernel<sym> (Gram record of the wide closed form)"
+        alg_bytes = 1.0 * n_local * hidden * 4
+        mfma_flop = 1.0 * n_local * hidden * (hidden + 1)
     elif kernel == "simple" and ktimes.get("dif_simple_layer_f32"):
         # closed-form layer: reads the layer input once, writes the output once (SURVEY 8d counts q, k, v, out: 4 N d s;
         # q, k, v never exist here)
@@ -291,7 +328,7 @@ def main():
     # correction + WRITE_SIZE, calibrated; scripts/pmc_traffic.sh) stored under profiles/ -- a counter run cannot
     # share a process with this timed run.  Only valid for the single-GPU workload it was collected on.
     traffic = tsrc = None
-    for tfile in ("r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
+    for tfile in ("r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
         tpath = os.path.join(ROOT, "profiles", tfile)
         if world == 1 and use_graph and os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -302,7 +339,36 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": tsrc,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms}
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                "avg_launch_ms_source": "HIP events on the launching stream, only this entry point bracketed (bench.py::dominant_alone)"}
+    if dom == "dif_gram_sym_f32" and dom_ms:
+        tf = mfma_flop / (dom_ms * 1e-3) / 1e12
+        roofline.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "algorithmic_flop_per_launch": mfma_flop})
+    if dom == "dif_sliced_spmm_f32" and dom_ms:
+        # What actually limits the sliced product is the LDS array (profiles/r03_experiments.md section 1): every entry is
+        # one 16-byte LDS read per 16-byte feature slice -- nnz x F x 4 bytes per launch whatever the padding -- against
+        # 256 B/clk/CU.  Reported beside the HBM figures the metric asks for.
+        lds_bytes = 1.0 * nnz * (n_local / n) * hidden * 4
+        lds_tbs = lds_bytes / (dom_ms * 1e-3) / 1e12
+        roofline["limiter"] = "lds"
+        roofline["lds"] = {"algorithmic_bytes_per_launch": lds_bytes, "achieved": lds_tbs, "peak": LDS_PEAK_TBS,
+                           "unit": "TB/s", "frac": lds_tbs / LDS_PEAK_TBS,
+                           "note": "one ds_read_b128 per (entry, 16-byte slice); peak = 256 CUs x 256 B/clk x 2.4 GHz; "
+                                   "padded lane-steps and the issue limit of the step are in profiles/r03_experiments.md"}
+    # the rocprofv3 figure the event bracket is checked against (same workload, tracked summary of this round if present)
+    import glob
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r03_*{args.workload}*kernel_stats.csv")), reverse=True):
+        try:
+            import csv
+            rows = [r for r in csv.DictReader(open(cand)) if r.get("Name", "").find(dom_key) >= 0]
+            if rows:
+                best = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+                roofline["avg_launch_ms_rocprofv3"] = float(best["AverageNs"]) / 1e6
+                roofline["rocprofv3_source"] = "profiles/" + os.path.basename(cand)
+                break
+        except Exception:
+            continue
 
     if args.per_kernel and rank == 0:
         for k, v in sorted(ktimes.items()):

@@ -187,7 +187,11 @@ class DIFFormerConv(nn.Module):
             if self.use_graph:
                 n_global = shard.n_global if shard is not None else x.shape[0]
                 esz = x.element_size()
-                csr = ops.csr_cache.get(edge_index, edge_weight, n_global, x.shape[1] * esz, shard, esz)
+                if ops.slice_sharded(shard, x.shape[1], x.dtype) and x.shape[1] <= 64 and self.out_channels <= 64:
+                    # slice-sharded product: every rank multiplies the WHOLE graph at its C / world columns
+                    csr = ops.csr_cache.get(edge_index, edge_weight, n_global, shard.slice_width(x.shape[1]) * esz, None, esz)
+                else:
+                    csr = ops.csr_cache.get(edge_index, edge_weight, n_global, x.shape[1] * esz, shard, esz)
             a_s, g_s = (1.0 - self.graph_weight, float(self.graph_weight)) if self.graph_weight > 0 else (1.0, 1.0)
             if not self.use_graph:
                 a_s = 1.0                                       # difformer.py:130-136: the mix only exists with a graph

@@ -9,6 +9,10 @@ exchange step:
   a3 gcn_conv         : destination rows are local but sources are arbitrary -> ONE all-gather of
                         the value rows, then a local SpMM over this rank's CSR row range
   a2 sigmoid attention: query rows local; all-gather K and V; row sums are local
+Closed-form layers (one head, inference) can also split the aggregation by FEATURE SLICES instead of rows
+(`RowShard.product = "slice"`): rank p multiplies all N rows of columns [p C/P, (p+1) C/P) -- an all-to-all of its rows'
+other column blocks in, one of the other ranks' rows of its block out (2 x N C 4 (P-1)/P^2 bytes per rank and layer,
+7.4 MB at C4 on 8 ranks) instead of an all-gather that delivers N C 4 (P-1)/P bytes (30 MB) to every rank.
 The collectives go through torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo"
 in the CPU tests).  The reduce buffer is latency-bound (far below the per-link bandwidth
 regime), the all-gather moves N*H*D*4 bytes per layer in one call.
@@ -52,6 +56,10 @@ class RowShard:
     # second communicator for the small all-reduce, so it can run while the all-gather of the value rows
     # (issued first, on `group`) is still in flight; None = use `group` for both (serialised)
     side_group: Optional[object] = None
+    # how the aggregation of a closed-form layer is split over the ranks: "row" = every rank gathers ALL source rows and
+    # multiplies its own destination rows (one all-gather of N*C elements per layer); "slice" = every rank multiplies ALL
+    # rows of ITS feature columns (two all-to-alls of N*C/world elements per rank and layer).  DIFFORMER_SHARD_PRODUCT.
+    product: str = field(default_factory=lambda: os.environ.get("DIFFORMER_SHARD_PRODUCT", "row"))
 
     def __post_init__(self):
         if not self.counts:
@@ -120,6 +128,31 @@ class RowShard:
             return None
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM,
                                group=self.side_group if self.side_group is not None else self.group, async_op=True)
+
+    # ---- slice-sharded product: columns out, columns back ------------------------------------
+    def slice_width(self, C: int) -> int:
+        """Feature columns per rank of the slice-sharded product, or 0 when C does not split into 16-byte slices."""
+        return C // self.world if (self.world > 1 and C % (4 * self.world) == 0) else 0
+
+    def all_to_all_columns(self, local: torch.Tensor) -> torch.Tensor:
+        """[n_local, C] (this rank's rows) -> [n_global, C / world]: column block `rank` of EVERY row.  Rank r sends
+        rank p the columns p*C/world .. of its rows: (world - 1) / world of N*C/world elements in and out per rank."""
+        P, n = self.world, self.n_local
+        w = local.shape[1] // P
+        send = local.reshape(n, P, w).permute(1, 0, 2).contiguous()            # [P, n_local, w]: destination-major
+        out = torch.empty((self.n_global, w), dtype=local.dtype, device=local.device)
+        dist.all_to_all_single(out, send.reshape(P * n, w), output_split_sizes=list(self.counts),
+                               input_split_sizes=[n] * P, group=self.group)
+        return out
+
+    def all_to_all_rows(self, cols: torch.Tensor) -> torch.Tensor:
+        """The inverse exchange: [n_global, C / world] (this rank's column block of every row) -> [n_local, C]."""
+        P, n = self.world, self.n_local
+        w = cols.shape[1]
+        recv = torch.empty((P * n, w), dtype=cols.dtype, device=cols.device)
+        dist.all_to_all_single(recv, cols.contiguous(), output_split_sizes=[n] * P, input_split_sizes=list(self.counts),
+                               group=self.group)
+        return recv.reshape(P, n, w).permute(1, 0, 2).reshape(n, P * w)
 
     def all_gather_rows_async(self, local: torch.Tensor):
         """Start the all-gather of the value rows and return a handle; `handle.wait()` gives the gathered tensor.

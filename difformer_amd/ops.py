@@ -673,6 +673,41 @@ def invalidate_param_caches():
     _F32_PARAMS.clear()
 
 
+def slice_sharded(shard, C, dtype=torch.float32):
+    """True when a closed-form layer of width C on this shard splits its aggregation by feature slices (dist.py)."""
+    return (shard is not None and shard.world > 1 and shard.product == "slice" and dtype == torch.float32 and
+            shard.slice_width(C) > 0)
+
+
+def _closed_form_slice_sharded(be, x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
+                               ln_bias, eps, relu, shard, head):
+    """The closed-form layer on a row shard with the aggregation split by FEATURE SLICES: this rank multiplies all
+    n_global destination rows of its C / world columns (the sliced product of the whole graph at that width -- or the
+    gather kernel where the graph does not take it), between two all-to-alls; Gram record, coefficients and the layer
+    kernel stay on the rank's own rows exactly as in the row-sharded layer.  `csr` is the FULL graph's (built without a
+    shard: csr_cache.get(..., shard=None) at the slice width)."""
+    n, C = x.shape
+    D = Wq.shape[0]
+    N, w = shard.n_global, shard.slice_width(C)
+    xs = shard.all_to_all_columns(x)                                        # [N, w]: my columns of every row
+    record, _ = be.gram(x, None, None)                                      # local rows; runs while the exchange lands
+    shard.all_reduce_sum(record)
+    coef = be.simple_coeffs(record, N, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
+    sl = csr.sliced(0, N, w) if hasattr(csr, "sliced") else None
+    if sl is not None:
+        ys = be.sliced_prescale(xs, csr.rowptr, N, sl.plan)
+        axs = be.sliced_spmm(sl, ys, csr.rowptr, N, 0, N, w, None, 1.0, gcn_scale)
+    else:
+        axs = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, N, csr.nnz, xs, 0, N, None, 1.0, gcn_scale,
+                      None, csr.row_order(0, N))
+    ax = shard.all_to_all_rows(axs)                                         # [n, C]: every column block of my rows
+    rs = None
+    if Wv is not None:
+        rs = csr.row_sums()[shard.row_begin: shard.row_begin + n]
+    return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu,
+                           **({"head": head} if head is not None else {}))
+
+
 def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
                              ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None, factors=None, head=None):
     """One DIFFormer layer with the `simple` kernel, query == source == x [n, C] (this rank's rows), one head
@@ -691,6 +726,9 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     Wq, bq, Wk, bk, Wv, bv, ln_weight, ln_bias = (f32_param(t) for t in (Wq, bq, Wk, bk, Wv, bv, ln_weight, ln_bias))
     sharded = shard is not None and shard.world > 1
     n_global, row_begin = (shard.n_global, shard.row_begin) if sharded else (n, 0)
+    if sharded and csr is not None and slice_sharded(shard, C, x.dtype):
+        return _closed_form_slice_sharded(be, x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha,
+                                          ln_weight, ln_bias, eps, relu, shard, head)
     sl = None
     if csr is not None and (sharded or n == csr.num_nodes) and x.dtype == torch.float32:
         sl = csr.sliced(row_begin, n, C)

@@ -91,6 +91,76 @@ def test_row_sharded_forward_matches_single_process(kernel, world, n, heads):
         assert err < 1e-5, (rank, err)
 
 
+def _slice_worker(rank, world, port, n, hidden, out_q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from difformer_amd import DIFFormer, RowShard, ops
+        from fake_backend import OracleBackend
+        ops._BACKEND = OracleBackend()
+        torch.manual_seed(7)
+        model = DIFFormer(12, hidden, 5, num_layers=3, num_heads=1, kernel="simple", use_source=True).eval()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(n, 12, generator=g)
+        ei = torch.cat([torch.randint(0, n, (2, 6 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+        with torch.no_grad():
+            full = model(x, ei)
+            shard = RowShard.from_process_group(n)
+            shard.product = "slice"
+            model.set_row_shard(shard)
+            # the two exchanges are inverse to each other and move the right columns
+            xl = shard.local_rows(full).contiguous()
+            w = shard.slice_width(full.shape[1]) if full.shape[1] % (4 * world) == 0 else 0
+            t = torch.arange(n * hidden, dtype=torch.float32).reshape(n, hidden)
+            cols = shard.all_to_all_columns(shard.local_rows(t).contiguous())
+            wh = hidden // world
+            ok = bool(torch.equal(cols, t[:, rank * wh: (rank + 1) * wh]))
+            ok = ok and bool(torch.equal(shard.all_to_all_rows(cols), shard.local_rows(t)))
+            ops._BACKEND.closed_form_calls = 0
+            local = model(shard.local_rows(x).contiguous(), ei)
+            ok = ok and ops._BACKEND.closed_form_calls == 3 and ops.slice_sharded(shard, hidden)
+            # row-sharded run of the same model for comparison
+            shard.product = "row"
+            local_row = model(shard.local_rows(x).contiguous(), ei)
+        want = shard.local_rows(full)
+        err = float((local - want).abs().max() / full.abs().max())
+        err_row = float((local_row - want).abs().max() / full.abs().max())
+        out_q.put((rank, err, err_row, tuple(local.shape), ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,hidden", [(2, 64, 16), (3, 50, 24), (2, 301, 64), (8, 203, 32)])
+def test_slice_sharded_product_matches_single_process(world, n, hidden):
+    """RowShard.product = "slice": closed-form layers split the aggregation by feature columns (all-to-all in, product of
+    the whole graph at C / world columns, all-to-all out); rows stay where they are for everything else."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slice_worker, args=(r, world, port, n, hidden, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from difformer_amd.dist import split_rows
+    counts = split_rows(n, world)
+    for rank, err, err_row, shape, ok in sorted(results):
+        assert shape == (counts[rank], 5) and ok
+        assert err < 1e-5 and err_row < 1e-5, (rank, err, err_row)
+
+
+def test_slice_width_rules():
+    from difformer_amd.dist import RowShard
+    assert RowShard(100, 0, 8).slice_width(64) == 8 and RowShard(100, 0, 2).slice_width(64) == 32
+    assert RowShard(100, 0, 3).slice_width(64) == 0          # 64 columns do not split into three 16-byte-aligned blocks
+    assert RowShard(100, 0, 1).slice_width(64) == 0
+
+
 def _bench_worker(rank, world, port, out_q):
     for p in (ROOT, HERE):
         if p not in sys.path:

@@ -95,6 +95,60 @@ def test_two_ranks_on_one_gpu_forward_and_training_step(kernel, n, deg, heads):
             assert n_sliced >= 1 and splits == 1
 
 
+def _slice_worker(rank, world, port, n, deg, out_q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from difformer_amd import DIFFormer, RowShard, ops
+        dev = torch.device("cuda:0")
+        torch.manual_seed(3)
+        model = DIFFormer(24, 64, 7, num_layers=3, num_heads=1, kernel="simple", use_source=True).to(dev).eval()
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(n, 24, generator=g).to(dev)
+        ei = torch.cat([torch.randint(0, n, (2, deg * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+        shard = RowShard.from_process_group(n)
+        shard.product = "slice"
+        be = ops.get_backend()
+        with torch.no_grad():
+            full = model(x, ei)
+            model.set_row_shard(shard)
+            be.kernel_events = {}
+            local = model(shard.local_rows(x).contiguous(), ei)
+            launched = set(be.kernel_events)
+            be.kernel_events = None
+        err = float((local - shard.local_rows(full)).abs().max() / full.abs().max())
+        torch.cuda.synchronize()
+        # the product ran over ALL rows at the slice width (64 / world columns)
+        widths = sorted({k[2] for _, _, csr in ops.csr_cache.entries.values() for k, sl in csr._sliced.items()
+                         if sl is not None and k[1] == n})
+        out_q.put((rank, err, widths, "dif_sliced_spmm_f32" in launched))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,deg", [(20000, 60), (9001, 50)])
+def test_two_ranks_on_one_gpu_slice_sharded_product(n, deg):
+    """RowShard.product = "slice" on the HIP kernels: both ranks sweep the whole graph at 32 of the 64 columns between
+    two all-to-alls (over gloo here); every rank's rows equal the single-process run."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slice_worker, args=(r, world, port, n, deg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=420) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, widths, sliced in sorted(results):
+        assert err < 1e-5, (rank, err)
+        assert sliced and 32 in widths, (rank, widths)
+
+
 @pytest.mark.parametrize("workload", ["ogbn-proteins-s", "pokec-batch-s-bf16"])
 def test_bench_with_two_ranks_runs_end_to_end(workload):
     """The command the driver launches for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), with both ranks

@@ -632,15 +632,15 @@ def test_rccl_single_rank_collectives(dev):
         dist.destroy_process_group()
 
 
-def _full_config_parity(dev, n, pairs, f_in, classes, layers, tol=TOL, zipf=False):
+def _full_config_parity(dev, n, pairs, f_in, classes, layers, tol=TOL, zipf=False, blocks=0, hidden=64):
     from difformer_amd import DIFFormer
     from bench import make_graph
     torch.manual_seed(123)
-    model = DIFFormer(f_in, 64, classes, num_layers=layers, kernel="simple", use_graph=True).eval()
+    model = DIFFormer(f_in, hidden, classes, num_layers=layers, kernel="simple", use_graph=True).eval()
     gx = torch.Generator().manual_seed(1)
     x = torch.randn(n, f_in, generator=gx)
-    ei = make_graph(n, pairs, dev, zipf=zipf)
-    cfg = dict(hidden_channels=64, num_layers=layers, num_heads=1, kernel="simple", alpha=0.5, use_bn=True,
+    ei = make_graph(n, pairs, dev, zipf=zipf, blocks=blocks)
+    cfg = dict(hidden_channels=hidden, num_layers=layers, num_heads=1, kernel="simple", alpha=0.5, use_bn=True,
                use_residual=True, use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
     p = {k: v.double().numpy() for k, v in model.state_dict().items()}
     model = model.to(dev)
@@ -668,6 +668,23 @@ def test_model_forward_c4_zipf_degree_profile_full_size(dev):
     degree ~13, as the real ogbn-proteins) -- the blocked SpMM walks the rows in degree order with split hub rows here;
     2 layers keep the oracle time bounded."""
     _full_config_parity(dev, 132534, 39561252, 8, 112, 2, zipf=True)
+
+
+def test_model_forward_c4_zipf_degrees_inside_communities_full_size(dev):
+    """The two properties of the real ogbn-proteins TOGETHER at C4 size: 8 contiguous communities (95 % of the pairs
+    inside) with Zipf degrees inside each -- the model runs in the mixed node order AND the hub rows are split."""
+    from difformer_amd import ops
+    _full_config_parity(dev, 132534, 39561252, 8, 112, 2, zipf=True, blocks=8)
+    mixed = [m for _, m in ops.mix_cache.entries.values() if m is not None]
+    assert mixed, "the community structure should have switched the model to the mixed node order"
+
+
+@pytest.mark.parametrize("hidden,layers", [(64, 3), (128, 2)])
+def test_model_forward_pokec_full_graph(hidden, layers, dev):
+    """The evaluation pass of the mini-batch scripts (node classification/eval.py:40-43, main-batch.py:144-145): ONE forward
+    over the whole Pokec-sized graph -- 1,632,803 nodes, 32.4 M entries (mean degree ~19: gather kernels), F_in = 65,
+    hidden 64 (closed-form layers) and 128 (the script's width, run.sh:42-44: operator path) -- against the float64 oracle."""
+    _full_config_parity(dev, 1632803, 15400000, 65, 2, layers, hidden=hidden)
 
 
 # ------------------------------------------------------------------ bfloat16 storage variants (config C5)
