@@ -675,8 +675,8 @@ def invalidate_param_caches():
 
 def slice_sharded(shard, C, dtype=torch.float32):
     """True when a closed-form layer of width C on this shard splits its aggregation by feature slices (dist.py)."""
-    return (shard is not None and shard.world > 1 and shard.product == "slice" and dtype == torch.float32 and
-            shard.slice_width(C) > 0)
+    return (shard is not None and shard.world > 1 and getattr(shard, "product", "row") == "slice" and
+            dtype == torch.float32 and shard.slice_width(C) > 0)
 
 
 def _closed_form_slice_sharded(be, x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
