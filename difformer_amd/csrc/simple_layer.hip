@@ -25,6 +25,10 @@ using dif::f32x4;
 using dif::Elem;
 
 constexpr int kWaves = 4;
+#ifndef DIF_HEAD_WAVES
+#define DIF_HEAD_WAVES 8      // waves per workgroup of the HEAD variant (four 64 x 64 weight blocks in LDS: two workgroups per CU)
+#endif
+constexpr int kHeadWaves = DIF_HEAD_WAVES;
 constexpr int kWStride = 68;     // padded LDS row (floats): 16 lanes x b128 land on 64 distinct banks
 constexpr int kRecordChunksPerCU = 3;   // most workgroups per CU of any kernel that writes partial Gram records
 
@@ -148,9 +152,9 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const T* __res
 }
 
 // workgroups of kWaves waves; `per_cu` = how many of them fit a CU (registers / LDS of the kernel in question)
-int row_chunks(int64_t n_rows, int per_cu) {
+int row_chunks(int64_t n_rows, int per_cu, int waves = kWaves) {
     const int64_t tiles = (n_rows + 15) / 16;
-    int64_t p = (tiles + kWaves - 1) / kWaves;
+    int64_t p = (tiles + waves - 1) / waves;
     if (p > static_cast<int64_t>(per_cu) * dif::kCUs) p = static_cast<int64_t>(per_cu) * dif::kCUs;
     if (p < 1) p = 1;
     return static_cast<int>(p);
@@ -368,13 +372,32 @@ __device__ __forceinline__ void load_rows(f32x4 (&xa)[4], const T* __restrict__ 
     }
 }
 
-// y[ft] (+)= W_tile x^T for the four feature tiles; W in LDS [64 x kWStride]
+// LDS layout of a 64 x 64 weight block for project_t: element (f, c) at [f/16][c/16][(c/4)%4][f%16][c%4].  The A fragment of
+// a lane (lg, l15) is then the 16 bytes at lg * 256 + l15 * 16 inside the (ft, cq) sub-block: the bank quad depends on l15
+// only, and every hardware lane group of a ds_read_b128 ({0-3,12-15,20-27}, ... MI355X_MICROARCH.md, LDS table) holds each
+// l15 exactly once -> no bank conflicts.  (The row-major layout with a 68-float stride, conflict-free for groups of 16
+// CONSECUTIVE lanes, put lanes (0, 12) and (1, 11) of the first hardware group on one quad: SQ_LDS_BANK_CONFLICT was 34 %
+// of the kernel's LDS cycles, profiles/r02_pmc_traffic_c4.json.)
+#ifdef DIF_LAYER_OLD_LAYOUT
+constexpr int kWBlock = 64 * 68;
+#else
+constexpr int kWBlock = 64 * 64;           // (the NEXT variant folds 2 x 40 x 64 floats through the two blocks: 8,192 there)
+#endif
+__device__ __forceinline__ int widx(int f, int c) {
+#ifdef DIF_LAYER_OLD_LAYOUT          // measurement build: the row-major layout with a 68-float stride (needs 64 * 68 floats)
+    return f * 68 + c;
+#else
+    return ((((f >> 4) * 4 + (c >> 4)) * 4 + ((c >> 2) & 3)) << 6) + ((f & 15) << 2) + (c & 3);
+#endif
+}
+
+// y[ft] (+)= W_tile x^T for the four feature tiles; W in LDS in the widx layout
 __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], const float* __restrict__ w, int l15, int lg) {
 #pragma unroll
     for (int cq = 0; cq < 4; ++cq) {
         f32x4 wf[4];
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) wf[ft] = *reinterpret_cast<const f32x4*>(&w[(16 * ft + l15) * kWStride + 16 * cq + 4 * lg]);
+        for (int ft = 0; ft < 4; ++ft) wf[ft] = *reinterpret_cast<const f32x4*>(&w[widx(16 * ft + l15, 16 * cq + 4 * lg)]);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -384,37 +407,49 @@ __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], c
 }
 
 template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float, bool HEAD = false>
-__global__ __launch_bounds__(64 * kWaves, (NEXT || HEAD) ? 2 : 4) void simple_layer_kernel(LayerArgsT<T> a) {
-    __shared__ __attribute__((aligned(16))) float sm_w[2][64 * kWStride];   // MnT, Wv (zero padded)
-    __shared__ __attribute__((aligned(16))) float sm_wo[HEAD ? 2 : 1][HEAD ? 64 * kWStride : 4];   // HEAD: up to 128 output classes
+__global__ __launch_bounds__(64 * (HEAD ? kHeadWaves : kWaves), HEAD ? (2 * kHeadWaves + 3) / 4 : (NEXT ? 2 : 4))
+void simple_layer_kernel(LayerArgsT<T> a) {
+    constexpr int NW = HEAD ? kHeadWaves : kWaves;          // waves per workgroup
+    __shared__ __attribute__((aligned(16))) float sm_w[2][kWBlock];   // MnT, Wv (zero padded; widx layout)
+    __shared__ __attribute__((aligned(16))) float sm_wo[HEAD ? 2 : 1][HEAD ? kWBlock : 4];   // HEAD: up to 128 output classes
     __shared__ __attribute__((aligned(16))) float sm_bo[HEAD ? 128 : 4];
     __shared__ __attribute__((aligned(16))) float sm_cn[64], sm_u[64], sm_bv[64], sm_lw[64], sm_lb[64];
-    __shared__ __attribute__((aligned(16))) float sm_t[NEXT ? kWaves : 1][16 * kWStride];   // NEXT: a wave's finished tile
-    __shared__ float sm_s[kWaves][64];
+    __shared__ __attribute__((aligned(16))) float sm_t[NEXT ? NW : 1][16 * kWStride];   // NEXT: a wave's finished tile
+    __shared__ float sm_s[NW][64];
     __shared__ float sm_cd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int C = a.C, D = a.D;
+    const int64_t n_tiles = (a.n_rows + 15) / 16;
+    const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * NW + wave, stride = static_cast<int64_t>(gridDim.x) * NW;
     if (EXACT && (reinterpret_cast<uintptr_t>(a.coef) & 15u) == 0 && (!GRAPH_W || (reinterpret_cast<uintptr_t>(a.Wv) & 15u) == 0)) {
         // dense 64 x 64 blocks: all eight 16-byte loads of a thread are in flight before the first LDS store (an
         // element-wise loop runs 32 load -> store round trips back to back: ~30 us of prologue per workgroup)
-        f32x4 wreg[2][4];
+        // Thread -> fragment map of the staging: a wave instruction reads eight ROWS x 128 contiguous bytes (whole cache
+        // lines), and the eight consecutive lanes that share a cycle of ds_write_b128 hold eight different rows, i.e.
+        // eight different bank quads of the widx layout (conflict-free stores).
+        constexpr int NL = 16 / NW;                 // 16-byte loads per thread and matrix
+        f32x4 wreg[2][NL];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wreg[0][i] = *reinterpret_cast<const f32x4*>(a.coef + 4 * (threadIdx.x + 256 * i));
-            if (GRAPH_W) wreg[1][i] = *reinterpret_cast<const f32x4*>(a.Wv + 4 * (threadIdx.x + 256 * i));
+        for (int i = 0; i < NL; ++i) {
+            const int idx = wave + NW * i;                          // 0..15: (row block of 8, half row)
+            const int f = 8 * (idx & 7) + (lane & 7), c = 32 * (idx >> 3) + 4 * (lane >> 3);
+            wreg[0][i] = *reinterpret_cast<const f32x4*>(a.coef + f * 64 + c);
+            if (GRAPH_W) wreg[1][i] = *reinterpret_cast<const f32x4*>(a.Wv + f * 64 + c);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = 4 * (threadIdx.x + 256 * i);
-            *reinterpret_cast<f32x4*>(&sm_w[0][(e >> 6) * kWStride + (e & 63)]) = wreg[0][i];
-            if (GRAPH_W) *reinterpret_cast<f32x4*>(&sm_w[1][(e >> 6) * kWStride + (e & 63)]) = wreg[1][i];
+        for (int i = 0; i < NL; ++i) {
+            const int idx = wave + NW * i;
+            const int f = 8 * (idx & 7) + (lane & 7), c = 32 * (idx >> 3) + 4 * (lane >> 3);
+            *reinterpret_cast<f32x4*>(&sm_w[0][widx(f, c)]) = wreg[0][i];
+            if (GRAPH_W) *reinterpret_cast<f32x4*>(&sm_w[1][widx(f, c)]) = wreg[1][i];
         }
     } else {
-        for (int e = threadIdx.x; e < 64 * 64; e += 64 * kWaves) {
-            const int f = e >> 6, c = e & 63;
-            sm_w[0][f * kWStride + c] = (f < D && c < C) ? a.coef[f * C + c] : 0.f;
-            if (GRAPH_W) sm_w[1][f * kWStride + c] = (f < D && c < C) ? a.Wv[f * C + c] : 0.f;
+        for (int e = threadIdx.x; e < 64 * 64; e += 64 * NW) {         // e = LDS dword: [ft][cq][lg][l15][t]
+            const int f = 16 * (e >> 10) + ((e >> 2) & 15), c = 16 * ((e >> 8) & 3) + 4 * ((e >> 6) & 3) + (e & 3);
+            sm_w[0][widx(f, c)] = (f < D && c < C) ? a.coef[f * C + c] : 0.f;
+            if (GRAPH_W) sm_w[1][widx(f, c)] = (f < D && c < C) ? a.Wv[f * C + c] : 0.f;
         }
     }
     if (threadIdx.x < 64) {
@@ -427,9 +462,10 @@ __global__ __launch_bounds__(64 * kWaves, (NEXT || HEAD) ? 2 : 4) void simple_la
     }
     if (threadIdx.x == 0) sm_cd = a.coef[D * C + D + C];
     if (HEAD) {
-        for (int e = threadIdx.x; e < 2 * 64 * 64; e += 64 * kWaves) {
-            const int cls = e >> 6, c = e & 63;
-            sm_wo[cls >> 6][(cls & 63) * kWStride + c] = (cls < a.Co && c < D) ? a.Wo[cls * D + c] : 0.f;
+        for (int e = threadIdx.x; e < 2 * 64 * 64; e += 64 * NW) {     // LDS dword order again (conflict-free stores)
+            const int blk = e >> 12, r = e & 4095;
+            const int cls = 64 * blk + 16 * (r >> 10) + ((r >> 2) & 15), c = 16 * ((r >> 8) & 3) + 4 * ((r >> 6) & 3) + (r & 3);
+            sm_wo[blk][widx(cls & 63, c)] = (cls < a.Co && c < D) ? a.Wo[cls * D + c] : 0.f;
         }
         if (threadIdx.x < 128) sm_bo[threadIdx.x] = threadIdx.x < a.Co ? a.bo[threadIdx.x] : 0.f;
     }
@@ -437,9 +473,6 @@ __global__ __launch_bounds__(64 * kWaves, (NEXT || HEAD) ? 2 : 4) void simple_la
     const float cd = sm_cd;
     const float inv_d = 1.0f / static_cast<float>(D);
 
-    const int64_t n_tiles = (a.n_rows + 15) / 16;
-    const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * kWaves + wave, stride = static_cast<int64_t>(gridDim.x) * kWaves;
     f32x4 gacc[NEXT ? 10 : 1];          // NEXT: upper half of out^T out (see gram_kernel)
     f32x4 gsx = zero4();
 #pragma unroll
@@ -625,7 +658,7 @@ __global__ __launch_bounds__(64 * kWaves, (NEXT || HEAD) ? 2 : 4) void simple_la
         }
         // fold the four waves' Gram partials through the weight region (no longer needed): (w0 + w2) + (w1 + w3)
         __syncthreads();
-        float* buf = &sm_w[0][0];                       // 2 x 40 x 64 floats needed, 2 x 64 x 68 there
+        float* buf = &sm_w[0][0];                       // 2 x 40 x 64 floats needed, 2 x 64 x 68 there (NEXT keeps the padded size)
         if (wave >= 2) {
 #pragma unroll
             for (int i = 0; i < 10; ++i)
@@ -770,7 +803,7 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
     const bool f32 = std::is_same<T, float>::value;
     DIF_REQUIRE(f32 || (!next_record && !next_ys), DIF_E_BADARG, "dif_simple_layer: products for the next layer are float32-only");
     const bool next = next_record != nullptr;          // Gram record of the output from the same pass (slower)
-    const int P = row_chunks(n_rows, next ? kRecordChunksPerCU : 4);
+    const int P = head ? row_chunks(n_rows, 2, kHeadWaves) : row_chunks(n_rows, next ? kRecordChunksPerCU : 4);
     const int64_t rec = (static_cast<int64_t>(D) * D + D + 3) & ~int64_t(3);
     int64_t npad = 0;
     if (next) {
@@ -793,7 +826,7 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
     const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
     const bool gw = ax != nullptr && Wv != nullptr;
 #define DIF_LAYER(E, G, N) hipLaunchKernelGGL((simple_layer_kernel<E, G, N, T>), dim3(P), dim3(64 * kWaves), 0, st, a)
-#define DIF_LAYER_HEAD(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, (std::is_same<T, float>::value)>), dim3(P), dim3(64 * kWaves), 0, st, a)
+#define DIF_LAYER_HEAD(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, (std::is_same<T, float>::value)>), dim3(P), dim3(64 * kHeadWaves), 0, st, a)
 #define DIF_LAYER2(E, G) do { if (head) DIF_LAYER_HEAD(E, G); else if (f32 && next) DIF_LAYER(E, G, (std::is_same<T, float>::value)); else DIF_LAYER(E, G, false); } while (0)
     if (exact) { if (gw) DIF_LAYER2(true, true); else DIF_LAYER2(true, false); }
     else { if (gw) DIF_LAYER2(false, true); else DIF_LAYER2(false, false); }
