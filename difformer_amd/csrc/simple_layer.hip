@@ -186,60 +186,86 @@ __device__ __forceinline__ f32x4 tile_product(FA A, FB B, int ti, int tj, int l1
     return d;
 }
 
-__global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ rec, float n_global, int C, int D,
-                                                      const float* __restrict__ Wq, const float* __restrict__ bq,
-                                                      const float* __restrict__ Wk, const float* __restrict__ bk,
-                                                      const float* __restrict__ Wv, const float* __restrict__ bv,
-                                                      float attn_scale, float* __restrict__ coef) {
-    __shared__ __attribute__((aligned(16))) float sG[64 * kLd], sWq[64 * kLd], sWk[64 * kLd], sWv[64 * kLd], sT[64 * kLd], sKtV[64 * kLd];
-    __shared__ float s_sx[64], s_bq[64], s_bk[64], s_bv[64], s_wk[64], s_wq[64], s_wv[64], s_ks[64], s_vs[64];
-    __shared__ float s_red[2][16];
-    __shared__ float s_scal[4];
+// LDS of the coefficient stage (1024 threads): six padded 64 x 64 blocks and a few vectors
+struct CoefSmem {
+    float *sG, *sWq, *sWk, *sWv, *sT, *sKtV;                                   // 64 x kLd each
+    float *s_sx, *s_bq, *s_bk, *s_bv, *s_wk, *s_wq, *s_wv, *s_ks, *s_vs;       // 64 each
+    float* s_red;                                                              // [2][16]
+    float* s_scal;                                                             // [4]
+};
+constexpr int kCoefSmemFloats = 6 * 64 * kLd + 9 * 64 + 32 + 4;
+
+__device__ __forceinline__ CoefSmem carve_coef_smem(float* base) {
+    CoefSmem m;
+    m.sG = base; m.sWq = m.sG + 64 * kLd; m.sWk = m.sWq + 64 * kLd; m.sWv = m.sWk + 64 * kLd; m.sT = m.sWv + 64 * kLd;
+    m.sKtV = m.sT + 64 * kLd;
+    m.s_sx = m.sKtV + 64 * kLd; m.s_bq = m.s_sx + 64; m.s_bk = m.s_bq + 64; m.s_bv = m.s_bk + 64; m.s_wk = m.s_bv + 64;
+    m.s_wq = m.s_wk + 64; m.s_wv = m.s_wq + 64; m.s_ks = m.s_wv + 64; m.s_vs = m.s_ks + 64;
+    m.s_red = m.s_vs + 64; m.s_scal = m.s_red + 32;
+    return m;
+}
+
+// weights (and, with rec != nullptr, the Gram record) -> LDS.  1024 threads; no barrier at the end.
+__device__ __forceinline__ void coeffs_stage(const CoefSmem& m, const float* __restrict__ rec, int C, int D,
+                                             const float* __restrict__ Wq, const float* __restrict__ bq,
+                                             const float* __restrict__ Wk, const float* __restrict__ bk,
+                                             const float* __restrict__ Wv, const float* __restrict__ bv) {
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-    const int ti = wave >> 2, tj = wave & 3;       // this wave's 16 x 16 tile of every 64 x 64 product
     const bool has_wv = Wv != nullptr;            // use_weight = False: v = x (needs C == D), Wv = I, bv = 0
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    if (C == 64 && D == 64 && al16(rec) && al16(Wq) && al16(Wk) && (!has_wv || al16(Wv))) {
+    if (C == 64 && D == 64 && (!rec || al16(rec)) && al16(Wq) && al16(Wk) && (!has_wv || al16(Wv))) {
         // dense 64 x 64 blocks: one 16-byte load per matrix and thread, all in flight together
         const int e = 4 * tid, a = e >> 6, b = e & 63;
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(rec + e), q4 = *reinterpret_cast<const f32x4*>(Wq + e),
-                    k4 = *reinterpret_cast<const f32x4*>(Wk + e);
+        f32x4 g4 = zero4();
+        if (rec) g4 = *reinterpret_cast<const f32x4*>(rec + e);
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(Wq + e), k4 = *reinterpret_cast<const f32x4*>(Wk + e);
         f32x4 v4 = zero4();
         if (has_wv) v4 = *reinterpret_cast<const f32x4*>(Wv + e);
         else
             for (int r = 0; r < 4; ++r) v4[r] = (a == b + r) ? 1.f : 0.f;
-        *reinterpret_cast<f32x4*>(&sG[a * kLd + b]) = g4;
-        *reinterpret_cast<f32x4*>(&sWq[a * kLd + b]) = q4;
-        *reinterpret_cast<f32x4*>(&sWk[a * kLd + b]) = k4;
-        *reinterpret_cast<f32x4*>(&sWv[a * kLd + b]) = v4;
+        if (rec) *reinterpret_cast<f32x4*>(&m.sG[a * kLd + b]) = g4;
+        *reinterpret_cast<f32x4*>(&m.sWq[a * kLd + b]) = q4;
+        *reinterpret_cast<f32x4*>(&m.sWk[a * kLd + b]) = k4;
+        *reinterpret_cast<f32x4*>(&m.sWv[a * kLd + b]) = v4;
     } else {
         for (int e = tid; e < 64 * 64; e += 1024) {
             const int a = e >> 6, b = e & 63;
-            sG[a * kLd + b] = (a < C && b < C) ? rec[a * C + b] : 0.f;
-            sWq[a * kLd + b] = (a < D && b < C) ? Wq[a * C + b] : 0.f;
-            sWk[a * kLd + b] = (a < D && b < C) ? Wk[a * C + b] : 0.f;
-            sWv[a * kLd + b] = has_wv ? ((a < D && b < C) ? Wv[a * C + b] : 0.f) : (a == b && a < D ? 1.f : 0.f);
+            if (rec) m.sG[a * kLd + b] = (a < C && b < C) ? rec[a * C + b] : 0.f;
+            m.sWq[a * kLd + b] = (a < D && b < C) ? Wq[a * C + b] : 0.f;
+            m.sWk[a * kLd + b] = (a < D && b < C) ? Wk[a * C + b] : 0.f;
+            m.sWv[a * kLd + b] = has_wv ? ((a < D && b < C) ? Wv[a * C + b] : 0.f) : (a == b && a < D ? 1.f : 0.f);
         }
     }
     if (tid < 64) {
-        s_sx[tid] = tid < C ? rec[C * C + tid] : 0.f;
-        s_bq[tid] = tid < D ? bq[tid] : 0.f;
-        s_bk[tid] = tid < D ? bk[tid] : 0.f;
-        s_bv[tid] = (has_wv && tid < D) ? bv[tid] : 0.f;
+        if (rec) m.s_sx[tid] = tid < C ? rec[C * C + tid] : 0.f;
+        m.s_bq[tid] = tid < D ? bq[tid] : 0.f;
+        m.s_bk[tid] = tid < D ? bk[tid] : 0.f;
+        m.s_bv[tid] = (has_wv && tid < D) ? bv[tid] : 0.f;
     }
-    __syncthreads();
+}
+
+// Mn, cn, u, cd from G, sx and the weights, all staged in LDS (a barrier must separate the staging from this call).
+// 1024 threads = 16 waves = the 16 tiles of each 64^3 product.
+__device__ __forceinline__ void coeffs_compute(const CoefSmem& m, float n_global, int C, int D, float attn_scale,
+                                               float* __restrict__ coef) {
+    float *sG = m.sG, *sWq = m.sWq, *sWk = m.sWk, *sWv = m.sWv, *sT = m.sT, *sKtV = m.sKtV;
+    float *s_sx = m.s_sx, *s_bq = m.s_bq, *s_bk = m.s_bk, *s_bv = m.s_bv, *s_wk = m.s_wk, *s_wq = m.s_wq, *s_wv = m.s_wv,
+          *s_ks = m.s_ks, *s_vs = m.s_vs, *s_scal = m.s_scal;
+    float (*s_red)[16] = reinterpret_cast<float (*)[16]>(m.s_red);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int ti = wave >> 2, tj = wave & 3;       // this wave's 16 x 16 tile of every 64 x 64 product
     // W sx for the three projections: 192 dot products, four lanes per row (16 columns each), folded by two shuffles
     if (tid < 768) {
         const int r = tid >> 2, part = tid & 3;
-        const int m = r & 63, which = r >> 6;
-        const float* W = (which == 0 ? sWk : which == 1 ? sWq : sWv) + m * kLd + 16 * part;
+        const int mm = r & 63, which = r >> 6;
+        const float* W = (which == 0 ? sWk : which == 1 ? sWq : sWv) + mm * kLd + 16 * part;
         float a = 0.f;
 #pragma unroll
         for (int c = 0; c < 16; ++c) a += W[c] * s_sx[16 * part + c];
         a += __shfl_xor(a, 1, 64);
         a += __shfl_xor(a, 2, 64);
-        if (part == 0) (which == 0 ? s_wk : which == 1 ? s_wq : s_wv)[m] = a;
+        if (part == 0) (which == 0 ? s_wk : which == 1 ? s_wq : s_wv)[mm] = a;
     }
     // T = Wk G (kept), Wq G (only its trace against Wq): |K|^2, |Q|^2 main terms
     {
@@ -250,10 +276,10 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
         float pk = 0.f, pq = 0.f;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int m = 16 * ti + 4 * lg + reg, c = 16 * tj + l15;
-            sT[m * kLd + c] = tk[reg];
-            pk += tk[reg] * sWk[m * kLd + c];
-            pq += tq[reg] * sWq[m * kLd + c];
+            const int mm = 16 * ti + 4 * lg + reg, c = 16 * tj + l15;
+            sT[mm * kLd + c] = tk[reg];
+            pk += tk[reg] * sWk[mm * kLd + c];
+            pq += tq[reg] * sWq[mm * kLd + c];
         }
         pq = dif::wave_sum(pq);
         pk = dif::wave_sum(pk);
@@ -266,8 +292,8 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
                                       ti, tj, l15, lg);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int m = 16 * ti + 4 * lg + reg, d = 16 * tj + l15;
-            sKtV[m * kLd + d] = kv[reg] + s_wk[m] * s_bv[d] + s_bk[m] * s_wv[d] + n_global * s_bk[m] * s_bv[d];
+            const int mm = 16 * ti + 4 * lg + reg, d = 16 * tj + l15;
+            sKtV[mm * kLd + d] = kv[reg] + s_wk[mm] * s_bv[d] + s_bk[mm] * s_wv[d] + n_global * s_bk[mm] * s_bv[d];
         }
     }
     if (tid < 64) {
@@ -304,7 +330,7 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
         const int d = tid >> 2, part = tid & 3;
         float a = 0.f;
 #pragma unroll
-        for (int m = 16 * part; m < 16 * part + 16; ++m) a += s_bq[m] * sKtV[m * kLd + d];
+        for (int mm = 16 * part; mm < 16 * part + 16; ++mm) a += s_bq[mm] * sKtV[mm * kLd + d];
         a += __shfl_xor(a, 1, 64);
         a += __shfl_xor(a, 2, 64);
         if (part == 0 && d < D) cn[d] = attn_scale * (s * a + s_vs[d]);
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
         const int c = (tid - 256) >> 2, part = tid & 3;
         float a = 0.f;
 #pragma unroll
-        for (int m = 16 * part; m < 16 * part + 16; ++m) a += sWq[m * kLd + c] * s_ks[m];
+        for (int mm = 16 * part; mm < 16 * part + 16; ++mm) a += sWq[mm * kLd + c] * s_ks[mm];
         a += __shfl_xor(a, 1, 64);
         a += __shfl_xor(a, 2, 64);
         if (part == 0 && c < C) u[c] = s * a;
@@ -325,6 +351,18 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
             u[C + 3] = s_scal[2];
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ rec, float n_global, int C, int D,
+                                                      const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                      const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                      const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                      float attn_scale, float* __restrict__ coef) {
+    __shared__ __attribute__((aligned(16))) float smem[kCoefSmemFloats];
+    const CoefSmem m = carve_coef_smem(smem);
+    coeffs_stage(m, rec, C, D, Wq, bq, Wk, bk, Wv, bv);
+    __syncthreads();
+    coeffs_compute(m, n_global, C, D, attn_scale, coef);
 }
 
 // ------------------------------------------------------------------------------------------------------------

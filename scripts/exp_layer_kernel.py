@@ -38,12 +38,15 @@ for n, classes in ((132534, 112), (50000, 10), (100000, 2)):
     coef = be.simple_coeffs(rec, n, C, D, W[0], b[0], W[1], b[1], W[2], b[2], 1.0)
     t_gram = timed(lambda: be.gram(x))
     t_coef = timed(lambda: be.simple_coeffs(rec, n, C, D, W[0], b[0], W[1], b[1], W[2], b[2], 1.0))
+    t_fused = (0, 0)      # the fused Gram + coefficients kernel of profiles/r03_experiments.md section 3 (removed: slower)
+    t_chain = timed(lambda: be.simple_coeffs(be.gram(x)[0], n, C, D, W[0], b[0], W[1], b[1], W[2], b[2], 1.0))
     t_plain = timed(lambda: be.simple_layer(x, coef, D, ax, W[2], b[2], rs, 1.0, None, True, 0.5, lw, lb, 1e-5))
     t_nog = timed(lambda: be.simple_layer(x, coef, D, None, W[2], b[2], None, 1.0, None, True, 0.5, lw, lb, 1e-5))
     t_head = timed(lambda: be.simple_layer(x, coef, D, ax, W[2], b[2], rs, 1.0, None, True, 0.5, lw, lb, 1e-5, head=(Wo, bo)))
     t_head_nog = timed(lambda: be.simple_layer(x, coef, D, None, W[2], b[2], None, 1.0, None, True, 0.5, lw, lb, 1e-5, head=(Wo, bo)))
     gb = lambda byt, us: byt / us / 1e3
-    print(f"n={n}: gram {t_gram[0]:.1f}/{t_gram[1]:.1f} us, coeffs {t_coef[0]:.1f}/{t_coef[1]:.1f}, layer with graph {t_plain[0]:.1f}/{t_plain[1]:.1f} "
+    print(f"n={n}: gram {t_gram[0]:.1f}/{t_gram[1]:.1f} us, coeffs {t_coef[0]:.1f}/{t_coef[1]:.1f}, gram -> finalize -> coeffs {t_chain[0]:.1f}/{t_chain[1]:.1f}, "
+          f"fused gram + coeffs {t_fused[0]:.1f}/{t_fused[1]:.1f}, layer with graph {t_plain[0]:.1f}/{t_plain[1]:.1f} "
           f"({gb(3 * n * C * 4, t_plain[0]):.0f} GB/s), no graph {t_nog[0]:.1f}/{t_nog[1]:.1f} ({gb(2 * n * C * 4, t_nog[0]):.0f} GB/s), "
           f"head({classes}) with graph {t_head[0]:.1f}/{t_head[1]:.1f} ({gb(2 * n * C * 4 + n * classes * 4, t_head[0]):.0f} GB/s), "
           f"head no graph {t_head_nog[0]:.1f}/{t_head_nog[1]:.1f}   [min/median us]", flush=True)
