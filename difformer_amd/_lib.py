@@ -72,7 +72,6 @@ SIGNATURES = {
     "dif_gram_workspace_bytes": (c_sz, [c_i64, c_int]),
     "dif_gram_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dif_simple_coeffs_len": (c_sz, [c_int, c_int]),
-
     "dif_simple_coeffs_f32": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp]),
     "dif_simple_layer_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp,
                                      c_i64, c_int, c_f32, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
