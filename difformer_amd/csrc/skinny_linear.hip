@@ -12,6 +12,9 @@
 //   B[k=lane/16][j=lane%16] = W[fb + 4*(lane%16) + ft][16cq + 4*(lane/16) + t]        (LDS row 16 ft + lane%16 of the block)
 //   lane then holds out[r0 + 4*(lane/16) + reg][fb + 4*(lane%16) + ft]: one 16-byte store per reg.
 // HBM-bound: (C_in + C_out) * 4 bytes per row.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "dif_common.h"
 
 namespace {
@@ -170,6 +173,226 @@ __global__ __launch_bounds__(256) void long_linear_kernel(const T* __restrict__ 
     }
 }
 
+// ---- long rows into a narrow layer, float32 storage, on the bfloat16 matrix core with split operands --------------------
+// 512 -> 64 at CIFAR scale is 3.3 GFLOP per 115 MB: on the fp32 MFMA (157 TFLOP/s) the product alone takes 21 us, more than
+// the 14 us the bytes take at 8 TB/s (measured 55 us).  Every float32 operand is split into two bfloat16 numbers,
+//     x = xh + xl,   xh = bf16(x),  xl = bf16(x - xh)            (|x - xh - xl| <= 2^-17 |x|)
+// and the product is formed as  xh wh + xh wl + xl wh  with float32 accumulation on v_mfma_f32_16x16x32_bf16 (16x the fp32
+// rate): three MFMAs of K = 32 instead of eight of K = 4 per 32 input channels.  The dropped terms (xl wl and the second
+// truncation) are <= 2^-16 relative per product: the result agrees with the fp32 kernel to ~1e-5 norm-wise, inside the 1e-4
+// budget of the path (tests/test_gpu_parity.py holds it to the float64 oracle).
+// The contraction index may be permuted freely as long as both operands agree: k-slot s of lane group lg in half h of a
+// 64-channel chunk is channel 32 h + 16 (s / 4) + 4 lg + s % 4 -- exactly the columns a lane already holds after its four
+// coalesced 16-byte loads of x.  W is split while it is staged: fragment (part, h, ft) of a chunk is 64 lanes x 16 bytes
+// (8 bfloat16 = the lane's eight k-slots of feature 4 l15 + ft), read back with one conflict-free ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+    hi = __builtin_convertvector(v, bf16x4);
+    const f32x4 back = __builtin_convertvector(hi, f32x4);
+    lo = __builtin_convertvector(v - back, bf16x4);
+}
+__device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+__global__ __launch_bounds__(256) void long_linear_split_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C_in,
+                                                                const float* __restrict__ W, const float* __restrict__ bias,
+                                                                int C_out, const float* __restrict__ ln_w,
+                                                                const float* __restrict__ ln_b, float eps, int relu,
+                                                                float* __restrict__ out, int64_t ldo, int ovec) {
+    __shared__ __attribute__((aligned(16))) bf16x8 sm_w[2][16 * 64];        // [buffer][(part * 2 + h) * 4 + ft][lane]
+    __shared__ float sm_b[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    if (threadIdx.x < 64) sm_b[threadIdx.x] = threadIdx.x < C_out ? bias[threadIdx.x] : 0.f;
+    f32x4 lw = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};
+    if (ln_w) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f = 4 * l15 + ft;
+            if (f < C_out) { lw[ft] = ln_w[f]; lb[ft] = ln_b[f]; }
+        }
+    }
+    const float inv_c = 1.0f / static_cast<float>(C_out);
+    const int n_chunks = (C_in + 63) / 64;
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t n_groups = (n_tiles + 3) / 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // staging of a weight chunk: thread t owns fragment lanes id = t, t + 256 (frag = id / 64 = 4 h + ft): two 16-byte loads
+    auto load_w = [&](f32x4 (&wv)[4], int ch) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = threadIdx.x + 256 * u, ln_ = id & 63, frag = id >> 6;
+            const int f = 4 * (ln_ & 15) + (frag & 3), c = 64 * ch + 32 * (frag >> 2) + 4 * (ln_ >> 4);
+            const float* wp = W + static_cast<int64_t>(f) * C_in + c;
+            wv[2 * u] = (f < C_out && c < C_in) ? *reinterpret_cast<const f32x4*>(wp) : z4;
+            wv[2 * u + 1] = (f < C_out && c + 16 < C_in) ? *reinterpret_cast<const f32x4*>(wp + 16) : z4;
+        }
+    };
+    auto store_w = [&](const f32x4 (&wv)[4], int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = threadIdx.x + 256 * u, ln_ = id & 63, frag = id >> 6;
+            bf16x4 h0, l0, h1, l1;
+            split_bf16(wv[2 * u], h0, l0);
+            split_bf16(wv[2 * u + 1], h1, l1);
+            sm_w[buf][frag * 64 + ln_] = cat8(h0, h1);
+            sm_w[buf][(8 + frag) * 64 + ln_] = cat8(l0, l1);
+        }
+    };
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t tile = grp * 4 + wave;
+        const int64_t r0 = tile * 16, r = r0 + l15;
+        const bool rok = r < n_rows;
+        auto load_x = [&](f32x4 (&xa)[4], int ch) {
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                const int c = 64 * ch + 16 * cq + 4 * lg;
+                xa[cq] = (rok && c < C_in) ? *reinterpret_cast<const f32x4*>(x + r * ldx + c) : z4;
+            }
+        };
+        f32x4 wv[4], xa[4], xn[4];
+        load_w(wv, 0);
+        load_x(xa, 0);
+        __syncthreads();                       // the previous group is done with both buffers (and sm_b is there)
+        store_w(wv, 0);
+        __syncthreads();
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sm_b + 4 * l15);
+        f32x4 y[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] = f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const bool more = ch + 1 < n_chunks;
+            if (more) { load_w(wv, ch + 1); load_x(xn, ch + 1); }              // in flight under this chunk's MFMAs
+            const bf16x8* wb = sm_w[ch & 1] + lane;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x4 h0, l0, h1, l1;
+                split_bf16(xa[2 * h], h0, l0);
+                split_bf16(xa[2 * h + 1], h1, l1);
+                const bf16x8 xh = cat8(h0, h1), xl = cat8(l0, l1);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    const bf16x8 wh = wb[(4 * h + ft) * 64], wl = wb[(8 + 4 * h + ft) * 64];
+                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, y[ft], 0, 0, 0);      // small terms first
+                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, y[ft], 0, 0, 0);
+                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, y[ft], 0, 0, 0);
+                }
+            }
+            if (more) {
+                store_w(wv, (ch + 1) & 1);     // last read in iteration ch - 1, which every wave left at the barrier below
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) xa[cq] = xn[cq];
+            }
+            __syncthreads();
+        }
+        if (tile < n_tiles)
+            finish_tile<float>(y, r0, 0, l15, lg, C_out, ln_w != nullptr, lw, lb, inv_c, eps, relu, out, ldo, n_rows, ovec);
+    }
+}
+
+// C_in <= 512: the whole split weight matrix (C_in x 64 x 2 parts x 2 bytes <= 128 KiB) stays in LDS.  One workgroup of 16
+// waves per CU stages it once; after that a wave streams its 16-row tiles with no barrier at all: per 64-channel chunk four
+// 16-byte loads of x (the next chunk's already in flight), 16 ds_read_b128, 24 MFMAs.  (The chunked kernel above re-stages
+// every 16-KiB weight chunk for every group of 64 rows -- as many bytes out of L2 as x brings in from HBM -- and meets at
+// two barriers per chunk.)
+constexpr int kResidentChunks = 8;
+
+__global__ __launch_bounds__(1024) void long_linear_resident_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows,
+                                                                    int C_in, const float* __restrict__ W,
+                                                                    const float* __restrict__ bias, int C_out,
+                                                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                                    float eps, int relu, float* __restrict__ out, int64_t ldo,
+                                                                    int ovec) {
+    __shared__ __attribute__((aligned(16))) bf16x8 sm_w[kResidentChunks][16 * 64];   // [chunk][(part * 2 + h) * 4 + ft][lane]
+    __shared__ float sm_b[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int n_chunks = (C_in + 63) / 64;
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t t_stride = static_cast<int64_t>(gridDim.x) * 16;
+    int64_t tile = static_cast<int64_t>(blockIdx.x) * 16 + wave;
+    auto load_x = [&](f32x4 (&xa)[4], int64_t t, int ch) {
+        const int64_t r = t * 16 + l15;
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+            const int c = 64 * ch + 16 * cq + 4 * lg;
+            xa[cq] = (r < n_rows && c < C_in) ? *reinterpret_cast<const f32x4*>(x + r * ldx + c) : z4;
+        }
+    };
+    // A wave usually owns ONE tile (up to 65,536 rows): its first chunk of x is requested before the weights are staged, and
+    // the loop keeps one chunk in flight ahead of the one it multiplies (two ahead needs a third buffer: 100 VGPRs spilled,
+    // 56 us instead of 30 at 50,000 x 512).
+    f32x4 xa[4], xn[4];
+    if (tile < n_tiles) load_x(xa, tile, 0);
+    if (threadIdx.x < 64) sm_b[threadIdx.x] = threadIdx.x < C_out ? bias[threadIdx.x] : 0.f;
+    {   // all of a thread's weight loads (up to eight 16-byte loads) are in flight before the first conversion
+        f32x4 w0[kResidentChunks / 2], w1[kResidentChunks / 2];
+#pragma unroll
+        for (int it = 0; it < kResidentChunks / 2; ++it) {
+            const int idx = threadIdx.x + 1024 * it;
+            const int ch = idx >> 9, id = idx & 511, ln_ = id & 63, frag = id >> 6;
+            const int f = 4 * (ln_ & 15) + (frag & 3), c = 64 * ch + 32 * (frag >> 2) + 4 * (ln_ >> 4);
+            const float* wp = W + static_cast<int64_t>(f) * C_in + c;
+            w0[it] = (ch < n_chunks && f < C_out && c < C_in) ? *reinterpret_cast<const f32x4*>(wp) : z4;
+            w1[it] = (ch < n_chunks && f < C_out && c + 16 < C_in) ? *reinterpret_cast<const f32x4*>(wp + 16) : z4;
+        }
+#pragma unroll
+        for (int it = 0; it < kResidentChunks / 2; ++it) {
+            const int idx = threadIdx.x + 1024 * it;
+            const int ch = idx >> 9, id = idx & 511, ln_ = id & 63, frag = id >> 6;
+            if (ch < n_chunks) {
+                bf16x4 h0, l0, h1, l1;
+                split_bf16(w0[it], h0, l0);
+                split_bf16(w1[it], h1, l1);
+                sm_w[ch][frag * 64 + ln_] = cat8(h0, h1);
+                sm_w[ch][(8 + frag) * 64 + ln_] = cat8(l0, l1);
+            }
+        }
+    }
+    f32x4 lw = z4, lb = z4;
+    if (ln_w) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f = 4 * l15 + ft;
+            if (f < C_out) { lw[ft] = ln_w[f]; lb[ft] = ln_b[f]; }
+        }
+    }
+    const float inv_c = 1.0f / static_cast<float>(C_out);
+    __syncthreads();
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(sm_b + 4 * l15);
+    for (; tile < n_tiles; tile += t_stride) {
+        f32x4 y[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] = f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            if (ch + 1 < n_chunks) load_x(xn, tile, ch + 1);
+            else if (tile + t_stride < n_tiles) load_x(xn, tile + t_stride, 0);
+            const bf16x8* wb = sm_w[ch] + lane;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x4 h0, l0, h1, l1;
+                split_bf16(xa[2 * h], h0, l0);
+                split_bf16(xa[2 * h + 1], h1, l1);
+                const bf16x8 xh = cat8(h0, h1), xl = cat8(l0, l1);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    const bf16x8 wh = wb[(4 * h + ft) * 64], wl = wb[(8 + 4 * h + ft) * 64];
+                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, y[ft], 0, 0, 0);      // small terms first
+                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, y[ft], 0, 0, 0);
+                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, y[ft], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) xa[cq] = xn[cq];
+        }
+        finish_tile<float>(y, tile * 16, 0, l15, lg, C_out, ln_w != nullptr, lw, lb, inv_c, eps, relu, out, ldo, n_rows, ovec);
+    }
+}
+
 // grid (row chunks, ceil(C_out/256)); 256 threads; dynamic LDS = blocks * 64 * (kLinStride + 1) floats.
 // KQ = number of 16-channel groups of C_in actually used (1..8).
 template <int KQ, typename T>
@@ -310,6 +533,25 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
         const int64_t groups = ((n_rows + 15) / 16 + 3) / 4;
         int64_t g = groups < 4 * dif::kCUs ? groups : 4 * dif::kCUs;      // 35 KB of LDS: four workgroups per CU
         const int ov = (ldo % 4 == 0) && dif::aligned_v4<T>(out);
+        if constexpr (std::is_same<T, float>::value) {
+            // float32 storage: split-bfloat16 operands on the bf16 matrix core (DIFFORMER_LINEAR_FP32_MFMA=1: the exact
+            // fp32-MFMA kernel, for A/B measurements)
+            static const bool exact = [] { const char* e = getenv("DIFFORMER_LINEAR_FP32_MFMA"); return e && e[0] == '1'; }();
+            if (!exact && C_in <= 64 * kResidentChunks && n_rows >= 32768) {     // below: the chunked kernel's many small workgroups win
+                const int64_t tiles = (n_rows + 15) / 16;
+                const int64_t wg = (tiles + 15) / 16 < dif::kCUs ? (tiles + 15) / 16 : dif::kCUs;      // one 16-wave workgroup per CU
+                hipLaunchKernelGGL(long_linear_resident_kernel, dim3(static_cast<unsigned>(wg)), dim3(1024), 0,
+                                   static_cast<hipStream_t>(stream), x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, ln_bias, ln_eps,
+                                   relu, out, ldo, ov);
+                return dif::launch_status("long_linear_resident_kernel");
+            }
+            if (!exact) {
+                hipLaunchKernelGGL(long_linear_split_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0,
+                                   static_cast<hipStream_t>(stream), x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, ln_bias, ln_eps,
+                                   relu, out, ldo, ov);
+                return dif::launch_status("long_linear_split_kernel");
+            }
+        }
         hipLaunchKernelGGL((long_linear_kernel<T>), dim3(static_cast<unsigned>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                            ldx, n_rows, C_in, W, bias, C_out, ln_weight, ln_bias, ln_eps, relu, out, ldo, ov);
         return dif::launch_status("long_linear_kernel");
