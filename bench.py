@@ -381,6 +381,14 @@ def main():
                    use_residual=True, use_weight=True, use_graph=use_graph, graph_weight=-1, use_source=False)
         cpu = cpu_baseline(model, x_full, edge_index, cfg)
 
+    if cpu is not None:
+        # beside the port timed here: the reference file imported VERBATIM, timed in the build container (the GPU box has no
+        # /root/reference); scripts/cpu_reference_verbatim.py, BASELINE.md section 2
+        vpath = os.path.join(ROOT, "profiles", "cpu_reference_verbatim.json")
+        if os.path.exists(vpath):
+            ver = json.load(open(vpath)).get(args.workload)
+            if ver:
+                cpu["reference_verbatim"] = {k: ver[k] for k in ("value", "unit", "cores", "kind", "where", "sample")}
     if rank == 0:
         print(json.dumps({
             "metric": "DIFFormer-layer forward nodes/sec", "value": value, "unit": "nodes/s", "n_gpus": world,
