@@ -222,7 +222,9 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        if bias is not None and x.shape[1] <= 128 and weight.shape[0] <= 64:
+        # the narrow-Linear kernel keeps up to 256 output features per workgroup in LDS for C_in <= 64 (the fused q | k | v
+        # projection 64 -> 192: one launch, x read once), 128 for C_in <= 128
+        if bias is not None and ((x.shape[1] <= 64 and weight.shape[0] <= 256) or (x.shape[1] <= 128 and weight.shape[0] <= 64)):
             return ops.linear(x, weight, bias)
         return torch.nn.functional.linear(x, weight, bias)
 
@@ -242,6 +244,29 @@ class _Linear(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 gb = red[co * ci: co * ci + co]
         return gx, gw, gb
+
+
+class _SplitColumns(torch.autograd.Function):
+    """q | k | v as column slices of the fused projection [n, (2|3) H D].  Plain slicing would have autograd build one
+    zero-filled [n, 3 H D] buffer per slice gradient and add them up (three fills, three copies, two adds of 102 MB at
+    C4); the gradients of the slices are simply the columns of the gradient, so backward is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, t, *sizes):
+        ctx.sizes, ctx.n = sizes, t.shape[0]
+        return tuple(t.split(list(sizes), dim=1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros((ctx.n, w)) for g, w in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, dim=1),) + (None,) * len(ctx.sizes)
+
+
+def split_columns(t, *sizes):
+    if _needs_grad(t):
+        return _SplitColumns.apply(t, *sizes)
+    return t.split(list(sizes), dim=1)
 
 
 def _row_linear(x, weight, bias):

@@ -193,14 +193,17 @@ class HipBackend:
         D = v.shape[2]
         for t_, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (g, "grad")):
             _f32(t_, nm)
-        q, k, v, out, g = (t_.contiguous() for t_ in (q, k, v, out, g))
+        # q, k, v are usually column slices of one fused projection [n, 3 H D]: every kernel below takes a leading
+        # dimension, so they go in as they are (three 34-MB copies per layer at C4 otherwise)
+        (q, ldq), (k, ldk), (v, ldv) = _row_major(q, H * M), _row_major(k, H * M), _row_major(v, H * D)
+        out, g = out.contiguous(), g.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
         gn, gd = torch.empty((n, H, D), **f32), torch.empty((n, H), **f32)
         sums = torch.empty(H * M + 1, **f32)
         ws_bytes = self.lib.dif_simple_bwd_workspace_bytes(n, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _Timed(self, "dif_simple_bwd_prep_f32", dev):
-            rc = self.lib.dif_simple_bwd_prep_f32(_ptr(q), H * M, _ptr(g), H * D, _ptr(out), H * D, _ptr(reduced), n,
+            rc = self.lib.dif_simple_bwd_prep_f32(_ptr(q), ldq, _ptr(g), H * D, _ptr(out), H * D, _ptr(reduced), n,
                                                   int(n_global), H, M, D, _ptr(gn), _ptr(gd), _ptr(sums), _ptr(ws),
                                                   ws_bytes, _stream(dev))
         _lib.check(rc, "dif_simple_bwd_prep_f32")
@@ -219,10 +222,10 @@ class HipBackend:
         dks = (sums[: H * M] * s).contiguous()
         dq, dk, dv = torch.empty((n, H, M), **f32), torch.empty((n, H, M), **f32), torch.empty((n, H, D), **f32)
 
-        def rowgemm(A, K, mat, mat_t, bias, r, u, cin, beta, C, dst):
+        def rowgemm(A, K, mat, mat_t, bias, r, u, cin, beta, C, dst, lda=None, ldc=None):
             with _Timed(self, "dif_rowgemm_f32", dev):
-                rc_ = self.lib.dif_rowgemm_f32(_ptr(A), H * K, _ptr(mat), D, M * D, mat_t, 1.0, _ptr(bias), _ptr(r), _ptr(u),
-                                               1.0, _ptr(cin), H * C, _ptr(beta), n, H, K, C, _ptr(dst), H * C,
+                rc_ = self.lib.dif_rowgemm_f32(_ptr(A), lda or H * K, _ptr(mat), D, M * D, mat_t, 1.0, _ptr(bias), _ptr(r), _ptr(u),
+                                               1.0, _ptr(cin), ldc or H * C, _ptr(beta), n, H, K, C, _ptr(dst), H * C,
                                                _stream(dev))
             _lib.check(rc_, "dif_rowgemm_f32")
 
@@ -234,8 +237,8 @@ class HipBackend:
             T = shard.all_reduce_sum(T.reshape(1))[0]
         dq.addcmul_(q, (-T / reduced[-2]).expand_as(q))               # - (T/|Q|^2) q
         beta_k = (-T / reduced[-1]).reshape(1).contiguous()
-        rowgemm(v, D, dktv, 1, dks, None, None, k, beta_k, M, dk)     # v dKtV^T + dks - (T/|K|^2) k
-        rowgemm(k, M, dktv, 0, dvs, None, None, None, None, D, dv)    # k dKtV + dvs
+        rowgemm(v, D, dktv, 1, dks, None, None, k, beta_k, M, dk, lda=ldv, ldc=ldk)     # v dKtV^T + dks - (T/|K|^2) k
+        rowgemm(k, M, dktv, 0, dvs, None, None, None, None, D, dv, lda=ldk)             # k dKtV + dvs
         return dq, dk, dv
 
     # ---- a2 --------------------------------------------------------------------------------

@@ -126,9 +126,9 @@ class DIFFormerConv(nn.Module):
             # [n, (2|3)*H*D]; q/k/v are column slices.  Narrow inputs take the hand-written Linear kernel (one launch,
             # x read once), wide ones the vendor GEMM (autograd_ops.linear decides).
             qkv = ag.linear(source_input, w, b) if w.shape[0] <= 256 else F.linear(source_input, w, b)
-            q = qkv[:, : H * D].reshape(-1, H, D)
-            k = qkv[:, H * D: 2 * H * D].reshape(-1, H, D)
-            v = qkv[:, 2 * H * D:].reshape(-1, H, D) if self.use_weight else None
+            cols = ag.split_columns(qkv, *([H * D] * (3 if self.use_weight else 2)))
+            q, k = cols[0].reshape(-1, H, D), cols[1].reshape(-1, H, D)
+            v = cols[2].reshape(-1, H, D) if self.use_weight else None
         else:
             q = self.Wq(query_input).reshape(-1, H, D)
             k = self.Wk(source_input).reshape(-1, H, D)
@@ -239,7 +239,8 @@ class DIFFormerConv(nn.Module):
             else:
                 raise ValueError(f"unknown attention kernel {self.kernel!r}")
             if (self.use_graph and not v.is_contiguous() and v.shape[0] >= 65536 and edge_index is not None and
-                    edge_index.shape[1] >= 32 * v.shape[0]):
+                    edge_index.shape[1] >= 32 * v.shape[0] and
+                    ops.sliced_tiling(v.shape[0], v.shape[1] * v.shape[2], edge_index.shape[1], edge_weight, shard, v.element_size()) is None):
                 v = v.contiguous()   # the blocked SpMM gathers whole rows: contiguous rows are ~8 % faster on big dense
                                      # graphs; small or sparse graphs (a Pokec batch: 18 us of copy for a 55-us product)
                                      # take the strided view as it is (every kernel has a leading dimension)
