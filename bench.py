@@ -272,6 +272,15 @@ def main():
             model(x, edge_index)
         torch.cuda.synchronize()
         fwd_ms = sorted(a.elapsed_time(b) for a, b in fwd_events)
+    ag = getattr(model, "_ag_state", None)
+    if use_graph_replay:
+        launch_mode = "hipGraph replay"
+    elif ag is not None and ag[2] is not None:
+        # plain model(x, edge_index) calls: DIFFormer.forward captured itself as one hipGraph on the third identical call
+        # (warm-up) and the timed steps replayed it; DIFFORMER_AUTO_GRAPH=0 gives the kernel-by-kernel launches
+        launch_mode = "model(x, edge_index): auto-captured hipGraph replay"
+    else:
+        launch_mode = "eager"
     ktimes = be.kernel_times_ms()
     be.kernel_events = None
     elapsed = max_over_ranks(elapsed, dev)
@@ -400,7 +409,7 @@ def main():
                        "hidden": hidden, "heads": 1, "layers": layers, "kernel": kernel, "use_graph": use_graph,
                        "parallelism": plan["parallelism"],
                        "csr": "warm (cached); cold build reported in cold_csr_build_ms",
-                       "launch": "hipGraph replay" if use_graph_replay else "eager"},
+                       "launch": launch_mode},
             "cold_csr_build_ms": cold_ms, "roofline": roofline, "cpu_baseline": cpu,
         }))
     if world > 1:

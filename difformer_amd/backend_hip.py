@@ -15,7 +15,9 @@ from . import _lib
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """Device address as a plain int (None = NULL): ctypes converts it for `c_void_p` argtypes itself, and a Python int is
+    several times cheaper to make than a c_void_p object -- the host path has ~20 of these per call."""
+    return t.data_ptr() if t is not None else None
 
 
 # Part 0 of the row-sharded SpMM runs while the all-gather of the value rows is in flight.  A workgroup of the blocked
@@ -29,8 +31,8 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 def _stream(dev):
     """Raw handle of torch's current HIP stream on `dev` (the fast accessor when this torch has it)."""
     if _raw_stream is not None and dev.index is not None:
-        return ctypes.c_void_p(_raw_stream(dev.index))
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        return _raw_stream(dev.index)
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _require_device(*tensors):
@@ -117,6 +119,24 @@ class _Timed:
         return self.ctx.__exit__(*exc) if self.ctx is not None else False
 
 
+class _NoBracket:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_BRACKET = _NoBracket()
+
+
+def _timed(backend, name, dev):
+    """The common case -- no event collection, operands on the current device -- costs one shared no-op context."""
+    if backend.kernel_events is None and dev.index is not None and torch.cuda.current_device() == dev.index:
+        return _NO_BRACKET
+    return _Timed(backend, name, dev)
+
+
 class HipBackend:
     name = "hip"
 
@@ -144,7 +164,7 @@ class HipBackend:
         ws_bytes = self.lib.dif_simple_workspace_bytes(n, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         fn = getattr(self.lib, "dif_simple_reduce_" + sfx)
-        with _Timed(self, "dif_simple_reduce_f32", dev):
+        with _timed(self, "dif_simple_reduce_f32", dev):
             rc = fn(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, n, H, M, D, _ptr(reduced), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_simple_reduce_" + sfx)
         return reduced
@@ -162,7 +182,7 @@ class HipBackend:
         ws_bytes = self.lib.dif_project_reduce_workspace_bytes(n, H, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         fn = getattr(self.lib, "dif_project_reduce_" + sfx)
-        with _Timed(self, "dif_project_reduce_f32", dev):
+        with _timed(self, "dif_project_reduce_f32", dev):
             rc = fn(_ptr(x), ldx, n, C, *[_ptr(t) for t in ws_], H, D, _ptr(q), H * D, _ptr(v), H * D, _ptr(reduced),
                     _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_project_reduce_" + sfx)
@@ -176,7 +196,7 @@ class HipBackend:
         q, ldq = _row_major(q, H * M)
         out = torch.empty((n, H, D), dtype=dt, device=dev)
         fn = getattr(self.lib, "dif_simple_apply_" + sfx)
-        with _Timed(self, "dif_simple_apply_f32", dev):
+        with _timed(self, "dif_simple_apply_f32", dev):
             rc = fn(_ptr(q), ldq, _ptr(reduced), n, int(n_global), H, M, D, _ptr(out), H * D, _stream(dev))
         _lib.check(rc, "dif_simple_apply_" + sfx)
         return out
@@ -202,7 +222,7 @@ class HipBackend:
         sums = torch.empty(H * M + 1, **f32)
         ws_bytes = self.lib.dif_simple_bwd_workspace_bytes(n, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_simple_bwd_prep_f32", dev):
+        with _timed(self, "dif_simple_bwd_prep_f32", dev):
             rc = self.lib.dif_simple_bwd_prep_f32(_ptr(q), ldq, _ptr(g), H * D, _ptr(out), H * D, _ptr(reduced), n,
                                                   int(n_global), H, M, D, _ptr(gn), _ptr(gd), _ptr(sums), _ptr(ws),
                                                   ws_bytes, _stream(dev))
@@ -223,7 +243,7 @@ class HipBackend:
         dq, dk, dv = torch.empty((n, H, M), **f32), torch.empty((n, H, M), **f32), torch.empty((n, H, D), **f32)
 
         def rowgemm(A, K, mat, mat_t, bias, r, u, cin, beta, C, dst, lda=None, ldc=None):
-            with _Timed(self, "dif_rowgemm_f32", dev):
+            with _timed(self, "dif_rowgemm_f32", dev):
                 rc_ = self.lib.dif_rowgemm_f32(_ptr(A), lda or H * K, _ptr(mat), D, M * D, mat_t, 1.0, _ptr(bias), _ptr(r), _ptr(u),
                                                1.0, _ptr(cin), ldc or H * C, _ptr(beta), n, H, K, C, _ptr(dst), H * C,
                                                _stream(dev))
@@ -257,13 +277,13 @@ class HipBackend:
         if want_den:
             _f32(q, "q")
             den = torch.empty((N, H), dtype=torch.float32, device=dev)
-            with _Timed(self, "dif_sigmoid_attn_fwd_f32", dev):
+            with _timed(self, "dif_sigmoid_attn_fwd_f32", dev):
                 rc = self.lib.dif_sigmoid_attn_fwd_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, N, L, H, M, D, _ptr(out),
                                                        H * D, _ptr(den), _ptr(ws), ws_bytes, _stream(dev))
             _lib.check(rc, "dif_sigmoid_attn_fwd_f32")
             return out, den
         name = "dif_sigmoid_attn_" + sfx
-        with _Timed(self, name, dev):
+        with _timed(self, name, dev):
             rc = getattr(self.lib, name)(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, N, L, H, M, D, _ptr(out), H * D, _ptr(ws),
                                          ws_bytes, _stream(dev))
         _lib.check(rc, name)
@@ -286,7 +306,7 @@ class HipBackend:
         dq, dk, dv = torch.empty((N, H, M), **f32), torch.empty((L, H, M), **f32), torch.empty((L, H, D), **f32)
         ws_bytes = self.lib.dif_sigmoid_bwd_workspace_bytes(N, L, H, M, D)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_sigmoid_attn_bwd_f32", dev):
+        with _timed(self, "dif_sigmoid_attn_bwd_f32", dev):
             rc = self.lib.dif_sigmoid_attn_bwd_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(out), H * D, _ptr(den),
                                                    _ptr(g), ldg, N, L, H, M, D, _ptr(dq), H * M, _ptr(dk), H * M, _ptr(dv),
                                                    H * D, _ptr(ws), ws_bytes, _stream(dev))
@@ -312,13 +332,13 @@ class HipBackend:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         if want_den:
             den = torch.empty((N, H), dtype=torch.float32, device=dev)
-            with _Timed(self, "dif_batched_simple_attn_fwd_f32", dev):
+            with _timed(self, "dif_batched_simple_attn_fwd_f32", dev):
                 rc = self.lib.dif_batched_simple_attn_fwd_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(graph_ptr),
                                                               graph_ptr.numel() - 1, N, H, M, D, _ptr(out), H * D, _ptr(den),
                                                               _ptr(ws), ws_bytes, _stream(dev))
             _lib.check(rc, "dif_batched_simple_attn_fwd_f32")
             return out, den, ws.view(torch.float32)[-2:].clone()
-        with _Timed(self, "dif_batched_simple_attn_f32", dev):
+        with _timed(self, "dif_batched_simple_attn_f32", dev):
             rc = self.lib.dif_batched_simple_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(graph_ptr),
                                                       graph_ptr.numel() - 1, N, H, M, D, _ptr(out), H * D, _ptr(ws),
                                                       ws_bytes, _stream(dev))
@@ -342,7 +362,7 @@ class HipBackend:
         def raw(a, b, c, rs, vw, vs_is_s):
             Ma, Dc = a.shape[2], c.shape[2]
             dst = torch.empty((N, H, Dc), dtype=torch.float32, device=dev)
-            with _Timed(self, "dif_batched_simple_raw_f32", dev):
+            with _timed(self, "dif_batched_simple_raw_f32", dev):
                 rc = self.lib.dif_batched_simple_raw_f32(_ptr(a), H * Ma, _ptr(b), H * Ma, _ptr(c), H * Dc, _ptr(graph_ptr), B, N,
                                                          H, Ma, Dc, _ptr(sumsq), _ptr(rs), _ptr(vw), int(vs_is_s), _ptr(dst),
                                                          H * Dc, _stream(dev))
@@ -371,7 +391,7 @@ class HipBackend:
         k, ldk = _row_major(k, H * M)
         v, ldv = _row_major(v, H * D)
         out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
-        with _Timed(self, "dif_batched_sigmoid_attn_f32", dev):
+        with _timed(self, "dif_batched_sigmoid_attn_f32", dev):
             rc = self.lib.dif_batched_sigmoid_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(ranked_first),
                                                        _ptr(pos_count), ranked_first.numel(), pos_count.numel(), H, M, D,
                                                        _ptr(out), H * D, _stream(dev))
@@ -399,7 +419,7 @@ class HipBackend:
             blkptr = torch.empty((n_blocks + 1) * num_nodes, dtype=torch.int32, device=dev)
         ws_bytes = self.lib.dif_csr_workspace_bytes(E, num_nodes, n_blocks)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_csr_build", dev):
+        with _timed(self, "dif_csr_build", dev):
             rc = self.lib.dif_csr_build(_ptr(ei), E, num_nodes, _ptr(ew), n_blocks, int(block_rows), int(bool(transpose)), _ptr(rowptr),
                                         _ptr(blkptr),
                                         _ptr(src), _ptr(val), _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
@@ -423,7 +443,7 @@ class HipBackend:
         status = torch.empty(1, dtype=torch.int32, device=dev)
         ws_bytes = self.lib.dif_subgraph_workspace_bytes(E, num_nodes)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_subgraph", dev):
+        with _timed(self, "dif_subgraph", dev):
             rc = self.lib.dif_subgraph(_ptr(ei), E, num_nodes, _ptr(sub), B, _ptr(ew), _ptr(out_ei), _ptr(out_w),
                                        _ptr(count), _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_subgraph")
@@ -446,7 +466,7 @@ class HipBackend:
         status = torch.empty(1, dtype=torch.int32, device=dev)
         ws_bytes = self.lib.dif_graph_prepare_workspace_bytes(E, num_nodes, int(bool(undirected)))
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_graph_prepare", dev):
+        with _timed(self, "dif_graph_prepare", dev):
             rc = self.lib.dif_graph_prepare(_ptr(ei), E, num_nodes, int(bool(undirected)), int(bool(remove_loops)),
                                             int(bool(add_loops)), max(cap, 1), _ptr(out), _ptr(count), _ptr(status), _ptr(ws),
                                             ws_bytes, _stream(dev))
@@ -472,7 +492,7 @@ class HipBackend:
         status = torch.empty(1, dtype=torch.int32, device=dev)
         ws_bytes = self.lib.dif_subgraph_batches_workspace_bytes(E, num_nodes, nb)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_subgraph_batches", dev):
+        with _timed(self, "dif_subgraph_batches", dev):
             rc = self.lib.dif_subgraph_batches_group(_ptr(ei), E, num_nodes, _ptr(pm), M, int(batch_size), _ptr(bptr),
                                                      _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_subgraph_batches_group")
@@ -485,7 +505,7 @@ class HipBackend:
         kept = ptr[-1]
         out_ei = torch.empty((2, max(kept, 1)), dtype=torch.int64, device=dev)
         out_w = None if ew is None else torch.empty(max(kept, 1), dtype=torch.float32, device=dev)
-        with _Timed(self, "dif_subgraph_batches", dev):
+        with _timed(self, "dif_subgraph_batches", dev):
             rc = self.lib.dif_subgraph_batches_emit(_ptr(ei), E, num_nodes, M, int(batch_size), _ptr(ew), _ptr(bptr), kept,
                                                     _ptr(out_ei), _ptr(out_w), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_subgraph_batches_emit")
@@ -496,7 +516,7 @@ class HipBackend:
             val = torch.empty(max(kept, 1), dtype=torch.float32, device=dev)
             ws2_bytes = self.lib.dif_subgraph_batches_csr_workspace_bytes(kept, M)
             ws2 = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
-            with _Timed(self, "dif_subgraph_batches", dev):
+            with _timed(self, "dif_subgraph_batches", dev):
                 rc = self.lib.dif_subgraph_batches_csr(_ptr(ei), E, num_nodes, M, int(batch_size), _ptr(ew), kept, _ptr(ws),
                                                        ws_bytes, _ptr(rowptr), _ptr(src), _ptr(val), _ptr(ws2), ws2_bytes,
                                                        _stream(dev))
@@ -518,7 +538,7 @@ class HipBackend:
         g, ldg = _row_major(g, F)
         x, ldx = _row_major(x, F)
         dw = torch.empty(E, dtype=torch.float32, device=dev)
-        with _Timed(self, "dif_gcn_edge_weight_grad_f32", dev):
+        with _timed(self, "dif_gcn_edge_weight_grad_f32", dev):
             rc = self.lib.dif_gcn_edge_weight_grad_f32(_ptr(ei), E, n_nodes, _ptr(w), _ptr(rowptr), _ptr(g), ldg, _ptr(x), ldx,
                                                        F, float(scale), _ptr(dw), _stream(dev))
         _lib.check(rc, "dif_gcn_edge_weight_grad_f32")
@@ -570,12 +590,12 @@ class HipBackend:
             xp = ctypes.c_void_p(x.data_ptr() - int(x_row0) * ldx * x.element_size())
             head = head[:7] + (xp,) + head[8:]
             fn = self.lib.dif_gcn_spmm_part_bf16 if sfx == "bf16" else self.lib.dif_gcn_spmm_part_f32
-            with _Timed(self, "dif_gcn_spmm_f32", dev):
+            with _timed(self, "dif_gcn_spmm_f32", dev):
                 rc = fn(*head, int(tail is not None), *tail_args, int(phase), int(own_lo), int(own_hi),
                         PART0_WORKGROUPS if phase == 0 else 0, _ptr(scratch), sbytes, _ptr(out), F, _stream(dev))
             _lib.check(rc, "dif_gcn_spmm_part")
             return scratch if phase == 0 else out
-        with _Timed(self, "dif_gcn_spmm_f32", dev):
+        with _timed(self, "dif_gcn_spmm_f32", dev):
             if sfx == "bf16":
                 name = "dif_gcn_spmm_tail_bf16"
                 rc = self.lib.dif_gcn_spmm_tail_bf16(*head, int(tail is not None), *tail_args, _ptr(out), F, _stream(dev))
@@ -604,14 +624,14 @@ class HipBackend:
         if sfx == "bf16":        # bfloat16 rows, float32 record; no slice-major copy (the sliced product is float32-only)
             if plan is not None:
                 raise TypeError("difformer_amd: the slice-major copy of the sliced product is float32-only")
-            with _Timed(self, "dif_gram_f32", dev):
+            with _timed(self, "dif_gram_f32", dev):
                 rc = self.lib.dif_gram_bf16(_ptr(x), ldx, n, C, _ptr(record), _ptr(ws), ws_bytes, _stream(dev))
             _lib.check(rc, "dif_gram_bf16")
             return record, None
         ys = None
         if plan is not None:
             ys = torch.empty((C // 4, int(plan[6]) * int(plan[7]), 4), dtype=torch.float32, device=dev)
-        with _Timed(self, "dif_gram_f32", dev):
+        with _timed(self, "dif_gram_f32", dev):
             rc = self.lib.dif_gram_f32(_ptr(x), ldx, n, C, _ptr(rowptr) if plan is not None else None, plan, _ptr(ys),
                                        _ptr(record), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_gram_f32")
@@ -621,7 +641,7 @@ class HipBackend:
         dev = _require_device(record, Wq, bq, Wk, bk, Wv, bv)
         ws_ = [None if t is None else _f32(t, "weight").contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
         coef = torch.empty(self.lib.dif_simple_coeffs_len(C, D), dtype=torch.float32, device=dev)
-        with _Timed(self, "dif_simple_coeffs_f32", dev):
+        with _timed(self, "dif_simple_coeffs_f32", dev):
             rc = self.lib.dif_simple_coeffs_f32(_ptr(record), int(n_global), C, D, *[_ptr(t) for t in ws_], float(attn_scale),
                                                 _ptr(coef), _stream(dev))
         _lib.check(rc, "dif_simple_coeffs_f32")
@@ -658,7 +678,7 @@ class HipBackend:
             if sfx != "f32" or next_plan is not None or next_record or Co > 128 or Wo.shape[1] != D:
                 raise TypeError("difformer_amd: the fused output Linear needs float32 rows, Co <= 128, no next-layer products")
             logits = torch.empty((n, Co), dtype=torch.float32, device=dev)
-            with _Timed(self, "dif_simple_layer_f32", dev):
+            with _timed(self, "dif_simple_layer_f32", dev):
                 rc = self.lib.dif_simple_layer_head_f32(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
                                                         _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
                                                         float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
@@ -672,7 +692,7 @@ class HipBackend:
         if sfx == "bf16":
             if next_plan is not None or next_record:
                 raise TypeError("difformer_amd: products for the next layer are float32-only")
-            with _Timed(self, "dif_simple_layer_f32", dev):
+            with _timed(self, "dif_simple_layer_f32", dev):
                 rc = self.lib.dif_simple_layer_bf16(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
                                                     _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
                                                     float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
@@ -685,7 +705,7 @@ class HipBackend:
             record = torch.empty(D * D + D + 2, dtype=torch.float32, device=dev)
             ws_bytes = self.lib.dif_gram_workspace_bytes(n, D)
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_simple_layer_f32", dev):
+        with _timed(self, "dif_simple_layer_f32", dev):
             rc = self.lib.dif_simple_layer_f32(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
                                                _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
                                                float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps), int(bool(relu)),
@@ -719,7 +739,7 @@ class HipBackend:
         lengths = torch.empty(G * NT * 4, **i32)
         table = torch.empty((R + 1) * panels * NT * W + 1, **i32)
         status = torch.empty(1, **i32)
-        with _Timed(self, "dif_sliced_measure", dev):
+        with _timed(self, "dif_sliced_measure", dev):
             rc = self.lib.dif_sliced_measure(_ptr(rowptr), _ptr(blkptr), _ptr(src), int(n_src), int(nnz), int(row_begin),
                                              int(n_rows), int(F), plan, _ptr(order), _ptr(parts), n_pos, _ptr(srt),
                                              _ptr(counts), _ptr(lengths), _ptr(table), _ptr(status), _stream(dev))
@@ -728,7 +748,7 @@ class HipBackend:
         if bad:
             return None
         entries = torch.empty(512 * max(n_blocks, 1), dtype=torch.int16, device=dev)
-        with _Timed(self, "dif_sliced_emit", dev):
+        with _timed(self, "dif_sliced_emit", dev):
             rc = self.lib.dif_sliced_emit(_ptr(rowptr), _ptr(blkptr), int(n_src), int(row_begin), int(n_rows), int(F), plan,
                                           _ptr(order), _ptr(parts), n_pos, _ptr(srt), _ptr(counts), _ptr(table),
                                           max(n_blocks, 1), _ptr(entries), _stream(dev))
@@ -744,7 +764,7 @@ class HipBackend:
         if ldx % 4 or x.data_ptr() % 16:
             x, ldx = x.contiguous(), F
         ys = torch.empty((F // 4, int(plan[6]) * int(plan[7]), 4), dtype=torch.float32, device=dev)
-        with _Timed(self, "dif_sliced_prescale_f32", dev):
+        with _timed(self, "dif_sliced_prescale_f32", dev):
             rc = self.lib.dif_sliced_prescale_f32(_ptr(x), ldx, _ptr(rowptr), _ptr(dinv), int(n_src), F, plan, _ptr(ys),
                                                   _stream(dev))
         _lib.check(rc, "dif_sliced_prescale_f32")
@@ -763,7 +783,7 @@ class HipBackend:
         n_pos = int(n_rows) if sl.n_pos is None else int(sl.n_pos)
         ws_bytes = self.lib.dif_sliced_spmm_workspace_bytes(int(n_src), n_pos, int(F))   # > 0: a row shard (source splits)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        with _Timed(self, "dif_sliced_spmm_f32", dev):
+        with _timed(self, "dif_sliced_spmm_f32", dev):
             rc = self.lib.dif_sliced_spmm_f32(_ptr(sl.entries), _ptr(sl.table), sl.plan, _ptr(ys), _ptr(rowptr), _ptr(dinv),
                                               _ptr(sl.order), _ptr(sl.parts), n_pos, int(n_src), int(row_begin), int(n_rows),
                                               int(F), _ptr(attn), lda, float(attn_scale), float(gcn_scale), _ptr(out), F,
@@ -779,7 +799,7 @@ class HipBackend:
         stats = torch.empty(2, dtype=torch.int32, device=dev)
         ws_bytes = self.lib.dif_row_order_workspace_bytes(n_rows)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_row_order", dev):
+        with _timed(self, "dif_row_order", dev):
             rc = self.lib.dif_row_order(_ptr(rowptr), row_begin, n_rows, _ptr(order), _ptr(stats), _ptr(ws), ws_bytes,
                                         _stream(dev))
         _lib.check(rc, "dif_row_order")
@@ -799,7 +819,7 @@ class HipBackend:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
         out = torch.empty((n, Co), dtype=dt, device=dev)
         fn = getattr(self.lib, "dif_linear_" + sfx)
-        with _Timed(self, "dif_linear_f32", dev):
+        with _timed(self, "dif_linear_f32", dev):
             rc = fn(_ptr(x), ldx, n, C, _ptr(weight), _ptr(bias), Co, _ptr(ln_weight), _ptr(ln_bias), float(eps),
                     int(bool(relu)), _ptr(out), Co, _stream(dev))
         _lib.check(rc, "dif_linear_" + sfx)
@@ -834,7 +854,7 @@ class HipBackend:
             d_ln = torch.empty(2 * D, **f32)
             ws_bytes = self.lib.dif_layer_tail_bwd_workspace_bytes(n, D)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_layer_tail_bwd_f32", dev):
+        with _timed(self, "dif_layer_tail_bwd_f32", dev):
             rc = self.lib.dif_layer_tail_bwd_f32(_ptr(conv), ldc, n, H, D, _ptr(x0), ldx0, _ptr(prev), ldp, float(alpha),
                                                  _ptr(ln_weight), _ptr(ln_bias), float(eps), int(bool(relu)), _ptr(g), ldg,
                                                  _ptr(d_conv), H * D, _ptr(d_x0), D, _ptr(d_prev), D, _ptr(d_ln), _ptr(ws),
@@ -859,13 +879,13 @@ class HipBackend:
             ws_bytes = self.lib.dif_gram_bg_workspace_bytes(n, C)
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
             xp = x
-        with _Timed(self, "dif_gram_bg_f32", dev):
+        with _timed(self, "dif_gram_bg_f32", dev):
             rc = self.lib.dif_gram_bg_f32(_ptr(xp), ldx, n, C, int(n_global), _ptr(factors.st), _ptr(gt), _ptr(ws), ws_bytes,
                                           _stream(dev))
         _lib.check(rc, "dif_gram_bg_f32")
         scratch = torch.empty(80 * 80 + 4, **f32)
         coef = torch.empty(self.lib.dif_simple_coeffs_len(C, D), **f32)
-        with _Timed(self, "dif_simple_coeffs_bg_f32", dev):
+        with _timed(self, "dif_simple_coeffs_bg_f32", dev):
             rc = self.lib.dif_simple_coeffs_bg_f32(_ptr(gt), _ptr(factors.pt), _ptr(factors.vtt), _ptr(factors.st), C, D,
                                                    float(attn_scale), _ptr(scratch), _ptr(coef), _stream(dev))
         _lib.check(rc, "dif_simple_coeffs_bg_f32")
@@ -881,7 +901,7 @@ class HipBackend:
         rec = torch.empty(self.lib.dif_simple_reduced_len(1, C, C), dtype=torch.float32, device=dev)
         ws_bytes = self.lib.dif_simple_workspace_bytes(n, 1, C, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with _Timed(self, "dif_gram_sym_f32", dev):
+        with _timed(self, "dif_gram_sym_f32", dev):
             rc = self.lib.dif_gram_sym_f32(_ptr(x), ldx, n, C, _ptr(rec), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_gram_sym_f32")
         return rec
@@ -891,7 +911,7 @@ class HipBackend:
         dev = _require_device(rec, S)
         Gt = torch.empty((C + 1, C + 1), dtype=torch.float64, device=dev)
         partial = torch.empty(2 * self.lib.dif_wide_partials(C), dtype=torch.float64, device=dev)
-        with _Timed(self, "dif_wide_gram_f64", dev):
+        with _timed(self, "dif_wide_gram_f64", dev):
             rc = self.lib.dif_wide_gram_f64(_ptr(rec), C, int(n_global), _ptr(S), _ptr(Gt), _ptr(partial), _stream(dev))
         _lib.check(rc, "dif_wide_gram_f64")
         return Gt, partial
@@ -903,7 +923,7 @@ class HipBackend:
         R, T = R.contiguous(), T.contiguous()
         B = torch.empty((C, DV), dtype=torch.float32, device=dev)
         bias = torch.empty(DV, dtype=torch.float32, device=dev)
-        with _Timed(self, "dif_wide_scale_f64", dev):
+        with _timed(self, "dif_wide_scale_f64", dev):
             rc = self.lib.dif_wide_scale_f64(_ptr(R), _ptr(T), _ptr(partial), C, DV, _ptr(B), _ptr(bias), _stream(dev))
         _lib.check(rc, "dif_wide_scale_f64")
         return B, bias
@@ -932,7 +952,7 @@ class HipBackend:
             rs, bv = rs.contiguous(), bv.contiguous()
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
         den_ptr = None if den_col is None else Z.data_ptr() + 4 * int(den_col)
-        with _Timed(self, "dif_layer_tail_mix_f32", dev):
+        with _timed(self, "dif_layer_tail_mix_f32", dev):
             rc = self.lib.dif_layer_tail_mix_f32(_ptr(Z), ldz, den_ptr, ldz, float(conv_scale), _ptr(add), lda,
                                                  float(add_scale), _ptr(rs), _ptr(bv), n, D, _ptr(x0), ldx0, _ptr(prev), ldp,
                                                  float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps), int(bool(relu)),
@@ -954,7 +974,7 @@ class HipBackend:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
         out = torch.empty((n, D), dtype=dt, device=dev)
         fn = getattr(self.lib, "dif_layer_tail_" + sfx)
-        with _Timed(self, "dif_layer_tail_f32", dev):
+        with _timed(self, "dif_layer_tail_f32", dev):
             rc = fn(_ptr(conv), ldc, n, H, D, _ptr(x0), ldx0, _ptr(prev), ldp, float(alpha), _ptr(ln_weight),
                     _ptr(ln_bias), float(eps), int(bool(relu)), _ptr(out), D, _stream(dev))
         _lib.check(rc, "dif_layer_tail_" + sfx)

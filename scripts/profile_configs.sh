@@ -6,6 +6,7 @@ for W in cora-s cora-a cifar50k-s pokec-batch-s-bf16 pokec-batch-s pokec-batch-h
   # the eager line carries the cpu_baseline leg (oracle port on the host cores; skipped by bench.py for bf16 storage)
   python bench.py --workload $W --steps 50 --warmup 5 > $OUT/bench_${W}_eager.json 2>> $OUT/err.log
   python bench.py --workload $W --steps 50 --warmup 5 --no-cpu-baseline --graph > $OUT/bench_${W}_graph.json 2>> $OUT/err.log
+  DIFFORMER_AUTO_GRAPH=0 python bench.py --workload $W --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_${W}_nograph.json 2>> $OUT/err.log
   (cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python $R/bench.py --workload $W --steps 50 --warmup 5 --no-cpu-baseline > $OUT/stats_$W.log 2>&1)
   find $OUT/stats_$W -name "*kernel_stats.csv" -exec cp {} $OUT/${W}_kernel_stats.csv \;
 done

@@ -1514,3 +1514,42 @@ def test_simple_apply_wide_heads(n, h, m, d, bf16, dev):
     num = s * np.einsum("nhm,hmd->nhd", q64, np.einsum("lhm,lhd->hmd", k64, v64)) + v64.sum(0)
     den = s * np.einsum("nhm,hm->nh", q64, k64.sum(0)) + n
     assert rel_err(out, num / den[..., None]) < (2e-2 if bf16 else TOL)
+
+
+# ------------------------------------------------------------------ repeated inference forwards replay as one hipGraph
+def test_repeated_inference_forwards_are_captured_and_stay_correct(dev):
+    """DIFFormer.forward: the third consecutive eval / no_grad call with the same operands captures the forward as a hipGraph;
+    replays are bitwise equal to the eager result, see new VALUES written into x in place, never alias one another, and any
+    change of operands or parameters falls back to the eager path."""
+    from difformer_amd import DIFFormer
+    torch.manual_seed(11)
+    n = 3000
+    model = DIFFormer(40, 64, 6, num_layers=2, kernel="simple").to(dev).eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, 40, generator=g).to(dev)
+    x2 = torch.randn(n, 40, generator=g).to(dev)
+    ei = torch.cat([torch.randint(0, n, (2, 12000), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    model.auto_graph = False
+    with torch.no_grad():
+        ref, ref2 = model(x, ei).clone(), model(x2, ei).clone()
+    model.auto_graph = True
+    with torch.no_grad():
+        outs = [model(x, ei) for _ in range(6)]
+    assert model._ag_state is not None and model._ag_state[2] is not None, "the forward should have been captured"
+    assert all(torch.equal(o, ref) for o in outs)
+    assert len({o.data_ptr() for o in outs[3:]}) == 3                  # replays return fresh tensors
+    with torch.no_grad():
+        x.copy_(x2)                                                    # new values at the same address: the replay reads them
+        assert torch.equal(model(x, ei), ref2)
+        other = x2.clone()
+        assert torch.equal(model(other, ei), ref2)                     # another tensor: eager (and the capture is dropped)
+        assert model._ag_state[2] is None
+        for _ in range(3):
+            model(x, ei)
+        assert model._ag_state[2] is not None
+        model.fcs[1].bias.add_(1.0)                                    # a parameter changed (in place: version bump)
+        shifted = model(x, ei)
+        assert model._ag_state[2] is None and torch.allclose(shifted, ref2 + 1.0, atol=1e-5)
+    model.train()
+    out_t = model(x, ei)                                               # training: never captured
+    assert out_t.requires_grad and model._ag_state[2] is None
