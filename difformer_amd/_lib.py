@@ -49,6 +49,12 @@ SIGNATURES = {
                                            c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp]),
     "dif_batched_sigmoid_attn_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                              c_int, c_vp, c_i64, c_vp]),
+    "dif_batched_sigmoid_attn_fwd_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                                 c_int, c_vp, c_i64, c_vp, c_vp]),
+    "dif_batched_sigmoid_bwd_workspace_bytes": (c_sz, [c_i64, c_int]),
+    "dif_batched_sigmoid_attn_bwd_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                                 c_int, c_int, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                                 c_vp, c_sz, c_vp]),
     "dif_csr_workspace_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "dif_csr_build": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                               c_vp]),

@@ -2,7 +2,8 @@
 keep working: the FORWARD of every operator is the HIP kernel; the BACKWARD of the simple and the sigmoid
 attention, the aggregation (adjoint product on the same SpMM kernels), the layer tail (LayerNorm / residual /
 head mean) and the weight gradients of the Linear layers are HIP kernels too (SURVEY.md section 8f, row 3);
-the batched (v2) attention and heads wider than 64 re-derive their gradient on the device with tensor ops.
+the batched (v2) attentions too (simple: raw mode of the forward kernel; sigmoid: the sweep kernels per position group); only
+heads wider than 64 re-derive their gradient on the device with tensor ops.
 Under torch.no_grad() / eval these wrappers are pass-throughs to ops.py.  Nothing here touches the CPU.
 """
 from __future__ import annotations
@@ -326,8 +327,9 @@ def _batched_sigmoid_expr(layout):
 
 class _BatchedAttention(torch.autograd.Function):
     """'simple' (fp32, widths up to 256, more than one graph): forward with the row denominators kept, backward as three
-    launches of the forward kernel's raw mode (csrc/batched_attn.hip).  'sigmoid' and the other shapes re-derive the
-    gradient with tensor ops on the padded batch."""
+    launches of the forward kernel's raw mode (csrc/batched_attn.hip).  'sigmoid' (fp32, heads up to 64 wide): forward with
+    the full denominators kept, backward on the sweep kernel of csrc/sigmoid_attn_bwd.hip with the position groups' row
+    mapping.  Other shapes re-derive the gradient with tensor ops on the padded batch."""
 
     @staticmethod
     def forward(ctx, q, k, v, layout, kernel):
@@ -340,6 +342,13 @@ class _BatchedAttention(torch.autograd.Function):
             out, den, sumsq = be.batched_simple_attention(q, k, v, layout.graph_ptr, want_den=True)
             ctx.save_for_backward(q, k, v, out, den, sumsq)
             return out
+        ctx.hip_sigmoid = (kernel == "sigmoid" and hasattr(be, "batched_sigmoid_backward") and
+                           all(t.dtype == torch.float32 for t in (q, k, v)) and q.shape[2] <= 64 and v.shape[2] <= 64)
+        if ctx.hip_sigmoid:
+            ops._check_batch(q, k, v, layout)
+            out, den = be.batched_sigmoid_attention(q, k, v, layout.ranked_first, layout.pos_count, want_den=True)
+            ctx.save_for_backward(q, k, v, out, den)
+            return out
         ctx.save_for_backward(q, k, v)
         fwd = ops.batched_simple_attention if kernel == "simple" else ops.batched_sigmoid_attention
         return fwd(q, k, v, layout)
@@ -349,6 +358,10 @@ class _BatchedAttention(torch.autograd.Function):
         if ctx.hip:
             q, k, v, out, den, sumsq = ctx.saved_tensors
             return ops.get_backend().batched_simple_backward(q, k, v, out, den, sumsq, g, ctx.layout.graph_ptr) + (None, None)
+        if getattr(ctx, "hip_sigmoid", False):
+            q, k, v, out, den = ctx.saved_tensors
+            return ops.get_backend().batched_sigmoid_backward(q, k, v, out, den, g, ctx.layout.ranked_first,
+                                                              ctx.layout.pos_count) + (None, None)
         expr = _batched_simple_expr if ctx.kernel == "simple" else _batched_sigmoid_expr
         return _grad_by_recompute(expr(ctx.layout), ctx.saved_tensors, g.contiguous()) + (None, None)
 

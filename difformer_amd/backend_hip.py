@@ -377,8 +377,9 @@ class HipBackend:
         dk.addcmul_(k, (-T / sumsq[1]).expand_as(k))
         return dq, dk, dv
 
-    def batched_sigmoid_attention(self, q, k, v, ranked_first, pos_count):
-        """ranked_first: int32 [B] first row of the r-th largest graph; pos_count: int32 [max_nodes]."""
+    def batched_sigmoid_attention(self, q, k, v, ranked_first, pos_count, want_den=False):
+        """ranked_first: int32 [B] first row of the r-th largest graph; pos_count: int32 [max_nodes].
+        want_den (training, D <= 64): -> (out, den float32 [N, H]) for batched_sigmoid_backward."""
         dev = _require_device(q, k, v, ranked_first, pos_count)
         N, H, M = q.shape
         D = v.shape[2]
@@ -391,12 +392,44 @@ class HipBackend:
         k, ldk = _row_major(k, H * M)
         v, ldv = _row_major(v, H * D)
         out = torch.empty((N, H, D), dtype=torch.float32, device=dev)
+        if want_den:
+            den = torch.empty((N, H), dtype=torch.float32, device=dev)
+            with _timed(self, "dif_batched_sigmoid_attn_fwd_f32", dev):
+                rc = self.lib.dif_batched_sigmoid_attn_fwd_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(ranked_first),
+                                                               _ptr(pos_count), ranked_first.numel(), pos_count.numel(), H, M,
+                                                               D, _ptr(out), H * D, _ptr(den), _stream(dev))
+            _lib.check(rc, "dif_batched_sigmoid_attn_fwd_f32")
+            return out, den
         with _timed(self, "dif_batched_sigmoid_attn_f32", dev):
             rc = self.lib.dif_batched_sigmoid_attn_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(ranked_first),
                                                        _ptr(pos_count), ranked_first.numel(), pos_count.numel(), H, M, D,
                                                        _ptr(out), H * D, _stream(dev))
         _lib.check(rc, "dif_batched_sigmoid_attn_f32")
         return out
+
+    def batched_sigmoid_backward(self, q, k, v, out, den, g, ranked_first, pos_count):
+        """(dq, dk, dv) of the batched sigmoid attention (difformer-v2.py:113-135) for fp32 operands with M, D <= 64:
+        csrc/sigmoid_attn_bwd.hip with the position groups' row mapping; nothing of size B x B x max_nodes is stored."""
+        dev = _require_device(q, k, v, out, den, g, ranked_first, pos_count)
+        N, H, M = q.shape
+        D = v.shape[2]
+        for t_, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (den, "den"), (g, "grad")):
+            _f32(t_, nm)
+        q, ldq = _row_major(q, H * M)
+        k, ldk = _row_major(k, H * M)
+        v, ldv = _row_major(v, H * D)
+        out, den, g = out.contiguous(), den.contiguous(), g.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        dq, dk, dv = torch.empty((N, H, M), **f32), torch.empty((N, H, M), **f32), torch.empty((N, H, D), **f32)
+        ws_bytes = self.lib.dif_batched_sigmoid_bwd_workspace_bytes(N, H)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        with _timed(self, "dif_batched_sigmoid_attn_bwd_f32", dev):
+            rc = self.lib.dif_batched_sigmoid_attn_bwd_f32(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(out), H * D, _ptr(den),
+                                                           _ptr(g), H * D, _ptr(ranked_first), _ptr(pos_count),
+                                                           ranked_first.numel(), pos_count.numel(), N, H, M, D, _ptr(dq), H * M,
+                                                           _ptr(dk), H * M, _ptr(dv), H * D, _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_batched_sigmoid_attn_bwd_f32")
+        return dq, dk, dv
 
     # ---- a3 --------------------------------------------------------------------------------
     def csr_build(self, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False, block_rows=0):

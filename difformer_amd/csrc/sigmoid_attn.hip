@@ -207,7 +207,9 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const T* __restrict__
         if (row < N && d < D) {
             if (SEG) {
                 // difformer-v2.py:127-134: padded graphs add sigma(0) each, then + epsilon
-                dif::Elem<T>::st(out + qrow(row) * ldo + h * D + d, o / (dn + 0.5f * static_cast<float>(n_graphs - N) + 1e-9f));
+                const float dfull = dn + 0.5f * static_cast<float>(n_graphs - N) + 1e-9f;
+                dif::Elem<T>::st(out + qrow(row) * ldo + h * D + d, o / dfull);
+                if (den_out && d == 0) den_out[qrow(row) * H + h] = dfull;          // kept for the backward pass
             } else if (S == 1) {
                 dif::Elem<T>::st(out + row * ldo + h * D + d, o / dn);     // :55-56
                 if (den_out && d == 0) den_out[row * H + h] = dn;          // kept for the backward pass
@@ -347,10 +349,11 @@ extern "C" int dif_sigmoid_attn_bf16(const void* q, int64_t ldq, const void* k, 
 }
 
 // f4: TransConv.full_attention(kernel='sigmoid') over a batch of graphs -- physical particle/difformer-v2.py:113-135.
-extern "C" int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
-                                            int64_t ldv, const int32_t* ranked_first, const int32_t* pos_count,
-                                            int n_graphs, int max_nodes, int H, int M, int D, float* out, int64_t ldo,
-                                            dif_stream_t stream) {
+// den (optional, float [N, H]): the full denominators (row sum + 0.5 per padded graph + 1e-9) for dif_batched_sigmoid_attn_bwd_f32.
+static int batched_sigmoid_entry(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                 int64_t ldv, const int32_t* ranked_first, const int32_t* pos_count,
+                                 int n_graphs, int max_nodes, int H, int M, int D, float* out, int64_t ldo, float* den,
+                                 dif_stream_t stream) {
     DIF_REQUIRE(n_graphs > 0 && max_nodes > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG,
                 "dif_batched_sigmoid_attn_f32: n_graphs, max_nodes, H, M, D must be positive");
     DIF_REQUIRE(q && k && v && out && ranked_first && pos_count, DIF_E_BADARG, "dif_batched_sigmoid_attn_f32: null pointer");
@@ -367,11 +370,29 @@ extern "C" int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const f
     dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy), static_cast<unsigned>(max_nodes)), block(512);
 #define DIF_LAUNCH_SEG(V, Q) \
     hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, int64_t{0}, \
-                       int64_t{0}, H, M, D, out, ldo, nullptr, nullptr, nullptr, ranked_first, pos_count, n_graphs)
+                       int64_t{0}, H, M, D, out, ldo, nullptr, nullptr, den, ranked_first, pos_count, n_graphs)
     if (vec && qreg) DIF_LAUNCH_SEG(true, true);
     else if (vec) DIF_LAUNCH_SEG(true, false);
     else if (qreg) DIF_LAUNCH_SEG(false, true);
     else DIF_LAUNCH_SEG(false, false);
 #undef DIF_LAUNCH_SEG
     return dif::launch_status("sigmoid_attn_kernel<batched>");
+}
+
+extern "C" int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                            int64_t ldv, const int32_t* ranked_first, const int32_t* pos_count,
+                                            int n_graphs, int max_nodes, int H, int M, int D, float* out, int64_t ldo,
+                                            dif_stream_t stream) {
+    return batched_sigmoid_entry(q, ldq, k, ldk, v, ldv, ranked_first, pos_count, n_graphs, max_nodes, H, M, D, out, ldo, nullptr,
+                                 stream);
+}
+
+extern "C" int dif_batched_sigmoid_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                                int64_t ldv, const int32_t* ranked_first, const int32_t* pos_count,
+                                                int n_graphs, int max_nodes, int H, int M, int D, float* out, int64_t ldo,
+                                                float* den, dif_stream_t stream) {
+    DIF_REQUIRE(den != nullptr, DIF_E_BADARG, "dif_batched_sigmoid_attn_fwd_f32: den is null");
+    DIF_REQUIRE(D <= 64, DIF_E_SHAPE, "dif_batched_sigmoid_attn_fwd_f32: the backward pass covers D <= 64 (got %d)", D);
+    return batched_sigmoid_entry(q, ldq, k, ldk, v, ldv, ranked_first, pos_count, n_graphs, max_nodes, H, M, D, out, ldo, den,
+                                 stream);
 }

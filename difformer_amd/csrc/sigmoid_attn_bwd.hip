@@ -77,7 +77,11 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_prep_kernel(const float* __re
 // x*: stationary operands, y*: swept operands; 1 = the score pair (q / k), 2 = the value pair (g / v).
 // S == 1: results written to o1 (and o2); S > 1: partials to part1 [S][X][H*M] (part2 [S][X][H*D]), summed by
 // sum_parts_kernel.
-template <int MODE, bool VEC>
+// SEG (f4, physical particle/difformer-v2.py:113-135 under loss.backward()): blockIdx.z is a POSITION p inside the graphs of
+// a batch, stationary and swept side are both the seg_cnt[p] nodes at position p of their graph (local row r = node
+// seg_first[r] + p, graphs ranked by size as in the forward kernel); `cinv` already holds the FULL denominators (padded
+// graphs add constants only: no gradient flows into them), so the arithmetic is the unbatched kernel's.  No splits.
+template <int MODE, bool VEC, bool SEG = false>
 __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restrict__ x1, int64_t ldx1,
                                                           const float* __restrict__ x2, int64_t ldx2,
                                                           const float* __restrict__ y1, int64_t ldy1,
@@ -86,15 +90,23 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
                                                           int64_t X, int64_t Y, int H, int M, int D,
                                                           float* __restrict__ o1, int64_t ldo1, float* __restrict__ o2,
                                                           int64_t ldo2, float* __restrict__ part1,
-                                                          float* __restrict__ part2) {
+                                                          float* __restrict__ part2,
+                                                          const int32_t* __restrict__ seg_first = nullptr,
+                                                          const int32_t* __restrict__ seg_cnt = nullptr) {
     __shared__ __attribute__((aligned(16))) float sm_o[kWaves][kXGroup * kCols];   // 64 KiB
     const int h = blockIdx.y;
-    const int S = gridDim.z, split = blockIdx.z;
+    const int S = SEG ? 1 : gridDim.z, split = SEG ? 0 : blockIdx.z;
+    const int pos = SEG ? blockIdx.z : 0;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l15 = lane & 15;
     const int lg = lane >> 4;
     const int64_t x0 = static_cast<int64_t>(blockIdx.x) * kXGroup;
+    if (SEG) {
+        X = Y = seg_cnt[pos];
+        if (x0 >= X) return;                                   // uniform: before any barrier
+    }
+    auto mrow = [&](int64_t r) -> int64_t { return SEG ? static_cast<int64_t>(seg_first[r]) + pos : r; };   // local -> memory row
 
     // stationary fragments (B operands): row = x0 + 16 t + l15, columns 16 c + 4 lg .. + 3
     f32x4 xs1[kXT][4], xs2[kXT][4];
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
     for (int t = 0; t < kXT; ++t) {
         const int64_t r = x0 + 16 * t + l15;
         const bool ok = r < X;
-        const int64_t rc = ok ? r : X - 1;
+        const int64_t rc = mrow(ok ? r : X - 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             xs1[t][c] = ld4<VEC>(x1, ldx1, rc, ok, h * M, 16 * c + 4 * lg, M);
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
         // ---- swept fragments (A operands of the two score products): row = ybase + l15 ----
         const int64_t yr = ybase + l15;
         const bool yok = yr < Y;
-        const int64_t yrc = yok ? yr : Y - 1;
+        const int64_t yrc = mrow(yok ? yr : Y - 1);
         f32x4 ya1[4], ya2[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t yy = ybase + 4 * lg + reg;
             const bool ok = yy < Y;
-            const int64_t yc = ok ? yy : Y - 1;
+            const int64_t yc = mrow(ok ? yy : Y - 1);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 const int col = 16 * ct + l15;
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
             for (int w = 0; w < kWaves; ++w) o += sm_o[w][e];
             const int64_t row = x0 + ri;
             if (row < X && col < width) {
-                if (S == 1) dst[row * ldd + h * width + col] = o;
+                if (S == 1) dst[mrow(row) * ldd + h * width + col] = o;
                 else part[(static_cast<int64_t>(split) * X + row) * (static_cast<int64_t>(H) * width) + h * width + col] = o;
             }
         }
@@ -328,4 +340,53 @@ extern "C" int dif_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float
         if (int rc = combine(pv, S1, L, H * D, dv, lddv)) return rc;
     }
     return 0;
+}
+
+// f4: backward of TransConv.full_attention(kernel='sigmoid') over a batch of graphs (physical particle/difformer-v2.py:113-135
+// under loss.backward(), main.py:89-93).  `den` = the full denominators dif_batched_sigmoid_attn_fwd_f32 left.  Every node is
+// query and key of exactly one position group, so every row of dq / dk / dv is written once.  workspace: 2 x N x H floats.
+extern "C" size_t dif_batched_sigmoid_bwd_workspace_bytes(int64_t N, int H) {
+    if (N <= 0 || H <= 0) return 0;
+    return 2 * align16(static_cast<size_t>(N) * H * sizeof(float));
+}
+
+extern "C" int dif_batched_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                                int64_t ldv, const float* out, int64_t ldo, const float* den, const float* g,
+                                                int64_t ldg, const int32_t* ranked_first, const int32_t* pos_count,
+                                                int n_graphs, int max_nodes, int64_t N, int H, int M, int D, float* dq,
+                                                int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
+                                                void* workspace, size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(N > 0 && n_graphs > 0 && max_nodes > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG,
+                "dif_batched_sigmoid_attn_bwd_f32: sizes must be positive");
+    DIF_REQUIRE(M <= kCols && D <= kCols, DIF_E_SHAPE, "dif_batched_sigmoid_attn_bwd_f32: covers M, D <= 64 (got %d, %d)", M, D);
+    DIF_REQUIRE(q && k && v && out && den && g && dq && dk && dv && workspace && ranked_first && pos_count, DIF_E_BADARG,
+                "dif_batched_sigmoid_attn_bwd_f32: null pointer");
+    DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D && ldo >= H * D && ldg >= H * D && lddq >= H * M &&
+                    lddk >= H * M && lddv >= H * D, DIF_E_BADARG, "dif_batched_sigmoid_attn_bwd_f32: leading dimension smaller than a row");
+    DIF_REQUIRE(H <= 65535 && max_nodes <= 65535, DIF_E_RANGE, "dif_batched_sigmoid_attn_bwd_f32: too many heads / positions");
+    DIF_REQUIRE(workspace_bytes >= dif_batched_sigmoid_bwd_workspace_bytes(N, H) && dif::aligned16(workspace), DIF_E_WORKSPACE,
+                "dif_batched_sigmoid_attn_bwd_f32: workspace too small or not 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* w = static_cast<char*>(workspace);
+    float* cinv = reinterpret_cast<float*>(w);
+    float* delta = reinterpret_cast<float*>(w + align16(static_cast<size_t>(N) * H * sizeof(float)));
+    int64_t pg = (N * H * 16 + 255) / 256;
+    if (pg > 8 * dif::kCUs) pg = 8 * dif::kCUs;
+    hipLaunchKernelGGL(sigmoid_bwd_prep_kernel, dim3(static_cast<unsigned>(pg)), dim3(256), 0, st, g, ldg, out, ldo, den, N, H, D,
+                       cinv, delta);
+    if (int rc = dif::launch_status("sigmoid_bwd_prep_kernel")) return rc;
+    auto al = [](const void* p, int64_t ld) { return ld % 4 == 0 && dif::aligned16(p); };
+    const bool vec = (M % 4 == 0) && (D % 4 == 0) && al(q, ldq) && al(k, ldk) && al(v, ldv) && al(g, ldg);
+    dim3 grid(static_cast<unsigned>((n_graphs + kXGroup - 1) / kXGroup), H, static_cast<unsigned>(max_nodes)), block(512);
+    if (vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<0, true, true>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv, cinv, delta,
+                                int64_t{0}, int64_t{0}, H, M, D, dq, lddq, nullptr, int64_t{0}, nullptr, nullptr, ranked_first,
+                                pos_count);
+    else hipLaunchKernelGGL((sigmoid_bwd_kernel<0, false, true>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv, cinv, delta,
+                            int64_t{0}, int64_t{0}, H, M, D, dq, lddq, nullptr, int64_t{0}, nullptr, nullptr, ranked_first, pos_count);
+    if (int rc = dif::launch_status("sigmoid_bwd_kernel<dQ, batched>")) return rc;
+    if (vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<1, true, true>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg, cinv, delta,
+                                int64_t{0}, int64_t{0}, H, M, D, dk, lddk, dv, lddv, nullptr, nullptr, ranked_first, pos_count);
+    else hipLaunchKernelGGL((sigmoid_bwd_kernel<1, false, true>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg, cinv, delta,
+                            int64_t{0}, int64_t{0}, H, M, D, dk, lddk, dv, lddv, nullptr, nullptr, ranked_first, pos_count);
+    return dif::launch_status("sigmoid_bwd_kernel<dK dV, batched>");
 }

@@ -140,6 +140,20 @@ int dif_batched_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, in
                                  const float* v, int64_t ldv, const int32_t* ranked_first,
                                  const int32_t* pos_count, int n_graphs, int max_nodes, int H, int M, int D,
                                  float* out, int64_t ldo, dif_stream_t stream);
+/* Training (physical particle/main.py:89-93 differentiates through difformer-v2.py:113-135): the forward that also leaves the
+ * full denominators den float[N, H] (row sum + 0.5 per padded graph + 1e-9; D <= 64), and the backward that takes them:
+ * dq, dk [N,H,M], dv [N,H,D] with sigma recomputed tile by tile per position group (M, D <= 64, DIF_E_SHAPE beyond; the host
+ * then re-derives the gradient with tensor ops on the padded batch).  Padded graphs add constants to the denominator only, so
+ * the arithmetic is dif_sigmoid_attn_bwd_f32's.  workspace: dif_batched_sigmoid_bwd_workspace_bytes(N, H), 16-byte aligned. */
+int dif_batched_sigmoid_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                     const int32_t* ranked_first, const int32_t* pos_count, int n_graphs, int max_nodes, int H,
+                                     int M, int D, float* out, int64_t ldo, float* den, dif_stream_t stream);
+size_t dif_batched_sigmoid_bwd_workspace_bytes(int64_t N, int H);
+int dif_batched_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                     const float* out, int64_t ldo, const float* den, const float* g, int64_t ldg,
+                                     const int32_t* ranked_first, const int32_t* pos_count, int n_graphs, int max_nodes,
+                                     int64_t N, int H, int M, int D, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                                     int64_t lddv, void* workspace, size_t workspace_bytes, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a3  gcn_conv(x, edge_index, edge_weight)          node classification/difformer.py:63-79

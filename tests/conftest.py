@@ -47,7 +47,7 @@ def rel_err(y, ref):
     return float(np.max(np.abs(y - ref)) / denom) if ref.size else 0.0
 
 
-def grad_err(got, ref, gmax):
+def grad_err(got, ref, gmax, floor=1e-6):
     """Parity metric for ONE gradient tensor of a training step: max|got - ref| / max(max|ref|, 1e-6 * gmax), gmax = the
     largest |entry| over all gradients of the step.  Per-tensor norm-wise as rel_err, with a floor: the Wq / Wk gradients
     of the `simple` kernel are 1e-5..1e-7 of the others (its attention is close to uniform), and a float32 backward pass
@@ -56,7 +56,7 @@ def grad_err(got, ref, gmax):
     ref = np.asarray(ref, dtype=np.float64)
     if not ref.size:
         return 0.0
-    denom = max(float(np.max(np.abs(ref))), 1e-6 * float(gmax))
+    denom = max(float(np.max(np.abs(ref))), floor * float(gmax))
     return float(np.max(np.abs(got - ref)) / (denom if denom > 0 else 1.0))
 
 
