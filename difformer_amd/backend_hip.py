@@ -706,18 +706,19 @@ class HipBackend:
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
         if head is not None:
-            Wo, bo = (_f32(t_, "head").contiguous() for t_ in head)
+            Wo, bo = (_f32(t_, "head").contiguous() for t_ in head)          # float32 (exact copies of bf16 parameters)
             Co = Wo.shape[0]
-            if sfx != "f32" or next_plan is not None or next_record or Co > 128 or Wo.shape[1] != D:
-                raise TypeError("difformer_amd: the fused output Linear needs float32 rows, Co <= 128, no next-layer products")
-            logits = torch.empty((n, Co), dtype=torch.float32, device=dev)
+            if next_plan is not None or next_record or Co > 128 or Wo.shape[1] != D:
+                raise TypeError("difformer_amd: the fused output Linear needs Co <= 128 and no next-layer products")
+            logits = torch.empty((n, Co), dtype=dt, device=dev)
+            fn = self.lib.dif_simple_layer_head_bf16 if sfx == "bf16" else self.lib.dif_simple_layer_head_f32
             with _timed(self, "dif_simple_layer_f32", dev):
-                rc = self.lib.dif_simple_layer_head_f32(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
-                                                        _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
-                                                        float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
-                                                        int(bool(relu)), None, 0, _ptr(Wo), _ptr(bo), Co, _ptr(logits), Co,
-                                                        _stream(dev))
-            _lib.check(rc, "dif_simple_layer_head_f32")
+                rc = fn(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(ax), ldax, _ptr(Wv), _ptr(bv),
+                        _ptr(row_sums), float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)),
+                        float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
+                        int(bool(relu)), None, 0, _ptr(Wo), _ptr(bo), Co, _ptr(logits), Co,
+                        _stream(dev))
+            _lib.check(rc, "dif_simple_layer_head")
             return logits
         out = torch.empty((n, D), dtype=dt, device=dev)
         record = ys = ws = None

@@ -822,9 +822,8 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
                 T* logits = nullptr, int64_t ldl = 0) {
     const bool head = Wo != nullptr;
     DIF_REQUIRE(x && coef && (out || head) && n_rows > 0, DIF_E_BADARG, "dif_simple_layer: null pointer or no rows");
-    DIF_REQUIRE(!head || (bo && logits && Co > 0 && Co <= 128 && ldl >= Co && !next_record && !next_ys &&
-                          std::is_same<T, float>::value), DIF_E_BADARG,
-                "dif_simple_layer: the fused output Linear needs bo, logits, 1 <= Co <= 128, ldl >= Co, float32, no next-layer products");
+    DIF_REQUIRE(!head || (bo && logits && Co > 0 && Co <= 128 && ldl >= Co && !next_record && !next_ys), DIF_E_BADARG,
+                "dif_simple_layer: the fused output Linear needs bo, logits, 1 <= Co <= 128, ldl >= Co, no next-layer products");
     DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0 && D > 0 && D <= 64, DIF_E_SHAPE,
                 "dif_simple_layer: covers C <= 64 (C %% 4 == 0) and D <= 64 (got %d, %d)", C, D);
     DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned_v4<T>(x) && (!out || ldo >= D), DIF_E_BADARG,
@@ -864,7 +863,7 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
     const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
     const bool gw = ax != nullptr && Wv != nullptr;
 #define DIF_LAYER(E, G, N) hipLaunchKernelGGL((simple_layer_kernel<E, G, N, T>), dim3(P), dim3(64 * kWaves), 0, st, a)
-#define DIF_LAYER_HEAD(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, (std::is_same<T, float>::value)>), dim3(P), dim3(64 * kHeadWaves), 0, st, a)
+#define DIF_LAYER_HEAD(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, true>), dim3(P), dim3(64 * kHeadWaves), 0, st, a)
 #define DIF_LAYER2(E, G) do { if (head) DIF_LAYER_HEAD(E, G); else if (f32 && next) DIF_LAYER(E, G, (std::is_same<T, float>::value)); else DIF_LAYER(E, G, false); } while (0)
     if (exact) { if (gw) DIF_LAYER2(true, true); else DIF_LAYER2(true, false); }
     else { if (gw) DIF_LAYER2(false, true); else DIF_LAYER2(false, false); }
@@ -900,6 +899,21 @@ extern "C" int dif_simple_layer_head_f32(const float* x, int64_t ldx, int64_t n_
     return layer_entry<float>(x, ldx, n_rows, C, D, coef, ax, ldax, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha,
                               ln_weight, ln_bias, ln_eps, relu, out, ldo, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream,
                               Wo, bo, Co, logits, ldl);
+}
+
+// bfloat16 activations, output Linear in the same pass: logits [n, Co] bfloat16 (Wo, bo float32 copies of the parameters)
+extern "C" int dif_simple_layer_head_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                          const void* ax, int64_t ldax, const float* Wv, const float* bv,
+                                          const float* row_sums, float gcn_scale, const void* x0, int64_t ldx0, int residual,
+                                          float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                                          void* out, int64_t ldo, const float* Wo, const float* bo, int Co, void* logits,
+                                          int64_t ldl, dif_stream_t stream) {
+    using B = dif::bf16;
+    DIF_REQUIRE(Wo != nullptr, DIF_E_BADARG, "dif_simple_layer_head_bf16: Wo is null");
+    return layer_entry<B>(static_cast<const B*>(x), ldx, n_rows, C, D, coef, static_cast<const B*>(ax), ldax, Wv, bv, row_sums,
+                          gcn_scale, static_cast<const B*>(x0), ldx0, residual, alpha, ln_weight, ln_bias, ln_eps, relu,
+                          static_cast<B*>(out), ldo, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream, Wo, bo, Co,
+                          static_cast<B*>(logits), ldl);
 }
 
 // bfloat16 ACTIVATIONS (x, ax, x0, out); coefficients and parameters (Wv, bv, LayerNorm) float32 -- the host keeps exact

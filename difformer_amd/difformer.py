@@ -217,8 +217,7 @@ class DIFFormerConv(nn.Module):
                                                                Wv, bv))
                 factors = self._narrow[1]
             head = carry.get("head") if carry is not None else None
-            if head is not None and not (x.dtype == torch.float32 and head[0].dtype == torch.float32 and head[0].shape[0] <= 128
-                                         and head[1] is not None):
+            if head is not None and not (head[0].dtype == x.dtype and head[0].shape[0] <= 128 and head[1] is not None):
                 head = None
             out = ops.simple_layer_closed_form(x, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv, csr,
                                                a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps, carry=carry,

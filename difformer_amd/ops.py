@@ -784,6 +784,7 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     if carry is not None:
         carry["products"] = None
     if head is not None:                           # last layer: the model's output Linear rides in the same pass -> logits
+        head = tuple(f32_param(t) for t in head)   # bfloat16 storage: exact float32 copies, as for the other parameters
         return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu,
                                head=head)
     if not (want_next and (sl is not None or want_rec)):

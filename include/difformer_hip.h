@@ -543,6 +543,12 @@ int dif_simple_apply_bf16(const void* q, int64_t ldq, const float* reduced, int6
  * dif_simple_coeffs_f32 with them.  No products for a next layer (the sliced format is float32-only). */
 int dif_gram_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
                   size_t workspace_bytes, dif_stream_t stream);
+/* ... and with the model's output Linear in the same pass (dif_simple_layer_head_f32 with bfloat16 activations and logits) */
+int dif_simple_layer_head_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const void* ax,
+                               int64_t ldax, const float* Wv, const float* bv, const float* row_sums, float gcn_scale,
+                               const void* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,
+                               const float* ln_bias, float ln_eps, int relu, void* out, int64_t ldo, const float* Wo,
+                               const float* bo, int Co, void* logits, int64_t ldl, dif_stream_t stream);
 int dif_simple_layer_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const void* ax,
                           int64_t ldax, const float* Wv, const float* bv, const float* row_sums, float gcn_scale,
                           const void* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,
