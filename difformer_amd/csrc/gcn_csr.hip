@@ -96,8 +96,12 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restric
         }
         // forward: entries grouped by destination (col), blocked by source; transposed (backward of the aggregation):
         // grouped by source (row), blocked by destination
-        const int64_t key = transpose ? r * NB + c / block_rows : c * NB + r / block_rows;
-        keys[e] = static_cast<uint32_t>(key);
+        // node ids are < 2^31 here (range check above) and the key fits 32 bits (checked by the host): 32-bit arithmetic --
+        // a 64-bit integer division per edge made this pass 1.7 ms at C4 (1.1 TB/s for a streaming kernel)
+        const uint32_t ru = static_cast<uint32_t>(r), cu = static_cast<uint32_t>(c), br = static_cast<uint32_t>(block_rows),
+                       nb = static_cast<uint32_t>(NB);
+        const uint32_t key = transpose ? ru * nb + cu / br : cu * nb + ru / br;
+        keys[e] = key;
         vals[e] = weighted ? static_cast<uint32_t>(e) : static_cast<uint32_t>(transpose ? c : r);
         if (transpose) atomicAdd(&degc[c], 1); // the normalisation always uses the in-degree over `col` (:66)
     }

@@ -3,6 +3,7 @@ import csv,glob
 f=glob.glob("/tmp/st/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n=r["Name"]
-    if any(k in n for k in ("sliced_sort","sliced_color","sliced_table","sliced_fill")):
-        print(n[n.find("sliced_"):][:26], r["Calls"], r["AverageNs"])
+    if any(k in n for k in ("sliced_sort","sliced_color","sliced_table","sliced_fill","csr_","radix_","scan_")):
+        short = n.replace("(anonymous namespace)::", "").replace("void ", "")[:28]
+        print(short, r["Calls"], r["AverageNs"])
 P

@@ -33,7 +33,7 @@ for it in range(cases):
         cnt = max(1000, cnt // int(torch.randint(3, 9, (1,), generator=g)))
 
     class _Rows:                                                 # what csr_cache.get reads of a RowShard: the tiling of a shard
-        world, n_local, counts, offsets = 2, cnt, [cnt, n - cnt], [0, cnt, n]
+        world, n_local, counts, offsets, row_begin = 2, cnt, [cnt, n - cnt], [0, cnt, n], lo
     csr = ops.csr_cache.get(ei, None, n, F * 4, _Rows() if cnt < n else None)
     sl = csr.sliced(lo, cnt, F)
     x = torch.randn(n, F, generator=g).to(dev)
