@@ -149,8 +149,8 @@ def test_two_ranks_on_one_gpu_slice_sharded_product(n, deg):
         assert sliced and 32 in widths, (rank, widths)
 
 
-@pytest.mark.parametrize("workload", ["ogbn-proteins-s", "pokec-batch-s-bf16"])
-def test_bench_with_two_ranks_runs_end_to_end(workload):
+@pytest.mark.parametrize("workload,product", [("ogbn-proteins-s", "row"), ("pokec-batch-s-bf16", "row"), ("ogbn-proteins-s", "slice")])
+def test_bench_with_two_ranks_runs_end_to_end(workload, product):
     """The command the driver launches for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), with both ranks
     on this box's one GPU and the collectives over gloo: the row-sharded headline workload (closed-form layers, the
     shard's sliced product) and the replica workload print one well-formed JSON line from rank 0."""
@@ -159,7 +159,7 @@ def test_bench_with_two_ranks_runs_end_to_end(workload):
     env = dict(os.environ, DIFFORMER_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", workload]
+           "--workload", workload, "--shard-product", product]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
