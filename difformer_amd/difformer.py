@@ -12,6 +12,7 @@ There is no CPU path: tensors must be float32 on the GPU.
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -375,8 +376,13 @@ class DIFFormer(nn.Module):
         if key is None:
             return None
         st = self._ag_state
-        if st is None or st[0] != key:
-            self._ag_state = [key, 1, None, None, None]              # key, calls seen, graph, static output, CSR refs
+        # (id, data_ptr, shape, version) of a freed graph tensor can all come back with a NEW tensor: weak references tell
+        # the tensors the capture was made for from look-alikes, as in the CSR cache
+        alive = st is not None and all((r is None) == (t is None) and (r is None or r() is t)
+                                       for r, t in zip(st[5], (edge_index, edge_weight)))
+        if st is None or st[0] != key or not alive:
+            refs = tuple(None if t is None else weakref.ref(t) for t in (edge_index, edge_weight))
+            self._ag_state = [key, 1, None, None, None, refs]        # key, calls seen, graph, static output, CSR refs, tensors
             return None
         if st[2] is None:
             st[1] += 1
