@@ -119,6 +119,10 @@ for _n in ("dif_linear", "dif_project_reduce", "dif_simple_reduce", "dif_simple_
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f32"]
 SIGNATURES["dif_gcn_spmm_part_bf16"] = SIGNATURES["dif_gcn_spmm_part_f32"]
 SIGNATURES["dif_simple_layer_head_bf16"] = SIGNATURES["dif_simple_layer_head_f32"]
+SIGNATURES["dif_simple_layer_gather_f32"] = (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,
+                                                     c_vp, c_i64, c_int, c_f32, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp, c_vp,
+                                                     c_int, c_vp, c_i64, c_vp])
+SIGNATURES["dif_simple_layer_gather_bf16"] = SIGNATURES["dif_simple_layer_gather_f32"]
 SIGNATURES["dif_gram_bf16"] = (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_sz, c_vp])
 SIGNATURES["dif_simple_layer_bf16"] = (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp,
                                                c_i64, c_int, c_f32, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp])

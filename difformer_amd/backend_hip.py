@@ -682,12 +682,17 @@ class HipBackend:
 
     def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
                      alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, next_rowptr=None, next_plan=None,
-                     next_record=False, head=None):
+                     next_record=False, head=None, gather=None):
         """-> out [n, D]; with next_plan -> (out, ys, record | None): also the slice-major scaled copy of `out` for the
         next layer's SpMM (see gram()), and with next_record its Gram record from the same pass.
         head = (Wo [Co, D], bo [Co]) float32, Co <= 128 (the model's output Linear, difformer.py:208): -> logits [n, Co]
-        from the same pass; the layer's rows themselves are not stored."""
+        from the same pass; the layer's rows themselves are not stored.
+        gather = (rowptr, src, val) of a one-block CSR over the same n nodes: the aggregation runs inside the layer kernel
+        (no `ax`, no `row_sums`, no next-layer products)."""
         dev = _require_device(x, coef, ax, Wv, bv, row_sums, x0, ln_weight, ln_bias)
+        if gather is not None:
+            return self._simple_layer_gather(x, coef, D, gather, Wv, bv, gcn_scale, x0, residual, alpha, ln_weight, ln_bias,
+                                             eps, relu, head, ax is not None or next_plan is not None or next_record)
         dt, sfx = _storage(x, ax, x0)              # activations: float32 or bfloat16; parameters always float32 here
         for t_, nm in ((coef, "coef"), (Wv, "Wv"), (bv, "bv"), (ln_weight, "ln_weight"), (ln_bias, "ln_bias"), (row_sums, "row_sums")):
             if t_ is not None:
@@ -750,6 +755,46 @@ class HipBackend:
         if next_plan is None and not next_record:
             return out
         return out, ys, record
+
+    def _simple_layer_gather(self, x, coef, D, gather, Wv, bv, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu,
+                             head, conflicting):
+        dev = x.device
+        dt, sfx = _storage(x, None, x0)
+        rowptr, src, val = gather
+        n, C = x.shape
+        if conflicting or rowptr.numel() != n + 1 or rowptr.dtype != torch.int32 or src.dtype != torch.int32:
+            raise TypeError("difformer_amd: the in-kernel aggregation takes an int32 one-block CSR over the rows of x and "
+                            "neither ax nor next-layer products")
+        for t_, nm in ((coef, "coef"), (Wv, "Wv"), (bv, "bv"), (ln_weight, "ln_weight"), (ln_bias, "ln_bias"), (val, "val")):
+            if t_ is not None:
+                _f32(t_, nm)
+        x, ldx = _row_major(x, C)
+        if ldx % 4 or x.data_ptr() % (4 * x.element_size()):
+            x, ldx = x.contiguous(), C
+        ldx0 = 0
+        if x0 is not None:
+            x0, ldx0 = _row_major(x0, D)
+        if Wv is not None:
+            Wv, bv = Wv.contiguous(), bv.contiguous()
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        Wo = bo = out = logits = None
+        Co = 0
+        if head is not None:
+            Wo, bo = (_f32(t_, "head").contiguous() for t_ in head)
+            Co = Wo.shape[0]
+            if Co > 128 or Wo.shape[1] != D:
+                raise TypeError("difformer_amd: the fused output Linear needs Co <= 128")
+            logits = torch.empty((n, Co), dtype=dt, device=dev)
+        else:
+            out = torch.empty((n, D), dtype=dt, device=dev)
+        fn = self.lib.dif_simple_layer_gather_bf16 if sfx == "bf16" else self.lib.dif_simple_layer_gather_f32
+        with _timed(self, "dif_simple_layer_f32", dev):
+            rc = fn(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(rowptr), _ptr(src), _ptr(val), _ptr(Wv), _ptr(bv),
+                    float(gcn_scale), _ptr(x0), ldx0, int(bool(residual)), float(alpha), _ptr(ln_weight), _ptr(ln_bias),
+                    float(eps), int(bool(relu)), _ptr(out), D, _ptr(Wo), _ptr(bo), Co, _ptr(logits), Co, _stream(dev))
+        _lib.check(rc, "dif_simple_layer_gather")
+        return logits if head is not None else out
 
     # ---- a3, dense unweighted graphs: feature-sliced product with LDS-staged sources (csrc/gcn_sliced.hip) ----------
     def sliced_plan(self, n_src, n_rows, F):

@@ -391,6 +391,8 @@ struct LayerArgsT {
     const int32_t* rowptr; f32x4* ys_next; int64_t npad; float* ws; int64_t ws_stride;
     // HEAD: the model's output Linear (difformer.py:208) applied to the finished rows in the same pass
     const float* Wo; const float* bo; int Co; T* logits; int64_t ldl;
+    // GATHER: the aggregation itself in this pass (sparse graphs: a few entries per row) -- CSR over destination rows
+    const int32_t* g_rowptr; const int32_t* g_src; const float* g_val;
 };
 using LayerArgs = LayerArgsT<float>;
 
@@ -407,6 +409,60 @@ __device__ __forceinline__ void load_rows(f32x4 (&xa)[4], const T* __restrict__ 
             const int c = 16 * cq + 4 * lg;
             xa[cq] = (r < n && c < C) ? Elem<T>::ld4(x + r * ldx + c) : zero4();
         }
+    }
+}
+
+// GATHER: this lane's fragment of (A_hat x)[row] and the row sum of A_hat, straight from the CSR -- for graphs with a few
+// entries per row (a Pokec mini-batch: 3.3, Cora: 4.9) the separate SpMM launch costs more than the rows it moves (22 us
+// per layer at 100,000 rows).  The four lanes (lg) of a row walk its entries together; the 16 rows of a tile in lock step
+// up to the longest of them, two entries per step.  The chain rowptr -> (src, val) -> x rows is three dependent loads:
+// gather_begin issues the first two links BEFORE the tile's own projection (their latency hides under it), and inside the
+// loop the indices of the next step are requested before the rows of this step are consumed.
+struct GatherCursor {
+    int e, e1;
+    int s0, s1;
+    float w0, w1;
+};
+
+__device__ __forceinline__ void gather_fetch(GatherCursor& g, const int32_t* __restrict__ src, const float* __restrict__ val) {
+    const bool one = g.e < g.e1, two = g.e + 1 < g.e1;
+    g.s0 = one ? src[g.e] : 0;
+    g.w0 = one ? val[g.e] : 0.f;
+    g.s1 = two ? src[g.e + 1] : g.s0;
+    g.w1 = two ? val[g.e + 1] : 0.f;
+}
+
+__device__ __forceinline__ GatherCursor gather_begin(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                     const float* __restrict__ val, int64_t row, bool row_ok) {
+    GatherCursor g = {0, 0, 0, 0, 0.f, 0.f};
+    if (row_ok) { g.e = rowptr[row]; g.e1 = rowptr[row + 1]; }
+    gather_fetch(g, src, val);
+    return g;
+}
+
+template <bool EXACT, typename T>
+__device__ __forceinline__ void gather_rows(f32x4 (&ga)[4], float& wsum, GatherCursor g, const T* __restrict__ x, int64_t ldx,
+                                            const int32_t* __restrict__ src, const float* __restrict__ val, int lg, int C) {
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) ga[cq] = zero4();
+    wsum = 0.f;
+    while (g.e < g.e1) {
+        const T* p0 = x + static_cast<int64_t>(g.s0) * ldx;
+        const T* p1 = x + static_cast<int64_t>(g.s1) * ldx;
+        const float w0 = g.w0, w1 = g.w1;
+        f32x4 r0[4], r1[4];
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+            const int c = 16 * cq + 4 * lg;
+            const bool ok = EXACT || c < C;
+            r0[cq] = ok ? Elem<T>::ld4(p0 + c) : zero4();
+            r1[cq] = ok ? Elem<T>::ld4(p1 + c) : zero4();
+        }
+        g.e += 2;
+        gather_fetch(g, src, val);                 // next step's indices: in flight while this step's rows arrive
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) ga[cq] += r0[cq] * w0 + r1[cq] * w1;
+        wsum += w0 + w1;
     }
 }
 
@@ -444,8 +500,12 @@ __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], c
     }
 }
 
-template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float, bool HEAD = false>
-__global__ __launch_bounds__(64 * (HEAD ? kHeadWaves : kWaves), HEAD ? (2 * kHeadWaves + 3) / 4 : (NEXT ? 2 : 4))
+#ifndef DIF_GATHER_WG
+#define DIF_GATHER_WG 4           // measurement builds: workgroups per CU the GATHER variants are compiled for
+#endif
+template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float, bool HEAD = false, bool GATHER = false>
+__global__ __launch_bounds__(64 * (HEAD ? kHeadWaves : kWaves),
+                             HEAD ? (2 * kHeadWaves + 3) / 4 : (NEXT ? 2 : (GATHER ? DIF_GATHER_WG : 4)))
 void simple_layer_kernel(LayerArgsT<T> a) {
     constexpr int NW = HEAD ? kHeadWaves : kWaves;          // waves per workgroup
     __shared__ __attribute__((aligned(16))) float sm_w[2][kWBlock];   // MnT, Wv (zero padded; widx layout)
@@ -494,7 +554,7 @@ void simple_layer_kernel(LayerArgsT<T> a) {
         const int i = threadIdx.x;
         sm_cn[i] = i < D ? a.coef[D * C + i] : 0.f;
         sm_u[i] = i < C ? a.coef[D * C + D + i] : 0.f;
-        sm_bv[i] = (GRAPH_W && a.rs && i < D) ? a.bv[i] * a.gcn_scale : 0.f;
+        sm_bv[i] = (GRAPH_W && (GATHER || a.rs) && i < D) ? a.bv[i] * a.gcn_scale : 0.f;
         sm_lw[i] = (a.ln_w && i < D) ? a.ln_w[i] : 1.f;
         sm_lb[i] = (a.ln_b && i < D) ? a.ln_b[i] : 0.f;
     }
@@ -520,6 +580,8 @@ void simple_layer_kernel(LayerArgsT<T> a) {
         constexpr bool G = decltype(guard_tag)::value;
         const int64_t row = tile * 16 + l15;
         const bool row_ok = !G || row < a.n_rows;
+        GatherCursor gc;
+        if (GATHER) gc = gather_begin(a.g_rowptr, a.g_src, a.g_val, row, row_ok);
         f32x4 xa[4];
         load_rows<G>(xa, a.x, a.ldx, row, a.n_rows, lg, C);
         // denominator of this lane's row: x.u + cd, folded over the four lane groups
@@ -539,11 +601,18 @@ void simple_layer_kernel(LayerArgsT<T> a) {
         project_t(y, xa, sm_w[0], l15, lg);
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) y[ft] *= rden;
-        if (a.ax) {
+        if (GATHER || a.ax) {
             f32x4 ga[4];
-            load_rows<G>(ga, a.ax, a.ldax, row, a.n_rows, lg, C);
+            float rsv = 0.f;
+            if (GATHER) {
+                gather_rows<EXACT, T>(ga, rsv, gc, a.x, a.ldx, a.g_src, a.g_val, lg, C);
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) ga[cq] *= a.gcn_scale;          // ax = g_s A_hat x; the bias term scales below
+            } else {
+                load_rows<G>(ga, a.ax, a.ldax, row, a.n_rows, lg, C);
+                rsv = (a.rs && row_ok) ? a.rs[row] : 0.f;
+            }
             if (GRAPH_W) {        // the second product accumulates on top of the attention term
-                const float rsv = (a.rs && row_ok) ? a.rs[row] : 0.f;
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft) y[ft] += *reinterpret_cast<const f32x4*>(&sm_bv[16 * ft + 4 * lg]) * rsv;
                 project_t(y, ga, sm_w[1], l15, lg);
@@ -819,7 +888,8 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
                 int residual, float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu, T* out,
                 int64_t ldo, float* next_record, const int32_t* rowptr, const int32_t* plan, float* next_ys, void* workspace,
                 size_t workspace_bytes, dif_stream_t stream, const float* Wo = nullptr, const float* bo = nullptr, int Co = 0,
-                T* logits = nullptr, int64_t ldl = 0) {
+                T* logits = nullptr, int64_t ldl = 0, const int32_t* g_rowptr = nullptr, const int32_t* g_src = nullptr,
+                const float* g_val = nullptr) {
     const bool head = Wo != nullptr;
     DIF_REQUIRE(x && coef && (out || head) && n_rows > 0, DIF_E_BADARG, "dif_simple_layer: null pointer or no rows");
     DIF_REQUIRE(!head || (bo && logits && Co > 0 && Co <= 128 && ldl >= Co && !next_record && !next_ys), DIF_E_BADARG,
@@ -840,7 +910,8 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
     const bool f32 = std::is_same<T, float>::value;
     DIF_REQUIRE(f32 || (!next_record && !next_ys), DIF_E_BADARG, "dif_simple_layer: products for the next layer are float32-only");
     const bool next = next_record != nullptr;          // Gram record of the output from the same pass (slower)
-    const int P = head ? row_chunks(n_rows, 2, kHeadWaves) : row_chunks(n_rows, next ? kRecordChunksPerCU : 4);
+    const bool gather = g_rowptr != nullptr;
+    const int P = head ? row_chunks(n_rows, 2, kHeadWaves) : row_chunks(n_rows, next ? kRecordChunksPerCU : (gather ? DIF_GATHER_WG : 4));
     const int64_t rec = (static_cast<int64_t>(D) * D + D + 3) & ~int64_t(3);
     int64_t npad = 0;
     if (next) {
@@ -856,18 +927,23 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
             DIF_REQUIRE(plan[0] == D / 4 && npad >= n_rows, DIF_E_BADARG, "dif_simple_layer: plan does not match D / n_rows");
         }
     }
+    DIF_REQUIRE(!gather || (g_src && g_val && !ax && !next && !next_ys), DIF_E_BADARG,
+                "dif_simple_layer: the in-kernel aggregation takes rowptr, src AND val, no ax and no next-layer products");
     LayerArgsT<T> a = {x, ldx, ax, ldax, coef, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha, ln_weight, ln_bias, ln_eps,
                        relu, out, ldo, n_rows, C, D, rowptr, reinterpret_cast<f32x4*>(next_ys), npad, static_cast<float*>(workspace), rec,
-                       Wo, bo, Co, logits, ldl};
+                       Wo, bo, Co, logits, ldl, g_rowptr, g_src, g_val};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
-    const bool gw = ax != nullptr && Wv != nullptr;
+    const bool gw = (ax != nullptr || gather) && Wv != nullptr;
 #define DIF_LAYER(E, G, N) hipLaunchKernelGGL((simple_layer_kernel<E, G, N, T>), dim3(P), dim3(64 * kWaves), 0, st, a)
 #define DIF_LAYER_HEAD(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, true>), dim3(P), dim3(64 * kHeadWaves), 0, st, a)
-#define DIF_LAYER2(E, G) do { if (head) DIF_LAYER_HEAD(E, G); else if (f32 && next) DIF_LAYER(E, G, (std::is_same<T, float>::value)); else DIF_LAYER(E, G, false); } while (0)
+#define DIF_LAYER_GATHER(E, G, H) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, H, true>), dim3(P), dim3(64 * (H ? kHeadWaves : kWaves)), 0, st, a)
+#define DIF_LAYER2(E, G) do { if (gather) { if (head) DIF_LAYER_GATHER(E, G, true); else DIF_LAYER_GATHER(E, G, false); } \
+                              else if (head) DIF_LAYER_HEAD(E, G); else if (f32 && next) DIF_LAYER(E, G, (std::is_same<T, float>::value)); else DIF_LAYER(E, G, false); } while (0)
     if (exact) { if (gw) DIF_LAYER2(true, true); else DIF_LAYER2(true, false); }
     else { if (gw) DIF_LAYER2(false, true); else DIF_LAYER2(false, false); }
 #undef DIF_LAYER2
+#undef DIF_LAYER_GATHER
 #undef DIF_LAYER_HEAD
 #undef DIF_LAYER
     if (int rc = dif::launch_status("simple_layer_kernel")) return rc;
@@ -899,6 +975,35 @@ extern "C" int dif_simple_layer_head_f32(const float* x, int64_t ldx, int64_t n_
     return layer_entry<float>(x, ldx, n_rows, C, D, coef, ax, ldax, Wv, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha,
                               ln_weight, ln_bias, ln_eps, relu, out, ldo, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream,
                               Wo, bo, Co, logits, ldl);
+}
+
+// The layer with the AGGREGATION in the same pass (graphs with a few entries per row, single GPU): instead of ax the kernel
+// takes the CSR (rowptr int32 [n_rows + 1], src int32, val float32: dif_csr_build's, n_blocks = 1) and gathers the rows of
+// x itself -- x holds all n_rows nodes.  Wo != NULL: also the output Linear (logits [n, Co]); then `out` may be NULL.
+extern "C" int dif_simple_layer_gather_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                           const int32_t* rowptr, const int32_t* src, const float* val, const float* Wv,
+                                           const float* bv, float gcn_scale, const float* x0, int64_t ldx0, int residual,
+                                           float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                                           float* out, int64_t ldo, const float* Wo, const float* bo, int Co, float* logits,
+                                           int64_t ldl, dif_stream_t stream) {
+    DIF_REQUIRE(rowptr && src && val, DIF_E_BADARG, "dif_simple_layer_gather_f32: rowptr / src / val are null");
+    return layer_entry<float>(x, ldx, n_rows, C, D, coef, nullptr, 0, Wv, bv, nullptr, gcn_scale, x0, ldx0, residual, alpha,
+                              ln_weight, ln_bias, ln_eps, relu, out, ldo, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream,
+                              Wo, bo, Co, logits, ldl, rowptr, src, val);
+}
+
+extern "C" int dif_simple_layer_gather_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                            const int32_t* rowptr, const int32_t* src, const float* val, const float* Wv,
+                                            const float* bv, float gcn_scale, const void* x0, int64_t ldx0, int residual,
+                                            float alpha, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                                            void* out, int64_t ldo, const float* Wo, const float* bo, int Co, void* logits,
+                                            int64_t ldl, dif_stream_t stream) {
+    using B = dif::bf16;
+    DIF_REQUIRE(rowptr && src && val, DIF_E_BADARG, "dif_simple_layer_gather_bf16: rowptr / src / val are null");
+    return layer_entry<B>(static_cast<const B*>(x), ldx, n_rows, C, D, coef, nullptr, 0, Wv, bv, nullptr, gcn_scale,
+                          static_cast<const B*>(x0), ldx0, residual, alpha, ln_weight, ln_bias, ln_eps, relu, static_cast<B*>(out),
+                          ldo, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream, Wo, bo, Co, static_cast<B*>(logits), ldl,
+                          rowptr, src, val);
 }
 
 // bfloat16 activations, output Linear in the same pass: logits [n, Co] bfloat16 (Wo, bo float32 copies of the parameters)

@@ -758,8 +758,15 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
         if sharded:
             shard.all_reduce_sum(record)
         coef = be.simple_coeffs(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
-    ax = rs = None
-    if csr is not None:
+    ax = rs = gather = None
+    want_next = (carry is not None and not sharded and carry.get("want_next", False) and D % 4 == 0 and D == C and
+                 x.dtype == torch.float32)
+    want_rec = want_next and carry.get("next_record", False)
+    if (csr is not None and sl is None and not sharded and not want_rec and LAYER_GATHER and csr.n_blocks == 1 and n == csr.num_nodes and
+            0 < csr.nnz <= LAYER_GATHER_MAX_DEGREE * n and hasattr(be, "_simple_layer_gather")):
+        # a few entries per row: the layer kernel walks the CSR itself, no separate SpMM launch and no `ax` round trip
+        gather = (csr.rowptr, csr.src, csr.val)
+    elif csr is not None:
         x_src = handle.wait() if sharded else x
         if sl is not None:
             if ys is None:
@@ -778,15 +785,15 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     if join is not None:                           # the layer kernel needs the coefficients: the side stream joins
         join[0].wait_stream(join[1])
         coef.record_stream(join[0])
-    want_next = (carry is not None and not sharded and carry.get("want_next", False) and D % 4 == 0 and D == C and
-                 x.dtype == torch.float32)
-    want_rec = want_next and carry.get("next_record", False)
     if carry is not None:
         carry["products"] = None
     if head is not None:                           # last layer: the model's output Linear rides in the same pass -> logits
         head = tuple(f32_param(t) for t in head)   # bfloat16 storage: exact float32 copies, as for the other parameters
         return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu,
-                               head=head)
+                               head=head, gather=gather)
+    if gather is not None:
+        return be.simple_layer(x, coef, D, None, Wv, bv, None, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu,
+                               gather=gather)
     if not (want_next and (sl is not None or want_rec)):
         return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu)
     out, ys2, record2 = be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps,
@@ -795,6 +802,11 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     carry["products"] = dict(x=out, sl=sl, record=record2, ys=ys2)
     return out
 
+
+# The closed-form layer aggregates inside its own kernel (dif_simple_layer_gather_*) up to this many entries per row on
+# average; above, the separate SpMM kernels (rows split over lanes, long rows over quads) balance the work better.
+LAYER_GATHER = os.environ.get("DIFFORMER_LAYER_GATHER", "1") != "0"
+LAYER_GATHER_MAX_DEGREE = int(os.environ.get("DIFFORMER_LAYER_GATHER_MAX_DEGREE", "12"))
 
 CLOSED_FORM_WIDE_MAX = 512      # widest layer the Gram-record formulation is used for (record = C x C floats)
 CLOSED_FORM_WIDE_MIN = 128      # up to here the q / k / v operator path is as fast (pokec-batch-h128: 1.01 vs 1.02 ms with the row

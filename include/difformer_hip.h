@@ -549,6 +549,20 @@ int dif_simple_layer_head_bf16(const void* x, int64_t ldx, int64_t n_rows, int C
                                const void* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,
                                const float* ln_bias, float ln_eps, int relu, void* out, int64_t ldo, const float* Wo,
                                const float* bo, int Co, void* logits, int64_t ldl, dif_stream_t stream);
+/* The closed-form layer with the AGGREGATION in the same pass, for graphs with a few entries per row on one GPU (replaces
+   the dif_gcn_spmm_* launch + dif_simple_layer_*; reference: gcn_conv difformer.py:59-73 folded into DIFFormerConv.forward
+   difformer.py:107-130): rowptr int32 [n_rows + 1] / src int32 / val float32 = dif_csr_build's CSR with n_blocks = 1 over the
+   SAME n_rows nodes that x holds.  Wo != NULL: also the output Linear (Co <= 128) -> logits [n_rows, Co], `out` may be NULL. */
+int dif_simple_layer_gather_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                const int32_t* rowptr, const int32_t* src, const float* val, const float* Wv, const float* bv,
+                                float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,
+                                const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo,
+                                const float* Wo, const float* bo, int Co, float* logits, int64_t ldl, dif_stream_t stream);
+int dif_simple_layer_gather_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                 const int32_t* rowptr, const int32_t* src, const float* val, const float* Wv, const float* bv,
+                                 float gcn_scale, const void* x0, int64_t ldx0, int residual, float alpha,
+                                 const float* ln_weight, const float* ln_bias, float ln_eps, int relu, void* out, int64_t ldo,
+                                 const float* Wo, const float* bo, int Co, void* logits, int64_t ldl, dif_stream_t stream);
 int dif_simple_layer_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const void* ax,
                           int64_t ldax, const float* Wv, const float* bv, const float* row_sums, float gcn_scale,
                           const void* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,

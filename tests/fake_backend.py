@@ -146,7 +146,8 @@ class OracleBackend:
 
     def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
                      alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, next_rowptr=None, next_plan=None,
-                     next_record=False, head=None):
+                     next_record=False, head=None, gather=None):
+        assert gather is None            # the in-kernel aggregation is the HIP backend's (ops checks for _simple_layer_gather)
         self.closed_form_calls = getattr(self, "closed_form_calls", 0) + 1
         xx, cf = _np(x).astype(np.float64), _np(coef).astype(np.float64)
         C = xx.shape[1]
