@@ -418,6 +418,10 @@ __device__ __forceinline__ void load_rows(f32x4 (&xa)[4], const T* __restrict__ 
 // up to the longest of them, two entries per step.  The chain rowptr -> (src, val) -> x rows is three dependent loads:
 // gather_begin issues the first two links BEFORE the tile's own projection (their latency hides under it), and inside the
 // loop the indices of the next step are requested before the rows of this step are consumed.
+// Measured at 100,000 rows x 64 columns (scripts/exp_layer_gather.py): +3.7 us per entry per row, i.e. 6.9 TB/s of gathered
+// rows (L2 / MALL): throughput-, not latency-bound.  Two variants came out no faster (profiles/r03_experiments.md, 5): a
+// walk over the tile's flattened entry range (4 rows per 16-lane group, eight rows in flight, transposed into this layout
+// by 16 selector MFMAs), and the graph term finished before the attention term (no spills, but +1.5 .. 5 us).
 struct GatherCursor {
     int e, e1;
     int s0, s1;
