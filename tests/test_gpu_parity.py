@@ -423,6 +423,29 @@ def test_skinny_linear_vs_numpy(n, ci, co, ln, relu, dev):
     assert rel_err(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("n,ci,co,dtype", [(100000, 65, 64, torch.float32), (100000, 65, 64, torch.bfloat16), (16, 5, 9, torch.float32),
+                                           (4099, 127, 64, torch.bfloat16), (1000, 3, 64, torch.bfloat16), (2049, 17, 130, torch.float32)])
+def test_skinny_linear_odd_widths_and_views(n, ci, co, dtype, dev):
+    """Rows whose width is not a multiple of four elements (Pokec: 65 features, main-batch.py), float32 and bfloat16, stored
+    back to back, with padded rows, and as a view that starts one row into the buffer: the same numbers every way."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(ci * 100 + co)
+    x = torch.randn(n + 1, ci, generator=g).to(dtype)
+    W, b = (torch.randn(co, ci, generator=g) / np.sqrt(ci)).to(dtype), torch.randn(co, generator=g).to(dtype)
+    xd = x.to(dev)
+    staged = ops.linear(xd[:n], W.to(dev), b.to(dev), None, None, 1e-5, False)
+    ref = x[:n].double().numpy() @ W.double().numpy().T + b.double().numpy()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert staged.dtype == dtype and rel_err(staged.float().cpu().numpy(), ref) < tol
+    padded = torch.zeros(n, ci + 3, dtype=dtype, device=dev)
+    padded[:, :ci] = xd[:n]
+    scalar = ops.linear(padded[:, :ci], W.to(dev), b.to(dev), None, None, 1e-5, False)          # ldx != C_in
+    assert torch.equal(staged, scalar)
+    ref1 = x[1:].double().numpy() @ W.double().numpy().T + b.double().numpy()
+    off = ops.linear(xd[1:], W.to(dev), b.to(dev), None, None, 1e-5, False)                     # starts one row in
+    assert rel_err(off.float().cpu().numpy(), ref1) < tol
+
+
 @pytest.mark.parametrize("n,ci,co,ln,relu", [(50000, 512, 64, True, True), (20000, 1432, 64, True, True), (3001, 132, 10, False, False),
                                               (17, 516, 33, True, False), (40000, 300, 64, False, True), (5000, 2048, 7, True, True)])
 def test_long_linear_vs_numpy(n, ci, co, ln, relu, dev):
