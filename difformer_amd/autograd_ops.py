@@ -247,6 +247,108 @@ class _Linear(torch.autograd.Function):
         return gx, gw, gb
 
 
+def _weighted_column_sum(be, rows, w):
+    """sum_r w[r] rows[r, :] as K^T V of the streaming reduce with K = w (one column): the vendor GEMV on the transposed
+    operand takes 0.9 ms for 132,534 x 64 floats, the reduce kernel reads the rows once."""
+    n, c = rows.shape
+    w3 = w.reshape(n, 1, 1)
+    return be.simple_reduce(w3, w3, rows.reshape(n, 1, c))[:c]
+
+
+class _ClosedFormLayer(torch.autograd.Function):
+    """One DIFFormer layer with the `simple` kernel through the Gram record (ops.simple_layer_closed_form), under autograd:
+    q, k, v are never formed, forward or backward.  With  att = (x Mn + cn) / (x u + cd)  and the coefficients
+    (Mn, cn, u, cd) = f(G~, W~)  of the record  G~ = [x | 1]^T [x | 1]  (difformer.py:18-39):
+        forward   Gram pass -> coefficients -> aggregation of x -> layer kernel (attention + graph term + tail)
+        backward  tail (LayerNorm, residual, + x0)                  dif_layer_tail_bwd on the recomputed pre-tail rows
+                  graph term  g_s (A x Wv^T + (A 1) bv^T)            d ax = d Wv, d Wv = d^T ax (one streaming reduce),
+                                                                    d x += g_s A^T d ax (adjoint product)
+                  attention   d num = d / den, d den = -<d num, att>  d x += d num Mn^T + d den u^T;
+                              d Mn = x^T d num, d cn = sum d num (one streaming reduce), d u = x^T d den, d cd = sum d den
+                  coefficients -> d G~, d W~                         ops.closed_form_coeffs_backward (C + 1 square matrices)
+                  record      d x += x (dG + dG^T) + 1 d sx^T
+    Single GPU, one head, query == source, float32, C, D <= 64 (DIFFormerConv._closed_form)."""
+
+    @staticmethod
+    def forward(ctx, x, Wq, bq, Wk, bk, Wv, bv, x0, ln_w, ln_b, csr, attn_scale, gcn_scale, residual, alpha, eps):
+        keep = {}
+        out = ops.simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_w,
+                                           ln_b, eps, keep=keep)
+        ctx.save_for_backward(x, Wq, bq, Wk, bk, Wv, bv, x0, ln_w, ln_b, keep["record"], keep["coef"], keep["ax"],
+                              keep["row_sums"])
+        ctx.csr, ctx.scales, ctx.tail = csr, (float(attn_scale), float(gcn_scale)), (bool(residual), float(alpha), float(eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Wq, bq, Wk, bk, Wv, bv, x0, ln_w, ln_b, record, coef, ax, rs = ctx.saved_tensors
+        (a_s, g_s), (residual, alpha, eps), csr = ctx.scales, ctx.tail, ctx.csr
+        be = ops.get_backend()
+        n, C = x.shape
+        D = Wq.shape[0]
+        g = g.contiguous()
+        # tail: the pre-tail rows come out of the layer kernel once more (no tail), then one backward pass
+        conv = be.simple_layer(x, coef, D, ax, Wv, bv, rs, g_s).view(n, 1, D)
+        prev = x if residual else None
+        want = (True, x0 is not None and ctx.needs_input_grad[7], residual)
+        got = be.layer_tail_bwd(conv, x0, prev, alpha, ln_w, ln_b, eps, False, g, want)
+        if got is None:
+            got = _grad_by_recompute(_tail_expr(alpha, eps, ln_w is not None), (conv, x0, prev, ln_w, ln_b), g)
+        d, d_x0, dx, d_lnw, d_lnb = got
+        d = d.reshape(n, D)
+        del conv
+        # graph term
+        d_Wv = d_bv = None
+        if csr is not None:
+            if Wv is not None:
+                d_ax = d @ Wv
+                d3 = d.view(n, 1, D)
+                red = be.simple_reduce(d3, d3, ax.view(n, 1, C))                    # K^T V with K = d, V = ax
+                d_Wv = red[: D * C].view(D, C).clone()
+                d_bv = g_s * _weighted_column_sum(be, d, rs)
+            else:
+                d_ax = d
+            gx = ops.gcn_aggregate(csr.adjoint(), d_ax.reshape(n, 1, C), None, 1.0, g_s, None).reshape(n, C)
+            dx = gx if dx is None else dx.add_(gx)
+            del d_ax, gx
+        # attention term
+        MnT, cn = coef[: D * C].view(D, C), coef[D * C: D * C + D]
+        u, cd = coef[D * C + D: D * C + D + C], coef[D * C + D + C]
+        got = be.closed_form_attn_backward(x, coef, D, d, dx) if hasattr(be, "closed_form_attn_backward") else None
+        if got is not None:
+            d_num, d_den, dx = got                                                  # one pass (csrc/simple_layer.hip)
+        else:
+            att = be.simple_layer(x, coef, D)                                       # (x Mn + cn) / (x u + cd)
+            den = torch.mul(x, u).sum(dim=1).add_(cd)
+            d_num = d / den[:, None]
+            d_den = (d_num * att).sum(dim=1).neg_()
+            del att, den
+            dx = torch.mm(d_num, MnT) if dx is None else dx.addmm_(d_num, MnT)
+            dx.addr_(d_den, u)
+        dn3 = d_num.view(n, 1, D)
+        red = be.simple_reduce(dn3, dn3, x.view(n, 1, C))                           # K^T V = d_num^T x, sum K = sum d_num
+        # red = [d_num^T x: D x C][sum d_num: D][...]: with d u and d cd written behind them it IS the gradient of coef
+        red[D * C + D: D * C + D + C] = _weighted_column_sum(be, x, d_den)
+        torch.sum(d_den, dim=0, out=red[D * C + D + C])
+        if hasattr(be, "simple_coeffs_backward"):
+            S, t, d_Wq, d_bq, d_Wk, d_bk, d_Wv_a, d_bv_a = be.simple_coeffs_backward(record, n, C, D, Wq, bq, Wk, bk, Wv, bv,
+                                                                                     a_s, coef, red)
+        else:
+            S, t, d_Wq, d_bq, d_Wk, d_bk, d_Wv_a, d_bv_a = ops.closed_form_coeffs_backward(
+                record, n, C, D, Wq, bq, Wk, bk, Wv, bv, a_s, red[: D * C].view(D, C), red[D * C: D * C + D],
+                red[D * C + D: D * C + D + C], red[D * C + D + C])
+        dx.addmm_(x, S).add_(t)
+        if Wv is not None:
+            d_Wv = d_Wv_a if d_Wv is None else d_Wv.add_(d_Wv_a)
+            d_bv = d_bv_a if d_bv is None else d_bv.add_(d_bv_a)
+        return dx, d_Wq, d_bq, d_Wk, d_bk, d_Wv, d_bv, d_x0, d_lnw, d_lnb, None, None, None, None, None, None
+
+
+def closed_form_layer(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps):
+    return _ClosedFormLayer.apply(x, Wq, bq, Wk, bk, Wv, bv, x0, ln_weight, ln_bias, csr, attn_scale, gcn_scale, residual,
+                                  alpha, eps)
+
+
 class _SplitColumns(torch.autograd.Function):
     """q | k | v as column slices of the fused projection [n, (2|3) H D].  Plain slicing would have autograd build one
     zero-filled [n, 3 H D] buffer per slice gradient and add them up (three fills, three copies, two adds of 102 MB at

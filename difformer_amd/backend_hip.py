@@ -680,6 +680,52 @@ class HipBackend:
         _lib.check(rc, "dif_simple_coeffs_f32")
         return coef
 
+    def closed_form_attn_backward(self, x, coef, D, d, dx_in=None):
+        """Backward of att = (x Mn + cn) / (x u + cd) in one pass (csrc/simple_layer.hip, closed_form_attn_bwd_kernel):
+        -> (d_num [n, D], d_den [n], dx [n, C] = dx_in + d_num Mn^T + d_den u^T), or None when the shape is not covered."""
+        dev = _require_device(x, coef, d, dx_in)
+        n, C = x.shape
+        if C % 4 or D % 4 or C > 64 or D > 64 or any(t_ is not None and t_.dtype != torch.float32 for t_ in (x, coef, d, dx_in)):
+            return None
+        x, ldx = _row_major(x, C)
+        d, ldd = _row_major(d, D)
+        ldi = 0
+        if dx_in is not None:
+            dx_in, ldi = _row_major(dx_in, C)
+        if any(ld % 4 for ld in (ldx, ldd, ldi)) or any(t_ is not None and t_.data_ptr() % 16 for t_ in (x, d, dx_in)):
+            return None
+        d_num = torch.empty((n, D), dtype=torch.float32, device=dev)
+        d_den = torch.empty((n,), dtype=torch.float32, device=dev)
+        dx = torch.empty((n, C), dtype=torch.float32, device=dev)
+        with _timed(self, "dif_simple_layer_f32", dev):
+            rc = self.lib.dif_closed_form_attn_bwd_f32(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(d), ldd, _ptr(dx_in), ldi,
+                                                       _ptr(d_num), _ptr(d_den), _ptr(dx), C, _stream(dev))
+        _lib.check(rc, "dif_closed_form_attn_bwd_f32")
+        return d_num, d_den, dx
+
+    def simple_coeffs_backward(self, record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale, coef, dcoef):
+        """Backward of simple_coeffs in one launch (csrc/simple_coeffs_bwd.hip): dcoef in coef's layout ->
+        (S [C, C], t [C], dWq, dbq, dWk, dbk, dWv | None, dbv | None): dx = x S + 1 t^T through the record."""
+        dev = _require_device(record, Wq, bq, Wk, bk, Wv, bv, coef, dcoef)
+        ws_ = [None if t_ is None else _f32(t_, "weight").contiguous() for t_ in (Wq, bq, Wk, bk, Wv, bv)]
+        if dcoef.numel() < D * C + D + C + 1 or not dcoef.is_contiguous():
+            raise TypeError("difformer_amd: dcoef must be contiguous with coef's layout [D*C | D | C | 1]")
+        out = torch.empty(self.lib.dif_simple_coeffs_bwd_len(C, D), dtype=torch.float32, device=dev)
+        with _timed(self, "dif_simple_coeffs_f32", dev):
+            rc = self.lib.dif_simple_coeffs_bwd_f32(_ptr(record), int(n_global), C, D, *[_ptr(t_) for t_ in ws_],
+                                                    float(attn_scale), _ptr(_f32(coef, "coef")), _ptr(_f32(dcoef, "dcoef")),
+                                                    _ptr(out), _stream(dev))
+        _lib.check(rc, "dif_simple_coeffs_bwd_f32")
+        o = 0
+        parts = []
+        for shape in ((C, C), (C,), (D, C), (D,), (D, C), (D,), (D, C), (D,)):
+            k = shape[0] * (shape[1] if len(shape) > 1 else 1)
+            parts.append(out[o: o + k].view(shape))
+            o += k
+        if Wv is None:
+            parts[6] = parts[7] = None
+        return parts
+
     def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
                      alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, next_rowptr=None, next_plan=None,
                      next_record=False, head=None, gather=None):

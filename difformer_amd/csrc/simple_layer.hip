@@ -868,6 +868,130 @@ extern "C" int dif_gram_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, 
                                  workspace_bytes, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Training through the record: backward of the attention term  att = (x Mn + cn) / (x u + cd)  of the layer kernel, given
+// d = dL/d(att) [n, D] (difformer_amd/autograd_ops.py, _ClosedFormLayer).  Per 16-row tile and wave, in one pass:
+//   att again (the first product of the layer kernel),  d_num = d / den,  d_den = -<d_num, att>,
+//   dx = dx_in + d_num Mn^T + d_den u^T                 (second product: the same weights, read transposed)
+// d_num and d_den go on to one streaming reduce (d Mn = x^T d_num, d cn, d u, d cd).  Replaces a recompute launch, four
+// element-wise passes, a vendor GEMV and a row GEMM of the tensor-op formulation (0.21 ms per layer at 132,534 rows).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+struct AttnBwdArgs {
+    const float* x; int64_t ldx;
+    const float* coef;
+    const float* d; int64_t ldd;
+    const float* dx_in; int64_t ldi;
+    float* d_num; float* d_den; float* dx; int64_t ldo;
+    int64_t n_rows; int C, D;
+};
+
+template <bool EXACT>
+__global__ __launch_bounds__(64 * kWaves, 4) void closed_form_attn_bwd_kernel(AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float sm_w[2][kWBlock];   // MnT as W[f][c], and its transpose W'[c][f]
+    __shared__ __attribute__((aligned(16))) float sm_cn[64], sm_u[64];
+    __shared__ float sm_cd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int C = a.C, D = a.D;
+    for (int e = threadIdx.x; e < 64 * 64; e += 64 * kWaves) {          // e = LDS dword of block 0: [ft][cq][lg][l15][t]
+        const int f = 16 * (e >> 10) + ((e >> 2) & 15), c = 16 * ((e >> 8) & 3) + 4 * ((e >> 6) & 3) + (e & 3);
+        const float v = (f < D && c < C) ? a.coef[f * C + c] : 0.f;
+        sm_w[0][widx(f, c)] = v;
+        sm_w[1][widx(c, f)] = v;
+    }
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        sm_cn[i] = i < D ? a.coef[D * C + i] : 0.f;
+        sm_u[i] = i < C ? a.coef[D * C + D + i] : 0.f;
+    }
+    if (threadIdx.x == 0) sm_cd = a.coef[D * C + D + C];
+    __syncthreads();
+    const float cd = sm_cd;
+    const int64_t n_tiles = (a.n_rows + 15) / 16;
+    const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kWaves + wave, stride = static_cast<int64_t>(gridDim.x) * kWaves;
+
+    auto body = [&](int64_t tile, auto guard_tag) {
+        constexpr bool G = decltype(guard_tag)::value;
+        const int64_t row = tile * 16 + l15;
+        const bool row_ok = !G || row < a.n_rows;
+        f32x4 xa[4], dn[4];
+        load_rows<G>(xa, a.x, a.ldx, row, a.n_rows, lg, C);
+        load_rows<G>(dn, a.d, a.ldd, row, a.n_rows, lg, D);
+        float den = 0.f;
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+            const f32x4 uu = *reinterpret_cast<const f32x4*>(&sm_u[16 * cq + 4 * lg]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) den += xa[cq][t] * uu[t];
+        }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        const float rden = 1.0f / (den + cd);
+        f32x4 y[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] = *reinterpret_cast<const f32x4*>(&sm_cn[16 * ft + 4 * lg]);
+        project_t(y, xa, sm_w[0], l15, lg);                                        // numerator of att
+        float dd = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            dn[ft] *= rden;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dd += dn[ft][r] * y[ft][r];
+        }
+        dd += __shfl_xor(dd, 16, 64);
+        dd += __shfl_xor(dd, 32, 64);
+        dd *= -rden;                                                               // -<d_num, att>
+        if (row_ok && lg == 0) a.d_den[row] = dd;
+        f32x4 z[4];
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+            const int c = 16 * cq + 4 * lg;
+            z[cq] = *reinterpret_cast<const f32x4*>(&sm_u[c]) * dd;
+            if (a.dx_in && row_ok && (EXACT || c < C)) z[cq] += *reinterpret_cast<const f32x4*>(a.dx_in + row * a.ldi + c);
+        }
+        project_t(z, dn, sm_w[1], l15, lg);                                        // + d_num Mn^T
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = 16 * q + 4 * lg;
+            if (row_ok && (EXACT || f < D)) *reinterpret_cast<f32x4*>(a.d_num + row * D + f) = dn[q];
+            if (row_ok && (EXACT || f < C)) *reinterpret_cast<f32x4*>(a.dx + row * a.ldo + f) = z[q];
+        }
+    };
+    int64_t tile = first;
+    if (EXACT) {
+        for (; tile < n_fast; tile += stride) {
+            asm volatile("" ::: "memory");
+            body(tile, std::false_type{});
+        }
+    }
+    for (; tile < n_tiles; tile += stride) {
+        asm volatile("" ::: "memory");
+        body(tile, std::true_type{});
+    }
+}
+}  // namespace
+
+// d [n, D] = gradient with respect to the attention term; dx_in (nullable) [n, C] = what dx already holds.
+// -> d_num [n, D] (dense), d_den [n], dx [n, C] = dx_in + d_num Mn^T + d_den u^T.  C, D multiples of 4, <= 64; 16-byte rows.
+extern "C" int dif_closed_form_attn_bwd_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
+                                            const float* d, int64_t ldd, const float* dx_in, int64_t ldi, float* d_num,
+                                            float* d_den, float* dx, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(x && coef && d && d_num && d_den && dx && n_rows > 0, DIF_E_BADARG, "dif_closed_form_attn_bwd: null pointer or no rows");
+    DIF_REQUIRE(C > 0 && C <= 64 && D > 0 && D <= 64 && C % 4 == 0 && D % 4 == 0, DIF_E_SHAPE,
+                "dif_closed_form_attn_bwd: covers C, D <= 64, multiples of 4 (got %d, %d)", C, D);
+    DIF_REQUIRE(ldx >= C && ldd >= D && ldo >= C && (!dx_in || ldi >= C) && ldx % 4 == 0 && ldd % 4 == 0 && ldo % 4 == 0 &&
+                (!dx_in || ldi % 4 == 0), DIF_E_BADARG, "dif_closed_form_attn_bwd: leading dimensions must cover a row and be multiples of 4");
+    DIF_REQUIRE(dif::aligned16(x) && dif::aligned16(d) && dif::aligned16(d_num) && dif::aligned16(dx) && (!dx_in || dif::aligned16(dx_in)),
+                DIF_E_BADARG, "dif_closed_form_attn_bwd: rows must be 16-byte aligned");
+    AttnBwdArgs a = {x, ldx, coef, d, ldd, dx_in, ldi, d_num, d_den, dx, ldo, n_rows, C, D};
+    const int P = row_chunks(n_rows, 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (C == 64 && D == 64) hipLaunchKernelGGL(closed_form_attn_bwd_kernel<true>, dim3(P), dim3(64 * kWaves), 0, st, a);
+    else hipLaunchKernelGGL(closed_form_attn_bwd_kernel<false>, dim3(P), dim3(64 * kWaves), 0, st, a);
+    return dif::launch_status("closed_form_attn_bwd_kernel");
+}
+
 extern "C" size_t dif_simple_coeffs_len(int C, int D) {
     if (C <= 0 || D <= 0) return 0;
     return static_cast<size_t>(D) * C + D + C + 4;

@@ -25,6 +25,7 @@ __all__ = ["full_attention_conv", "gcn_conv", "DIFFormerConv", "DIFFormer"]
 
 _CHAIN_GRAM = os.environ.get("DIFFORMER_CHAIN_GRAM", "0") == "1"
 _AUTO_GRAPH = os.environ.get("DIFFORMER_AUTO_GRAPH", "1") != "0"
+_CLOSED_FORM_TRAINING = os.environ.get("DIFFORMER_CLOSED_FORM_TRAINING", "1") != "0"
 
 
 def _dense_attention(qs, ks, kernel):
@@ -172,7 +173,11 @@ class DIFFormerConv(nn.Module):
         params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias]
         if self.use_weight:
             params += [self.Wv.weight, self.Wv.bias]
-        return not ag._needs_grad(x, *params)
+        if not ag._needs_grad(x, *params):
+            return True
+        # training: the narrow float32 single-GPU closed form has a backward through the record (ag._ClosedFormLayer)
+        return (_CLOSED_FORM_TRAINING and not wide and x.dtype == torch.float32 and self.row_shard is None and
+                hasattr(ops.get_backend(), "simple_reduce"))
 
     def _layer(self, query_input, source_input, edge_index, edge_weight, x0=None, prev=None, alpha=0.5,
                ln_weight=None, ln_bias=None, eps=1e-5, want_qk=False, carry=None):
@@ -207,6 +212,10 @@ class DIFFormerConv(nn.Module):
                                                                 Wv, bv))
                 out = ops.simple_layer_closed_form_wide(x, self._wide[1], Wv, bv, csr, a_s, g_s, x0, prev is not None, alpha,
                                                         ln_weight, ln_bias, eps)
+                return out, None, None
+            params = (self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv)
+            if ag._needs_grad(x, x0, ln_weight, ln_bias, *params):          # training: forward and backward through the record
+                out = ag.closed_form_layer(x, *params, csr, a_s, g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps)
                 return out, None, None
             factors = None
             if csr is not None and shard is None and x.dtype == torch.float32 and hasattr(ops.get_backend(), "coeffs_bg"):

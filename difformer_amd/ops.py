@@ -709,7 +709,8 @@ def _closed_form_slice_sharded(be, x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, g
 
 
 def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight,
-                             ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None, factors=None, head=None):
+                             ln_bias, eps, relu=False, carry=None, shard: Optional[RowShard] = None, factors=None, head=None,
+                             keep=None):
     """One DIFFormer layer with the `simple` kernel, query == source == x [n, C] (this rank's rows), one head
     (csrc/simple_layer.hip): Gram record -> coefficients -> SpMM on x -> the layer kernel.  q, k, v and the attention
     output never reach memory.  csr = None: use_graph = False.  Wv = None: use_weight = False.
@@ -718,7 +719,9 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     Gram pass and the coefficients run under it.
     `carry` (dict, optional; single GPU) chains layers over the same graph: with carry["want_next"] the layer kernel also
     writes the slice-major pre-scaled copy of its output (the next layer's SpMM operand) from its registers, and with
-    carry["next_record"] the Gram record of the output too; the next layer picks up what it finds."""
+    carry["next_record"] the Gram record of the output too; the next layer picks up what it finds.
+    `keep` (dict, optional; the training forward, autograd_ops._ClosedFormLayer): receives the record, the coefficients, the
+    aggregated rows and the row sums the backward pass starts from (the aggregation then stays a launch of its own)."""
     be = get_backend()
     n, C = x.shape
     D = Wq.shape[0]
@@ -762,7 +765,7 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     want_next = (carry is not None and not sharded and carry.get("want_next", False) and D % 4 == 0 and D == C and
                  x.dtype == torch.float32)
     want_rec = want_next and carry.get("next_record", False)
-    if (csr is not None and sl is None and not sharded and not want_rec and LAYER_GATHER and csr.n_blocks == 1 and n == csr.num_nodes and
+    if (csr is not None and sl is None and not sharded and not want_rec and keep is None and LAYER_GATHER and csr.n_blocks == 1 and n == csr.num_nodes and
             0 < csr.nnz <= LAYER_GATHER_MAX_DEGREE * n and hasattr(be, "_simple_layer_gather")):
         # a few entries per row: the layer kernel walks the CSR itself, no separate SpMM launch and no `ax` round trip
         gather = (csr.rowptr, csr.src, csr.val)
@@ -787,6 +790,8 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
         coef.record_stream(join[0])
     if carry is not None:
         carry["products"] = None
+    if keep is not None:
+        keep.update(record=record, coef=coef, ax=ax, row_sums=rs)
     if head is not None:                           # last layer: the model's output Linear rides in the same pass -> logits
         head = tuple(f32_param(t) for t in head)   # bfloat16 storage: exact float32 copies, as for the other parameters
         return be.simple_layer(x, coef, D, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps, relu,
@@ -807,6 +812,56 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
 # average; above, the separate SpMM kernels (rows split over lanes, long rows over quads) balance the work better.
 LAYER_GATHER = os.environ.get("DIFFORMER_LAYER_GATHER", "1") != "0"
 LAYER_GATHER_MAX_DEGREE = int(os.environ.get("DIFFORMER_LAYER_GATHER_MAX_DEGREE", "12"))
+
+def closed_form_coeffs_backward(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale, d_MnT, d_cn, d_u, d_cd):
+    """Backward of the coefficient stage (backend.simple_coeffs): gradients of a loss with respect to the Gram record and
+    the projection parameters, given its gradients with respect to MnT [D, C], cn [D], u [C] and cd.  float64 tensor ops on
+    (C + 1)-square matrices.  With the augmented matrices W~ = [W | b] and G~ = [[G, sx], [sx^T, N]] (difformer.py:18-38):
+        KtV = W~k G~ W~v^T,  sum k = W~k G~ e,  sum v = W~v G~ e,  |Q|^2 = <W~q G~, W~q>,  |K|^2 = <W~k G~, W~k>,  s = (|Q|^2 |K|^2)^-1/2
+        [Mn; cn - a sum v] = a s W~q^T KtV,    [u; cd - N] = s W~q^T sum k
+    -> (S [C, C], t [C]) with d x = x S + 1 t^T (S, t = the symmetrised gradient of G~), d_Wq, d_bq, d_Wk, d_bk, d_Wv, d_bv
+    (float32; the last two None when Wv is None: use_weight = False)."""
+    f64 = torch.float64
+    dev = record.device
+    N = float(n_global)
+    r = record.to(f64)
+    Gt = torch.empty((C + 1, C + 1), dtype=f64, device=dev)
+    Gt[:C, :C] = r[: C * C].view(C, C)
+    Gt[:C, C] = r[C * C: C * C + C]
+    Gt[C, :C] = r[C * C: C * C + C]
+    Gt[C, C] = N
+    aug = lambda W, b: torch.cat([W.to(f64), b.to(f64)[:, None]], dim=1)
+    Wq_, Wk_ = aug(Wq, bq), aug(Wk, bk)
+    if Wv is not None:
+        Wv_ = aug(Wv, bv)
+    else:
+        Wv_ = torch.cat([torch.eye(D, C, dtype=f64, device=dev), torch.zeros(D, 1, dtype=f64, device=dev)], dim=1)
+    a = float(attn_scale)
+    Aq, Ak, Av = Wq_ @ Gt, Wk_ @ Gt, Wv_ @ Gt
+    ktv, ksum = Ak @ Wv_.t(), Ak[:, C]
+    q2, k2 = (Aq * Wq_).sum(), (Ak * Wk_).sum()
+    s = (q2 * k2) ** -0.5
+    P, rr = Wq_.t() @ ktv, Wq_.t() @ ksum
+    Dm = torch.cat([d_MnT.to(f64).t(), d_cn.to(f64)[None, :]], dim=0)                   # [C + 1, D]
+    Du = torch.cat([d_u.to(f64).reshape(-1), d_cd.to(f64).reshape(1)])                  # [C + 1]
+    dP, dr = a * s * Dm, s * Du
+    ds = a * (Dm * P).sum() + (Du * rr).sum()
+    dvsum = a * d_cn.to(f64)
+    dktv, dksum = Wq_ @ dP, Wq_ @ dr
+    dq2, dk2 = -0.5 * ds * s / q2, -0.5 * ds * s / k2
+    e_col = Gt[:, C]
+    dWq_ = ktv @ dP.t() + torch.outer(ksum, dr) + 2.0 * dq2 * Aq
+    dWk_ = 2.0 * dk2 * Ak + dktv @ Av + torch.outer(dksum, e_col)
+    dWv_ = dktv.t() @ Ak + torch.outer(dvsum, e_col)
+    dGt = dq2 * (Wq_.t() @ Wq_) + dk2 * (Wk_.t() @ Wk_) + Wk_.t() @ dktv @ Wv_
+    dGt[:, C] += Wk_.t() @ dksum + Wv_.t() @ dvsum
+    S = dGt + dGt.t()
+    f32 = torch.float32
+    out = [S[:C, :C].to(f32).contiguous(), S[C, :C].to(f32).contiguous(), dWq_[:, :C].to(f32), dWq_[:, C].to(f32),
+           dWk_[:, :C].to(f32), dWk_[:, C].to(f32)]
+    out += [dWv_[:, :C].to(f32), dWv_[:, C].to(f32)] if Wv is not None else [None, None]
+    return out
+
 
 CLOSED_FORM_WIDE_MAX = 512      # widest layer the Gram-record formulation is used for (record = C x C floats)
 CLOSED_FORM_WIDE_MIN = 128      # up to here the q / k / v operator path is as fast (pokec-batch-h128: 1.01 vs 1.02 ms with the row

@@ -549,6 +549,21 @@ int dif_simple_layer_head_bf16(const void* x, int64_t ldx, int64_t n_rows, int C
                                const void* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,
                                const float* ln_bias, float ln_eps, int relu, void* out, int64_t ldo, const float* Wo,
                                const float* bo, int Co, void* logits, int64_t ldl, dif_stream_t stream);
+/* Backward of dif_simple_coeffs_f32 (training through the Gram record; difformer.py:18-38 under autograd without q, k, v).
+   dcoef = gradient with respect to coef, in coef's layout [dMnT: D x C][dcn: D][du: C][dcd]; coef = the forward's output.
+   out (dif_simple_coeffs_bwd_len floats) = [S: C x C][t: C][dWq: D x C][dbq: D][dWk: D x C][dbk: D][dWv: D x C][dbv: D]:
+   the gradient of the rows through the record is  dx = x S + 1 t^T;  dWv, dbv are left untouched when Wv == NULL. */
+size_t dif_simple_coeffs_bwd_len(int C, int D);
+int dif_simple_coeffs_bwd_f32(const float* record, int64_t n_global, int C, int D, const float* Wq, const float* bq,
+                              const float* Wk, const float* bk, const float* Wv, const float* bv, float attn_scale,
+                              const float* coef, const float* dcoef, float* out, dif_stream_t stream);
+/* Backward of the attention term of the closed-form layer, att = (x Mn + cn) / (x u + cd) (difformer.py:25-39 in closed
+   form), in one pass over the rows: d [n, D] = gradient with respect to att (ldd), dx_in [n, C] (nullable, ldi) = what dx
+   already holds.  -> d_num [n, D] (dense) = d / den, d_den [n] = -<d_num, att>, dx [n, C] (ldo) = dx_in + d_num Mn^T + d_den u^T.
+   C, D <= 64 and multiples of 4, rows 16-byte aligned (DIF_E_SHAPE / DIF_E_BADARG otherwise). */
+int dif_closed_form_attn_bwd_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const float* d,
+                                 int64_t ldd, const float* dx_in, int64_t ldi, float* d_num, float* d_den, float* dx,
+                                 int64_t ldo, dif_stream_t stream);
 /* The closed-form layer with the AGGREGATION in the same pass, for graphs with a few entries per row on one GPU (replaces
    the dif_gcn_spmm_* launch + dif_simple_layer_*; reference: gcn_conv difformer.py:59-73 folded into DIFFormerConv.forward
    difformer.py:107-130): rowptr int32 [n_rows + 1] / src int32 / val float32 = dif_csr_build's CSR with n_blocks = 1 over the

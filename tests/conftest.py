@@ -47,11 +47,13 @@ def rel_err(y, ref):
     return float(np.max(np.abs(y - ref)) / denom) if ref.size else 0.0
 
 
-def grad_err(got, ref, gmax, floor=1e-6):
-    """Parity metric for ONE gradient tensor of a training step: max|got - ref| / max(max|ref|, 1e-6 * gmax), gmax = the
+def grad_err(got, ref, gmax, floor=2e-6):
+    """Parity metric for ONE gradient tensor of a training step: max|got - ref| / max(max|ref|, 2e-6 * gmax), gmax = the
     largest |entry| over all gradients of the step.  Per-tensor norm-wise as rel_err, with a floor: the Wq / Wk gradients
     of the `simple` kernel are 1e-5..1e-7 of the others (its attention is close to uniform), and a float32 backward pass
-    cannot resolve a tensor that small to 1e-4 of ITSELF -- the float32 run of the reference does not either."""
+    cannot resolve a tensor that small to 1e-4 of ITSELF -- the float32 run of the reference does not either: with a floor
+    of 1e-6 its own grad_f32 of model/s_cli_flags convs.1.Wk.bias (7e-7 .. 3e-6 of gmax: bk moves every key alike and only
+    acts through |K|) sits at 1.07e-4 of its grad_f64 (tests/golden/golden_grad.npz)."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     if not ref.size:

@@ -400,3 +400,62 @@ def test_layer_kernel_aggregates_sparse_graphs_itself(n, c, dtype, use_weight, g
     if head:
         z = z @ hw.double().numpy().T + hb.double().numpy()
     assert rel_err(out.float().cpu().numpy(), z) < (TOL if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("n,c,d,use_weight", [(5000, 64, 64, True), (3000, 32, 64, True), (2000, 64, 16, True), (1500, 48, 48, False),
+                                              (700, 8, 12, True), (132534, 64, 64, True)])
+def test_coefficient_backward_kernel_vs_float64_tensor_ops(n, c, d, use_weight, dev):
+    """dif_simple_coeffs_bwd_f32 (training through the Gram record) against ops.closed_form_coeffs_backward: the same
+    formulas in float64 tensor ops, which tests/test_host_logic.py holds to torch autograd and, through the training step,
+    to the reference's gradients."""
+    from conftest import grad_err
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    be = ops.get_backend()
+    x = (torch.randn(n, c, generator=g) + 0.2).to(dev)
+    p = {k: (None if v is None else v.to(dev)) for k, v in _params(c, d, g, use_weight).items()}
+    rec, _ = be.gram(x)
+    a_s = 0.7
+    coef = be.simple_coeffs(rec, n, c, d, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], a_s)
+    dcoef = torch.randn(d * c + d + c + 2, generator=g).to(dev)
+    dcoef[: d * c] *= 3.0
+    got = be.simple_coeffs_backward(rec, n, c, d, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], a_s, coef, dcoef)
+    ref = ops.closed_form_coeffs_backward(rec, n, c, d, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], a_s,
+                                          dcoef[: d * c].view(d, c), dcoef[d * c: d * c + d], dcoef[d * c + d: d * c + d + c],
+                                          dcoef[d * c + d + c])
+    names = ("S", "t", "dWq", "dbq", "dWk", "dbk", "dWv", "dbv")
+    for name, a, b in zip(names, got, ref):
+        if b is None:
+            assert a is None
+            continue
+        b = b.cpu().numpy()
+        assert grad_err(a.cpu().numpy(), b, float(np.abs(b).max())) < 2e-5, name
+
+
+@pytest.mark.parametrize("n,c,d,with_dx", [(5000, 64, 64, True), (132534, 64, 64, False), (3001, 32, 64, True), (2000, 64, 16, False),
+                                           (17, 48, 48, True), (1, 8, 12, False)])
+def test_closed_form_attention_backward_kernel(n, c, d, with_dx, dev):
+    """dif_closed_form_attn_bwd_f32 against float64 autograd of att = (x Mn + cn) / (x u + cd) (difformer.py:25-39 in closed
+    form): d_num, d_den and the gradient of the rows at fixed coefficients."""
+    from conftest import grad_err
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + c + d)
+    be = ops.get_backend()
+    x = torch.randn(n, c, generator=g)
+    coef = torch.randn(d * c + d + c + 4, generator=g) * 0.2
+    coef[d * c + d + c] = 25.0                                       # cd: keeps the denominator away from zero
+    dd = torch.randn(n, d, generator=g)
+    dx0 = torch.randn(n, c, generator=g) if with_dx else None
+    d_num, d_den, dx = be.closed_form_attn_backward(x.to(dev), coef.to(dev), d, dd.to(dev), None if dx0 is None else dx0.to(dev))
+    x64 = x.double().requires_grad_(True)
+    cf = coef.double()
+    MnT, cn, u, cd = cf[: d * c].view(d, c), cf[d * c: d * c + d], cf[d * c + d: d * c + d + c], cf[d * c + d + c]
+    num, den = x64 @ MnT.t() + cn, x64 @ u + cd
+    (gx,) = torch.autograd.grad(num / den[:, None], x64, dd.double())
+    if dx0 is not None:
+        gx = gx + dx0.double()
+    rn = dd.double() / den.detach()[:, None]
+    rd = -(rn * (num / den[:, None]).detach()).sum(1)
+    for name, a, b in (("d_num", d_num, rn), ("d_den", d_den, rd), ("dx", dx, gx)):
+        b = b.numpy()
+        assert grad_err(a.cpu().numpy(), b, float(np.abs(b).max())) < 1e-5, name

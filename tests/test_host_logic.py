@@ -482,3 +482,49 @@ def test_parameter_caches_invalidate(fake_backend):
         ei = torch.randint(0, 30, (2, 50))
     assert ops.tensor_version(w) == -1 and ops.param_key([w]) is None
     assert ops.csr_cache.get(ei, None, 30) is ops.csr_cache.get(ei, None, 30)      # keyed without a version, no raise
+
+
+@pytest.mark.parametrize("use_graph,use_weight,graph_weight,use_source,ln,residual,c",
+                         [(True, True, -1, False, True, True, 16), (True, False, -1, False, True, True, 16),
+                          (True, True, 0.3, True, True, True, 8), (False, True, -1, True, False, True, 12),
+                          (True, True, -1, True, True, False, 16), (True, False, 0.6, False, False, False, 8),
+                          (False, False, -1, False, True, True, 16)])
+def test_closed_form_layer_backward_matches_the_operator_path(use_graph, use_weight, graph_weight, use_source, ln, residual, c,
+                                                              fake_backend, monkeypatch):
+    """ag._ClosedFormLayer (training through the Gram record: difformer.py:18-39, :107-140 without q, k, v) against the
+    q / k / v operator path, whose gradients the golden fixtures of the reference pin: every input and parameter gradient
+    of one layer, every flag of DIFFormerConv."""
+    from conftest import grad_err
+    from difformer_amd import DIFFormerConv
+    from difformer_amd import difformer as dmod
+    torch.manual_seed(c + int(use_graph) + 2 * int(use_weight))
+    n = 70
+    conv = DIFFormerConv(c, c, 1, kernel="simple", use_graph=use_graph, use_weight=use_weight, graph_weight=graph_weight,
+                         use_source=use_source).train()
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, n, (2, 300), generator=g) if use_graph else None
+    R = torch.randn(n, c, generator=g)
+    base = dict(x=torch.randn(n, c, generator=g), x0=torch.randn(n, c, generator=g), lw=torch.rand(c, generator=g) + 0.5,
+                lb=torch.randn(c, generator=g))
+
+    def run(closed):
+        monkeypatch.setattr(dmod, "_CLOSED_FORM_TRAINING", closed)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        conv.zero_grad()
+        fake_backend.closed_form_calls = 0
+        x = leaves["x"]
+        out, _, _ = conv._layer(x, x, ei, None, leaves["x0"] if use_source else None, x if residual else None, 0.4,
+                                leaves["lw"] if ln else None, leaves["lb"] if ln else None, 1e-5)
+        (out * R).sum().backward()
+        assert (fake_backend.closed_form_calls > 0) == closed
+        grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+        grads.update({k: p.grad.clone() for k, p in conv.named_parameters() if p.grad is not None})
+        return out.detach(), grads
+
+    out_c, g_c = run(True)
+    out_o, g_o = run(False)
+    assert rel_err(out_c.numpy(), out_o.numpy()) < 1e-5
+    assert set(g_c) == set(g_o)
+    gmax = max(float(v.abs().max()) for v in g_o.values())
+    for k in g_o:
+        assert grad_err(g_c[k].numpy(), g_o[k].numpy(), gmax) < 1e-4, k
