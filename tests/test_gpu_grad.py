@@ -142,7 +142,8 @@ def _oracle_step(model, x, ei, cfg, y, idx, kind="nll", w=None):
     out = og.difformer_forward(p, x64, None if ei is None else ei.cpu(), w, cfg)
     loss = og.training_loss(out, y.cpu(), idx.cpu(), kind)
     loss.backward()
-    return out.detach().numpy(), float(loss.detach()), {k: v.grad.numpy() for k, v in p.items()}, x64.grad.numpy()
+    grads = {k: (None if v.grad is None else v.grad.numpy()) for k, v in p.items()}      # None: unused (LayerNorms of use_bn=False)
+    return out.detach().numpy(), float(loss.detach()), grads, x64.grad.numpy()
 
 
 def _check_step(model, x, ei, cfg, y, idx, launched=None, kind="nll"):
@@ -152,10 +153,13 @@ def _check_step(model, x, ei, cfg, y, idx, launched=None, kind="nll"):
     r_out, r_loss, r_grads, r_dx = _oracle_step(model, x, ei, cfg, y, idx, kind)
     assert rel_err(out.detach().cpu().numpy(), r_out) < TOL
     assert abs(float(loss.detach()) - r_loss) < TOL * abs(r_loss)
-    gmax = max(float(np.abs(v).max()) for v in r_grads.values())
+    gmax = max(float(np.abs(v).max()) for v in r_grads.values() if v is not None)
     if x.grad is not None:
         assert grad_err(x.grad.cpu().numpy(), r_dx, gmax) < TOL
     for k, prm in model.named_parameters():
+        if r_grads[k] is None:
+            assert prm.grad is None or not prm.grad.any(), k
+            continue
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
         assert grad_err(prm.grad.cpu().numpy(), r_grads[k], gmax) < TOL, k
 
@@ -189,6 +193,42 @@ def test_training_step_on_a_graph_that_takes_the_sliced_product(layers, heads, s
     finally:
         be.kernel_events = None
     assert "dif_sliced_spmm_f32" in launched, launched
+
+
+@pytest.mark.parametrize("hidden,use_graph,use_weight,graph_weight,use_source,use_bn,use_residual,deg",
+                         [(64, True, True, 0.3, True, True, True, 4), (64, True, False, -1, False, True, True, 60),
+                          (32, True, True, -1, True, False, False, 6), (48, False, True, -1, True, True, True, 0),
+                          (64, True, False, 0.7, True, False, True, 3), (16, False, False, -1, False, True, False, 0)])
+def test_training_step_through_the_record_every_flag(hidden, use_graph, use_weight, graph_weight, use_source, use_bn,
+                                                     use_residual, deg, dev):
+    """Layers that train through the Gram record (autograd_ops._ClosedFormLayer: one head, `simple`, up to 64 columns) with
+    every flag of DIFFormerConv / DIFFormer (difformer.py:107-140, :195-207), on sparse graphs (gather product) and on one
+    that takes the sliced product, against float64 autograd of the oracle; the record path is the one that ran."""
+    from difformer_amd import DIFFormer, ops
+    n = 9000 if deg >= 48 else 3001
+    g = torch.Generator().manual_seed(hidden + deg)
+    ei = None
+    if use_graph:
+        pairs = torch.randint(0, n, (2, n * deg // 2), generator=g)
+        ei = torch.cat([pairs, pairs.flip(0), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    torch.manual_seed(7)
+    kw = dict(num_layers=2, num_heads=1, kernel="simple", alpha=0.4, use_bn=use_bn, use_residual=use_residual,
+              use_weight=use_weight, use_graph=use_graph, graph_weight=graph_weight, use_source=use_source)
+    model = DIFFormer(20, hidden, 6, dropout=0.0, **kw).to(dev).train()
+    cfg = dict(hidden_channels=hidden, **kw)
+    x = torch.randn(n, 20, generator=g).to(dev).requires_grad_(True)
+    y = torch.randint(0, 6, (n,), generator=g).to(dev)
+    idx = torch.randperm(n, generator=g)[: n // 3].to(dev)
+    be = ops.get_backend()
+    be.kernel_events = {}
+    try:
+        _check_step(model, x, ei, cfg, y, idx)
+        launched = set(be.kernel_events)
+    finally:
+        be.kernel_events = None
+    assert "dif_gram_f32" in launched and "dif_simple_coeffs_f32" in launched and "dif_simple_apply_f32" not in launched, launched
+    if deg >= 48:
+        assert "dif_sliced_spmm_f32" in launched
 
 
 def test_training_step_at_cora_size(dev):
