@@ -309,6 +309,11 @@ def main():
         alg_bytes = 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * esz
         if ktimes.get("dif_sliced_spmm_f32"):
             dom, dom_name, dom_key = "dif_sliced_spmm_f32", "sliced_spmm_kernel (gcn_conv)", "sliced_spmm_kernel"
+        elif not ktimes.get("dif_gcn_spmm_f32") and ktimes.get("dif_simple_layer_f32"):
+            # a few entries per row: the closed-form layer kernel aggregates itself (dif_simple_layer_gather_*): the CSR, the
+            # layer input once and the output once are its algorithmic bytes (the gathered rows are re-reads of the input)
+            dom, dom_key = "dif_simple_layer_f32", "simple_layer_kernel"
+            dom_name = "simple_layer_kernel<GATHER> (closed-form layer with gcn_conv's aggregation inside)"
         else:
             dom, dom_name, dom_key = "dif_gcn_spmm_f32", "spmm_blocked_kernel (gcn_conv)", "spmm_blocked_kernel"
     elif kernel == "simple" and ktimes.get("dif_gram_sym_f32"):
