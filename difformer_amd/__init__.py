@@ -11,8 +11,8 @@ call does, and fails loudly if it has not been built.
 from .difformer import DIFFormer, DIFFormerConv, full_attention_conv, gcn_conv  # noqa: F401
 from .difformer_v2 import DIFFormer_v2, TransConv  # noqa: F401
 from .dist import RowShard  # noqa: F401
-from .graphs import GraphedForward  # noqa: F401
+from .graphs import GraphedForward, GraphedTrainStep, graphed_training  # noqa: F401
 
 __all__ = ["DIFFormer", "DIFFormerConv", "full_attention_conv", "gcn_conv", "DIFFormer_v2", "TransConv", "RowShard",
-           "GraphedForward"]
+           "GraphedForward", "GraphedTrainStep", "graphed_training"]
 __version__ = "0.1.0"

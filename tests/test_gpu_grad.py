@@ -340,3 +340,74 @@ def test_v2_sigmoid_attention_backward_kernel_vs_oracle(n_graphs, max_n, h, d, d
     # reference's own expression is off by exactly as much (measured 1.97e-6 against this kernel's 1.59e-6)
     for got, want, name in ((qd, q64, "dq"), (kd, k64, "dk"), (vd, v64, "dv")):
         assert grad_err(got.grad.cpu().numpy(), want.grad.numpy(), gmax, floor=1e-2) < TOL, name
+
+
+@pytest.mark.parametrize("kernel,hidden", [("simple", 64), ("sigmoid", 32)])
+def test_graphed_training_replays_forward_and_backward(kernel, hidden, dev):
+    """difformer_amd.graphed_training: the training forward and its backward of main.py:117-131 as two hipGraphs -- three
+    optimiser steps give the losses, outputs and parameters of the kernel-by-kernel run; eval calls keep the plain forward."""
+    import copy
+    import difformer_amd
+    from difformer_amd import DIFFormer
+    n, f_in, classes = 2708, 96, 7
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, f_in, generator=g).to(dev)
+    pairs = torch.randint(0, n, (2, 5278), generator=g)
+    ei = torch.cat([pairs, pairs.flip(0), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    y = torch.randint(0, classes, (n,), generator=g).to(dev)
+    idx = torch.randperm(n, generator=g)[:300].to(dev)
+    torch.manual_seed(11)
+    eager = DIFFormer(f_in, hidden, classes, num_layers=2, kernel=kernel, dropout=0.0).to(dev).train()
+    twin = copy.deepcopy(eager)
+    graphed = difformer_amd.graphed_training(twin, x, ei)
+    assert graphed.training
+    opts = [torch.optim.SGD(m.parameters(), lr=0.05) for m in (eager, graphed)]
+    for step in range(3):
+        losses = []
+        for m, opt in zip((eager, graphed), opts):
+            opt.zero_grad(set_to_none=True)
+            out = m(x, ei)
+            loss = F.nll_loss(F.log_softmax(out, dim=1)[idx], y[idx])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        assert abs(losses[0] - losses[1]) < 1e-5 * abs(losses[0]), (step, losses)
+    for (k, a), (_, b) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert rel_err(b.detach().cpu().numpy(), a.detach().cpu().numpy()) < 1e-5, k
+    eager.eval()
+    graphed.eval()
+    with torch.no_grad():
+        assert rel_err(graphed(x, ei).cpu().numpy(), eager(x, ei).cpu().numpy()) < 1e-5
+
+
+def test_whole_training_step_as_one_graph(dev):
+    """difformer_amd.GraphedTrainStep: forward, loss, backward and Adam of main.py:117-131 in ONE hipGraph; the warm-up
+    steps and three replays end on the parameters of the same number of kernel-by-kernel steps."""
+    import copy
+    import difformer_amd
+    from difformer_amd import DIFFormer
+    n, f_in, classes = 2708, 64, 7
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, f_in, generator=g).to(dev)
+    pairs = torch.randint(0, n, (2, 5278), generator=g)
+    ei = torch.cat([pairs, pairs.flip(0), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    y = torch.randint(0, classes, (n,), generator=g).to(dev)
+    idx = torch.randperm(n, generator=g)[:300].to(dev)
+    loss_fn = lambda out: F.nll_loss(F.log_softmax(out, dim=1)[idx], y[idx])
+    torch.manual_seed(12)
+    eager = DIFFormer(f_in, 64, classes, num_layers=2, kernel="simple", dropout=0.0).to(dev).train()
+    twin = copy.deepcopy(eager)
+    opt_e = torch.optim.Adam(eager.parameters(), lr=1e-3)
+    opt_g = torch.optim.Adam(twin.parameters(), lr=1e-3, capturable=True)
+    step = difformer_amd.GraphedTrainStep(twin, opt_g, loss_fn, x, ei, warmup=3)      # 3 warm-up steps run; the capture does not
+    losses_g = [float(step()) for _ in range(3)]
+    losses_e = []
+    for _ in range(3 + 3):
+        opt_e.zero_grad(set_to_none=True)
+        loss = loss_fn(eager(x, ei))
+        loss.backward()
+        opt_e.step()
+        losses_e.append(float(loss.detach()))
+    assert max(abs(a - b) / abs(b) for a, b in zip(losses_g, losses_e[-3:])) < 1e-4, (losses_g, losses_e)
+    for (k, a), (_, b) in zip(eager.named_parameters(), twin.named_parameters()):
+        assert rel_err(b.detach().cpu().numpy(), a.detach().cpu().numpy()) < 1e-3, k
