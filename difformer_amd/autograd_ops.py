@@ -277,6 +277,8 @@ class _ClosedFormLayer(torch.autograd.Function):
         ctx.save_for_backward(x, Wq, bq, Wk, bk, Wv, bv, x0, ln_w, ln_b, keep["record"], keep["coef"], keep["ax"],
                               keep["row_sums"])
         ctx.csr, ctx.scales, ctx.tail = csr, (float(attn_scale), float(gcn_scale)), (bool(residual), float(alpha), float(eps))
+        # the adjoint CSR is built from the edge list on first use (in backward): keep the caller's tensors alive until then
+        ctx.edges = csr.hold_edges() if (csr is not None and csr._adjoint is None) else None
         return out
 
     @staticmethod

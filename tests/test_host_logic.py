@@ -528,3 +528,17 @@ def test_closed_form_layer_backward_matches_the_operator_path(use_graph, use_wei
     gmax = max(float(v.abs().max()) for v in g_o.values())
     for k in g_o:
         assert grad_err(g_c[k].numpy(), g_o[k].numpy(), gmax) < 1e-4, k
+
+
+def test_closed_form_training_keeps_a_temporary_edge_index_alive(fake_backend):
+    """`model(x, ei.to(dev))`: the edge tensor is a temporary that dies with the call, while the adjoint CSR of the backward
+    pass is built from it on first use -- the autograd node of the record path holds it (as the aggregation's node does)."""
+    import gc
+    from difformer_amd import DIFFormer
+    torch.manual_seed(0)
+    model = DIFFormer(6, 8, 3, num_layers=2, kernel="simple", dropout=0.0).train()
+    x = torch.randn(40, 6)
+    out = model(x, torch.randint(0, 40, (2, 150)).clone())
+    gc.collect()
+    out.sum().backward()
+    assert fake_backend.closed_form_calls > 0 and all(p.grad is not None for p in model.parameters())
