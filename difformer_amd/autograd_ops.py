@@ -310,9 +310,10 @@ class _ClosedFormLayer(torch.autograd.Function):
                 d_bv = g_s * _weighted_column_sum(be, d, rs)
             else:
                 d_ax = d
-            gx = ops.gcn_aggregate(csr.adjoint(), d_ax.reshape(n, 1, C), None, 1.0, g_s, None).reshape(n, C)
-            dx = gx if dx is None else dx.add_(gx)
-            del d_ax, gx
+            # g_s A^T d_ax, added to what dx already holds in the product's epilogue (its `attn` operand)
+            dx = ops.gcn_aggregate(csr.adjoint(), d_ax.reshape(n, 1, C), None if dx is None else dx.reshape(n, 1, C), 1.0, g_s,
+                                   None).reshape(n, C)
+            del d_ax
         # attention term
         MnT, cn = coef[: D * C].view(D, C), coef[D * C: D * C + D]
         u, cd = coef[D * C + D: D * C + D + C], coef[D * C + D + C]
