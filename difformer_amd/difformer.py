@@ -176,8 +176,8 @@ class DIFFormerConv(nn.Module):
         if not ag._needs_grad(x, *params):
             return True
         # training: the narrow float32 single-GPU closed form has a backward through the record (ag._ClosedFormLayer)
-        return (_CLOSED_FORM_TRAINING and not wide and x.dtype == torch.float32 and self.row_shard is None and
-                hasattr(ops.get_backend(), "simple_reduce"))
+        return (_CLOSED_FORM_TRAINING and not wide and x.dtype == torch.float32 and
+                (self.row_shard is None or self.row_shard.world <= 1) and hasattr(ops.get_backend(), "simple_reduce"))
 
     def _layer(self, query_input, source_input, edge_index, edge_weight, x0=None, prev=None, alpha=0.5,
                ln_weight=None, ln_bias=None, eps=1e-5, want_qk=False, carry=None):
