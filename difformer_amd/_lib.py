@@ -80,7 +80,8 @@ SIGNATURES = {
     "dif_simple_coeffs_len": (c_sz, [c_int, c_int]),
     "dif_simple_coeffs_f32": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp]),
     "dif_closed_form_attn_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
-                                             c_i64, c_vp]),
+                                             c_i64, c_vp, c_vp, c_vp]),
+    "dif_closed_form_attn_bwd_groups": (c_int, [c_i64]),
     "dif_simple_coeffs_bwd_len": (c_sz, [c_int, c_int]),
     "dif_simple_coeffs_bwd_f32": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp,
                                           c_vp]),

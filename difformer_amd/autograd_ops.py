@@ -301,13 +301,14 @@ class _ClosedFormLayer(torch.autograd.Function):
         del conv
         # graph term
         d_Wv = d_bv = None
+        need_rs_d = False
         if csr is not None:
             if Wv is not None:
                 d_ax = d @ Wv
                 d3 = d.view(n, 1, D)
                 red = be.simple_reduce(d3, d3, ax.view(n, 1, C))                    # K^T V with K = d, V = ax
                 d_Wv = red[: D * C].view(D, C).clone()
-                d_bv = g_s * _weighted_column_sum(be, d, rs)
+                need_rs_d = True                      # d_bv of this branch = g_s rs^T d: from the attention pass below
             else:
                 d_ax = d
             # g_s A^T d_ax, added to what dx already holds in the product's epilogue (its `attn` operand)
@@ -317,10 +318,16 @@ class _ClosedFormLayer(torch.autograd.Function):
         # attention term
         MnT, cn = coef[: D * C].view(D, C), coef[D * C: D * C + D]
         u, cd = coef[D * C + D: D * C + D + C], coef[D * C + D + C]
-        got = be.closed_form_attn_backward(x, coef, D, d, dx) if hasattr(be, "closed_form_attn_backward") else None
-        if got is not None:
-            d_num, d_den, dx = got                                                  # one pass (csrc/simple_layer.hip)
+        got = (be.closed_form_attn_backward(x, coef, D, d, dx, rs if need_rs_d else None)
+               if hasattr(be, "closed_form_attn_backward") else None)
+        d_u = d_cd = None
+        if got is not None:                           # one pass (csrc/simple_layer.hip): also x^T d_den, sum d_den, rs^T d
+            d_num, d_den, dx, d_u, d_cd, rs_d = got
+            if need_rs_d:
+                d_bv = g_s * rs_d
         else:
+            if need_rs_d:
+                d_bv = g_s * _weighted_column_sum(be, d, rs)
             att = be.simple_layer(x, coef, D)                                       # (x Mn + cn) / (x u + cd)
             den = torch.mul(x, u).sum(dim=1).add_(cd)
             d_num = d / den[:, None]
@@ -331,8 +338,11 @@ class _ClosedFormLayer(torch.autograd.Function):
         dn3 = d_num.view(n, 1, D)
         red = be.simple_reduce(dn3, dn3, x.view(n, 1, C))                           # K^T V = d_num^T x, sum K = sum d_num
         # red = [d_num^T x: D x C][sum d_num: D][...]: with d u and d cd written behind them it IS the gradient of coef
-        red[D * C + D: D * C + D + C] = _weighted_column_sum(be, x, d_den)
-        torch.sum(d_den, dim=0, out=red[D * C + D + C])
+        red[D * C + D: D * C + D + C] = d_u if d_u is not None else _weighted_column_sum(be, x, d_den)
+        if d_cd is not None:
+            red[D * C + D + C] = d_cd
+        else:
+            torch.sum(d_den, dim=0, out=red[D * C + D + C])
         if hasattr(be, "simple_coeffs_backward"):
             S, t, d_Wq, d_bq, d_Wk, d_bk, d_Wv_a, d_bv_a = be.simple_coeffs_backward(record, n, C, D, Wq, bq, Wk, bk, Wv, bv,
                                                                                      a_s, coef, red)

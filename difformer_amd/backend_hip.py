@@ -680,10 +680,11 @@ class HipBackend:
         _lib.check(rc, "dif_simple_coeffs_f32")
         return coef
 
-    def closed_form_attn_backward(self, x, coef, D, d, dx_in=None):
+    def closed_form_attn_backward(self, x, coef, D, d, dx_in=None, row_sums=None):
         """Backward of att = (x Mn + cn) / (x u + cd) in one pass (csrc/simple_layer.hip, closed_form_attn_bwd_kernel):
-        -> (d_num [n, D], d_den [n], dx [n, C] = dx_in + d_num Mn^T + d_den u^T), or None when the shape is not covered."""
-        dev = _require_device(x, coef, d, dx_in)
+        -> (d_num [n, D], d_den [n], dx [n, C] = dx_in + d_num Mn^T + d_den u^T, d_u [C] = x^T d_den, d_cd [] = sum d_den,
+        rs_d [D] = row_sums^T d or None), or None when the shape is not covered."""
+        dev = _require_device(x, coef, d, dx_in, row_sums)
         n, C = x.shape
         if C % 4 or D % 4 or C > 64 or D > 64 or any(t_ is not None and t_.dtype != torch.float32 for t_ in (x, coef, d, dx_in)):
             return None
@@ -697,11 +698,16 @@ class HipBackend:
         d_num = torch.empty((n, D), dtype=torch.float32, device=dev)
         d_den = torch.empty((n,), dtype=torch.float32, device=dev)
         dx = torch.empty((n, C), dtype=torch.float32, device=dev)
+        if row_sums is not None:
+            row_sums = _f32(row_sums, "row_sums").contiguous()
+        parts = torch.empty((self.lib.dif_closed_form_attn_bwd_groups(n), 132), dtype=torch.float32, device=dev)
         with _timed(self, "dif_simple_layer_f32", dev):
             rc = self.lib.dif_closed_form_attn_bwd_f32(_ptr(x), ldx, n, C, D, _ptr(coef), _ptr(d), ldd, _ptr(dx_in), ldi,
-                                                       _ptr(d_num), _ptr(d_den), _ptr(dx), C, _stream(dev))
+                                                       _ptr(d_num), _ptr(d_den), _ptr(dx), C, _ptr(row_sums), _ptr(parts),
+                                                       _stream(dev))
         _lib.check(rc, "dif_closed_form_attn_bwd_f32")
-        return d_num, d_den, dx
+        sums = parts.sum(dim=0)                      # one partial record per workgroup, added in a fixed order
+        return d_num, d_den, dx, sums[:C], sums[128], (sums[64: 64 + D] if row_sums is not None else None)
 
     def simple_coeffs_backward(self, record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale, coef, dcoef):
         """Backward of simple_coeffs in one launch (csrc/simple_coeffs_bwd.hip): dcoef in coef's layout ->

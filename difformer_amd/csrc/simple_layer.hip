@@ -932,10 +932,18 @@ struct AttnBwdArgs {
     const float* dx_in; int64_t ldi;
     float* d_num; float* d_den; float* dx; int64_t ldo;
     int64_t n_rows; int C, D;
+    const float* rs;            // SUMS: row sums of the adjacency (nullable)
+    float* sums;                // SUMS: [workgroups][kAttnBwdSums] partial column sums
 };
+constexpr int kAttnBwdSums = 132;       // [sum_r d_den[r] x[r, :]: 64][sum_r rs[r] d[r, :]: 64][sum_r d_den[r]][pad: 3]
 
-template <bool EXACT>
-__global__ __launch_bounds__(64 * kWaves, 4) void closed_form_attn_bwd_kernel(AttnBwdArgs a) {
+// SUMS: the three row-contracted sums the backward needs besides the streaming reduce (d u = x^T d_den, d cd = sum d_den,
+// and the bias gradient of the graph branch, rs^T d) are folded over the rows this workgroup sees -- per-lane accumulators,
+// one butterfly over the 16 rows of the lane groups at the end, the waves' sums through LDS -- and left as one partial
+// record per workgroup (summed by the caller): two streaming reduces + two finalize launches fewer per layer.
+template <bool EXACT, bool SUMS>
+__global__ __launch_bounds__(64 * kWaves, SUMS ? 3 : 4) void closed_form_attn_bwd_kernel(AttnBwdArgs a) {
+    __shared__ float sm_part[SUMS ? kWaves : 1][SUMS ? kAttnBwdSums : 1];
     __shared__ __attribute__((aligned(16))) float sm_w[2][kWBlock];   // MnT as W[f][c], and its transpose W'[c][f]
     __shared__ __attribute__((aligned(16))) float sm_cn[64], sm_u[64];
     __shared__ float sm_cd;
@@ -959,6 +967,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void closed_form_attn_bwd_kernel(At
     const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * kWaves + wave, stride = static_cast<int64_t>(gridDim.x) * kWaves;
 
+    f32x4 au[4], ab[4];
+    float acd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) au[i] = ab[i] = zero4();
     auto body = [&](int64_t tile, auto guard_tag) {
         constexpr bool G = decltype(guard_tag)::value;
         const int64_t row = tile * 16 + l15;
@@ -966,6 +978,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void closed_form_attn_bwd_kernel(At
         f32x4 xa[4], dn[4];
         load_rows<G>(xa, a.x, a.ldx, row, a.n_rows, lg, C);
         load_rows<G>(dn, a.d, a.ldd, row, a.n_rows, lg, D);
+        if (SUMS && a.rs) {
+            const float rsv = row_ok ? a.rs[row] : 0.f;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) ab[ft] += dn[ft] * rsv;
+        }
         float den = 0.f;
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
@@ -991,6 +1008,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void closed_form_attn_bwd_kernel(At
         dd += __shfl_xor(dd, 32, 64);
         dd *= -rden;                                                               // -<d_num, att>
         if (row_ok && lg == 0) a.d_den[row] = dd;
+        if (SUMS) {                                   // rows past the end contribute zeros (their d and x were loaded as 0)
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) au[cq] += xa[cq] * dd;
+            acd += (lg == 0) ? dd : 0.f;
+        }
         f32x4 z[4];
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
@@ -1017,14 +1039,53 @@ __global__ __launch_bounds__(64 * kWaves, 4) void closed_form_attn_bwd_kernel(At
         asm volatile("" ::: "memory");
         body(tile, std::true_type{});
     }
+    if constexpr (SUMS) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {            // over the 16 rows of a lane group (lanes with the same lg)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    au[i][t] += __shfl_xor(au[i][t], m, 64);
+                    ab[i][t] += __shfl_xor(ab[i][t], m, 64);
+                }
+            acd += __shfl_xor(acd, m, 64);
+        }
+        if (l15 == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    sm_part[wave][16 * i + 4 * lg + t] = au[i][t];
+                    sm_part[wave][64 + 16 * i + 4 * lg + t] = ab[i][t];
+                }
+            if (lg == 0) sm_part[wave][128] = acd;
+        }
+        __syncthreads();
+        if (threadIdx.x < kAttnBwdSums) {
+            float v = 0.f;
+            if (threadIdx.x <= 128) {
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) v += sm_part[w][threadIdx.x];
+            }
+            a.sums[static_cast<int64_t>(blockIdx.x) * kAttnBwdSums + threadIdx.x] = v;
+        }
+    }
 }
 }  // namespace
 
+extern "C" int dif_closed_form_attn_bwd_groups(int64_t n_rows) {       // partial records dif_closed_form_attn_bwd_f32 leaves in `sums`
+    return n_rows > 0 ? row_chunks(n_rows, 3) : 0;
+}
+
 // d [n, D] = gradient with respect to the attention term; dx_in (nullable) [n, C] = what dx already holds.
 // -> d_num [n, D] (dense), d_den [n], dx [n, C] = dx_in + d_num Mn^T + d_den u^T.  C, D multiples of 4, <= 64; 16-byte rows.
+// sums (nullable) [dif_closed_form_attn_bwd_groups(n)][132]: per-workgroup partial sums [x^T d_den: 64][row_sums^T d: 64][sum d_den]
+// (row_sums nullable: that block stays zero); the caller adds the records up.
 extern "C" int dif_closed_form_attn_bwd_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
                                             const float* d, int64_t ldd, const float* dx_in, int64_t ldi, float* d_num,
-                                            float* d_den, float* dx, int64_t ldo, dif_stream_t stream) {
+                                            float* d_den, float* dx, int64_t ldo, const float* row_sums, float* sums,
+                                            dif_stream_t stream) {
     DIF_REQUIRE(x && coef && d && d_num && d_den && dx && n_rows > 0, DIF_E_BADARG, "dif_closed_form_attn_bwd: null pointer or no rows");
     DIF_REQUIRE(C > 0 && C <= 64 && D > 0 && D <= 64 && C % 4 == 0 && D % 4 == 0, DIF_E_SHAPE,
                 "dif_closed_form_attn_bwd: covers C, D <= 64, multiples of 4 (got %d, %d)", C, D);
@@ -1032,11 +1093,18 @@ extern "C" int dif_closed_form_attn_bwd_f32(const float* x, int64_t ldx, int64_t
                 (!dx_in || ldi % 4 == 0), DIF_E_BADARG, "dif_closed_form_attn_bwd: leading dimensions must cover a row and be multiples of 4");
     DIF_REQUIRE(dif::aligned16(x) && dif::aligned16(d) && dif::aligned16(d_num) && dif::aligned16(dx) && (!dx_in || dif::aligned16(dx_in)),
                 DIF_E_BADARG, "dif_closed_form_attn_bwd: rows must be 16-byte aligned");
-    AttnBwdArgs a = {x, ldx, coef, d, ldd, dx_in, ldi, d_num, d_den, dx, ldo, n_rows, C, D};
-    const int P = row_chunks(n_rows, 4);
+    DIF_REQUIRE(sums || !row_sums, DIF_E_BADARG, "dif_closed_form_attn_bwd: row_sums without sums");
+    AttnBwdArgs a = {x, ldx, coef, d, ldd, dx_in, ldi, d_num, d_den, dx, ldo, n_rows, C, D, row_sums, sums};
+    const int P = row_chunks(n_rows, sums ? 3 : 4);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (C == 64 && D == 64) hipLaunchKernelGGL(closed_form_attn_bwd_kernel<true>, dim3(P), dim3(64 * kWaves), 0, st, a);
-    else hipLaunchKernelGGL(closed_form_attn_bwd_kernel<false>, dim3(P), dim3(64 * kWaves), 0, st, a);
+    const bool exact = C == 64 && D == 64;
+    if (sums) {
+        if (exact) hipLaunchKernelGGL((closed_form_attn_bwd_kernel<true, true>), dim3(P), dim3(64 * kWaves), 0, st, a);
+        else hipLaunchKernelGGL((closed_form_attn_bwd_kernel<false, true>), dim3(P), dim3(64 * kWaves), 0, st, a);
+    } else {
+        if (exact) hipLaunchKernelGGL((closed_form_attn_bwd_kernel<true, false>), dim3(P), dim3(64 * kWaves), 0, st, a);
+        else hipLaunchKernelGGL((closed_form_attn_bwd_kernel<false, false>), dim3(P), dim3(64 * kWaves), 0, st, a);
+    }
     return dif::launch_status("closed_form_attn_bwd_kernel");
 }
 

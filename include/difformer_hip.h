@@ -563,7 +563,11 @@ int dif_simple_coeffs_bwd_f32(const float* record, int64_t n_global, int C, int 
    C, D <= 64 and multiples of 4, rows 16-byte aligned (DIF_E_SHAPE / DIF_E_BADARG otherwise). */
 int dif_closed_form_attn_bwd_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const float* d,
                                  int64_t ldd, const float* dx_in, int64_t ldi, float* d_num, float* d_den, float* dx,
-                                 int64_t ldo, dif_stream_t stream);
+                                 int64_t ldo, const float* row_sums, float* sums, dif_stream_t stream);
+/* sums (nullable): dif_closed_form_attn_bwd_groups(n_rows) records of 132 floats, one per workgroup, to be added up by the
+   caller: [x^T d_den: 64][row_sums^T d: 64][sum d_den][3 unused] -- the gradients of u and cd and, with row_sums [n]
+   (nullable) = the row sums of the adjacency, the bias gradient of the weighted graph branch (difformer.py:118, :130-134). */
+int dif_closed_form_attn_bwd_groups(int64_t n_rows);
 /* The closed-form layer with the AGGREGATION in the same pass, for graphs with a few entries per row on one GPU (replaces
    the dif_gcn_spmm_* launch + dif_simple_layer_*; reference: gcn_conv difformer.py:59-73 folded into DIFFormerConv.forward
    difformer.py:107-130): rowptr int32 [n_rows + 1] / src int32 / val float32 = dif_csr_build's CSR with n_blocks = 1 over the

@@ -446,7 +446,9 @@ def test_closed_form_attention_backward_kernel(n, c, d, with_dx, dev):
     coef[d * c + d + c] = 25.0                                       # cd: keeps the denominator away from zero
     dd = torch.randn(n, d, generator=g)
     dx0 = torch.randn(n, c, generator=g) if with_dx else None
-    d_num, d_den, dx = be.closed_form_attn_backward(x.to(dev), coef.to(dev), d, dd.to(dev), None if dx0 is None else dx0.to(dev))
+    rs = torch.rand(n, generator=g) + 0.5
+    d_num, d_den, dx, d_u, d_cd, rs_d = be.closed_form_attn_backward(x.to(dev), coef.to(dev), d, dd.to(dev),
+                                                                     None if dx0 is None else dx0.to(dev), rs.to(dev))
     x64 = x.double().requires_grad_(True)
     cf = coef.double()
     MnT, cn, u, cd = cf[: d * c].view(d, c), cf[d * c: d * c + d], cf[d * c + d: d * c + d + c], cf[d * c + d + c]
@@ -456,6 +458,7 @@ def test_closed_form_attention_backward_kernel(n, c, d, with_dx, dev):
         gx = gx + dx0.double()
     rn = dd.double() / den.detach()[:, None]
     rd = -(rn * (num / den[:, None]).detach()).sum(1)
-    for name, a, b in (("d_num", d_num, rn), ("d_den", d_den, rd), ("dx", dx, gx)):
+    sums = (("d_u", d_u, x.double().t() @ rd), ("d_cd", d_cd.reshape(1), rd.sum().reshape(1)), ("rs_d", rs_d, dd.double().t() @ rs.double()))
+    for name, a, b in (("d_num", d_num, rn), ("d_den", d_den, rd), ("dx", dx, gx)) + sums:
         b = b.numpy()
         assert grad_err(a.cpu().numpy(), b, float(np.abs(b).max())) < 1e-5, name
