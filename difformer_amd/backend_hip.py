@@ -145,6 +145,7 @@ class HipBackend:
         # bench.py sets this to a dict to collect (start, end) HIP events per entry point
         self.kernel_events = None
         self.kernel_events_only = None
+        self._ones = {}                             # device -> float32 [1] = 1.0 (device-side beta of dif_rowgemm_f32)
 
     def kernel_times_ms(self):
         """{entry point: [ms per call]} from the collected events (synchronises)."""
@@ -679,6 +680,31 @@ class HipBackend:
                                                 _ptr(coef), _stream(dev))
         _lib.check(rc, "dif_simple_coeffs_f32")
         return coef
+
+    def row_gemm(self, A, mat, bias=None, accumulate=None):
+        """A [n, K] @ mat [K, C] (+ bias [C]) (+ accumulate [n, C]) in one pass over the rows (dif_rowgemm_f32; K, C <= 64,
+        float32) -> [n, C], or None when the shape is not covered (the caller then uses the vendor GEMM)."""
+        dev = _require_device(A, mat, bias, accumulate)
+        n, K = A.shape
+        C = mat.shape[1]
+        if K > 64 or C > 64 or any(t_ is not None and t_.dtype != torch.float32 for t_ in (A, mat, bias, accumulate)):
+            return None
+        A, lda = _row_major(A, K)
+        mat = mat.contiguous()
+        ldc = 0
+        one = None
+        if accumulate is not None:
+            accumulate, ldc = _row_major(accumulate, C)
+            one = self._ones.get(dev)
+            if one is None:
+                one = self._ones[dev] = torch.ones(1, dtype=torch.float32, device=dev)
+        out = torch.empty((n, C), dtype=torch.float32, device=dev)
+        with _timed(self, "dif_rowgemm_f32", dev):
+            rc = self.lib.dif_rowgemm_f32(_ptr(A), lda, _ptr(mat), C, 0, 0, 1.0, _ptr(None if bias is None else bias.contiguous()),
+                                          None, None, 1.0, _ptr(accumulate), ldc, _ptr(one), n, 1, K, C, _ptr(out), C,
+                                          _stream(dev))
+        _lib.check(rc, "dif_rowgemm_f32")
+        return out
 
     def closed_form_attn_backward(self, x, coef, D, d, dx_in=None, row_sums=None):
         """Backward of att = (x Mn + cn) / (x u + cd) in one pass (csrc/simple_layer.hip, closed_form_attn_bwd_kernel):
