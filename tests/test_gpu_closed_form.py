@@ -462,3 +462,26 @@ def test_closed_form_attention_backward_kernel(n, c, d, with_dx, dev):
     for name, a, b in (("d_num", d_num, rn), ("d_den", d_den, rd), ("dx", dx, gx)) + sums:
         b = b.numpy()
         assert grad_err(a.cpu().numpy(), b, float(np.abs(b).max())) < 1e-5, name
+
+
+def test_closed_form_attention_backward_without_the_partial_sums(dev):
+    """dif_closed_form_attn_bwd_f32 with sums = NULL (the lean variant): the same d_num, d_den, dx as with the sums."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    n, c, d = 4099, 64, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, c, generator=g).to(dev)
+    coef = (torch.randn(d * c + d + c + 4, generator=g) * 0.2).to(dev)
+    coef[d * c + d + c] = 25.0
+    dd = torch.randn(n, d, generator=g).to(dev)
+    d_num, d_den, dx, _, _, _ = be.closed_form_attn_backward(x, coef, d, dd)
+    o_num, o_den, o_dx = torch.empty_like(d_num), torch.empty_like(d_den), torch.empty_like(dx)
+    rc = be.lib.dif_closed_form_attn_bwd_f32(x.data_ptr(), c, n, c, d, coef.data_ptr(), dd.data_ptr(), d, None, 0, o_num.data_ptr(),
+                                             o_den.data_ptr(), o_dx.data_ptr(), c, None, None, torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o_num, d_num) and torch.equal(o_den, d_den) and torch.equal(o_dx, dx)
+    rs = torch.ones(n, device=dev)
+    assert be.lib.dif_closed_form_attn_bwd_f32(x.data_ptr(), c, n, c, d, coef.data_ptr(), dd.data_ptr(), d, None, 0, o_num.data_ptr(),
+                                               o_den.data_ptr(), o_dx.data_ptr(), c, rs.data_ptr(), None,
+                                               torch.cuda.current_stream(dev).cuda_stream) != 0        # row_sums without sums
