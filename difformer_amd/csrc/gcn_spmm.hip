@@ -198,6 +198,7 @@ __device__ __forceinline__ typename Vec<W>::T apply_tail(typename Vec<W>::T o, c
 }
 
 constexpr int kGatherUnroll = 8;
+constexpr int kLongRow = 64;          // entries; longer rows of a low-degree graph are taken by a whole block (spmm_group_row_kernel)
 
 // Element offset of source row `s`: 32-bit arithmetic (one v_mul_lo_u32) when the whole matrix spans < 2^31 elements
 // -- the 64-bit form costs five extra VALU instructions per gather.
@@ -274,31 +275,74 @@ __global__ __launch_bounds__(256) void spmm_group_row_kernel(
     const int col = blockIdx.y * (G * W) + li * W;
     const bool active = col < F;
     const E* xcol = x + col;
-    const int64_t nrb = (n_rows + RPB - 1) / RPB;
-    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
-        const int64_t row = rb * RPB + threadIdx.x / G;
-        const bool rok = row < n_rows;
-        const int64_t r = row_begin + (rok ? row : 0);
-        const int32_t e0 = rok ? rowptr[r] : 0, e1 = rok ? rowptr[r + 1] : 0;
-        V acc = vzero<W>();
-        for (int32_t e = e0; e < e1; e += 4) {
+    // LONG ROWS.  A lane group walks its row four entries at a time; a hub row (citation and social graphs have rows of
+    // hundreds to thousands of entries among rows of three) would hold its group -- and with it the kernel -- for ~0.3 us per
+    // entry (a 4,100-entry row: 1.2 ms at 100,000 rows, scripts/exp_layer_gather.py hubs).  Rows longer than kLongRow entries
+    // are therefore left out of the walk and noted in LDS; when the block has finished its ordinary rows, ALL its lane groups
+    // take the noted rows together, striding through a row four entries each, and group 0 adds their partial rows in group
+    // order (deterministic) and finishes the row.  The ordinary rows pay one LDS counter and one barrier per block.
+    constexpr int NG = RPB;              // lane groups per block
+    constexpr int kNoted = 64;           // long rows a block can defer (further ones are walked in place)
+    __shared__ int64_t s_row[kNoted];
+    __shared__ int s_count;
+    __shared__ V s_part[256];
+    const int grp = threadIdx.x / G;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    auto walk = [&](int32_t a0, int32_t a1, int32_t step) {
+        V sum = vzero<W>();
+        for (int32_t e = a0; e < a1; e += step) {
             V xv[4];
             float w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool ok = e + u < e1;
+                const bool ok = e + u < a1;
                 const int32_t s = ok ? src[e + u] : 0;
                 w[u] = ok ? val[e + u] : 0.f;
                 xv[u] = (ok && active) ? gload<W, E>(xcol + static_cast<int64_t>(s) * ldx) : vzero<W>();
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc += w[u] * xv[u];
+            for (int u = 0; u < 4; ++u) sum += w[u] * xv[u];
         }
-        const bool ok = active && rok;
+        return sum;
+    };
+    auto finish = [&](V acc, int64_t row, bool ok) {
         V o = gcn_scale * acc;
         if (ok && attn) o += attn_scale * gload<W, E>(attn + row * lda + col);
         if (tail.enabled) o = apply_tail<G, W, E>(o, tail, row, col, ok, F);
         if (ok) gstore<W, E>(out + row * ldo + col, o);
+    };
+    const int64_t nrb = (n_rows + RPB - 1) / RPB;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int64_t row = rb * RPB + grp;
+        const bool rok = row < n_rows;
+        const int64_t r = row_begin + (rok ? row : 0);
+        const int32_t e0 = rok ? rowptr[r] : 0, e1 = rok ? rowptr[r + 1] : 0;
+        if (e1 - e0 > kLongRow) {
+            int slot = 0;
+            if (li == 0) slot = atomicAdd(&s_count, 1);
+            slot = __shfl(slot, (threadIdx.x & 63) / G * G, 64);          // the group's first lane
+            if (slot < kNoted) {
+                if (li == 0) s_row[slot] = row;
+                continue;
+            }
+        }
+        finish(walk(e0, e1, 4), row, active && rok);
+    }
+    __syncthreads();
+    const int noted = s_count < kNoted ? s_count : kNoted;             // the same in every thread
+    for (int j = 0; j < noted; ++j) {
+        const int64_t row = s_row[j];
+        const int64_t r = row_begin + row;
+        s_part[threadIdx.x] = walk(rowptr[r] + 4 * grp, rowptr[r + 1], 4 * NG);
+        __syncthreads();
+        V sum = vzero<W>();
+        if (grp == 0) {
+            sum = s_part[li];
+            for (int q = 1; q < NG; ++q) sum += s_part[q * G + li];
+        }
+        if (threadIdx.x < 64) finish(sum, row, grp == 0 && active);      // the first wave: group 0 holds the row
+        __syncthreads();
     }
 }
 

@@ -49,6 +49,10 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
         rowptr, src, val = csr
         m, bs = int(perm.numel()), int(batch_size)
         ops.csr_cache.reserve(nb + ops.csr_cache.capacity)
+        # longest row of every batch from one reduction and one host read (the layer kernel's choice of path needs it)
+        deg = (rowptr[1:] - rowptr[:-1]).float()
+        sizes = torch.tensor([min((b + 1) * bs, m) - b * bs for b in range(nb)], device=deg.device)
+        longest = torch.segment_reduce(deg, "max", lengths=sizes).tolist() if m > 0 else [0] * nb
         for b, (eb, wb) in enumerate(out):
             lo, hi = b * bs, min((b + 1) * bs, m)
             if ops.csr_cache.blocking(eb, wb, hi - lo) != (1, 0):
@@ -58,6 +62,7 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
             g = ops.GraphCSR(rp, None, 1, src[e0: max(e1, e0 + 1)], val[e0: max(e1, e0 + 1)], hi - lo, e1 - e0)
             g.weighted = wb is not None
             g._edges = (weakref.ref(eb), None if wb is None else weakref.ref(wb))
+            g._max_degree = int(longest[b])
             ops.csr_cache.put(eb, wb, hi - lo, g)
     return out
 

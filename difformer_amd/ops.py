@@ -249,6 +249,7 @@ class GraphCSR:
         self.dinv = None            # adjoint CSR only: deg^-1/2 of the FORWARD graph (its own row lengths are out-degrees)
         self._sliced = {}           # (row_begin, n_rows, F) -> SlicedAdjacency | None
         self._row_sums = None
+        self._max_degree = None
 
     def row_order(self, row_begin, n_rows):
         """(order, n_split) for the blocked SpMM over a shard: its rows by descending degree, the first n_split of them
@@ -327,6 +328,15 @@ class GraphCSR:
                           self.num_nodes, None, 1.0, 1.0, None, self.row_order(0, self.num_nodes))
             self._row_sums = out[:, 0].contiguous()
         return self._row_sums
+
+    def max_degree(self):
+        """Longest row (entries), cached: one tiny device reduction and one host read per graph.  The closed-form layer kernel
+        that aggregates inside (dif_simple_layer_gather_*) walks the 16 rows of a tile in lock step to the longest of them,
+        so it is only taken for graphs without long rows (a citation graph's hub of a few hundred entries would hold its wave
+        for tens of microseconds; the SpMM kernels split such rows over lanes)."""
+        if self._max_degree is None:
+            self._max_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.num_nodes > 0 else 0
+        return self._max_degree
 
     def weight_leaf(self):
         """The edge_weight tensor this CSR was built from when the caller wants its gradient (difformer.py:73 is
@@ -766,7 +776,8 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
                  x.dtype == torch.float32)
     want_rec = want_next and carry.get("next_record", False)
     if (csr is not None and sl is None and not sharded and not want_rec and keep is None and LAYER_GATHER and csr.n_blocks == 1 and n == csr.num_nodes and
-            0 < csr.nnz <= LAYER_GATHER_MAX_DEGREE * n and hasattr(be, "_simple_layer_gather")):
+            0 < csr.nnz <= LAYER_GATHER_MAX_DEGREE * n and hasattr(be, "_simple_layer_gather") and
+            csr.max_degree() <= LAYER_GATHER_MAX_ROW):
         # a few entries per row: the layer kernel walks the CSR itself, no separate SpMM launch and no `ax` round trip
         gather = (csr.rowptr, csr.src, csr.val)
     elif csr is not None:
@@ -812,6 +823,9 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
 # average; above, the separate SpMM kernels (rows split over lanes, long rows over quads) balance the work better.
 LAYER_GATHER = os.environ.get("DIFFORMER_LAYER_GATHER", "1") != "0"
 LAYER_GATHER_MAX_DEGREE = int(os.environ.get("DIFFORMER_LAYER_GATHER_MAX_DEGREE", "12"))
+# ... and only without long rows: the 16 rows of a tile walk in lock step to the longest (GraphCSR.max_degree); from ~64
+# entries on the SpMM kernel, which hands long rows to a whole block, is faster (profiles/r03_experiments.md, 5b)
+LAYER_GATHER_MAX_ROW = int(os.environ.get("DIFFORMER_LAYER_GATHER_MAX_ROW", "64"))
 
 def closed_form_coeffs_backward(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale, d_MnT, d_cn, d_u, d_cd):
     """Backward of the coefficient stage (backend.simple_coeffs): gradients of a loss with respect to the Gram record and

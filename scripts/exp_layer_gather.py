@@ -57,5 +57,33 @@ def main():
                       f"   gather-in-layer {timed(one):6.1f} us   max diff {err:.2e}")
 
 
+def hubs():
+    """One long row among short ones: the lock-step walk of the layer kernel waits for it (LAYER_GATHER_MAX_ROW)."""
+    dev = torch.device("cuda:0")
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(1)
+    for n in (100000, 2708):
+        for hub in (0, 32, 64, 128, 512, 4096):
+            e = int(n * 2.3)
+            ei = torch.cat([torch.randint(0, n, (2, e), generator=g), torch.arange(n).repeat(2, 1),
+                            torch.stack([torch.randint(0, n, (hub,), generator=g), torch.full((hub,), 7)])], dim=1).to(dev)
+            csr = ops.csr_cache.get(ei, None, n, 64 * 4)
+            x = torch.randn(n, 64, generator=g).to(dev)
+            coef = torch.randn(64 * 64 + 64 + 64 + 4, generator=g).to(dev) * 0.1
+            Wv, bv = (torch.randn(64, 64, generator=g) * 0.1).to(dev), torch.randn(64, generator=g).to(dev)
+            lw, lb = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+            rs = csr.row_sums()
+
+            def two():
+                ax = be.spmm(csr.rowptr, csr.blkptr, csr.n_blocks, csr.src, csr.val, n, csr.nnz, x, 0, n, None, 1.0, 1.0, None, None)
+                return be.simple_layer(x, coef, 64, ax, Wv, bv, rs, 1.0, None, True, 0.5, lw, lb, 1e-5, False)
+
+            def one():
+                return be.simple_layer(x, coef, 64, None, Wv, bv, rs, 1.0, None, True, 0.5, lw, lb, 1e-5, False,
+                                       gather=(csr.rowptr, csr.src, csr.val))
+
+            print(f"n={n:6d} longest row {csr.max_degree():5d}: spmm+layer {timed(two):6.1f} us   gather-in-layer {timed(one):6.1f} us")
+
+
 if __name__ == "__main__":
-    main()
+    hubs() if len(sys.argv) > 1 and sys.argv[1] == "hubs" else main()

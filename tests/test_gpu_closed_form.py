@@ -485,3 +485,31 @@ def test_closed_form_attention_backward_without_the_partial_sums(dev):
     assert be.lib.dif_closed_form_attn_bwd_f32(x.data_ptr(), c, n, c, d, coef.data_ptr(), dd.data_ptr(), d, None, 0, o_num.data_ptr(),
                                                o_den.data_ptr(), o_dx.data_ptr(), c, rs.data_ptr(), None,
                                                torch.cuda.current_stream(dev).cuda_stream) != 0        # row_sums without sums
+
+
+def test_graphs_with_a_long_row_keep_the_spmm_kernels(dev):
+    """The layer kernel's own aggregation walks the rows of a tile in lock step, so a graph with a hub row (a citation
+    graph's few-hundred-entry node) stays on the SpMM kernels, which split long rows over lanes: same numbers either way."""
+    from difformer_amd import DIFFormerConv, ops
+    n, c = 5000, 64
+    g = torch.Generator().manual_seed(21)
+    ei = torch.cat([torch.randint(0, n, (2, 3 * n), generator=g), torch.arange(n).repeat(2, 1),
+                    torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 11)])], dim=1).to(dev)
+    conv = DIFFormerConv(c, c, 1, kernel="simple", use_graph=True).to(dev).eval()
+    x = torch.randn(n, c, generator=g).to(dev)
+    be = ops.get_backend()
+    be.kernel_events = {}
+    with torch.no_grad():
+        out, _, _ = conv._layer(x, x, ei, None, None, x, 0.5, None, None, 1e-5)
+    launched, be.kernel_events = set(be.kernel_events), None
+    assert ops.csr_cache.get(ei, None, n, c * 4).max_degree() >= 700 and "dif_gcn_spmm_f32" in launched
+    prev, ops.LAYER_GATHER_MAX_ROW = ops.LAYER_GATHER_MAX_ROW, 1 << 30
+    try:
+        be.kernel_events = {}
+        with torch.no_grad():
+            forced, _, _ = conv._layer(x, x, ei, None, None, x, 0.5, None, None, 1e-5)
+        launched, be.kernel_events = set(be.kernel_events), None
+    finally:
+        ops.LAYER_GATHER_MAX_ROW = prev
+    assert "dif_gcn_spmm_f32" not in launched
+    assert rel_err(forced.cpu().numpy(), out.cpu().numpy()) < 1e-5
