@@ -513,3 +513,32 @@ def test_graphs_with_a_long_row_keep_the_spmm_kernels(dev):
         ops.LAYER_GATHER_MAX_ROW = prev
     assert "dif_gcn_spmm_f32" not in launched
     assert rel_err(forced.cpu().numpy(), out.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_on_a_sparse_graph_with_zipf_in_degrees(dtype, dev):
+    """A citation-like graph: three entries per row on average, Zipf-distributed in-degrees (the longest rows have hundreds
+    to thousands of entries).  The closed-form layers keep the SpMM launch there and its kernel hands the long rows to whole
+    blocks (csrc/gcn_spmm.hip, spmm_group_row_kernel); the model against the float64 oracle."""
+    from difformer_amd import DIFFormer, ops
+    n, f_in, hidden, classes = 20000, 24, 64, 5
+    g = torch.Generator().manual_seed(31)
+    wgt = 1.0 / torch.arange(1, n + 1, dtype=torch.float64) ** 0.9
+    dst = torch.multinomial(wgt, 3 * n, replacement=True, generator=g)
+    src = torch.randint(0, n, (3 * n,), generator=g)
+    ei = torch.cat([torch.stack([src, dst]), torch.arange(n).repeat(2, 1)], dim=1)
+    torch.manual_seed(2)
+    model = DIFFormer(f_in, hidden, classes, num_layers=2, kernel="simple").to(dev).to(dtype).eval()
+    x = torch.randn(n, f_in, generator=g).to(dtype)
+    be = ops.get_backend()
+    be.kernel_events = {}
+    with torch.no_grad():
+        out = model(x.to(dev), ei.to(dev))
+    launched, be.kernel_events = set(be.kernel_events), None
+    csr = ops.csr_cache.get(ei.to(dev), None, n, hidden * x.element_size())
+    assert csr.max_degree() > 500 and "dif_gcn_spmm_f32" in launched
+    cfg = dict(hidden_channels=hidden, num_layers=2, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    p = {k: v.detach().float().cpu().double().numpy() for k, v in model.state_dict().items()}
+    ref = orc.difformer_forward(p, x.double().numpy(), ei.numpy(), None, cfg)
+    assert rel_err(out.float().cpu().numpy(), ref) < (TOL if dtype == torch.float32 else 2e-2)
