@@ -397,6 +397,11 @@ class DIFFormer(nn.Module):
             st[1] += 1
             if st[1] < 3:
                 return None
+            if edge_index is not None:
+                # the capture freezes which kernels run: settle the one choice that waits on a lazily read graph statistic
+                # (the longest row decides whether the closed-form layer aggregates itself) -- one host read, once per capture
+                for entry in ops.csr_cache.entries.values():
+                    entry[2].max_degree()
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):

@@ -49,10 +49,12 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
         rowptr, src, val = csr
         m, bs = int(perm.numel()), int(batch_size)
         ops.csr_cache.reserve(nb + ops.csr_cache.capacity)
-        # longest row of every batch from one reduction and one host read (the layer kernel's choice of path needs it)
-        deg = (rowptr[1:] - rowptr[:-1]).float()
-        sizes = torch.tensor([min((b + 1) * bs, m) - b * bs for b in range(nb)], device=deg.device)
-        longest = torch.segment_reduce(deg, "max", lengths=sizes).tolist() if m > 0 else [0] * nb
+        # longest row of every batch from one reduction and one copy that nobody waits for (the layer kernel's choice of path)
+        deg = rowptr[1:] - rowptr[:-1]
+        longest = None
+        if m > 0 and nb <= 4096:
+            per_batch = torch.nn.functional.pad(deg, (0, nb * bs - m)).view(nb, bs).max(dim=1).values
+            longest = ops.enqueue_host_reads(per_batch) if per_batch.is_cuda else per_batch.tolist()
         for b, (eb, wb) in enumerate(out):
             lo, hi = b * bs, min((b + 1) * bs, m)
             if ops.csr_cache.blocking(eb, wb, hi - lo) != (1, 0):
@@ -62,7 +64,11 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
             g = ops.GraphCSR(rp, None, 1, src[e0: max(e1, e0 + 1)], val[e0: max(e1, e0 + 1)], hi - lo, e1 - e0)
             g.weighted = wb is not None
             g._edges = (weakref.ref(eb), None if wb is None else weakref.ref(wb))
-            g._max_degree = int(longest[b])
+            if longest is not None:             # on the device: a read nobody waits for, picked up at the batch's first forward
+                if isinstance(longest[b], tuple):
+                    g._max_pending = longest[b]
+                else:
+                    g._max_degree = int(longest[b])
             ops.csr_cache.put(eb, wb, hi - lo, g)
     return out
 

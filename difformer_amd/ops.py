@@ -235,6 +235,32 @@ def split_positions(deg_sorted, order, cap, max_parts=SLICED_MAX_PARTS):
     return order2, parts, n_pos
 
 
+# Small device -> host reads that nobody waits for (GraphCSR.max_degree_if_known): one pinned ring for the process (a pinned
+# allocation per read costs ~0.1 ms), a slot per value, an event per copy.
+_PIN_SLOTS = 8192
+_PIN_RING = [None]
+_PIN_NEXT = [0]
+
+
+def enqueue_host_reads(values):
+    """values: int32-convertible device tensor [k] -> k pending reads (host slot view [1], event, ticket), copy enqueued on
+    the current stream."""
+    k = int(values.numel())
+    if _PIN_RING[0] is None:
+        _PIN_RING[0] = torch.empty(_PIN_SLOTS, dtype=torch.int32, pin_memory=True)
+    start = _PIN_NEXT[0] % _PIN_SLOTS
+    if start + k > _PIN_SLOTS:                          # keep the k slots contiguous
+        _PIN_NEXT[0] += _PIN_SLOTS - start
+        start = 0
+    ticket = _PIN_NEXT[0]
+    _PIN_NEXT[0] += k
+    ring = _PIN_RING[0]
+    ring[start: start + k].copy_(values.reshape(-1).to(torch.int32), non_blocking=True)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(values.device))
+    return [(ring[start + i: start + i + 1], done, ticket) for i in range(k)]
+
+
 class GraphCSR:
     """Normalised adjacency in CSR over destination rows (built once per graph, on device)."""
 
@@ -250,6 +276,8 @@ class GraphCSR:
         self._sliced = {}           # (row_begin, n_rows, F) -> SlicedAdjacency | None
         self._row_sums = None
         self._max_degree = None
+        self._max_pending = None     # (pinned host int32[1], event, ticket) of an enqueued max-degree read
+        self._asked = 0              # calls of max_degree_if_known before the read is enqueued
 
     def row_order(self, row_begin, n_rows):
         """(order, n_split) for the blocked SpMM over a shard: its rows by descending degree, the first n_split of them
@@ -336,6 +364,35 @@ class GraphCSR:
         for tens of microseconds; the SpMM kernels split such rows over lanes)."""
         if self._max_degree is None:
             self._max_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.num_nodes > 0 else 0
+        return self._max_degree
+
+    def max_degree_if_known(self):
+        """max_degree() without ever stalling the host: the first call on a new graph only ENQUEUES the reduction and a copy
+        into pinned memory and answers None (callers then take the path that is safe for any row length); a later call picks
+        the value up once it has arrived.  A host read right after the CSR build would drain the queue in front of the
+        forward -- measured at ~0.1 ms per mini-batch of a Pokec epoch, more than the faster path saves on a graph used once."""
+        if self._max_degree is not None:
+            return self._max_degree
+        if not self.rowptr.is_cuda:
+            return self.max_degree()
+        if self._max_pending is None:
+            if self.num_nodes <= 0:
+                self._max_degree = 0
+                return 0
+            # a graph used once (a mini-batch of main-batch.py) never asks: even the enqueue costs a handful of launches on a
+            # host-bound forward; a graph that keeps coming back (main.py's full-graph loops) asks on its twelfth layer call
+            self._asked += 1
+            if self._asked < 12:
+                return None
+            self._max_pending = enqueue_host_reads((self.rowptr[1:] - self.rowptr[:-1]).max().reshape(1))[0]
+            return None
+        host, done, ticket = self._max_pending
+        if _PIN_NEXT[0] - ticket >= _PIN_SLOTS:          # the ring went round before anybody looked: ask again
+            self._max_pending = None
+            return None
+        if not done.query():
+            return None
+        self._max_degree, self._max_pending = int(host[0]), None
         return self._max_degree
 
     def weight_leaf(self):
@@ -777,7 +834,7 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     want_rec = want_next and carry.get("next_record", False)
     if (csr is not None and sl is None and not sharded and not want_rec and keep is None and LAYER_GATHER and csr.n_blocks == 1 and n == csr.num_nodes and
             0 < csr.nnz <= LAYER_GATHER_MAX_DEGREE * n and hasattr(be, "_simple_layer_gather") and
-            csr.max_degree() <= LAYER_GATHER_MAX_ROW):
+            (csr.max_degree_if_known() or LAYER_GATHER_MAX_ROW + 1) <= LAYER_GATHER_MAX_ROW):
         # a few entries per row: the layer kernel walks the CSR itself, no separate SpMM launch and no `ax` round trip
         gather = (csr.rowptr, csr.src, csr.val)
     elif csr is not None:

@@ -372,6 +372,8 @@ def test_layer_kernel_aggregates_sparse_graphs_itself(n, c, dtype, use_weight, g
     xd, eid = x.to(dev), ei.to(dev)
     run = lambda: conv._layer(xd, xd, eid, None, x0.to(dev) if use_source else None, xd, 0.4, lw.to(dev) if ln else None,
                               lb.to(dev) if ln else None, 1e-5, carry={"head": (cast(hw).to(dev), cast(hb).to(dev))} if head else None)[0]
+    # (a graph seen for the first time keeps the SpMM launch until its longest row is known: the read is not waited for)
+    assert ops.csr_cache.get(eid, None, n, c * xd.element_size(), None, xd.element_size()).max_degree() <= ops.LAYER_GATHER_MAX_ROW
     be.kernel_events = {}
     with torch.no_grad():
         out = run()
