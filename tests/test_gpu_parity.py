@@ -1554,7 +1554,9 @@ def test_repeated_inference_forwards_are_captured_and_stay_correct(dev):
     x = torch.randn(n, 40, generator=g).to(dev)
     x2 = torch.randn(n, 40, generator=g).to(dev)
     ei = torch.cat([torch.randint(0, n, (2, 12000), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
-    model.auto_graph = False
+    from difformer_amd import ops
+    ops.csr_cache.get(ei, None, n, 64 * 4).max_degree()    # settle the statistic the first forwards of a new graph run without
+    model.auto_graph = False                               # (it picks the aggregation kernel: otherwise eager #1 and the capture differ by rounding)
     with torch.no_grad():
         ref, ref2 = model(x, ei).clone(), model(x2, ei).clone()
     model.auto_graph = True
