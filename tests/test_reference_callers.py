@@ -219,3 +219,47 @@ def test_physical_particle_callers(fake_backend):
             out = model(x, ei, n_nodes)                                  # main.py:85 (through models.GraphModel)
         assert out.shape == (n, args.hidden_channels) and torch.isfinite(out).all()
         _roundtrip(model, lambda: parse.parse_method(args, 1, d, torch.device("cpu")))
+
+
+def test_reference_evaluate_and_training_loop_run_on_the_dropin(fake_backend):
+    """`node classification/eval.py::evaluate` loaded verbatim and called as main.py:132 calls it, between optimisation steps
+    written as main.py:114-131 writes them (model.train(), zero_grad, forward, log_softmax + NLL on the training split,
+    backward, Adam step), on the model parse_method builds for the `cora` line of run.sh, with that line's learning rate: the
+    loss goes down over twelve steps and the evaluation returns accuracies and a finite validation loss -- the drop-in under the reference's own evaluation code and call sequence."""
+    import torch.nn.functional as F
+    parse, dropin = _load("node classification", "difformer.py", extra=("gnns",))
+    spec = importlib.util.spec_from_file_location("ref_eval", os.path.join(REF, "node classification", "eval.py"))
+    ref_eval = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_eval)
+    n, c, d = 80, 4, 10
+    g = torch.Generator().manual_seed(5)
+    y = torch.randint(0, c, (n, 1), generator=g)
+    x = torch.randn(n, d, generator=g) + 2.0 * F.one_hot(y.squeeze(1), d).float()          # learnable labels
+    dataset = types.SimpleNamespace(graph={"node_feat": x, "edge_index": _graph(n, 300, seed=6), "num_nodes": n}, label=y)
+    perm = torch.randperm(n, generator=g)
+    split_idx = {"train": perm[:40], "valid": perm[40:60], "test": perm[60:]}
+    argv = next(a for a in NODE_CMDS if "cora" in a)
+    args = _args(parse, argv)
+    model = parse.parse_method(args, n, c, d, torch.device("cpu"))
+    assert isinstance(model, dropin.DIFFormer)
+    criterion = nn.NLLLoss()                                             # main.py:95
+    eval_func = lambda y_true, out: float((out.argmax(dim=-1, keepdim=True) == y_true).float().mean())   # data_utils.eval_acc
+    model.reset_parameters()
+    optimizer = torch.optim.Adam(model.parameters(), weight_decay=args.weight_decay, lr=args.lr)
+    train_idx = split_idx["train"]
+    losses = []
+    torch.manual_seed(0)
+    for epoch in range(12):
+        model.train()                                                    # main.py:115-131
+        optimizer.zero_grad()
+        out = model(dataset.graph["node_feat"], dataset.graph["edge_index"])
+        out = F.log_softmax(out, dim=1)
+        loss = criterion(out[train_idx], dataset.label.squeeze(1)[train_idx])
+        loss.backward()
+        optimizer.step()
+        result = ref_eval.evaluate(model, dataset, split_idx, eval_func, criterion, args)    # main.py:132
+        losses.append(float(loss))
+    train_acc, valid_acc, test_acc, valid_loss, out = result
+    assert losses[-1] < losses[0] and all(0.0 <= a <= 1.0 for a in (train_acc, valid_acc, test_acc))
+    assert torch.isfinite(valid_loss) and out.shape == (n, c)
+    assert fake_backend.closed_form_calls > 0                            # the `simple` layers of the cora line: closed form
