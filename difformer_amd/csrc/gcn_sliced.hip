@@ -44,6 +44,19 @@ using dif::f32x4;
 #ifndef DIF_SLICED_WG_PER_CU
 #define DIF_SLICED_WG_PER_CU 1
 #endif
+// Timing probes (results are WRONG; profiles/r04_experiments.md): 1 = entry registers never reloaded inside a tile, 2 = LDS
+// reads without the adds, 3 = adds without the LDS reads, 4 = tiles loaded once (barriers kept), 5 = no tile loads, no barriers
+#ifndef DIF_SLICED_PROBE
+#define DIF_SLICED_PROBE 0
+#endif
+// Entry format of measurement builds (profiles/r04_experiments.md): -DDIF_SLICED_ENTRY32 stores every entry as the 32-bit
+// LDS byte address of its row (no address shift in the sweep) in blocks of FOUR steps x 64 lanes -- the same 1-KiB block,
+// twice the entry stream.  The default is the 16-bit tile-local row number in blocks of eight steps.
+#ifdef DIF_SLICED_ENTRY32
+constexpr int kSteps = 4;
+#else
+constexpr int kSteps = 8;
+#endif
 constexpr int kTileRowsMax = DIF_SLICED_TILE_ROWS;   // + 16 zero rows = 10,224 rows x 16 B = 163,584 B of LDS
 constexpr int kLdsRows = kTileRowsMax + 16;
 constexpr int kWgPerCU = DIF_SLICED_WG_PER_CU;
@@ -301,11 +314,11 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(int64_t n_p
     // of lanes 8-15 (4 bits each), mask of lanes holding a real entry, 0} at uint4 grp * 8 + (step & 7);
     // sliced_fill_kernel then turns the records of a block into its entries, in place.
     auto record_at = [&](int step) -> uint4* {
-        return reinterpret_cast<uint4*>(ell) + (blk0 + rowbase + j) * 64 + grp * 8 + (step & 7);
+        return reinterpret_cast<uint4*>(ell) + (blk0 + rowbase + j) * 64 + grp * kSteps + (step % kSteps);
     };
     auto new_row = [&](int step) {
-        if (EMIT && (step & 7) == 0) {
-            const int k = step >> 3;
+        if (EMIT && (step % kSteps) == 0) {
+            const int k = step / kSteps;
             rowbase = 0;
             for (int j2 = 0; j2 < pl.R; ++j2) { const int v = tb[1 + j2]; rowbase += v < k ? v : k; }
         }
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(kColorThreads) void sliced_color_kernel(int64_t n_p
     if (!EMIT) {
         len[gid] = step;
     } else {
-        for (; step < nbj * 8; ++step) {            // padding steps: lane i reads zero row i
+        for (; step < nbj * kSteps; ++step) {       // padding steps: lane i reads zero row i
             new_row(step);
             *record_at(step) = uint4{0x76543210u, 0xfedcba98u, 0u, 0u};
         }
@@ -385,12 +398,12 @@ __device__ __forceinline__ void fill_blocks(const uint16_t* __restrict__ mine, c
         int64_t rowbase = 0;
         for (int j2 = 0; j2 < R; ++j2) { const int v = tb[1 + j2]; rowbase += v < k ? v : k; }
         uint4* blk = ell + (blk0 + rowbase + j) * 64;
-        uint4 rec[8];
+        uint4 rec[kSteps];
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) rec[s8] = blk[grp * 8 + s8];
-        uint32_t ent[8];
+        for (int s8 = 0; s8 < kSteps; ++s8) rec[s8] = blk[grp * kSteps + s8];
+        uint32_t ent[kSteps];
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
+        for (int s8 = 0; s8 < kSteps; ++s8) {
             // masks, not selects between array elements: those turn `rec` / `next` into indexed scratch arrays
             const uint32_t q = ((((rec[s8].x & ~himask) | (rec[s8].y & himask)) >> sh)) & 15u;
             const bool real = (rec[s8].z >> i) & 1u;
@@ -407,7 +420,11 @@ __device__ __forceinline__ void fill_blocks(const uint16_t* __restrict__ mine, c
         }
         // every lane has read its records (the loads above belong to instructions that completed for the whole wave
         // before the first dependent use); now the block takes its final content
+#ifdef DIF_SLICED_ENTRY32
+        blk[lane] = uint4{ent[0] << 4, ent[1] << 4, ent[2] << 4, ent[3] << 4};
+#else
         blk[lane] = uint4{ent[0] | (ent[1] << 16), ent[2] | (ent[3] << 16), ent[4] | (ent[5] << 16), ent[6] | (ent[7] << 16)};
+#endif
     }
 }
 
@@ -506,7 +523,7 @@ __global__ __launch_bounds__(1024) void sliced_table_kernel(const int32_t* __res
                 int32_t nb = 0;
                 if (g < pl.G) {
                     for (int q = 0; q < 4; ++q) {
-                        const int32_t v = (len[(g * pl.NT + t) * 4 + q] + 7) >> 3;
+                        const int32_t v = (len[(g * pl.NT + t) * 4 + q] + kSteps - 1) / kSteps;
                         nb = v > nb ? v : nb;
                     }
                 }
@@ -593,7 +610,31 @@ struct Epilogue {
 // one block of a round: eight entries (four packed dwords), 16-bit row number -> LDS byte address with one SDWA shift
 // each; the entry register is reloaded (its next block) as soon as the addresses are out, BEFORE the LDS reads, so the
 // load has the whole block in flight even in the phases where few rounds are active
+// float4 sum; measurement builds: -DDIF_SLICED_SCALAR_ADD forces four v_add_f32 instead of two v_pk_add_f32
+__device__ __forceinline__ f32x4 add4(f32x4 x, f32x4 y) {
+#ifdef DIF_SLICED_SCALAR_ADD
+    f32x4 r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.x) : "v"(x.x), "v"(y.x));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.y) : "v"(x.y), "v"(y.y));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.z) : "v"(x.z), "v"(y.z));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.w) : "v"(x.w), "v"(y.w));
+    return r;
+#else
+    return x + y;
+#endif
+}
+
 __device__ __forceinline__ void block8(const f32x4* tile, uint4& e, const uint4* reload, f32x4& a) {
+#ifdef DIF_SLICED_ENTRY32
+    // four steps: the entries ARE the LDS byte addresses
+    const uint32_t ad[4] = {e.x, e.y, e.z, e.w};
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[q]);
+    e = *reload;
+    a = add4(a, add4(add4(v[0], v[1]), add4(v[2], v[3])));
+    asm volatile("" : "+v"(a));          // the sum is due HERE (the machine sinker otherwise parks every round's adds behind the last round's reads)
+#else
     const uint32_t four = 4;
     const uint32_t wds[4] = {e.x, e.y, e.z, e.w};
     uint32_t ad[8];
@@ -604,14 +645,50 @@ __device__ __forceinline__ void block8(const f32x4* tile, uint4& e, const uint4*
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
             : "=v"(ad[2 * q + 1]) : "v"(four), "v"(wds[q]));
     }
+#if DIF_SLICED_PROBE != 1
     e = *reload;
+#endif
+#if DIF_SLICED_PROBE == 2          // reads only: results kept alive, no adds
+    {
+        f32x4 v[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[4 * h + q]);
+            asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        }
+        return;
+    }
+#elif DIF_SLICED_PROBE == 3        // adds only: the addresses stand in for the rows
+    {
+        f32x4 v[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float f = __uint_as_float(ad[4 * h + q]); v[q] = f32x4{f, f, f, f}; }
+            a = add4(a, add4(add4(v[0], v[1]), add4(v[2], v[3])));
+            asm volatile("" : "+v"(a));
+        }
+        return;
+    }
+#endif
+#ifdef DIF_SLICED_READS8
+    // all eight reads in flight before the first add (32 result registers instead of 16)
+    f32x4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[q]);
+    a = add4(a, add4(add4(add4(v[0], v[1]), add4(v[2], v[3])), add4(add4(v[4], v[5]), add4(v[6], v[7]))));
+    asm volatile("" : "+v"(a));
+#else
     f32x4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[q]);
-    a += (v[0] + v[1]) + (v[2] + v[3]);
+    a = add4(a, add4(add4(v[0], v[1]), add4(v[2], v[3])));
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[4 + q]);
-    a += (v[0] + v[1]) + (v[2] + v[3]);
+    a = add4(a, add4(add4(v[0], v[1]), add4(v[2], v[3])));
+#endif
+#endif
 }
 
 // Phase M: the block rows in which exactly the rounds 0 .. M-1 are active (nb[M] <= k < nb[M-1]).
@@ -712,6 +789,9 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
                 e[j] = *((nb[j] > 0) ? cur + j * 64 : ell);                  // in flight across the tile load
             }
         }
+#if DIF_SLICED_PROBE == 5
+        if (tt == 0)
+#endif
         {
             // The tile's first loads are issued BEFORE the barrier (they land in registers, not in LDS), so their latency
             // runs under the wait for the slowest wave of the previous tile; the registers written first take the tail
@@ -729,6 +809,9 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
             DIF_STAMP(0);
             __syncthreads();                                                  // everyone is done with the previous tile
             DIF_STAMP(1);
+#if DIF_SLICED_PROBE == 4
+            if (tt == 0)
+#endif
 #pragma unroll
             for (int b = 0; b < 11; b += U) {                                 // batches of U rows per thread, 11 in all
 #pragma unroll
@@ -749,6 +832,9 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
         // pending" into every phase loop and wait for ALL loads at the top of each block row.  They are complete here
         // (the LDS stores consumed them, and the entry loads were issued before them): say so.
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+#if DIF_SLICED_PROBE == 5
+        if (tt == 0)
+#endif
         __syncthreads();
         DIF_STAMP(2);
         if (NR > 0) {

@@ -7,7 +7,9 @@ working once `difformer.py` in a task folder is replaced by `dropin/difformer.py
 
 What differs is where the arithmetic runs: every propagation operator is a hand-written gfx950
 kernel behind the C ABI of include/difformer_hip.h (see ops.py); this file only sequences them.
-There is no CPU path: tensors must be float32 on the GPU.
+There is no CPU arithmetic: tensors must be float32 (or bfloat16) on the GPU.  Callers that keep the model AND its
+operands in host memory (`test_large_dataset.py:69,91-93`, `eval.py::evaluate_cpu`) are staged onto the GPU and get their
+result back on the host (staging.py); without a GPU such a call raises.
 """
 from __future__ import annotations
 
@@ -20,6 +22,7 @@ import torch.nn.functional as F
 
 from . import ops
 from . import autograd_ops as ag
+from . import staging
 
 __all__ = ["full_attention_conv", "gcn_conv", "DIFFormerConv", "DIFFormer"]
 
@@ -42,6 +45,10 @@ def _dense_attention(qs, ks, kernel):
 
 def full_attention_conv(qs, ks, vs, kernel, output_attn=False):
     """qs [N,H,M], ks [L,H,M], vs [L,H,D] -> [N,H,D]  (reference: difformer.py:10-61)."""
+    dev = staging.staging_device(None, (qs, ks, vs))
+    if dev is not None:      # host operands: computed on the GPU, returned on the host (`.to` is differentiable)
+        out = full_attention_conv(qs.to(dev), ks.to(dev), vs.to(dev), kernel, output_attn)
+        return tuple(o.to(qs.device) for o in out) if output_attn else out.to(qs.device)
     if kernel == "simple":
         out = ag.simple_attention(qs, ks, vs)
     elif kernel == "sigmoid":
@@ -56,6 +63,12 @@ def full_attention_conv(qs, ks, vs, kernel, output_attn=False):
 def gcn_conv(x, edge_index, edge_weight):
     """x [N,H,D], edge_index [2,E] int64, edge_weight [E] or None -> [N,H,D]
     (reference: difformer.py:63-79).  The normalised CSR is built on first use and cached."""
+    dev = staging.staging_device(None, (x, edge_index, edge_weight))
+    if dev is not None:      # host operands: the device copy of edge_index is kept, so the cached CSR is found again
+        ew = edge_weight
+        if ew is not None:
+            ew = ew.to(dev) if ew.requires_grad else staging.operands.get(ew, dev)
+        return gcn_conv(x.to(dev), staging.operands.get(edge_index, dev), ew).to(x.device)
     csr = ops.csr_cache.get(edge_index, edge_weight, x.shape[0], x.shape[1] * x.shape[2] * x.element_size(),
                             elem_size=x.element_size())
     return ag.gcn_aggregate(csr, x)
@@ -83,6 +96,13 @@ class DIFFormerConv(nn.Module):
         self._fused_wb = None  # (key, weight, bias) of the concatenated projections (inference only)
         self._wide = None      # (key, ops.WideCoefficients): weight-only factors of the closed form at hidden > 64
         self._narrow = None    # (key, ops.NarrowFactors): weight-only factors of the background coefficient chain
+
+    def __getstate__(self):
+        # copy.deepcopy / torch.save(model): the inference caches are rebuilt on demand and must not travel
+        state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        state = dict(state)
+        state.update(_fused_wb=None, _wide=None, _narrow=None, row_shard=None)
+        return state
 
     def reset_parameters(self):
         self.Wk.reset_parameters()
@@ -311,6 +331,15 @@ class DIFFormer(nn.Module):
         self._ag_state = None
         self._ag_params = None
 
+    def __getstate__(self):
+        # copy.deepcopy(model) for a best-checkpoint / EMA copy and torch.save(model) must keep working after eval calls:
+        # the hipGraph capture, its weak references and the device twin of a host-resident model stay behind
+        state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        state = dict(state)
+        state.update(_ag_state=None, _ag_params=None)
+        state.pop("_staged", None)
+        return state
+
     def reset_parameters(self):
         for conv in self.convs:
             conv.reset_parameters()
@@ -327,6 +356,7 @@ class DIFFormer(nn.Module):
             conv.invalidate_caches()
         ops.invalidate_param_caches()
         self._ag_state = self._ag_params = None
+        staging.drop(self)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -419,6 +449,9 @@ class DIFFormer(nn.Module):
         return st[3].clone()
 
     def forward(self, x, edge_index, edge_weight=None):
+        dev = staging.staging_device(self, (x, edge_index, edge_weight))
+        if dev is not None:      # model and operands in host memory (test_large_dataset.py:91-93, eval.py:38-41)
+            return staging.staged_forward(self, dev, lambda m, *a: m.forward(*a), x, edge_index, edge_weight)
         out = self._forward_graphed(x, edge_index, edge_weight)
         return out if out is not None else self._forward_eager(x, edge_index, edge_weight)
 
@@ -463,6 +496,9 @@ class DIFFormer(nn.Module):
     def get_attentions(self, x):
         """Dense per-layer attention [layers, N, N, H] (difformer.py:211-226; no graph term,
         as in the reference, which passes no edge_index here)."""
+        dev = staging.staging_device(self, (x,))
+        if dev is not None:
+            return staging.staged_forward(self, dev, lambda m, a: m.get_attentions(a), x)
         layer_, attentions = [], []
         x = self._input_layer(x, False)
         layer_.append(x)

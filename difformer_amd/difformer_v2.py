@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from . import ops
 from . import autograd_ops as ag
+from . import staging
 from .difformer import gcn_conv
 
 __all__ = ["make_batch_mask", "make_batch", "to_pad", "gcn_conv", "TransConv", "DIFFormer_v2"]
@@ -56,6 +57,13 @@ class TransConv(nn.Module):
         self.use_graph = use_graph
         self.use_weight = use_weight
         self.graph_weight = graph_weight
+
+    def __getstate__(self):
+        state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        state = dict(state)
+        for k in ("_cat_key", "_cat_w", "_cat_b"):
+            state.pop(k, None)
+        return state
 
     def reset_parameters(self):
         self.Wk.reset_parameters()
@@ -156,11 +164,21 @@ class DIFFormer_v2(nn.Module):
         for fc in self.fcs:
             fc.reset_parameters()
 
+    def __getstate__(self):
+        state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        state = dict(state)
+        state.pop("_staged", None)
+        return state
+
     def invalidate_caches(self):
         for conv in self.convs:
             conv.invalidate_caches()
+        staging.drop(self)
 
     def forward(self, x, edge_index, n_nodes):
+        dev = staging.staging_device(self, (x, edge_index))
+        if dev is not None:      # model and batch in host memory: staged onto the GPU, result back on the host
+            return staging.staged_forward(self, dev, lambda m, *a: m.forward(*a), x, edge_index, n_nodes)
         layer_ = []
         bn = self.bns[0] if self.use_bn else None                                        # :197-200 in one kernel
         x = ag.linear(x, self.fcs[0].weight, self.fcs[0].bias, bn.weight if bn is not None else None,

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Measurement builds of the feature-sliced product (profiles/r04_experiments.md): one shared library per variant under
+# scripts/bin/ (git-ignored, shipped to the GPU box), identical to the product's except for csrc/gcn_sliced.hip's macros.
+#   scripts/build_sliced_variants.sh name="flags" ...   then   scripts/run_sliced_variants.sh name ...   on the GPU box
+set -e
+cd "$(dirname "$0")/.."
+make -C difformer_amd/csrc -j8 >/dev/null
+mkdir -p scripts/bin
+for spec in "$@"; do
+    name=${spec%%=*}; flags=${spec#*=}
+    obj=/tmp/dif_obj_$name
+    rm -rf $obj && cp -r difformer_amd/lib/obj $obj && rm -f $obj/gcn_sliced.o
+    make -C difformer_amd/csrc OBJDIR=$obj OUT=../../scripts/bin/libdifformer_hip_$name.so EXTRA="$flags" >/dev/null
+    echo "built scripts/bin/libdifformer_hip_$name.so ($flags)"
+done

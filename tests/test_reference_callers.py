@@ -244,11 +244,11 @@ def test_reference_evaluate_and_training_loop_run_on_the_dropin(fake_backend):
     assert isinstance(model, dropin.DIFFormer)
     criterion = nn.NLLLoss()                                             # main.py:95
     eval_func = lambda y_true, out: float((out.argmax(dim=-1, keepdim=True) == y_true).float().mean())   # data_utils.eval_acc
+    torch.manual_seed(0)
     model.reset_parameters()
     optimizer = torch.optim.Adam(model.parameters(), weight_decay=args.weight_decay, lr=args.lr)
     train_idx = split_idx["train"]
     losses = []
-    torch.manual_seed(0)
     for epoch in range(12):
         model.train()                                                    # main.py:115-131
         optimizer.zero_grad()
@@ -263,3 +263,110 @@ def test_reference_evaluate_and_training_loop_run_on_the_dropin(fake_backend):
     assert losses[-1] < losses[0] and all(0.0 <= a <= 1.0 for a in (train_acc, valid_acc, test_acc))
     assert torch.isfinite(valid_loss) and out.shape == (n, c)
     assert fake_backend.closed_form_calls > 0                            # the `simple` layers of the cora line: closed form
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU-RESIDENT callers (eval.py:43 through evaluate_cpu, test_large_dataset.py:93): model and graph in host
+# memory.  The product stages such a call onto the GPU (difformer_amd/staging.py); here the staging logic itself -- the
+# device twin and its refresh after optimiser steps / load_state_dict / .to(), the operand cache, the gradient routing --
+# runs with the "device" forced to the host so that the test backend can do the arithmetic.  The same call sequences
+# run on the real backend in tests/test_gpu_staging.py.
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def staged_on_host(fake_backend, monkeypatch):
+    from difformer_amd import staging
+    monkeypatch.setattr(staging, "FORCE_DEVICE", torch.device("cpu"))
+    staging.operands.clear()
+    yield staging
+    staging.operands.clear()
+
+
+def _ref_eval_module():
+    spec = importlib.util.spec_from_file_location("ref_eval", os.path.join(REF, "node classification", "eval.py"))
+    ref_eval = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_eval)
+    return ref_eval
+
+
+def test_reference_evaluate_cpu_runs_staged(staged_on_host):
+    """`eval.py::evaluate_cpu` verbatim, called as main-batch.py:144-145 calls it after an epoch of optimiser steps: the
+    model goes `.to(cpu)`, the full graph is forwarded from host memory, the result is a host tensor -- and equals the plain
+    (unstaged) forward of the same parameters; a second evaluation after another optimiser step sees the new parameters."""
+    import torch.nn.functional as F
+    from difformer_amd import staging
+    parse, dropin = _load("node classification", "difformer.py", extra=("gnns",))
+    ref_eval = _ref_eval_module()
+    n, c, d = 70, 3, 9
+    g = torch.Generator().manual_seed(11)
+    y = torch.randint(0, c, (n, 1), generator=g)
+    x = torch.randn(n, d, generator=g)
+    dataset = types.SimpleNamespace(graph={"node_feat": x, "edge_index": _graph(n, 250, seed=12), "num_nodes": n}, label=y)
+    perm = torch.randperm(n, generator=g)
+    split_idx = {"train": perm[:30], "valid": perm[30:50], "test": perm[50:]}
+    argv = next(a for a in _difformer_commands("node classification") if "pokec" in a)         # a main-batch.py line
+    args = _args(parse, argv)
+    model = parse.parse_method(args, n, c, d, torch.device("cpu"))
+    criterion = nn.NLLLoss()
+    eval_func = lambda y_true, out: float((out.argmax(dim=-1, keepdim=True) == y_true).float().mean())
+    model.reset_parameters()
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
+    outs = []
+    for epoch in range(2):
+        model.to(torch.device("cpu"))                                   # main-batch.py:121 (`device` is the host here)
+        model.train()
+        optimizer.zero_grad()
+        out = model(x, dataset.graph["edge_index"])                     # :135 -- a staged call with gradients
+        loss = criterion(F.log_softmax(out, dim=1)[split_idx["train"]], y.squeeze(1)[split_idx["train"]])
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        optimizer.step()
+        result = ref_eval.evaluate_cpu(model, dataset, split_idx, eval_func, criterion, args, torch.device("cpu"))   # :144-145
+        out = result[-1]
+        assert out.device.type == "cpu" and out.shape == (n, c) and torch.isfinite(result[3])
+        monkey_off = staging.FORCE_DEVICE
+        staging.FORCE_DEVICE = None                                     # the same parameters, unstaged (test backend on the host)
+        try:
+            with torch.no_grad():
+                plain = F.log_softmax(model(x, dataset.graph["edge_index"]), dim=1)
+        finally:
+            staging.FORCE_DEVICE = monkey_off
+        assert torch.allclose(out, plain, atol=1e-6)
+        outs.append(out)
+    assert not torch.allclose(outs[0], outs[1])                          # the twin followed the optimiser step
+    assert "_staged" in model.__dict__ and not any(k.startswith("_staged") for k in model.state_dict())
+
+
+def test_reference_test_large_dataset_body_runs_staged(staged_on_host, tmp_path, monkeypatch):
+    """The model-handling lines of `test_large_dataset.py` (:68-69 parse_method(...).to(cpu); :85-88 torch.load +
+    load_state_dict; :90-93 eval + no_grad forward of host tensors) EXECUTED from the reference source, for both command
+    lines of run_test_large.sh, around a stub dataset and a checkpoint saved from another instance."""
+    from difformer_amd import staging
+    parse, dropin = _load("node classification", "difformer.py", extra=("gnns",))
+    src = open(os.path.join(REF, "node classification", "test_large_dataset.py")).read().splitlines()
+    pick = lambda lo, hi: "\n".join(src[lo - 1: hi])
+    body = "\n".join([pick(69, 69), pick(87, 88), pick(91, 93)])
+    assert "parse_method(args, n, c, d, device).to(torch.device(\"cpu\"))" in body and "model.load_state_dict(checkpoint)" in body
+    assert "out = model(dataset.graph['node_feat'], dataset.graph['edge_index'])" in body
+    n, c, d = 64, 4, 11
+    x, ei = torch.randn(n, d), _graph(n, 220, seed=3)
+    dataset = types.SimpleNamespace(graph={"node_feat": x, "edge_index": ei, "num_nodes": n})
+    for argv in _difformer_commands("node classification", "run_test_large.sh"):
+        args = _args(parse, argv)
+        trained = parse.parse_method(args, n, c, d, torch.device("cpu"))
+        trained.reset_parameters()
+        ckpt = tmp_path / "ckpt.pkl"
+        torch.save(trained.state_dict(), ckpt)
+        ns = dict(parse_method=parse.parse_method, args=args, n=n, c=c, d=d, device=torch.device("cpu"), torch=torch,
+                  dataset=dataset, checkpoint_dir=str(ckpt))
+        exec(compile(body, "test_large_dataset.py", "exec"), ns)
+        out = ns["out"]
+        assert out.device.type == "cpu" and out.shape == (n, c)
+        assert "_staged" in ns["model"].__dict__                        # it did go through the staging path
+        staging_dev = staging.FORCE_DEVICE
+        staging.FORCE_DEVICE = None
+        try:
+            with torch.no_grad():
+                plain = trained.eval()(x, ei)
+        finally:
+            staging.FORCE_DEVICE = staging_dev
+        assert torch.allclose(out, plain, atol=1e-6)
