@@ -447,7 +447,7 @@ class HipBackend:
         rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
         src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         val = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
-        status = torch.empty(1, dtype=torch.int32, device=dev)
+        status = torch.empty(2, dtype=torch.int32, device=dev)          # {index out of range, longest row}
         blkptr = None
         if n_blocks > 1:
             blkptr = torch.empty((n_blocks + 1) * num_nodes, dtype=torch.int32, device=dev)
@@ -458,9 +458,10 @@ class HipBackend:
                                         _ptr(blkptr),
                                         _ptr(src), _ptr(val), _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_csr_build")
-        if int(status.item()) != 0:  # one sync per (cold) build
+        bad, longest = status.tolist()  # one sync per (cold) build; the longest row rides along (kernel selection)
+        if bad != 0:
             raise IndexError(f"difformer_amd: edge_index holds node ids outside [0, {num_nodes})")
-        return rowptr, blkptr, src, val
+        return rowptr, blkptr, src, val, int(longest)
 
     def subgraph(self, subset, edge_index, edge_weight, num_nodes):
         """Induced subgraph with relabelling (main-batch.py:131) -> (edge_index [2,E'], edge_weight [E'] | None)."""

@@ -213,18 +213,27 @@ int exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* out_tota
 // dinv[n] = sqrt(1/deg[n])  (float32, correctly rounded: difformer.py:67-68); deg 0 -> inf
 __global__ __launch_bounds__(256) void csr_ptrs_kernel(const int32_t* __restrict__ kptr, int64_t N, int64_t NB,
                                                        int32_t* __restrict__ rowptr, int32_t* __restrict__ blkptr,
-                                                       const int32_t* __restrict__ degc, float* __restrict__ dinv) {
+                                                       const int32_t* __restrict__ degc, float* __restrict__ dinv,
+                                                       int32_t* __restrict__ longest) {
     const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (r > N) return;
-    const int32_t start = kptr[r * NB];
-    rowptr[r] = start;                         // r == N: kptr[N*NB] = E
-    if (r == N) return;
-    const int32_t end = kptr[(r + 1) * NB];
-    dinv[r] = sqrtf(1.0f / static_cast<float>(degc ? degc[r] : end - start));
-    if (blkptr) {
-        for (int64_t b = 0; b < NB; ++b) blkptr[b * N + r] = kptr[r * NB + b];
-        blkptr[NB * N + r] = end;
+    int32_t len = 0;
+    if (r <= N) {
+        const int32_t start = kptr[r * NB];
+        rowptr[r] = start;                         // r == N: kptr[N*NB] = E
+        if (r < N) {
+            const int32_t end = kptr[(r + 1) * NB];
+            len = end - start;
+            dinv[r] = sqrtf(1.0f / static_cast<float>(degc ? degc[r] : end - start));
+            if (blkptr) {
+                for (int64_t b = 0; b < NB; ++b) blkptr[b * N + r] = kptr[r * NB + b];
+                blkptr[NB * N + r] = end;
+            }
+        }
     }
+    // the longest row of the CSR (status[1]): one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int32_t o = __shfl_xor(len, off, 64); len = o > len ? o : len; }
+    if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(longest, len);
 }
 
 // ---- stable LSD radix sort, 8 bits per pass; each WAVE owns a 4096-key chunk -------------------
@@ -719,7 +728,7 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     int32_t* table = reinterpret_cast<int32_t*>(ws + p.off_table);
     int32_t* bsum = reinterpret_cast<int32_t*>(ws + p.off_bsum);
 
-    hipError_t he = hipMemsetAsync(status, 0, 4, st);
+    hipError_t he = hipMemsetAsync(status, 0, 8, st);            // {bad index flag, longest row}
     if (he == hipSuccess && transpose) he = hipMemsetAsync(degc, 0, static_cast<size_t>(N + 1) * 4, st);
     if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_csr_build: memset: %s", hipGetErrorString(he));
 
@@ -728,7 +737,7 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
         he = hipMemsetAsync(kcnt, 0, static_cast<size_t>(p.n_keys + 1) * 4, st);
         if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_csr_build: memset: %s", hipGetErrorString(he));
         hipLaunchKernelGGL(csr_ptrs_kernel, dim3(static_cast<unsigned>((N + 256) / 256)), dim3(256), 0, st, kcnt, N, p.NB,
-                           rowptr, n_blocks > 1 ? blkptr : nullptr, degc, dinv);
+                           rowptr, n_blocks > 1 ? blkptr : nullptr, degc, dinv, status + 1);
         return dif::launch_status("csr_ptrs_kernel");
     }
     {
@@ -759,7 +768,7 @@ extern "C" int dif_csr_build(const int64_t* edge_index, int64_t E, int64_t N, co
     hipLaunchKernelGGL(csr_bounds_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, kin, E, p.n_keys, kcnt);
     if (int rc = dif::launch_status("csr_bounds_kernel")) return rc;
     hipLaunchKernelGGL(csr_ptrs_kernel, dim3(static_cast<unsigned>((N + 256) / 256)), dim3(256), 0, st, kcnt, N, p.NB,
-                       rowptr, n_blocks > 1 ? blkptr : nullptr, degc, dinv);
+                       rowptr, n_blocks > 1 ? blkptr : nullptr, degc, dinv, status + 1);
     if (int rc = dif::launch_status("csr_ptrs_kernel")) return rc;
     hipLaunchKernelGGL(csr_fill_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, edge_index, E, N,
                        static_cast<uint32_t>(p.NB), transpose, edge_weight, kin, vin, dinv, src, val);

@@ -169,9 +169,10 @@ class DIFFormerConv(nn.Module):
         params = (self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, self.Wv.weight, self.Wv.bias)
         return not ag._needs_grad(source_input, *params)
 
-    def _closed_form(self, query_input, source_input, prev, want_qk):
+    def _closed_form(self, query_input, source_input, prev, want_qk, tail_operands=()):
         """The whole layer through the Gram-record formulation (csrc/simple_layer.hip): `simple` kernel, one head,
-        query == source, narrow fp32 rows, inference; the residual must mix with the layer input itself."""
+        query == source, narrow fp32 rows; the residual must mix with the layer input itself.  `tail_operands`: x0 and the
+        LayerNorm parameters -- a gradient wanted for ANY operand of the layer makes it a training call."""
         x = source_input
         if not (self.kernel == 'simple' and query_input is source_input and self.num_heads == 1 and not want_qk):
             return False
@@ -193,7 +194,7 @@ class DIFFormerConv(nn.Module):
         params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias]
         if self.use_weight:
             params += [self.Wv.weight, self.Wv.bias]
-        if not ag._needs_grad(x, *params):
+        if not ag._needs_grad(x, *params, *tail_operands):
             return True
         # training: the narrow float32 single-GPU closed form has a backward through the record (ag._ClosedFormLayer)
         return (_CLOSED_FORM_TRAINING and not wide and x.dtype == torch.float32 and
@@ -206,7 +207,7 @@ class DIFFormerConv(nn.Module):
         shard = self.row_shard
         q = k = None
         w_grad = ag._needs_grad(edge_weight)     # difformer.py:73 is differentiable in edge_weight: operator path then
-        if not w_grad and self._closed_form(query_input, source_input, prev, want_qk):
+        if not w_grad and self._closed_form(query_input, source_input, prev, want_qk, (x0, ln_weight, ln_bias)):
             if self.use_graph and edge_index is None:
                 raise ValueError("use_graph=True needs an edge_index")
             x = source_input
@@ -329,14 +330,13 @@ class DIFFormer(nn.Module):
         self.alpha = alpha
         self.auto_graph = True     # repeated inference forwards over the same operands replay as one hipGraph (_forward_graphed)
         self._ag_state = None
-        self._ag_params = None
 
     def __getstate__(self):
         # copy.deepcopy(model) for a best-checkpoint / EMA copy and torch.save(model) must keep working after eval calls:
         # the hipGraph capture, its weak references and the device twin of a host-resident model stay behind
         state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
         state = dict(state)
-        state.update(_ag_state=None, _ag_params=None)
+        state.update(_ag_state=None)
         state.pop("_staged", None)
         return state
 
@@ -355,7 +355,7 @@ class DIFFormer(nn.Module):
         for conv in self.convs:
             conv.invalidate_caches()
         ops.invalidate_param_caches()
-        self._ag_state = self._ag_params = None
+        self._ag_state = None
         staging.drop(self)
 
     def _apply(self, fn, *args, **kwargs):
@@ -390,16 +390,28 @@ class DIFFormer(nn.Module):
         if (be is None or getattr(be, "kernel_events", None) is not None or not x.is_cuda or x.dim() != 2 or
                 torch.cuda.is_current_stream_capturing()):
             return None
-        if any(c.row_shard is not None for c in self.convs):
-            return None
-        if self._ag_params is None:
-            self._ag_params = list(self.parameters())
+        # everything the capture bakes in: the operands, the model's and every layer's flags, and the parameters as they are
+        # NOW (walked afresh through the registration dicts -- plain dict reads, this runs on every replayed call -- so a
+        # module swapped in after the first call does not leave a stale list behind)
+        mods = self._modules
+        convs = mods["convs"]._modules.values()
         key = [x.data_ptr(), x.shape, x.stride(), x.dtype, torch.cuda.current_stream(x.device).cuda_stream,
-               self.alpha, self.use_bn, self.residual, ops.SIDE_CHAIN]
+               self.alpha, self.use_bn, self.residual, ops.SIDE_CHAIN, len(convs)]
+        lin = []
+        for m in mods["fcs"]._modules.values():
+            lin.append(m)
+        for m in mods["bns"]._modules.values():
+            lin.append(m)
+        for c in convs:
+            if c.row_shard is not None:
+                return None
+            key.append((id(c), c.kernel, c.use_graph, c.use_weight, c.use_source, c.graph_weight, c.num_heads, c.out_channels))
+            lin.extend(c._modules.values())              # Wk, Wq (, Wv)
         for t in (edge_index, edge_weight):
             key.append(None if t is None else (id(t), t.data_ptr(), t.shape, ops.tensor_version(t)))
-        for p in self._ag_params:
-            key.append((p.data_ptr(), ops.tensor_version(p)))
+        for m in lin:
+            for p in m._parameters.values():
+                key.append((id(p), p.data_ptr(), ops.tensor_version(p)) if p is not None else None)
         return tuple(key)
 
     def _forward_graphed(self, x, edge_index, edge_weight):
@@ -409,7 +421,11 @@ class DIFFormer(nn.Module):
         edge_index / edge_weight tensors, unchanged parameters) captures it; later calls replay and return a copy of the
         captured output.  The graph reads x, the graph tensors and the parameters in place, so new VALUES at the same
         addresses are seen; anything else (another shape, another tensor, an optimiser step, train mode, gradients, a row
-        shard) runs eagerly and drops the capture.  DIFFORMER_AUTO_GRAPH=0 or `model.auto_graph = False` turns it off;
+        shard, a flag of the model or of a layer flipped, a sub-module replaced) runs eagerly and drops the capture.
+        Derived caches (concatenated projections, weight-only factors, float32 copies of bfloat16 parameters) are frozen
+        into the capture; they are keyed on the same parameter versions as the capture itself.  The capture keeps a private
+        memory pool with every intermediate of one forward for as long as it lives (about a second forward's worth of HBM:
+        ~0.5 GB at C4, ~3 GB on the full Pokec graph).  DIFFORMER_AUTO_GRAPH=0 or `model.auto_graph = False` turns it off;
         `invalidate_caches()` drops it (needed after parameter writes through `.data`, as for the other caches)."""
         key = self._graph_key(x, edge_index, edge_weight)
         if key is None:
@@ -427,11 +443,6 @@ class DIFFormer(nn.Module):
             st[1] += 1
             if st[1] < 3:
                 return None
-            if edge_index is not None:
-                # the capture freezes which kernels run: settle the one choice that waits on a lazily read graph statistic
-                # (the longest row decides whether the closed-form layer aggregates itself) -- one host read, once per capture
-                for entry in ops.csr_cache.entries.values():
-                    entry[2].max_degree()
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):

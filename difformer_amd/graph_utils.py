@@ -30,6 +30,41 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes=
     return ei, ew
 
 
+class _LongestRows:
+    """Longest row of every batch of ONE subgraph_batches call, on its way to the host: a device reduction and a copy into
+    pinned memory are enqueued behind the CSR sort, and the first batch that needs its value WAITS for the copy (by then it
+    has landed: the wait is a completed-event check) and keeps the values of all batches.  The kernel choice that depends
+    on the statistic is therefore the same on every run; nothing polls, and the epoch has no extra host synchronisation in
+    front of its first forward."""
+    _pinned = None          # one pinned buffer for the process (a pinned allocation costs ~0.1 ms), re-used per epoch ...
+    _in_flight = None       # ... once the previous epoch's values have been taken out of it
+
+    def __init__(self, per_batch):
+        n = int(per_batch.numel())
+        self.values = None
+        if not per_batch.is_cuda:
+            self.values = per_batch.tolist()
+            return
+        cls = _LongestRows
+        if cls._in_flight is not None:
+            cls._in_flight.resolve()
+        if cls._pinned is None or cls._pinned.numel() < n:
+            cls._pinned = torch.empty(max(n, 1024), dtype=torch.int32, pin_memory=True)
+        self.n, self.host = n, cls._pinned
+        self.host[:n].copy_(per_batch.to(torch.int32), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(per_batch.device))
+        cls._in_flight = self
+
+    def resolve(self):
+        if self.values is None:
+            self.event.synchronize()
+            self.values = self.host[: self.n].tolist()
+            if _LongestRows._in_flight is self:
+                _LongestRows._in_flight = None
+        return self.values
+
+
 def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=None, build_csr=True):
     """Every mini-batch subgraph of an epoch from ONE pass over the edge list (csrc/gcn_csr.hip, dif_subgraph_batches_*).
 
@@ -49,12 +84,11 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
         rowptr, src, val = csr
         m, bs = int(perm.numel()), int(batch_size)
         ops.csr_cache.reserve(nb + ops.csr_cache.capacity)
-        # longest row of every batch from one reduction and one copy that nobody waits for (the layer kernel's choice of path)
+        # longest row of every batch (the layer kernel's choice of path): one reduction per EPOCH, read when first needed
         deg = rowptr[1:] - rowptr[:-1]
         longest = None
-        if m > 0 and nb <= 4096:
-            per_batch = torch.nn.functional.pad(deg, (0, nb * bs - m)).view(nb, bs).max(dim=1).values
-            longest = ops.enqueue_host_reads(per_batch) if per_batch.is_cuda else per_batch.tolist()
+        if m > 0:
+            longest = _LongestRows(torch.nn.functional.pad(deg, (0, nb * bs - m)).view(nb, bs).max(dim=1).values)
         for b, (eb, wb) in enumerate(out):
             lo, hi = b * bs, min((b + 1) * bs, m)
             if ops.csr_cache.blocking(eb, wb, hi - lo) != (1, 0):
@@ -64,11 +98,11 @@ def subgraph_batches(perm, batch_size, edge_index, edge_attr=None, num_nodes=Non
             g = ops.GraphCSR(rp, None, 1, src[e0: max(e1, e0 + 1)], val[e0: max(e1, e0 + 1)], hi - lo, e1 - e0)
             g.weighted = wb is not None
             g._edges = (weakref.ref(eb), None if wb is None else weakref.ref(wb))
-            if longest is not None:             # on the device: a read nobody waits for, picked up at the batch's first forward
-                if isinstance(longest[b], tuple):
-                    g._max_pending = longest[b]
-                else:
-                    g._max_degree = int(longest[b])
+            if longest is None:
+                g._max_degree = 0
+            else:
+                g._max_source = (longest, b)
+            g._format_checked = True            # a sparse batch by construction (`blocking` above): nothing to build at first use
             ops.csr_cache.put(eb, wb, hi - lo, g)
     return out
 

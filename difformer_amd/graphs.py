@@ -49,8 +49,6 @@ class GraphedForward:
             torch.cuda.current_stream(dev).wait_stream(side)
             # the captured kernels hold raw pointers into the CSR: keep it alive with this object
             self._csr = [v[2] for v in ops.csr_cache.entries.values()] if edge_index is not None else []
-            for csr in self._csr:
-                csr.max_degree()             # settles the kernel choice that waits on this lazily read statistic
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = model(self.x, edge_index, edge_weight)

@@ -235,32 +235,6 @@ def split_positions(deg_sorted, order, cap, max_parts=SLICED_MAX_PARTS):
     return order2, parts, n_pos
 
 
-# Small device -> host reads that nobody waits for (GraphCSR.max_degree_if_known): one pinned ring for the process (a pinned
-# allocation per read costs ~0.1 ms), a slot per value, an event per copy.
-_PIN_SLOTS = 8192
-_PIN_RING = [None]
-_PIN_NEXT = [0]
-
-
-def enqueue_host_reads(values):
-    """values: int32-convertible device tensor [k] -> k pending reads (host slot view [1], event, ticket), copy enqueued on
-    the current stream."""
-    k = int(values.numel())
-    if _PIN_RING[0] is None:
-        _PIN_RING[0] = torch.empty(_PIN_SLOTS, dtype=torch.int32, pin_memory=True)
-    start = _PIN_NEXT[0] % _PIN_SLOTS
-    if start + k > _PIN_SLOTS:                          # keep the k slots contiguous
-        _PIN_NEXT[0] += _PIN_SLOTS - start
-        start = 0
-    ticket = _PIN_NEXT[0]
-    _PIN_NEXT[0] += k
-    ring = _PIN_RING[0]
-    ring[start: start + k].copy_(values.reshape(-1).to(torch.int32), non_blocking=True)
-    done = torch.cuda.Event()
-    done.record(torch.cuda.current_stream(values.device))
-    return [(ring[start + i: start + i + 1], done, ticket) for i in range(k)]
-
-
 class GraphCSR:
     """Normalised adjacency in CSR over destination rows (built once per graph, on device)."""
 
@@ -275,9 +249,9 @@ class GraphCSR:
         self.dinv = None            # adjoint CSR only: deg^-1/2 of the FORWARD graph (its own row lengths are out-degrees)
         self._sliced = {}           # (row_begin, n_rows, F) -> SlicedAdjacency | None
         self._row_sums = None
-        self._max_degree = None
-        self._max_pending = None     # (pinned host int32[1], event, ticket) of an enqueued max-degree read
-        self._asked = 0              # calls of max_degree_if_known before the read is enqueued
+        self._format_checked = False # csr_cache.get(build_format=True) has built (or ruled out) the sliced format for this CSR
+        self._max_degree = None      # longest row: known from the build (status[1] of dif_csr_build) ...
+        self._max_source = None      # ... or (graph_utils._LongestRows, batch) for the batches of one subgraph_batches call
 
     def row_order(self, row_begin, n_rows):
         """(order, n_split) for the blocked SpMM over a shard: its rows by descending degree, the first n_split of them
@@ -297,9 +271,10 @@ class GraphCSR:
 
     @classmethod
     def build(cls, edge_index, edge_weight, num_nodes, n_blocks=1, transpose=False, block_rows=0):
-        rowptr, blkptr, src, val = get_backend().csr_build(edge_index, edge_weight, int(num_nodes), int(n_blocks),
-                                                           transpose, int(block_rows))
+        rowptr, blkptr, src, val, longest = get_backend().csr_build(edge_index, edge_weight, int(num_nodes), int(n_blocks),
+                                                                    transpose, int(block_rows))
         csr = cls(rowptr, blkptr, n_blocks, src, val, num_nodes, edge_index.shape[1], block_rows)
+        csr._max_degree = int(longest)
         csr.weighted, csr.transposed = edge_weight is not None, bool(transpose)
         if not transpose:
             csr._edges = (weakref.ref(edge_index), None if edge_weight is None else weakref.ref(edge_weight))
@@ -358,41 +333,16 @@ class GraphCSR:
         return self._row_sums
 
     def max_degree(self):
-        """Longest row (entries), cached: one tiny device reduction and one host read per graph.  The closed-form layer kernel
-        that aggregates inside (dif_simple_layer_gather_*) walks the 16 rows of a tile in lock step to the longest of them,
-        so it is only taken for graphs without long rows (a citation graph's hub of a few hundred entries would hold its wave
-        for tens of microseconds; the SpMM kernels split such rows over lanes)."""
+        """Longest row (entries).  `build` gets it from the CSR kernels with the host read a build has anyway
+        (dif_csr_build status[1]) and graph_utils.subgraph_batches sets it for the batches it registers, so the kernel
+        choice that depends on it (the closed-form layer kernel aggregates inside only when no row is long: its 16 rows of a
+        tile walk in lock step) is a function of the graph alone -- identical calls launch identical kernels.  A CSR put
+        together by hand pays one reduction and one host read here, once."""
+        if self._max_degree is None and self._max_source is not None:
+            rows, b = self._max_source
+            self._max_degree, self._max_source = int(rows.resolve()[b]), None
         if self._max_degree is None:
             self._max_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.num_nodes > 0 else 0
-        return self._max_degree
-
-    def max_degree_if_known(self):
-        """max_degree() without ever stalling the host: the first call on a new graph only ENQUEUES the reduction and a copy
-        into pinned memory and answers None (callers then take the path that is safe for any row length); a later call picks
-        the value up once it has arrived.  A host read right after the CSR build would drain the queue in front of the
-        forward -- measured at ~0.1 ms per mini-batch of a Pokec epoch, more than the faster path saves on a graph used once."""
-        if self._max_degree is not None:
-            return self._max_degree
-        if not self.rowptr.is_cuda:
-            return self.max_degree()
-        if self._max_pending is None:
-            if self.num_nodes <= 0:
-                self._max_degree = 0
-                return 0
-            # a graph used once (a mini-batch of main-batch.py) never asks: even the enqueue costs a handful of launches on a
-            # host-bound forward; a graph that keeps coming back (main.py's full-graph loops) asks on its twelfth layer call
-            self._asked += 1
-            if self._asked < 12:
-                return None
-            self._max_pending = enqueue_host_reads((self.rowptr[1:] - self.rowptr[:-1]).max().reshape(1))[0]
-            return None
-        host, done, ticket = self._max_pending
-        if _PIN_NEXT[0] - ticket >= _PIN_SLOTS:          # the ring went round before anybody looked: ask again
-            self._max_pending = None
-            return None
-        if not done.query():
-            return None
-        self._max_degree, self._max_pending = int(host[0]), None
         return self._max_degree
 
     def weight_leaf(self):
@@ -462,14 +412,22 @@ class _CSRCache:
         n_blocks, block_rows = self.blocking(edge_index, edge_weight, num_nodes, row_bytes, shard, elem_size)
         key = self._key(edge_index, edge_weight, num_nodes, n_blocks, block_rows)
         hit = self.entries.get(key)
+        csr = None
         if hit is not None:
             ei_ref, ew_ref, csr = hit
             if ei_ref() is edge_index and (edge_weight is None or ew_ref() is edge_weight):
                 self.entries.move_to_end(key)
-                return csr
-            del self.entries[key]
-        csr = GraphCSR.build(edge_index, edge_weight, num_nodes, n_blocks, block_rows=block_rows)
+                if csr._format_checked or not build_format:
+                    return csr
+            else:
+                del self.entries[key]
+                csr = None
+        if csr is None:
+            csr = GraphCSR.build(edge_index, edge_weight, num_nodes, n_blocks, block_rows=block_rows)
         F = row_bytes // elem_size
+        if build_format:
+            # (also the first `build_format` request for a CSR that a pointers-only probe left here: _MixCache.get)
+            csr._format_checked = True
         if build_format and sliced_tiling(num_nodes, F, edge_index.shape[1], edge_weight, shard, elem_size) is not None:
             # the blocking above is the tiling of the sliced product: build its format now, and if the graph turns out not
             # to fit it (a (row, tile) group beyond the 16-bit counters, a split plan with another tiling), fall back to a
@@ -487,6 +445,7 @@ class _CSRCache:
                         warnings.warn("difformer_amd: this graph does not fit the feature-sliced product (see "
                                       "GraphCSR._build_sliced); using the gather kernels on their own blocking")
                     csr = GraphCSR.build(edge_index, edge_weight, num_nodes, nb2, block_rows=br2)
+                    csr._format_checked = True
         self.entries[key] = (weakref.ref(edge_index), weakref.ref(edge_weight) if edge_weight is not None else None,
                              csr)
         while len(self.entries) > max(self.capacity, getattr(self, "_floor", 0)):
@@ -834,7 +793,7 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
     want_rec = want_next and carry.get("next_record", False)
     if (csr is not None and sl is None and not sharded and not want_rec and keep is None and LAYER_GATHER and csr.n_blocks == 1 and n == csr.num_nodes and
             0 < csr.nnz <= LAYER_GATHER_MAX_DEGREE * n and hasattr(be, "_simple_layer_gather") and
-            (csr.max_degree_if_known() or LAYER_GATHER_MAX_ROW + 1) <= LAYER_GATHER_MAX_ROW):
+            csr.max_degree() <= LAYER_GATHER_MAX_ROW):
         # a few entries per row: the layer kernel walks the CSR itself, no separate SpMM launch and no `ax` round trip
         gather = (csr.rowptr, csr.src, csr.val)
     elif csr is not None:

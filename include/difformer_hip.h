@@ -169,8 +169,9 @@ int dif_batched_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float* k
  * [(n_blocks+1) x N] int32 (block-major) receives the start of every (row, block) group and the
  * SpMM sweeps the blocks in order so the gathered slice of x stays L2-resident (choose
  * n_blocks ~ N*F*4 / 2.5 MiB; 1 = plain CSR).  block_rows = 0 means ceil(N/n_blocks); a row-sharded run passes the
- * rows per rank divided by a small integer so that block boundaries coincide with rank boundaries.  status[0] (device int32) is set non-zero if any
- * index is outside [0,N).  transpose = 1 files every entry under its SOURCE row instead (same values,
+ * rows per rank divided by a small integer so that block boundaries coincide with rank boundaries.  status (device int32 [2]): status[0] is set non-zero if any
+ * index is outside [0,N); status[1] receives the length of the LONGEST row (the host reads both with the one
+ * synchronisation a build has anyway: kernel selection then never depends on when a statistic arrives).  transpose = 1 files every entry under its SOURCE row instead (same values,
  * `src` then holds the destination): the SpMM over that CSR is the adjoint A_hat^T g, i.e. the gradient
  * of gcn_conv with respect to x (loss.backward() in main.py:130).
  * dif_gcn_spmm_f32: out[r, :] = gcn_scale * sum_{e in row r} val_e * x[src_e, :]

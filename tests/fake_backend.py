@@ -72,7 +72,7 @@ class OracleBackend:
             blk = np.concatenate([kptr[:-1].reshape(num_nodes, n_blocks).T, kptr[n_blocks::n_blocks][None]], axis=0)
             blk = torch.from_numpy(blk.astype(np.int32).ravel())
         return (torch.from_numpy(rowptr), blk, torch.from_numpy(row[order].astype(np.int32)),
-                torch.from_numpy(val[order]))
+                torch.from_numpy(val[order]), int(np.diff(rowptr.astype(np.int64)).max()) if num_nodes > 0 else 0)
 
     def edge_weight_grad(self, edge_index, edge_weight, rowptr, n_nodes, g, x, scale=1.0):
         """difformer.py:73-74 under autograd, restated term by term in float32 (NaN where the source has no incoming entry)."""

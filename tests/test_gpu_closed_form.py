@@ -544,3 +544,36 @@ def test_model_on_a_sparse_graph_with_zipf_in_degrees(dtype, dev):
     p = {k: v.detach().float().cpu().double().numpy() for k, v in model.state_dict().items()}
     ref = orc.difformer_forward(p, x.double().numpy(), ei.numpy(), None, cfg)
     assert rel_err(out.float().cpu().numpy(), ref) < (TOL if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("hub", [0, 900])
+def test_identical_calls_launch_identical_kernels(hub, dev):
+    """kernel selection is a function of the graph alone.  The longest row -- which decides whether the
+    closed-form layer kernel aggregates a sparse graph itself or the SpMM kernel is launched -- comes out of the CSR build
+    (dif_csr_build status[1]) instead of an un-awaited host read that used to land some calls later: twenty calls on one
+    graph give bitwise-equal logits and the same list of entry points, from the FIRST call on."""
+    from difformer_amd import DIFFormer, ops
+    n = 20000
+    g = torch.Generator().manual_seed(9)
+    ei = torch.cat([torch.randint(0, n, (2, 3 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+    if hub:
+        ei = torch.cat([ei, torch.stack([torch.randint(0, n, (hub,), generator=g), torch.full((hub,), 7)])], dim=1)
+    ei, x = ei.to(dev), torch.randn(n, 24, generator=g).to(dev)
+    torch.manual_seed(4)
+    model = DIFFormer(24, 64, 5, num_layers=3, kernel="simple").to(dev).eval()
+    be = ops.get_backend()
+    outs, lists = [], []
+    with torch.no_grad():
+        for _ in range(20):
+            be.kernel_events = {}
+            outs.append(model(x, ei).clone())
+            lists.append(sorted((k, len(v)) for k, v in be.kernel_events.items() if k != "dif_csr_build"))
+            be.kernel_events = None
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    # the first call also builds what is cached per graph (the CSR; with a bias in Wv one extra product for A_hat 1)
+    assert all(l == lists[1] for l in lists[2:]), lists[:3]
+    assert {k for k, _ in lists[0]} == {k for k, _ in lists[1]}
+    names = {k for k, _ in lists[0]}
+    assert ("dif_gcn_spmm_f32" in names) == bool(hub)              # no long row: the layer kernel aggregates itself
+    csr = ops.csr_cache.get(ei, None, n, 64 * 4)
+    assert csr._max_degree == int((csr.rowptr[1:] - csr.rowptr[:-1]).max())
