@@ -976,12 +976,43 @@ class HipBackend:
         if ln_weight is not None:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
         out = torch.empty((n, Co), dtype=dt, device=dev)
+        from . import ops
+        if (sfx == "f32" and C > 128 and Co <= 64 and C <= 8192 and not ops.EXACT_FP32 and
+                (n < 16384 or C % 4 or ldx % 4 or x.data_ptr() % 16 or weight.data_ptr() % 16)):
+            # few rows, or rows that are only 4-byte aligned (Cora: 2,708 x 1,433): K split over the waves of a workgroup,
+            # the weights packed once per parameter version (bfloat16 hi / lo parts in MFMA fragment order)
+            packed = self._packed_weight(weight, C, Co, dev)
+            with _timed(self, "dif_linear_f32", dev):
+                rc = self.lib.dif_linear_packed_f32(_ptr(x), ldx, n, C, _ptr(packed), _ptr(bias), Co, _ptr(ln_weight), _ptr(ln_bias),
+                                                    float(eps), int(bool(relu)), _ptr(out), Co, _stream(dev))
+            _lib.check(rc, "dif_linear_packed_f32")
+            return out
         fn = getattr(self.lib, "dif_linear_" + sfx)
         with _timed(self, "dif_linear_f32", dev):
             rc = fn(_ptr(x), ldx, n, C, _ptr(weight), _ptr(bias), Co, _ptr(ln_weight), _ptr(ln_bias), float(eps),
                     int(bool(relu)), _ptr(out), Co, _stream(dev))
         _lib.check(rc, "dif_linear_" + sfx)
         return out
+
+    def _packed_weight(self, weight, C, Co, dev):
+        """dif_linear_pack_f32 of a [Co, C] float32 weight, cached per (tensor identity, version): rebuilt after optimiser
+        steps / load_state_dict (they bump the version); `.data` writes need model.invalidate_caches()."""
+        from . import ops
+        ver = ops.tensor_version(weight)
+        key = (weight.data_ptr(), ver, C, Co, str(dev))
+        cache = self.__dict__.setdefault("_packed", {})
+        hit = cache.get(key)
+        if hit is not None and ver >= 0:
+            return hit
+        packed = torch.empty(self.lib.dif_linear_packed_bytes(C), dtype=torch.uint8, device=dev)
+        with _timed(self, "dif_linear_pack_f32", dev):
+            rc = self.lib.dif_linear_pack_f32(_ptr(weight), C, Co, _ptr(packed), _stream(dev))
+        _lib.check(rc, "dif_linear_pack_f32")
+        if ver >= 0 and not torch.cuda.is_current_stream_capturing():
+            if len(cache) >= 16:
+                cache.clear()
+            cache[key] = packed
+        return packed
 
     # ---- a4 / a5 tail ----------------------------------------------------------------------
     def layer_tail_bwd(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu, grad_out, want):

@@ -1,5 +1,6 @@
 // libdifformer_hip.so: version / error plumbing of the C ABI (include/difformer_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include "dif_common.h"
 
 namespace dif {
@@ -27,3 +28,8 @@ int launch_status(const char* what) {
 
 extern "C" int dif_version(void) { return DIF_ABI_VERSION; }
 extern "C" const char* dif_last_error(void) { return dif::err_buf(); }
+
+bool dif::exact_fp32() {
+    static const bool on = [] { const char* e = getenv("DIFFORMER_EXACT_FP32"); return e && e[0] == '1'; }();
+    return on;
+}

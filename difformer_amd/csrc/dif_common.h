@@ -20,6 +20,11 @@ int launch_status(const char* what);
 int launch_record_finalize(const float* ws, int P, int64_t ws_stride, int t_main, int tiles, float* reduced,
                            hipStream_t st);
 
+// DIFFORMER_EXACT_FP32=1: products that normally run on split-bfloat16 operands (x = hi + lo, three bf16 MFMAs per product,
+// ~4e-6 of the float64 result: the long-row input Linear, the output Linear inside the last layer kernel) stay on the fp32
+// MFMA (bitwise an fmaf chain).  Read once per process.
+bool exact_fp32();
+
 constexpr int kWave = 64;         // CDNA wavefront
 constexpr int kCUs = 256;         // MI355X
 

@@ -393,6 +393,201 @@ __global__ __launch_bounds__(1024) void long_linear_resident_kernel(const float*
     }
 }
 
+// ---- long rows, FEW rows or rows that are not 16-byte aligned (Cora: 2,708 x 1,433 -> 64, difformer.py:188-191) ------------
+// The chunked kernels above give every workgroup four whole row tiles and walk K chunk by chunk: at 170 row tiles that is 43
+// workgroups of 23 dependent chunk steps each.  Here a workgroup owns ONE 16-row tile and its eight waves split K: wave w takes
+// the 64-channel chunks w, w + 8, ... with two chunks of loads in flight, the partial tiles meet in LDS in wave order
+// (deterministic), then bias, LayerNorm, ReLU and the 16-byte stores.  Rows of x only need 4-byte alignment:
+// `global_load_dwordx4` takes dword-aligned addresses, a vector that straddles the end of a row is read element by element.
+// W comes PACKED (dif_linear_pack_f32, once per parameter version): already split into bfloat16 hi / lo parts and stored
+// fragment by fragment in the order a lane feeds the MFMA -- [chunk][part * 8 + h * 4 + ft][lane] x 16 bytes -- so a wave
+// reads each fragment as ONE contiguous KiB (a lane picking its own elements out of W touches 16 weight rows per load
+// instruction, two cache lines each: the vector-memory tag rate then bounds the kernel at ~20 us for Cora) and there is no
+// per-tile conversion work.  Exact mode (DIFFORMER_EXACT_FP32=1): long_linear_ksplit_exact_kernel on the fp32 MFMA.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ f32x4 ld4_tail(const float* __restrict__ row, int c, int C_in) {
+    if (c + 3 < C_in) return *reinterpret_cast<const f32x4u*>(row + c);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (c + i < C_in) v[i] = row[c + i];
+    return v;
+}
+
+// one thread per (chunk, h * 4 + ft, lane): the lane's eight k-slots of feature 4 l15 + ft in half h of the chunk (channels
+// 64 ch + 32 h + 4 lg .. + 3 and the same + 16), hi and lo parts
+__global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restrict__ W, int C_in, int C_out, int n_chunks,
+                                                          bf16x8* __restrict__ packed) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n_chunks * 512) return;
+    const int ch = id >> 9, fr = (id >> 6) & 7, lane = id & 63;
+    const int l15 = lane & 15, lg = lane >> 4, h = fr >> 2, ft = fr & 3;
+    const int f = 4 * l15 + ft, c = 64 * ch + 32 * h + 4 * lg;
+    f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+    if (f < C_out) {
+        const float* wr = W + static_cast<int64_t>(f) * C_in;
+        w0 = ld4_tail(wr, c, C_in);
+        w1 = ld4_tail(wr, c + 16, C_in);
+    }
+    bf16x4 h0, l0, h1, l1;
+    split_bf16(w0, h0, l0);
+    split_bf16(w1, h1, l1);
+    packed[(static_cast<int64_t>(ch) * 16 + fr) * 64 + lane] = cat8(h0, h1);
+    packed[(static_cast<int64_t>(ch) * 16 + 8 + fr) * 64 + lane] = cat8(l0, l1);
+}
+
+constexpr int kPackedWaves = 8;
+
+__global__ __launch_bounds__(64 * kPackedWaves) void long_linear_packed_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows,
+                                                                               int C_in, const bf16x8* __restrict__ packed,
+                                                                               const float* __restrict__ bias, int C_out,
+                                                                               const float* __restrict__ ln_w,
+                                                                               const float* __restrict__ ln_b, float eps, int relu,
+                                                                               float* __restrict__ out, int64_t ldo, int ovec) {
+    __shared__ __attribute__((aligned(16))) f32x4 part[kPackedWaves - 1][4][64];      // partial tiles of waves 1 ..
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;                         // min(kPackedWaves, chunks): no wave without a chunk
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int n_chunks = (C_in + 63) / 64;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 16, r = r0 + l15;
+    const bool rok = r < n_rows;
+    const float* xrow = x + (rok ? r : 0) * ldx;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](f32x4 (&xa)[4], bf16x8 (&wf)[16], int ch) {
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) xa[cq] = rok ? ld4_tail(xrow, 64 * ch + 16 * cq + 4 * lg, C_in) : z4;
+        const bf16x8* wp = packed + static_cast<int64_t>(ch) * 16 * 64 + lane;
+#pragma unroll
+        for (int fr = 0; fr < 16; ++fr) wf[fr] = wp[fr * 64];
+    };
+    f32x4 y[4] = {z4, z4, z4, z4};
+    auto multiply = [&](const f32x4 (&xa)[4], const bf16x8 (&wf)[16]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x4 h0, l0, h1, l1;
+            split_bf16(xa[2 * h], h0, l0);
+            split_bf16(xa[2 * h + 1], h1, l1);
+            const bf16x8 xh = cat8(h0, h1), xl = cat8(l0, l1);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wf[4 * h + ft], y[ft], 0, 0, 0);      // small terms first
+                y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wf[8 + 4 * h + ft], y[ft], 0, 0, 0);
+                y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wf[4 * h + ft], y[ft], 0, 0, 0);
+            }
+        }
+    };
+    f32x4 xa[4], xb[4];
+    bf16x8 wa[16], wb[16];
+    int ca = wave, cb = wave + nw;
+    if (ca < n_chunks) load(xa, wa, ca);
+    if (cb < n_chunks) load(xb, wb, cb);
+    while (ca < n_chunks) {
+        multiply(xa, wa);
+        ca += 2 * nw;
+        if (ca < n_chunks) load(xa, wa, ca);
+        if (cb < n_chunks) {
+            multiply(xb, wb);
+            cb += 2 * nw;
+            if (cb < n_chunks) load(xb, wb, cb);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) part[wave - 1][ft][lane] = y[ft];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < nw - 1; ++w)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] += part[w][ft][lane];
+    f32x4 lw = z4, lb = z4;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        const int f = 4 * l15 + ft;
+        const float b = f < C_out ? bias[f] : 0.f;
+        y[ft] += f32x4{b, b, b, b};
+        if (ln_w && f < C_out) { lw[ft] = ln_w[f]; lb[ft] = ln_b[f]; }
+    }
+    finish_tile<float>(y, r0, 0, l15, lg, C_out, ln_w != nullptr, lw, lb, 1.0f / static_cast<float>(C_out), eps, relu, out, ldo,
+                       n_rows, ovec);
+}
+
+// the same split of K over four waves on the exact fp32 MFMA, operands straight from global memory (DIFFORMER_EXACT_FP32=1)
+__global__ __launch_bounds__(256) void long_linear_ksplit_exact_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C_in,
+                                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                                       int C_out, const float* __restrict__ ln_w,
+                                                                       const float* __restrict__ ln_b, float eps, int relu,
+                                                                       float* __restrict__ out, int64_t ldo, int ovec) {
+    __shared__ __attribute__((aligned(16))) f32x4 part[3][4][64];           // partial tiles of waves 1..3
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int n_chunks = (C_in + 63) / 64;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 16, r = r0 + l15;
+    const bool rok = r < n_rows;
+    const float* xrow = x + (rok ? r : 0) * ldx;
+    const float* wrow[4];
+    bool fok[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        fok[ft] = 4 * l15 + ft < C_out;
+        wrow[ft] = W + static_cast<int64_t>(fok[ft] ? 4 * l15 + ft : 0) * C_in;
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](f32x4 (&xa)[4], f32x4 (&wa)[4][4], int ch) {
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+            const int c = 64 * ch + 16 * cq + 4 * lg;
+            xa[cq] = rok ? ld4_tail(xrow, c, C_in) : z4;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) wa[ft][cq] = fok[ft] ? ld4_tail(wrow[ft], c, C_in) : z4;
+        }
+    };
+    f32x4 y[4] = {z4, z4, z4, z4};
+    f32x4 xa[4], wa[4][4], xn[4], wn[4][4];
+    if (wave < n_chunks) load(xa, wa, wave);
+    for (int ch = wave; ch < n_chunks; ch += 4) {
+        const bool more = ch + 4 < n_chunks;
+        if (more) load(xn, wn, ch + 4);
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    y[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cq][t], wa[ft][cq][t], y[ft], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                xa[cq] = xn[cq];
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) wa[ft][cq] = wn[ft][cq];
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) part[wave - 1][ft][lane] = y[ft];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] += part[w][ft][lane];
+    f32x4 lw = z4, lb = z4;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        const int f = 4 * l15 + ft;
+        const float b = f < C_out ? bias[f] : 0.f;
+        y[ft] += f32x4{b, b, b, b};
+        if (ln_w && f < C_out) { lw[ft] = ln_w[f]; lb[ft] = ln_b[f]; }
+    }
+    finish_tile<float>(y, r0, 0, l15, lg, C_out, ln_w != nullptr, lw, lb, 1.0f / static_cast<float>(C_out), eps, relu, out, ldo,
+                       n_rows, ovec);
+}
+
 // grid (row chunks, ceil(C_out/256)); 256 threads; dynamic LDS = blocks * 64 * (kLinStride + 1) floats.
 // KQ = number of 16-channel groups of C_in actually used (1..8).
 template <int KQ, typename T>
@@ -524,19 +719,33 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
     DIF_REQUIRE(n_rows > 0 && C_in > 0 && C_out > 0, DIF_E_BADARG, "dif_linear: n_rows, C_in, C_out must be positive");
     DIF_REQUIRE(x && W && bias && out, DIF_E_BADARG, "dif_linear: null pointer");
     if (C_in > 128) {                                     // long rows into a narrow layer
-        DIF_REQUIRE(C_out <= 64 && C_in % 4 == 0 && C_in <= 8192 && ldx % 4 == 0 && dif::aligned_v4<T>(x) && dif::aligned_v4<T>(W),
-                    DIF_E_SHAPE, "dif_linear: C_in > 128 needs C_out <= 64, C_in %% 4 == 0 (<= 8192) and rows of x / W aligned to "
-                    "4 elements (got %d -> %d); use the vendor GEMM", C_in, C_out);
         DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
                     "dif_linear: ln_weight and ln_bias must be given together");
         DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear: leading dimension smaller than a row");
+        const bool aligned = C_in % 4 == 0 && ldx % 4 == 0 && dif::aligned_v4<T>(x) && dif::aligned_v4<T>(W);
+        if constexpr (std::is_same<T, float>::value) {
+            // few rows, or rows that are only 4-byte aligned (C_in % 4 != 0: Cora's 1,433 features): one workgroup per 16-row
+            // tile, K split over its waves (long_linear_ksplit_kernel)
+            if (C_out <= 64 && C_in <= 8192 && (dif::exact_fp32() ? (!aligned || n_rows < 16384) : !aligned)) {
+                // exact mode, or rows the chunked kernels cannot take: K split over four waves on the fp32 MFMA.  (The fast form
+                // of this shape is dif_linear_packed_f32, which the host calls with the packed weights it caches.)
+                const int ov = (ldo % 4 == 0) && dif::aligned_v4<T>(out);
+                const unsigned tiles = static_cast<unsigned>((n_rows + 15) / 16);
+                hipLaunchKernelGGL(long_linear_ksplit_exact_kernel, dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx,
+                                   n_rows, C_in, W, bias, C_out, ln_weight, ln_bias, ln_eps, relu, out, ldo, ov);
+                return dif::launch_status("long_linear_ksplit_exact_kernel");
+            }
+        }
+        DIF_REQUIRE(C_out <= 64 && C_in <= 8192 && aligned,
+                    DIF_E_SHAPE, "dif_linear: C_in > 128 needs C_out <= 64, C_in <= 8192 and (bfloat16 storage) C_in %% 4 == 0 with "
+                    "rows of x / W aligned to 4 elements (got %d -> %d); use the vendor GEMM", C_in, C_out);
         const int64_t groups = ((n_rows + 15) / 16 + 3) / 4;
         int64_t g = groups < 4 * dif::kCUs ? groups : 4 * dif::kCUs;      // 35 KB of LDS: four workgroups per CU
         const int ov = (ldo % 4 == 0) && dif::aligned_v4<T>(out);
         if constexpr (std::is_same<T, float>::value) {
             // float32 storage: split-bfloat16 operands on the bf16 matrix core (DIFFORMER_LINEAR_FP32_MFMA=1: the exact
             // fp32-MFMA kernel, for A/B measurements)
-            static const bool exact = [] { const char* e = getenv("DIFFORMER_LINEAR_FP32_MFMA"); return e && e[0] == '1'; }();
+            static const bool exact = dif::exact_fp32() || [] { const char* e = getenv("DIFFORMER_LINEAR_FP32_MFMA"); return e && e[0] == '1'; }();
             if (!exact && C_in <= 64 * kResidentChunks && n_rows >= 32768) {     // below: the chunked kernel's many small workgroups win
                 const int64_t tiles = (n_rows + 15) / 16;
                 const int64_t wg = (tiles + 15) / 16 < dif::kCUs ? (tiles + 15) / 16 : dif::kCUs;      // one 16-wave workgroup per CU
@@ -599,6 +808,38 @@ extern "C" int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C
                               int C_out, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
                               float* out, int64_t ldo, dif_stream_t stream) {
     return linear_entry<float>(x, ldx, n_rows, C_in, W, bias, C_out, ln_weight, ln_bias, ln_eps, relu, out, ldo, stream);
+}
+
+extern "C" int64_t dif_linear_packed_bytes(int C_in) {
+    return C_in > 0 ? static_cast<int64_t>((C_in + 63) / 64) * 16 * 64 * 16 : 0;
+}
+
+extern "C" int dif_linear_pack_f32(const float* W, int C_in, int C_out, void* packed, dif_stream_t stream) {
+    DIF_REQUIRE(W && packed && C_in > 0 && C_out > 0 && C_out <= 64, DIF_E_BADARG, "dif_linear_pack_f32: needs W, packed, 0 < C_out <= 64");
+    DIF_REQUIRE(dif::aligned16(packed), DIF_E_BADARG, "dif_linear_pack_f32: packed must be 16-byte aligned");
+    const int n_chunks = (C_in + 63) / 64;
+    hipLaunchKernelGGL(linear_pack_kernel, dim3(static_cast<unsigned>(n_chunks * 2)), dim3(256), 0, static_cast<hipStream_t>(stream), W,
+                       C_in, C_out, n_chunks, static_cast<bf16x8*>(packed));
+    return dif::launch_status("linear_pack_kernel");
+}
+
+extern "C" int dif_linear_packed_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const void* packed, const float* bias,
+                                     int C_out, const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out,
+                                     int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(n_rows > 0 && C_in > 0 && C_out > 0 && C_out <= 64, DIF_E_BADARG, "dif_linear_packed_f32: needs n_rows, C_in > 0 and 0 < C_out <= 64");
+    DIF_REQUIRE(x && packed && bias && out, DIF_E_BADARG, "dif_linear_packed_f32: null pointer");
+    DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
+                "dif_linear_packed_f32: ln_weight and ln_bias must be given together");
+    DIF_REQUIRE(ldx >= C_in && ldo >= C_out && dif::aligned16(packed), DIF_E_BADARG,
+                "dif_linear_packed_f32: leading dimension smaller than a row, or packed not 16-byte aligned");
+    DIF_REQUIRE((n_rows + 15) / 16 < (int64_t(1) << 31), DIF_E_RANGE, "dif_linear_packed_f32: too many rows");
+    const int ov = (ldo % 4 == 0) && dif::aligned16(out);
+    const int n_chunks = (C_in + 63) / 64;
+    hipLaunchKernelGGL(long_linear_packed_kernel, dim3(static_cast<unsigned>((n_rows + 15) / 16)),
+                       dim3(64 * (n_chunks < kPackedWaves ? n_chunks : kPackedWaves)), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, n_rows, C_in, static_cast<const bf16x8*>(packed), bias, C_out, ln_weight,
+                       ln_bias, ln_eps, relu, out, ldo, ov);
+    return dif::launch_status("long_linear_packed_kernel");
 }
 
 extern "C" int dif_linear_bf16(const void* x, int64_t ldx, int64_t n_rows, int C_in, const void* W, const void* bias,

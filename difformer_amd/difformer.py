@@ -491,7 +491,8 @@ class DIFFormer(nn.Module):
             # the last closed-form layer applies the output Linear (:208) to its rows in the same pass (inference)
             last = i + 1 == len(self.convs)
             fc = self.fcs[-1]
-            carry["head"] = (fc.weight, fc.bias) if (last and not self.training and not ag._needs_grad(x, fc.weight, fc.bias)) else None
+            carry["head"] = (fc.weight, fc.bias) if (last and not self.training and not ops.EXACT_FP32 and
+                                                     not ag._needs_grad(x, fc.weight, fc.bias)) else None
             # head mean, + layer_[0] (use_source), alpha-residual, LayerNorm ride in the last kernel of the
             # layer (:137-140, :200-203)
             x, _, _ = conv._layer(x, x, edge_index, edge_weight, layer_[0] if conv.use_source else None,

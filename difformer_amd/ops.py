@@ -670,6 +670,10 @@ def side_stream(dev):
 
 
 SIDE_CHAIN = os.environ.get("DIFFORMER_SIDE_CHAIN", "1") != "0"
+# DIFFORMER_EXACT_FP32=1: no product of the forward runs on split-bfloat16 operands -- the long-row input Linear takes the
+# fp32 MFMA (the library reads the same variable), and the output Linear is not folded into the last layer kernel (whose
+# extra product is a split-bfloat16 one) but runs as its own fp32-MFMA launch.  Results move by ~4e-6 of the logits' scale.
+EXACT_FP32 = os.environ.get("DIFFORMER_EXACT_FP32", "0") == "1"
 
 _F32_PARAMS = OrderedDict()
 
@@ -695,8 +699,11 @@ def f32_param(t):
 
 
 def invalidate_param_caches():
-    """Forget the cached float32 copies of bfloat16 parameters (see param_key for when this is needed)."""
+    """Forget the cached float32 copies of bfloat16 parameters and the packed weights of the long-row Linear (see
+    param_key for when this is needed)."""
     _F32_PARAMS.clear()
+    if _BACKEND is not None and hasattr(_BACKEND, "_packed"):
+        _BACKEND._packed.clear()
 
 
 def slice_sharded(shard, C, dtype=torch.float32):

@@ -491,11 +491,23 @@ int dif_layer_tail_bwd_f32(const float* conv, int64_t ldc, int64_t n_rows, int H
  * a5 ends  input MLP  difformer.py:188-191 (Linear -> LayerNorm -> ReLU)  and output Linear :208 for the
  * narrow shapes of this model:  out = x W^T + b  [-> LayerNorm(ln_weight, ln_bias, eps)] [-> ReLU].
  * x [n_rows, C_in], W [C_out, C_in] (nn.Linear layout), b [C_out].  Covers C_in <= 128 (and C_out <= 64
- * when LayerNorm is fused); DIF_E_SHAPE otherwise -- the host then uses the vendor GEMM.
+ * when LayerNorm is fused) and long rows into a narrow layer (128 < C_in <= 8192 -> C_out <= 64: the input MLP on
+ * bag-of-words / embedding features); DIF_E_SHAPE otherwise -- the host then uses the vendor GEMM.
+ * Long rows, float32: the products run on split-bfloat16 operands (x = hi + lo, three bf16 MFMAs, fp32 accumulation,
+ * ~4e-6 of the float64 result) unless DIFFORMER_EXACT_FP32=1 is set in the environment (fp32 MFMA = an fmaf chain).
+ * dif_linear_packed_f32 is the form for FEW rows (< 16,384) or rows that are only 4-byte aligned (C_in % 4 != 0: Cora's
+ * 1,433 features): one workgroup per 16-row tile, K split over its eight waves, W given PACKED -- split into bfloat16
+ * hi / lo parts and laid out fragment by fragment ([ceil(C_in / 64)][16][64 lanes] x 16 bytes = dif_linear_packed_bytes)
+ * by dif_linear_pack_f32, which the host runs once per parameter version.
  * ------------------------------------------------------------------------------------- */
 int dif_linear_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const float* W,
                    const float* bias, int C_out, const float* ln_weight, const float* ln_bias,
                    float ln_eps, int relu, float* out, int64_t ldo, dif_stream_t stream);
+int64_t dif_linear_packed_bytes(int C_in);
+int dif_linear_pack_f32(const float* W, int C_in, int C_out, void* packed, dif_stream_t stream);
+int dif_linear_packed_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const void* packed,
+                          const float* bias, int C_out, const float* ln_weight, const float* ln_bias,
+                          float ln_eps, int relu, float* out, int64_t ldo, dif_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a1 backward: gradient of full_attention_conv(..., 'simple') (difformer.py:18-39) w.r.t. q, k, v -- what

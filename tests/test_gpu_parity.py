@@ -447,10 +447,15 @@ def test_skinny_linear_odd_widths_and_views(n, ci, co, dtype, dev):
 
 
 @pytest.mark.parametrize("n,ci,co,ln,relu", [(50000, 512, 64, True, True), (20000, 1432, 64, True, True), (3001, 132, 10, False, False),
-                                              (17, 516, 33, True, False), (40000, 300, 64, False, True), (5000, 2048, 7, True, True)])
+                                              (17, 516, 33, True, False), (40000, 300, 64, False, True), (5000, 2048, 7, True, True),
+                                              (2708, 1433, 64, True, True),        # Cora (BASELINE C1 / C2): rows 4-byte aligned only
+                                              (19717, 500, 64, True, True),        # Pubmed
+                                              (30000, 1433, 64, True, True), (1, 129, 1, False, False), (33, 131, 64, True, False),
+                                              (2708, 8191, 64, False, True)])
 def test_long_linear_vs_numpy(n, ci, co, ln, relu, dev):
     """Long rows into a narrow layer (the input MLP on image / text embeddings, difformer.py:188-191): K in 64-channel chunks
-    through double-buffered LDS weights; row counts that leave waves without a tile, widths that are not multiples of 64."""
+    through double-buffered LDS weights; row counts that leave waves without a tile, widths that are not multiples of 64 --
+    and of 4: few rows or rows that are not 16-byte aligned take the kernel that splits K over a workgroup's waves."""
     from difformer_amd import ops
     g = torch.Generator().manual_seed(ci * 100 + co)
     x = torch.randn(n, ci, generator=g)
@@ -465,7 +470,7 @@ def test_long_linear_vs_numpy(n, ci, co, ln, relu, dev):
         ref = np.maximum(ref, 0)
     assert rel_err(out.cpu().numpy(), ref) < 1e-5
     assert torch.equal(out, be.linear(x.to(dev), W.to(dev), b.to(dev), lw.to(dev) if ln else None, lb.to(dev) if ln else None, 1e-5, relu))
-    if n >= 16384:      # bfloat16 storage of the same layer
+    if n >= 16384 and ci % 4 == 0:      # bfloat16 storage of the same layer (rows aligned to 4 elements)
         bf = lambda t: t.to(torch.bfloat16)
         ob = be.linear(bf(x).to(dev), bf(W).to(dev), bf(b).to(dev), bf(lw).to(dev) if ln else None, bf(lb).to(dev) if ln else None,
                        1e-5, relu)
@@ -1584,3 +1589,49 @@ def test_repeated_inference_forwards_are_captured_and_stay_correct(dev):
     model.train()
     out_t = model(x, ei)                                               # training: never captured
     assert out_t.requires_grad and model._ag_state[2] is None
+
+
+def test_exact_fp32_switch_keeps_every_product_on_the_fp32_core(dev):
+    """DIFFORMER_EXACT_FP32=1 (read once per process, so this runs in a child): the long-row input Linear takes the fp32
+    MFMA and the output Linear is its own launch instead of the split-bfloat16 product inside the last layer kernel; the
+    logits agree with the default build of the same forward to the few 1e-6 the split operands move them, and with the
+    float64 oracle to 1e-4."""
+    import os, subprocess, sys, json
+    code = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, ".")
+from difformer_amd import DIFFormer, ops
+from oracle import difformer_oracle as orc
+dev = torch.device("cuda:0")
+torch.manual_seed(5)
+n, f_in, c = 9000, 260, 12
+model = DIFFormer(f_in, 64, c, num_layers=2, kernel="simple").to(dev).eval()
+g = torch.Generator().manual_seed(6)
+x = torch.randn(n, f_in, generator=g)
+ei = torch.cat([torch.randint(0, n, (2, 50 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+be = ops.get_backend()
+be.kernel_events = {}
+with torch.no_grad():
+    y = model(x.to(dev), ei.to(dev)).cpu().numpy()
+calls = {k: len(v) for k, v in be.kernel_events.items()}
+cfg = dict(hidden_channels=64, num_layers=2, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+           use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+p = {k: v.detach().cpu().double().numpy() for k, v in model.state_dict().items()}
+ref = orc.difformer_forward(p, x.double().numpy(), ei.numpy(), None, cfg)
+np.save(sys.argv[1], y)
+print(json.dumps({"calls": calls, "err": float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            env = dict(os.environ, DIFFORMER_EXACT_FP32=flag)
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(td, f"y{flag}.npy")], cwd=root, env=env,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[flag] = (json.loads(r.stdout.strip().splitlines()[-1]), np.load(os.path.join(td, f"y{flag}.npy")))
+    (d0, y0), (d1, y1) = outs["0"], outs["1"]
+    assert d0["err"] < TOL and d1["err"] < TOL
+    assert d0["calls"].get("dif_linear_f32", 0) == 1 and d1["calls"].get("dif_linear_f32", 0) == 2     # input (+ output) Linear
+    assert rel_err(y1, y0) < 5e-5 and d1["err"] <= d0["err"] * 1.5 + 1e-7
