@@ -672,6 +672,32 @@ class HipBackend:
         _lib.check(rc, "dif_gram_f32")
         return record, ys
 
+    def input_gram(self, x, weight, bias, ln_weight, ln_bias, eps, relu, rowptr=None, plan=None):
+        """Input layer + the first closed-form layer's products in one pass (csrc/simple_layer.hip, input_gram_kernel):
+        x [n, C_in <= 64] fp32 -> (h = ReLU(LayerNorm(x W^T + b)) [n, D], record of h as `gram` leaves it, ys | None)."""
+        dev = _require_device(x, weight, bias, ln_weight, ln_bias, rowptr)
+        for t, name in ((x, "x"), (weight, "weight"), (bias, "bias")):
+            _f32(t, name)
+        n, C = x.shape
+        D = weight.shape[0]
+        x, ldx = _row_major(x, C)
+        weight, bias = weight.contiguous(), bias.contiguous()
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        record = torch.empty(D * D + D + 2, dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.dif_gram_workspace_bytes(n, D)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        ys = None
+        if plan is not None:
+            ys = torch.empty((D // 4, int(plan[6]) * int(plan[7]), 4), dtype=torch.float32, device=dev)
+        with _timed(self, "dif_input_gram_f32", dev):
+            rc = self.lib.dif_input_gram_f32(_ptr(x), ldx, n, C, _ptr(weight), _ptr(bias), D, _ptr(ln_weight), _ptr(ln_bias),
+                                             float(eps), int(bool(relu)), _ptr(out), D, _ptr(rowptr) if plan is not None else None,
+                                             plan, _ptr(ys), _ptr(record), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_input_gram_f32")
+        return out, record, ys
+
     def simple_coeffs(self, record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale):
         dev = _require_device(record, Wq, bq, Wk, bk, Wv, bv)
         ws_ = [None if t is None else _f32(t, "weight").contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
@@ -995,23 +1021,27 @@ class HipBackend:
         return out
 
     def _packed_weight(self, weight, C, Co, dev):
-        """dif_linear_pack_f32 of a [Co, C] float32 weight, cached per (tensor identity, version): rebuilt after optimiser
-        steps / load_state_dict (they bump the version); `.data` writes need model.invalidate_caches()."""
+        """dif_linear_pack_f32 of a [Co, C] float32 weight, cached per tensor (identity through a weak reference + data_ptr +
+        version, like the CSR cache: a new tensor at a recycled address must not find the old packing): rebuilt after
+        optimiser steps / load_state_dict (they bump the version); `.data` writes need model.invalidate_caches()."""
+        import weakref
         from . import ops
         ver = ops.tensor_version(weight)
-        key = (weight.data_ptr(), ver, C, Co, str(dev))
+        key = (id(weight), weight.data_ptr(), ver, C, Co, str(dev))
         cache = self.__dict__.setdefault("_packed", {})
         hit = cache.get(key)
-        if hit is not None and ver >= 0:
-            return hit
+        if hit is not None and ver >= 0 and hit[0]() is weight:
+            return hit[1]
         packed = torch.empty(self.lib.dif_linear_packed_bytes(C), dtype=torch.uint8, device=dev)
         with _timed(self, "dif_linear_pack_f32", dev):
             rc = self.lib.dif_linear_pack_f32(_ptr(weight), C, Co, _ptr(packed), _stream(dev))
         _lib.check(rc, "dif_linear_pack_f32")
-        if ver >= 0 and not torch.cuda.is_current_stream_capturing():
+        if ver >= 0:
+            for k in [k for k, v in cache.items() if v[0]() is None]:
+                del cache[k]
             if len(cache) >= 16:
                 cache.clear()
-            cache[key] = packed
+            cache[key] = (weakref.ref(weight), packed)
         return packed
 
     # ---- a4 / a5 tail ----------------------------------------------------------------------

@@ -30,6 +30,36 @@ constexpr int kCUs = 256;         // MI355X
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), every lane gets the total: four v_add_f32 with DPP operands
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute round trips through the
+// LDS crossbar.  Bitwise equal to the xor butterfly (1, 2, 4, 8): after each step all lanes of the merged group hold the
+// same partial sum, so the mirrored partner carries exactly the value the xor partner would.
+template <int CTRL>
+__device__ __forceinline__ float dpp_take(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_take<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_take<0x141>(v);     // row_half_mirror
+    v += dpp_take<0x140>(v);     // row_mirror
+    return v;
+}
+
+// Sum over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48), every lane gets the total: gfx950's
+// v_permlane16_swap / v_permlane32_swap (odd rows of one copy <-> even rows of the other; upper half <-> lower half) and two adds
+// instead of two ds_bpermute round trips.  Bitwise equal to `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`.  Inline assembly: the
+// compiler's builtin returns both results in one register on ROCm 7.2 (v_add v1, v1, v1), and it needs the two wait states
+// the compiler would insert after the VALU writes of the operands.
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // (not volatile: a pure function of a, b)
+    a += b;
+    b = a;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -81,8 +81,7 @@ __global__ __launch_bounds__(64) void gram_bg_kernel(const float* __restrict__ x
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         float a = sx[t];
-        a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
+        a = dif::rows4_sum(a);
         if (lg == 0 && 4 * l15 + t < C) rec[C * C + 4 * l15 + t] = a;
     }
 }

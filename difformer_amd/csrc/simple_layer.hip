@@ -151,6 +151,196 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const T* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Input layer + Gram record + slice-major copy in ONE pass (difformer.py:188-191 feeding the first closed-form layer on a
+// dense graph): h = ReLU(LayerNorm(x W^T + b)) for narrow inputs (C_in <= 64: ogbn-proteins has 8 features), written row-major
+// (the layer kernel's operand), written again slice-major and scaled by deg^-1/2 (the sliced product's operand), and
+// accumulated into h^T h | sum h (the coefficients' operand) -- three kernels of round 3 (skinny_linear 22 us, gram + copy
+// 24 us at C4: h written once and read back once) in one, with h never read back.
+// The product runs UNtransposed (rows of x as the A operand): a lane then holds y[ft][reg] = h[r0 + 4 lg + reg][4 l15 + ft],
+// (rows permuted inside the tile, see load_x), i.e. for each of its four rows the 16-byte slice l15 -- one row-major store,
+// one slice-major store -- and, read as
+// A[i = l15][k = lg] / B[k = lg][j = l15], the operands of the row-contracting Gram MFMAs without a trip through LDS:
+//   acc[(ta, tb)] += sum over reg of mfma(y[ta][reg], y[tb][reg])  ->  G[4 (4 lg + reg) + ta][4 l15 + tb], as gram_kernel.
+// ------------------------------------------------------------------------------------------------------------
+template <int KQ>
+__global__ __launch_bounds__(64 * kGramWaves, 2) void input_gram_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C_in,
+                                                                        const float* __restrict__ W, const float* __restrict__ bias,
+                                                                        int D, const float* __restrict__ ln_w,
+                                                                        const float* __restrict__ ln_b, float eps, int relu,
+                                                                        float* __restrict__ out, int64_t ldo,
+                                                                        const int32_t* __restrict__ rowptr, f32x4* __restrict__ ys,
+                                                                        int64_t npad, float* __restrict__ ws, int64_t ws_stride,
+                                                                        int xvec) {
+    constexpr int kStride = 16 * KQ + 4;             // floats per LDS weight row: b128 reads of 16 rows spread over the banks
+    __shared__ __attribute__((aligned(16))) float sm_w[64 * kStride];     // row 16 (f % 4) + f / 4 = feature f
+    __shared__ float sm_f[4 * 40 * 64];
+    __shared__ float sm_s[kGramWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    for (int e = threadIdx.x; e < 64 * 16 * KQ; e += 64 * kGramWaves) {
+        const int f = e / (16 * KQ), c = e % (16 * KQ);
+        sm_w[(16 * (f & 3) + (f >> 2)) * kStride + c] = (f < D && c < C_in) ? W[static_cast<int64_t>(f) * C_in + c] : 0.f;
+    }
+    f32x4 bv = zero4(), lw = zero4(), lb = zero4();
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        const int f = 4 * l15 + ft;
+        if (f < D) {
+            bv[ft] = bias[f];
+            if (ln_w) { lw[ft] = ln_w[f]; lb[ft] = ln_b[f]; }
+        }
+    }
+    const bool col_ok = 4 * l15 < D;                 // D % 4 == 0: the lane's four features are all real or all padding
+    const float inv_d = 1.0f / static_cast<float>(D);
+    __syncthreads();
+    f32x4 acc[10];
+#pragma unroll
+    for (int a = 0; a < 10; ++a) acc[a] = zero4();
+    f32x4 sx = zero4();
+    const int64_t n16 = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kGramWaves + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kGramWaves;
+    // Row i of the MFMA tile is row 4 (i % 4) + i / 4 of the 16-row tile: the lane's four result rows (i = 4 lg + reg) are
+    // then rows 4 reg + lg, so that for one reg the four lanes of a slice hold four CONSECUTIVE rows -- 64 contiguous bytes
+    // of the slice-major copy per store instruction instead of four 16-byte pieces 64 bytes apart.
+    const int prow = 4 * (l15 & 3) + (l15 >> 2);
+    auto load_x = [&](f32x4 (&xa)[KQ], int64_t tile) {
+        const int64_t r = tile * 16 + prow;
+#pragma unroll
+        for (int cq = 0; cq < KQ; ++cq) {
+            const int c = 16 * cq + 4 * lg;
+            f32x4 z = zero4();
+            if (r < n_rows) {
+                const float* p = x + r * ldx + c;
+                if (xvec && c + 3 < C_in) z = *reinterpret_cast<const f32x4*>(p);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (c + i < C_in) z[i] = p[i];
+                }
+            }
+            xa[cq] = z;
+        }
+    };
+    f32x4 xa[KQ], xn[KQ];
+    if (first < n16) load_x(xa, first);
+    for (int64_t tile = first; tile < n16; tile += stride) {
+        if (tile + stride < n16) load_x(xn, tile + stride);
+        f32x4 y[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] = f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
+        const float* wrow = sm_w + l15 * kStride + 4 * lg;
+#pragma unroll
+        for (int cq = 0; cq < KQ; ++cq)
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + 16 * ft * kStride + 16 * cq);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cq][t], wf[t], y[ft], 0, 0, 0);
+            }
+        // LayerNorm over the D features of each of the lane's four rows (a row's features: 16 lanes x 4 tiles), ReLU
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (ln_w) {
+                float sm = 0.f;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) sm += col_ok ? y[ft][reg] : 0.f;
+                sm = dif::row16_sum(sm);
+                const float mu = sm * inv_d;
+                float v = 0.f;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) { const float dz = col_ok ? y[ft][reg] - mu : 0.f; v += dz * dz; }
+                v = dif::row16_sum(v);
+                const float rstd = 1.0f / sqrtf(v * inv_d + eps);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) y[ft][reg] = (y[ft][reg] - mu) * rstd * lw[ft] + lb[ft];
+            }
+            const int64_t row = tile * 16 + 4 * reg + lg;
+            const bool ok = row < n_rows && col_ok;
+            f32x4 h = {y[0][reg], y[1][reg], y[2][reg], y[3][reg]};
+            if (relu) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = fmaxf(h[i], 0.f);
+            }
+            if (!ok) h = zero4();                       // rows past the matrix / padding columns stay out of the record
+            if (ok) {
+                *reinterpret_cast<f32x4*>(out + row * ldo + 4 * l15) = h;
+                if (ys) ys[static_cast<int64_t>(l15) * npad + row] = h * dinv_of(rowptr, row);
+            }
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) y[ft][reg] = h[ft];
+            sx += h;
+        }
+        // Gram: contraction over the 16 rows of the tile, four rows (k = lg) per MFMA
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            int a = 0;
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = ta; tb < 4; ++tb, ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[ta][reg], y[tb][reg], acc[a], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cq = 0; cq < KQ; ++cq) xa[cq] = xn[cq];
+    }
+    if (ys) {                 // rows n_rows .. npad-1 of the copy are read by the last tile of the sweep: zero them
+        const int64_t pad = npad - n_rows;
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pad * 16;
+             i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+            const int64_t sl = i / pad, r = n_rows + i % pad;
+            if (4 * sl < D) ys[sl * npad + r] = zero4();
+        }
+    }
+    // column sums: this lane's sx covers rows 4 lg + reg of every tile, features 4 l15 + t
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float a = sx[t];
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        if (lg == 0) sm_s[wave][4 * l15 + t] = a;
+    }
+    // fold the eight waves as gram_kernel does: ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
+#pragma unroll
+    for (int half = kGramWaves / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) sm_f[((wave - half) * 40 + i * 4 + reg) * 64 + lane] = acc[i][reg];
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[i][reg] += sm_f[(wave * 40 + i * 4 + reg) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
+    if (wave == 0) {
+        int i = 0;
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = ta; tb < 4; ++tb, ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int gi = 4 * (4 * lg + reg) + ta, gj = 4 * l15 + tb;
+                    if (gi < D && gj < D) {
+                        rec[gi * D + gj] = acc[i][reg];
+                        if (ta != tb) rec[gj * D + gi] = acc[i][reg];
+                    }
+                }
+    } else if (wave == 1 && lane < D) {
+        float a = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < kGramWaves; ++w2) a += sm_s[w2][lane];
+        rec[D * D + lane] = a;
+    }
+}
+
 // workgroups of kWaves waves; `per_cu` = how many of them fit a CU (registers / LDS of the kernel in question)
 int row_chunks(int64_t n_rows, int per_cu, int waves = kWaves) {
     const int64_t tiles = (n_rows + 15) / 16;
@@ -907,6 +1097,40 @@ int gram_entry(const T* x, int64_t ldx, int64_t n_rows, int C, const int32_t* ro
 extern "C" int dif_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C, const int32_t* rowptr, const int32_t* plan,
                             float* ys, float* record, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
     return gram_entry<float>(x, ldx, n_rows, C, rowptr, plan, ys, record, workspace, workspace_bytes, stream);
+}
+
+// Input layer (Linear -> LayerNorm -> ReLU, C_in <= 64 -> D <= 64, D % 4 == 0) + Gram record of its OUTPUT + slice-major copy
+// (ys / rowptr / plan nullable together) in one pass; out [n_rows, D] row-major.  workspace: dif_gram_workspace_bytes(n_rows, D).
+extern "C" int dif_input_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const float* W, const float* bias, int D,
+                                  const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo,
+                                  const int32_t* rowptr, const int32_t* plan, float* ys, float* record, void* workspace,
+                                  size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(x && W && bias && out && record && workspace && n_rows > 0, DIF_E_BADARG, "dif_input_gram: null pointer or no rows");
+    DIF_REQUIRE(C_in > 0 && C_in <= 64 && D > 0 && D <= 64 && D % 4 == 0, DIF_E_SHAPE,
+                "dif_input_gram: covers C_in <= 64 -> D <= 64, D %% 4 == 0 (got %d -> %d)", C_in, D);
+    DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG, "dif_input_gram: ln_weight and ln_bias must be given together");
+    DIF_REQUIRE(ldx >= C_in && ldo >= D && ldo % 4 == 0 && dif::aligned16(out), DIF_E_BADARG,
+                "dif_input_gram: rows of out must be 16-byte aligned, leading dimensions >= the row lengths");
+    DIF_REQUIRE(workspace_bytes >= dif_gram_workspace_bytes(n_rows, D), DIF_E_WORKSPACE, "dif_input_gram: workspace too small");
+    DIF_REQUIRE((ys == nullptr) || (rowptr && plan && dif::aligned16(ys)), DIF_E_BADARG,
+                "dif_input_gram: the slice-major copy needs rowptr, the plan and a 16-byte aligned buffer");
+    int64_t npad = 0;
+    if (ys) {
+        npad = static_cast<int64_t>(plan[6]) * plan[7];
+        DIF_REQUIRE(plan[0] == D / 4 && npad >= n_rows, DIF_E_BADARG, "dif_input_gram: plan does not match D / n_rows");
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int P = gram_chunks(n_rows);
+    const int64_t rec = (static_cast<int64_t>(D) * D + D + 3) & ~int64_t(3);
+    float* ws = static_cast<float*>(workspace);
+    const int xvec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned16(x);
+    const int kq = (C_in + 15) / 16;
+#define DIF_IG(KQ) hipLaunchKernelGGL((input_gram_kernel<KQ>), dim3(P), dim3(64 * kGramWaves), 0, st, x, ldx, n_rows, C_in, W, bias, D, \
+                                      ln_weight, ln_bias, ln_eps, relu, out, ldo, rowptr, reinterpret_cast<f32x4*>(ys), npad, ws, rec, xvec)
+    if (kq == 1) DIF_IG(1); else if (kq == 2) DIF_IG(2); else if (kq == 3) DIF_IG(3); else DIF_IG(4);
+#undef DIF_IG
+    if (int rc = dif::launch_status("input_gram_kernel")) return rc;
+    return dif::launch_record_finalize(ws, P, rec, D * D + D, 0, record, st);
 }
 
 // bfloat16 rows (BASELINE config C5), float32 record; no slice-major copy (the sliced product is float32-only)

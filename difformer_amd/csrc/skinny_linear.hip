@@ -41,15 +41,13 @@ __device__ __forceinline__ void finish_tile(f32x4 (&y)[4], int64_t r0, int fb, i
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft)
                 if (4 * l15 + ft < C_out) s += y[ft][reg];
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+            s = dif::row16_sum(s);
             const float mu = s * inv_c;
             float v = 0.f;
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft)
                 if (4 * l15 + ft < C_out) { const float dz = y[ft][reg] - mu; v += dz * dz; }
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+            v = dif::row16_sum(v);
             const float rstd = 1.0f / sqrtf(v * inv_c + eps);
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) y[ft][reg] = (y[ft][reg] - mu) * rstd * lw[ft] + lb[ft];

@@ -381,6 +381,34 @@ class DIFFormer(nn.Module):
                       bn.bias if bn is not None else None, bn.eps if bn is not None else 1e-5, relu=True)
         return F.dropout(x, p=self.dropout, training=training)
 
+    def _input_with_products(self, x, edge_index, edge_weight, conv0):
+        """Narrow input features in front of a closed-form first layer on a dense graph (BASELINE config C4: 8 -> 64): the
+        input layer's kernel also leaves the Gram record of its output and the slice-major copy the sliced product reads
+        (dif_input_gram_f32), so the hidden rows are written once and never read back before the product.
+        -> (h, products for ops.simple_layer_closed_form) or None when the shapes / flags take the separate kernels."""
+        if (self.training or conv0 is None or edge_index is None or edge_weight is not None or not conv0.use_graph or
+                conv0.row_shard is not None or conv0.kernel != 'simple' or conv0.num_heads != 1 or not self.use_bn or
+                x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.shape[1] > 64):
+            return None
+        fc, bn = self.fcs[0], self.bns[0]
+        hidden = fc.weight.shape[0]
+        if hidden > 64 or hidden % 4 or conv0.out_channels != hidden or fc.weight.dtype != torch.float32:
+            return None
+        be = ops.get_backend()
+        if not hasattr(be, "input_gram"):
+            return None
+        params = [fc.weight, fc.bias, bn.weight, bn.bias, conv0.Wq.weight, conv0.Wq.bias, conv0.Wk.weight, conv0.Wk.bias]
+        if conv0.use_weight:
+            params += [conv0.Wv.weight, conv0.Wv.bias]
+        if ag._needs_grad(x, *params):
+            return None
+        csr = ops.csr_cache.get(edge_index, None, x.shape[0], hidden * 4)
+        sl = csr.sliced(0, x.shape[0], hidden) if x.shape[0] == csr.num_nodes else None
+        if sl is None:
+            return None
+        h, record, ys = be.input_gram(x, fc.weight, fc.bias, bn.weight, bn.bias, bn.eps, True, csr.rowptr, sl.plan)
+        return h, dict(x=h, sl=sl, record=record, ys=ys)
+
     # ---- repeated inference forwards over the same operands replay as ONE hipGraph -------------------------------------
     def _graph_key(self, x, edge_index, edge_weight):
         """Identity of everything a captured forward has baked in, or None when this call must run eagerly."""
@@ -479,12 +507,16 @@ class DIFFormer(nn.Module):
             mix = ops.mix_cache.get(edge_index, x.shape[0], width)
         if mix is not None:
             x, edge_index = x[mix.perm], mix.edge_index
-        x = self._input_layer(x, self.training)                # difformer.py:188-192
-        layer_.append(x)
         # closed-form layers write the slice-major copy of their output (the next layer's SpMM operand) from their
         # registers; DIFFORMER_CHAIN_GRAM=1 makes them leave the Gram record of the output too (measured slower than the
         # stand-alone Gram pass at C4: 65 us against 33 + 23 us; profiles/r02_experiments.md)
         carry = {"next_record": _CHAIN_GRAM}
+        first = self._input_with_products(x, edge_index, edge_weight, conv0)
+        if first is not None:                                  # :188-192 and the first layer's Gram record / SpMM operand
+            x, carry["products"] = first
+        else:
+            x = self._input_layer(x, self.training)            # difformer.py:188-192
+        layer_.append(x)
         for i, conv in enumerate(self.convs):
             bn = self.bns[i + 1] if self.use_bn else None
             carry["want_next"] = (not self.training) and i + 1 < len(self.convs)

@@ -556,6 +556,14 @@ int dif_simple_apply_bf16(const void* q, int64_t ldq, const float* reduced, int6
  * dif_simple_coeffs_f32 with them.  No products for a next layer (the sliced format is float32-only). */
 int dif_gram_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
                   size_t workspace_bytes, dif_stream_t stream);
+/* Input layer + Gram record + slice-major copy in one pass (difformer.py:188-191 feeding the first closed-form layer on a
+ * dense graph): out = ReLU(LayerNorm(x W^T + b)) [n_rows, D] row-major for C_in <= 64 -> D <= 64 (D % 4 == 0), record =
+ * [out^T out | column sums] as dif_gram_f32 leaves it, ys (nullable with rowptr / plan) = the deg^-1/2-scaled slice-major
+ * copy the sliced product reads.  workspace: dif_gram_workspace_bytes(n_rows, D). */
+int dif_input_gram_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const float* W, const float* bias, int D,
+                       const float* ln_weight, const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo,
+                       const int32_t* rowptr, const int32_t* plan, float* ys, float* record, void* workspace,
+                       size_t workspace_bytes, dif_stream_t stream);
 /* ... and with the model's output Linear in the same pass (dif_simple_layer_head_f32 with bfloat16 activations and logits) */
 int dif_simple_layer_head_bf16(const void* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef, const void* ax,
                                int64_t ldax, const float* Wv, const float* bv, const float* row_sums, float gcn_scale,

@@ -577,3 +577,53 @@ def test_identical_calls_launch_identical_kernels(hub, dev):
     assert ("dif_gcn_spmm_f32" in names) == bool(hub)              # no long row: the layer kernel aggregates itself
     csr = ops.csr_cache.get(ei, None, n, 64 * 4)
     assert csr._max_degree == int((csr.rowptr[1:] - csr.rowptr[:-1]).max())
+
+
+@pytest.mark.parametrize("n,c_in,d,deg", [(9000, 8, 64, 50), (8200, 33, 64, 60), (12000, 64, 48, 50), (8193, 1, 64, 49)])
+def test_input_layer_with_gram_and_copy_in_one_pass(n, c_in, d, deg, dev):
+    """dif_input_gram_f32 (difformer.py:188-191 in front of a closed-form first layer on a dense graph): the hidden rows, their
+    Gram record and the slice-major copy against the three kernels it replaces, and against float64."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(n + c_in)
+    x = torch.randn(n, c_in, generator=g).to(dev)
+    W, b = (torch.randn(d, c_in, generator=g) / max(c_in, 1) ** 0.5).to(dev), torch.randn(d, generator=g).to(dev)
+    lw, lb = (torch.rand(d, generator=g) + 0.5).to(dev), torch.randn(d, generator=g).to(dev)
+    ei = torch.cat([torch.randint(0, n, (2, deg * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    csr = ops.csr_cache.get(ei, None, n, d * 4)
+    sl = csr.sliced(0, n, d)
+    assert sl is not None
+    h, record, ys = be.input_gram(x, W, b, lw, lb, 1e-5, True, csr.rowptr, sl.plan)
+    h_ref = be.linear(x, W, b, lw, lb, 1e-5, True)
+    rec_ref, ys_ref = be.gram(h_ref, csr.rowptr, sl.plan)
+    h64 = np.maximum(orc.layer_norm(x.double().cpu().numpy() @ W.double().cpu().numpy().T + b.double().cpu().numpy(),
+                                    lw.double().cpu().numpy(), lb.double().cpu().numpy()), 0)
+    assert rel_err(h.cpu().numpy(), h64) < 1e-5 and rel_err(h.cpu().numpy(), h_ref.cpu().numpy()) < 1e-6
+    g64 = np.concatenate([(h64.T @ h64).ravel(), h64.sum(0)])
+    assert rel_err(record[: d * d + d].cpu().numpy(), g64) < 1e-5
+    assert rel_err(record[: d * d + d].cpu().numpy(), rec_ref[: d * d + d].cpu().numpy()) < 1e-5
+    assert rel_err(ys.cpu().numpy(), ys_ref.cpu().numpy()) < 1e-6
+    h2, record2, ys2 = be.input_gram(x, W, b, lw, lb, 1e-5, True, csr.rowptr, sl.plan)
+    assert torch.equal(h, h2) and torch.equal(record, record2) and torch.equal(ys, ys2)          # deterministic
+    h3, record3, none = be.input_gram(x, W, b, None, None, 1e-5, False)                          # no LayerNorm / ReLU / copy
+    assert none is None and rel_err(h3.cpu().numpy(), x.double().cpu().numpy() @ W.double().cpu().numpy().T + b.double().cpu().numpy()) < 1e-5
+
+
+def test_model_takes_the_fused_input_kernel_on_a_dense_graph(dev):
+    from difformer_amd import DIFFormer, ops
+    n, f_in, c = 9000, 8, 11
+    torch.manual_seed(8)
+    model = DIFFormer(f_in, 64, c, num_layers=3, kernel="simple").to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, f_in, generator=g)
+    ei = torch.cat([torch.randint(0, n, (2, 50 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1)
+    be = ops.get_backend()
+    be.kernel_events = {}
+    with torch.no_grad():
+        y = model(x.to(dev), ei.to(dev)).cpu().numpy()
+    calls, be.kernel_events = {k: len(v) for k, v in be.kernel_events.items()}, None
+    assert calls.get("dif_input_gram_f32") == 1 and "dif_linear_f32" not in calls and "dif_gram_f32" not in calls, calls
+    cfg = dict(hidden_channels=64, num_layers=3, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    p = {k: v.detach().cpu().double().numpy() for k, v in model.state_dict().items()}
+    assert rel_err(y, orc.difformer_forward(p, x.double().numpy(), ei.numpy(), None, cfg)) < 1e-4

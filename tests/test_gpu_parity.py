@@ -1635,3 +1635,18 @@ print(json.dumps({"calls": calls, "err": float(np.max(np.abs(y - ref)) / np.max(
     assert d0["err"] < TOL and d1["err"] < TOL
     assert d0["calls"].get("dif_linear_f32", 0) == 1 and d1["calls"].get("dif_linear_f32", 0) == 2     # input (+ output) Linear
     assert rel_err(y1, y0) < 5e-5 and d1["err"] <= d0["err"] * 1.5 + 1e-7
+
+
+def test_packed_weight_cache_does_not_confuse_tensors_at_a_recycled_address(dev):
+    """The long-row Linear packs W once per tensor; a NEW weight that the allocator places at a freed weight's address (same
+    shape, version 0) must be packed afresh."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(300, 1433, generator=g).to(dev)
+    b = torch.zeros(64, device=dev)
+    for trial in range(6):
+        W = (torch.randn(64, 1433, generator=g) / 38.0).to(dev)
+        out = be.linear(x, W, b)
+        assert rel_err(out.cpu().numpy(), x.double().cpu().numpy() @ W.double().cpu().numpy().T) < 1e-5, trial
+        del W
