@@ -14,10 +14,13 @@ CSR build is timed separately and reported in `cold_csr_build_ms`.  With N>1 GPU
 sharded (strong scaling: total work fixed): one all-reduce of the 4,226-float reduce record and one
 all-gather of the value rows per layer over RCCL.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the gcn_conv SpMM): algorithmic
-bytes per launch = 8*nnz + 4*(N+1) + 2*n_rows*H*D*4 over its mean duration from
-HIP events recorded on the launching stream in a short pass right after the timed region (the timed
-region holds nothing but the K steps).  `cpu_baseline` times the whole forward of the oracle port
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel -- the C-ABI entry point with the largest
+share of the forward (the gcn_conv product on the headline workload): algorithmic bytes per launch =
+8*nnz + 4*(N+1) + 2*n_rows*H*D*4 over its mean duration from HIP events recorded on
+the launching stream in a short pass right after the timed region (the timed region holds nothing but the
+K steps).  For the feature-sliced product the primary figure is the LDS fraction (`"bound": "lds"`: its
+floor is above the HBM roofline, profiles/r04_experiments.md), the HBM fraction rides in `roofline.hbm`;
+the sigmoid kernel is priced against the fp32 MFMA peak.  `cpu_baseline` times the whole forward of the oracle port
 (numpy + OpenMP C) on the host cores, 1 warm-up + 3 runs, median (rank 0, N=1 only).
 """
 import argparse
@@ -303,46 +306,41 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = job_value(n, args.steps, elapsed, world, replicas)
 
-    # roofline of the dominant kernel on this rank
-    if use_graph:
-        esz = 2 if store == torch.bfloat16 else 4
-        alg_bytes = 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * esz
-        if ktimes.get("dif_sliced_spmm_f32"):
-            dom, dom_name, dom_key = "dif_sliced_spmm_f32", "sliced_spmm_kernel (gcn_conv)", "sliced_spmm_kernel"
-        elif not ktimes.get("dif_gcn_spmm_f32") and ktimes.get("dif_simple_layer_f32"):
-            # a few entries per row: the closed-form layer kernel aggregates itself (dif_simple_layer_gather_*): the CSR, the
-            # layer input once and the output once are its algorithmic bytes (the gathered rows are re-reads of the input)
-            dom, dom_key = "dif_simple_layer_f32", "simple_layer_kernel"
-            dom_name = "simple_layer_kernel<GATHER> (closed-form layer with gcn_conv's aggregation inside)"
-        else:
-            dom, dom_name, dom_key = "dif_gcn_spmm_f32", "spmm_blocked_kernel (gcn_conv)", "spmm_blocked_kernel"
-    elif kernel == "simple" and ktimes.get("dif_gram_sym_f32"):
-        # closed form beyond 128 columns (hidden 300 / 400): the Gram pass X~^T X~ on the fp32 MFMA is the largest kernel;
-        # its bound is the matrix core, not HBM: N * C * (C + 1) FLOP for the tiles on and above the diagonal
-        dom, dom_key = "dif_gram_sym_f32", "simple_reduce_kernel"
-        dom_name = "simple_reduce_kernel<sym> (Gram record of the wide closed form)"
-        alg_bytes = 1.0 * n_local * hidden * 4
-        mfma_flop = 1.0 * n_local * hidden * (hidden + 1)
-    elif kernel == "simple" and ktimes.get("dif_simple_layer_f32"):
-        # closed-form layer: reads the layer input once, writes the output once (SURVEY 8d counts q, k, v, out: 4 N d s;
-        # q, k, v never exist here)
-        dom, alg_bytes, dom_key = "dif_simple_layer_f32", 2.0 * n_local * hidden * 4, "simple_layer_kernel"
-        dom_name = "simple_layer_kernel (closed-form simple layer)"
-    elif kernel == "simple":
-        esz = 2 if store == torch.bfloat16 else 4
-        dom, alg_bytes, dom_key = "dif_simple_apply_f32", 2.0 * n_local * hidden * esz, "simple_apply_kernel"
-        dom_name = "simple_apply_kernel"
-    else:
-        dom, alg_bytes, dom_key = "dif_sigmoid_attn_f32", 4.0 * n_local * hidden * 4, "sigmoid_attn_kernel"
-        dom_name = "sigmoid_attn_kernel"
-    alone = dominant_alone(dom)        # unconditional: every rank runs the same number of forwards (collectives inside)
-    dom_ms = float(np.mean(alone)) if alone else (float(np.mean(ktimes[dom])) if ktimes.get(dom) else None)
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+    # roofline of the dominant kernel on this rank: the C-ABI entry point with the largest share of the forward (event
+    # brackets of the eager pass above), priced with the algorithmic bytes / FLOP of SURVEY.md section 8d
+    esz = 2 if store == torch.bfloat16 else 4
+    share = {k: float(np.sum(v)) for k, v in ktimes.items() if v and not k.startswith(("dif_csr", "dif_sliced_measure", "dif_sliced_emit",
+                                                                                       "dif_row_order", "dif_linear_pack"))}
+    gcn_bytes = 8.0 * nnz * (n_local / n) + 4.0 * (n + 1) + 2.0 * n_local * hidden * esz
+    # (entry point, kernel name, key into the tracked rocprofv3 / PMC files, bound, algorithmic bytes, algorithmic FLOP)
+    table = {
+        "dif_sliced_spmm_f32": ("sliced_spmm_kernel (gcn_conv)", "sliced_spmm_kernel", "lds", gcn_bytes, None),
+        "dif_gcn_spmm_f32": ("spmm_* (gcn_conv, gather kernels)", "spmm_", "hbm", gcn_bytes, None),
+        "dif_simple_layer_f32": (("simple_layer_kernel<GATHER> (closed-form layer with gcn_conv's aggregation inside)", "simple_layer_kernel",
+                                  "hbm", gcn_bytes, None) if (use_graph and not share.get("dif_gcn_spmm_f32") and not share.get("dif_sliced_spmm_f32"))
+                                 else ("simple_layer_kernel (closed-form simple layer)", "simple_layer_kernel", "hbm",
+                                       (3.0 if use_graph else 2.0) * n_local * hidden * esz, None)),
+        "dif_sigmoid_attn_f32": ("sigmoid_attn_kernel", "sigmoid_attn_kernel", "mfma", 4.0 * n_local * hidden * 4,
+                                 4.0 * n_local * n * hidden),
+        "dif_gram_sym_f32": ("simple_reduce_kernel<sym> (Gram record of the wide closed form)", "simple_reduce_kernel", "mfma",
+                             1.0 * n_local * hidden * 4, 1.0 * n_local * hidden * (hidden + 1)),
+        "dif_linear_f32": ("linear kernels (input MLP / output Linear)", "linear_", "hbm", 1.0 * n_local * (f_in + hidden) * esz, None),
+        "dif_input_gram_f32": ("input_gram_kernel (input layer + Gram record + slice-major copy)", "input_gram_kernel", "hbm",
+                               1.0 * n_local * (f_in + 2 * hidden) * 4, None),
+        "dif_simple_apply_f32": ("simple_apply_kernel", "simple_apply_kernel", "hbm", 2.0 * n_local * hidden * esz, None),
+        "dif_gram_f32": ("gram_kernel (Gram record of the layer input)", "gram_kernel", "hbm", 1.0 * n_local * hidden * esz, None),
+    }
+    ranked = sorted((k for k in share if k in table), key=lambda k: -share[k])
+    dom = ranked[0] if ranked else None
+    dom_name, dom_key, bound, alg_bytes, alg_flop = table[dom] if dom else ("none", "", "hbm", 0.0, None)
+    alone = dominant_alone(dom) if dom else None   # unconditional: every rank runs the same number of forwards (collectives inside)
+    dom_ms = float(np.mean(alone)) if alone else (float(np.mean(ktimes[dom])) if dom and ktimes.get(dom) else None)
+    hbm_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
     # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE, calibrated; scripts/pmc_traffic.sh) stored under profiles/ -- a counter run cannot
     # share a process with this timed run.  Only valid for the single-GPU workload it was collected on.
     traffic = tsrc = None
-    for tfile in ("r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
+    for tfile in ("r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
         tpath = os.path.join(ROOT, "profiles", tfile)
         if world == 1 and use_graph and os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -350,32 +348,37 @@ def main():
                 traffic = tj["kernels"][dom_key].get("hbm_bytes_per_launch")
                 tsrc = f"profiles/{tfile} (rocprofv3 PMC, separate passes)"
                 break
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                "traffic_source": tsrc,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                "avg_launch_ms_source": "HIP events on the launching stream, only this entry point bracketed (bench.py::dominant_alone)"}
-    if dom == "dif_gram_sym_f32" and dom_ms:
-        tf = mfma_flop / (dom_ms * 1e-3) / 1e12
-        roofline.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "algorithmic_flop_per_launch": mfma_flop})
-    if dom == "dif_sliced_spmm_f32" and dom_ms:
-        # What actually limits the sliced product is the LDS array (profiles/r03_experiments.md section 1): every entry is
-        # one 16-byte LDS read per 16-byte feature slice -- nnz x F x 4 bytes per launch whatever the padding -- against
-        # 256 B/clk/CU.  Reported beside the HBM figures the metric asks for.
+    src = "HIP events on the launching stream, only this entry point bracketed (bench.py::dominant_alone)"
+    hbm = {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
+           "algorithmic_bytes_per_launch": alg_bytes}
+    roofline = {"bound": bound, "kernel": dom_name, "entry_point": dom,
+                "share_of_forward": (share[dom] / sum(share.values())) if dom else None,
+                "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": dom_ms, "avg_launch_ms_source": src}
+    if bound == "hbm":
+        roofline.update(hbm)
+    elif bound == "mfma" and dom_ms:
+        tf = alg_flop / (dom_ms * 1e-3) / 1e12
+        roofline.update({"achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                         "algorithmic_flop_per_launch": alg_flop, "hbm": hbm})
+    elif bound == "lds" and dom_ms:
+        # What limits the sliced product is the LDS array together with the vector ALU (profiles/r04_experiments.md section 1):
+        # every entry is one 16-byte LDS read per 16-byte feature slice -- nnz x F x 4 bytes per launch whatever the padding --
+        # against 256 B/clk/CU; no fp32 gather-from-LDS design can reach 60 % of the HBM roofline on this graph (the LDS floor
+        # is above it), so the LDS fraction is the primary figure and the HBM fraction the metric asks for rides beside it.
         lds_bytes = 1.0 * nnz * (n_local / n) * hidden * 4
         lds_tbs = lds_bytes / (dom_ms * 1e-3) / 1e12
-        roofline["limiter"] = "lds"
-        roofline["lds"] = {"algorithmic_bytes_per_launch": lds_bytes, "achieved": lds_tbs, "peak": LDS_PEAK_TBS,
-                           "unit": "TB/s", "frac": lds_tbs / LDS_PEAK_TBS,
-                           "note": "one ds_read_b128 per (entry, 16-byte slice); peak = 256 CUs x 256 B/clk x 2.4 GHz; "
-                                   "padded lane-steps and the issue limit of the step are in profiles/r03_experiments.md"}
+        roofline.update({"achieved": lds_tbs, "peak": LDS_PEAK_TBS, "unit": "TB/s", "frac": lds_tbs / LDS_PEAK_TBS,
+                         "algorithmic_bytes_per_launch": lds_bytes, "hbm": hbm,
+                         "note": "one ds_read_b128 per (entry, 16-byte slice); peak = 256 CUs x 256 B/clk x 2.4 GHz; the step's "
+                                 "budget (adds, LDS-return register writes, entry stream) is measured in profiles/r04_experiments.md"})
     # the rocprofv3 figure the event bracket is checked against (same workload, tracked summary of this round if present)
     import glob
-    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r03_*{args.workload}*kernel_stats.csv")), reverse=True):
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r04_*{args.workload}*kernel_stats.csv")), reverse=True) + \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", f"r03_*{args.workload}*kernel_stats.csv")), reverse=True)
+    for cand in cands:
         try:
             import csv
-            rows = [r for r in csv.DictReader(open(cand)) if r.get("Name", "").find(dom_key) >= 0]
+            rows = [r for r in csv.DictReader(open(cand)) if dom_key and r.get("Name", "").find(dom_key) >= 0]
             if rows:
                 best = max(rows, key=lambda r: float(r["TotalDurationNs"]))
                 roofline["avg_launch_ms_rocprofv3"] = float(best["AverageNs"]) / 1e6
