@@ -275,6 +275,33 @@ def main():
             model(x, edge_index)
         torch.cuda.synchronize()
         fwd_ms = sorted(a.elapsed_time(b) for a, b in fwd_events)
+    # N > 1: where a rank's forward goes -- exposed collective waits (events on the compute stream around every exchange
+    # step, difformer_amd/dist.py) beside the kernels by group -- so that the first run on real xGMI links is diagnostic
+    per_rank = None
+    if shard is not None:
+        shard.timeline = []
+        be.kernel_events = {}
+        reps = min(args.steps, 3)
+        with torch.no_grad():
+            ta, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ta.record(torch.cuda.current_stream(dev))
+            for _ in range(reps):
+                model(x, edge_index)
+            tb.record(torch.cuda.current_stream(dev))
+        kt = be.kernel_times_ms()
+        be.kernel_events = None
+        coll = {k: v / reps for k, v in shard.timeline_ms().items()}
+        shard.timeline = None
+        group_of = lambda k: ("product" if ("spmm" in k or "prescale" in k) else "layer" if "simple_layer" in k or "layer_tail" in k
+                              else "record" if ("gram" in k or "coeffs" in k or "reduce" in k) else "other")
+        kern = {}
+        for k, v in kt.items():
+            kern[group_of(k)] = kern.get(group_of(k), 0.0) + float(np.sum(v)) / reps
+        mine = {"rank": rank, "rows": int(n_local), "forward_ms": ta.elapsed_time(tb) / reps, "collectives_ms": coll, "kernels_ms": kern,
+                "note": "instrumented eager forwards (an event pair around every call): read the SPLIT, not the total"}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
     ag = getattr(model, "_ag_state", None)
     if use_graph_replay:
         launch_mode = "hipGraph replay"
@@ -419,6 +446,7 @@ def main():
                        "csr": "warm (cached); cold build reported in cold_csr_build_ms",
                        "launch": launch_mode},
             "cold_csr_build_ms": cold_ms, "roofline": roofline, "cpu_baseline": cpu,
+            **({"per_rank_phases": per_rank} if per_rank is not None else {}),
         }))
     if world > 1:
         dist.destroy_process_group()

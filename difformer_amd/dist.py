@@ -60,6 +60,10 @@ class RowShard:
     # multiplies its own destination rows (one all-gather of N*C elements per layer); "slice" = every rank multiplies ALL
     # rows of ITS feature columns (two all-to-alls of N*C/world elements per rank and layer).  DIFFORMER_SHARD_PRODUCT.
     product: str = field(default_factory=lambda: os.environ.get("DIFFORMER_SHARD_PRODUCT", "row"))
+    # diagnostics (bench.py --gpus N): a list makes every exchange step append (name, begin, end) -- HIP events recorded on
+    # the compute stream around the call (what the compute stream WAITED, i.e. the exposed part of the collective), or
+    # perf_counter seconds for host tensors; None = no bookkeeping
+    timeline: Optional[list] = None
 
     def __post_init__(self):
         if not self.counts:
@@ -100,12 +104,40 @@ class RowShard:
     def local_rows(self, t: torch.Tensor) -> torch.Tensor:
         return t[self.row_begin:self.row_begin + self.n_local]
 
+    def _mark(self, t: torch.Tensor):
+        """A point on the compute stream (HIP event) or on the host clock, for `timeline`."""
+        if self.timeline is None:
+            return None
+        if t.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(t.device))
+            return ev
+        import time
+        return time.perf_counter()
+
+    def _span(self, name: str, begin, t: torch.Tensor):
+        if self.timeline is not None and begin is not None:
+            self.timeline.append((name, begin, self._mark(t)))
+
+    def timeline_ms(self):
+        """{name: total milliseconds} of the recorded exchange steps (synchronises the device)."""
+        out = {}
+        if not self.timeline:
+            return out
+        if any(not isinstance(b, float) for _, b, _ in self.timeline):
+            torch.cuda.synchronize()
+        for name, b, e in self.timeline:
+            out[name] = out.get(name, 0.0) + ((e - b) * 1e3 if isinstance(b, float) else b.elapsed_time(e))
+        return out
+
     # ---- the two exchange steps -----------------------------------------------------------
     def all_reduce_sum(self, buf: torch.Tensor) -> torch.Tensor:
         """In-place sum over ranks of the small `reduced` record of the simple kernel."""
         if self.world > 1:
+            t0 = self._mark(buf)
             dist.all_reduce(buf, op=dist.ReduceOp.SUM,
                             group=self.side_group if self.side_group is not None else self.group)
+            self._span("all_reduce(record)", t0, buf)
         return buf
 
     def all_reduce_gradients(self, params) -> None:
@@ -141,8 +173,10 @@ class RowShard:
         w = local.shape[1] // P
         send = local.reshape(n, P, w).permute(1, 0, 2).contiguous()            # [P, n_local, w]: destination-major
         out = torch.empty((self.n_global, w), dtype=local.dtype, device=local.device)
+        t0 = self._mark(local)
         dist.all_to_all_single(out, send.reshape(P * n, w), output_split_sizes=list(self.counts),
                                input_split_sizes=[n] * P, group=self.group)
+        self._span("all_to_all(columns)", t0, local)
         return out
 
     def all_to_all_rows(self, cols: torch.Tensor) -> torch.Tensor:
@@ -150,8 +184,10 @@ class RowShard:
         P, n = self.world, self.n_local
         w = cols.shape[1]
         recv = torch.empty((P * n, w), dtype=cols.dtype, device=cols.device)
+        t0 = self._mark(cols)
         dist.all_to_all_single(recv, cols.contiguous(), output_split_sizes=[n] * P, input_split_sizes=list(self.counts),
                                group=self.group)
+        self._span("all_to_all(rows)", t0, cols)
         return recv.reshape(P, n, w).permute(1, 0, 2).reshape(n, P * w)
 
     def all_gather_rows_async(self, local: torch.Tensor):
@@ -181,6 +217,7 @@ class _GatherHandle:
             padded[: shard.n_local] = local
             local = padded
         buf = torch.empty((shard.world * c,) + tail, dtype=local.dtype, device=local.device)
+        self._issued = shard._mark(local)
         self.work = dist.all_gather_into_tensor(buf, local, group=shard.group, async_op=True)
         self._keep = local
         if uniform:
@@ -193,7 +230,10 @@ class _GatherHandle:
 
     def wait(self) -> torch.Tensor:
         if self.work is not None:
+            t0 = self.shard._mark(self._keep)
             self.work.wait()
             self.work = None
+            self.shard._span("all_gather(rows): exposed wait", t0, self._keep)
+            self.shard._span("all_gather(rows): issue to landed", self._issued, self._keep)
             self.result = self.post()
         return self.result

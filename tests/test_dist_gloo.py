@@ -47,12 +47,18 @@ def _worker(rank, world, port, kernel, n, out_q, heads=2):
             shard = RowShard.from_process_group(n)
             assert shard.world == world and shard.rank == rank
             model.set_row_shard(shard)
+            shard.timeline = []                                  # bench.py --gpus N: where the exchange steps' time goes
             local = model(shard.local_rows(x).contiguous(), ei)  # LOCAL rows of x, GLOBAL edge_index
+            spans = shard.timeline_ms()
+            shard.timeline = None
+            spans_ok = "all_gather(rows): exposed wait" in spans and all(v >= 0.0 for v in spans.values())
+            if heads == 1 and kernel == "simple":
+                spans_ok = spans_ok and "all_reduce(record)" in spans          # closed form: the Gram record's all-reduce
         want = shard.local_rows(full)
         err = float((local - want).abs().max() / full.abs().max())
         # the gathered value rows must come back in global row order even when blocks are uneven
         gathered = shard.all_gather_rows(shard.local_rows(x).contiguous())
-        ok = bool(torch.equal(gathered, x))
+        ok = bool(torch.equal(gathered, x)) and spans_ok
         # ... and also for caller-chosen blocks that do not start at multiples of the largest block
         if world == 3:
             from difformer_amd.dist import RowShard as RS
@@ -216,7 +222,7 @@ def test_bench_sharding_arithmetic_dry_run(world):
     assert one["parallelism"] == "single GPU" and one["n_local"] == 132534
 
 
-def _train_worker(rank, world, port, kernel, n, heads, use_graph, out_q):
+def _train_worker(rank, world, port, kernel, n, heads, use_graph, out_q, product="row", hidden=16):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -227,7 +233,7 @@ def _train_worker(rank, world, port, kernel, n, heads, use_graph, out_q):
         from fake_backend import OracleBackend
         ops._BACKEND = OracleBackend()
         torch.manual_seed(11)
-        model = DIFFormer(12, 16, 5, num_layers=2, num_heads=heads, kernel=kernel, dropout=0.0, use_source=True,
+        model = DIFFormer(12, hidden, 5, num_layers=2, num_heads=heads, kernel=kernel, dropout=0.0, use_source=True,
                           use_graph=use_graph).train()
         g = torch.Generator().manual_seed(5)
         x = torch.randn(n, 12, generator=g)
@@ -241,6 +247,7 @@ def _train_worker(rank, world, port, kernel, n, heads, use_graph, out_q):
         model.zero_grad()
         # row-sharded: this rank's rows of the loss; parameter gradients summed over the ranks afterwards
         shard = RowShard.from_process_group(n)
+        shard.product = product
         model.set_row_shard(shard)
         xl = shard.local_rows(x).contiguous().requires_grad_(True)
         out = model(xl, ei)
@@ -254,17 +261,23 @@ def _train_worker(rank, world, port, kernel, n, heads, use_graph, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kernel,world,n,heads,use_graph", [("simple", 2, 64, 2, True), ("simple", 3, 50, 1, True),
-                                                            ("sigmoid", 2, 41, 2, True), ("simple", 2, 300, 2, True),
-                                                            ("simple", 2, 40, 1, False)])
-def test_row_sharded_training_step_matches_single_process(kernel, world, n, heads, use_graph):
+@pytest.mark.parametrize("kernel,world,n,heads,use_graph,product,hidden",
+                         [("simple", 2, 64, 2, True, "row", 16), ("simple", 3, 50, 1, True, "row", 16),
+                          ("sigmoid", 2, 41, 2, True, "row", 16), ("simple", 2, 300, 2, True, "row", 16),
+                          ("simple", 2, 40, 1, False, "row", 16),
+                          # the slice shard (RowShard.product = "slice") is an INFERENCE split of closed-form layers: a training
+                          # step under it must take the row-sharded operator path and give the same gradients -- at the
+                          # driver's largest world size, uneven last block
+                          ("simple", 8, 203, 1, True, "slice", 32), ("simple", 2, 64, 1, True, "slice", 16)])
+def test_row_sharded_training_step_matches_single_process(kernel, world, n, heads, use_graph, product, hidden):
     """loss.backward() on row shards (main.py:130): the attention's sums over nodes and the aggregation's gathered rows
     carry their gradients back through the same collectives; parameter gradients summed over ranks and the gradient
     of the local input rows equal the single-process ones."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, kernel, n, heads, use_graph, q)) for r in range(world)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, kernel, n, heads, use_graph, q, product, hidden))
+             for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]
