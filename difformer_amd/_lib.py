@@ -118,6 +118,8 @@ SIGNATURES = {
     "dif_linear_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
     "dif_input_gram_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp, c_vp, c_vp,
                                    c_vp, c_vp, c_sz, c_vp]),
+    "dif_simple_layer_wide_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32,
+                                          c_vp, c_i64, c_int, c_f32, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
     "dif_linear_packed_bytes": (c_i64, [c_int]),
     "dif_linear_pack_f32": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dif_linear_packed_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),

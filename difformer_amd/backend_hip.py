@@ -1179,6 +1179,43 @@ class HipBackend:
         _lib.check(rc, "dif_layer_tail_mix_f32")
         return out
 
+    def simple_layer_wide(self, x, B, bias, D, attn_scale, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias,
+                          eps, relu=False):
+        """Closed-form `simple` layer for 64 < max(C, D) <= 128 in one pass (csrc/simple_layer_wide.hip): x [n, C], B [C, dv]
+        = [Mn | u | ...], bias [dv] = [cn | cd | ...] (wide_scale), ax = A_hat x [n, C] or None, Wv [D, C] / bv [D] / rs [n]."""
+        dev = _require_device(x, B, bias, ax, Wv, bv, rs, x0, ln_weight, ln_bias)
+        n, C = x.shape
+        for t_, nm in ((x, "x"), (B, "B"), (bias, "bias"), (ax, "ax"), (Wv, "Wv"), (x0, "x0")):
+            if t_ is not None:
+                _f32(t_, nm)
+        x, ldx = _row_major(x, C)
+        if ldx % 4 or x.data_ptr() % 16:
+            x, ldx = x.contiguous(), C
+        B, bias = B.contiguous(), bias.contiguous()
+        ldax = ldx0 = 0
+        if ax is not None:
+            ax, ldax = _row_major(ax, C)
+            if ldax % 4 or ax.data_ptr() % 16:
+                ax, ldax = ax.contiguous(), C
+        if x0 is not None:
+            x0, ldx0 = _row_major(x0, D)
+            if ldx0 % 4 or x0.data_ptr() % 16:
+                x0, ldx0 = x0.contiguous(), D
+        if Wv is not None:
+            Wv, bv = Wv.contiguous(), bv.contiguous()
+        if rs is not None:
+            rs = rs.contiguous()
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        with _timed(self, "dif_simple_layer_f32", dev):
+            rc = self.lib.dif_simple_layer_wide_f32(_ptr(x), ldx, n, C, D, _ptr(B), int(B.shape[1]), _ptr(bias), float(attn_scale),
+                                                    _ptr(ax), ldax, _ptr(Wv), _ptr(bv), _ptr(rs), float(gcn_scale), _ptr(x0), ldx0,
+                                                    int(bool(residual)), float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
+                                                    int(bool(relu)), _ptr(out), D, _stream(dev))
+        _lib.check(rc, "dif_simple_layer_wide_f32")
+        return out
+
     def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         dev = _require_device(conv, x0, prev, ln_weight, ln_bias)
         n, H, D = conv.shape

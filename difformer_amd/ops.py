@@ -901,8 +901,11 @@ def closed_form_coeffs_backward(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, 
 
 
 CLOSED_FORM_WIDE_MAX = 512      # widest layer the Gram-record formulation is used for (record = C x C floats)
-CLOSED_FORM_WIDE_MIN = 128      # up to here the q / k / v operator path is as fast (pokec-batch-h128: 1.01 vs 1.02 ms with the row
-                                # GEMMs on the hand-written Linear kernel, 1.2 ms on the library's)
+# Layers wider than this take the Gram-record formulation at the scripts' widths: from 65 columns with the one-pass layer kernel
+# of csrc/simple_layer_wide.hip (up to 128 columns: pokec-batch-h128 0.95 -> see profiles/r04_experiments.md); under
+# DIFFORMER_EXACT_FP32=1 (that kernel runs split-bfloat16 products) from 129, where the library GEMMs around the tail pass win
+# over the q / k / v operator path (at 128 they cost the same: 1.01 vs 1.02 ms)
+CLOSED_FORM_WIDE_MIN = 128 if EXACT_FP32 else 64
 
 
 class WideCoefficients:
@@ -951,6 +954,15 @@ def simple_layer_closed_form_wide(x, coeffs: WideCoefficients, Wv, bv, csr, attn
     T = Gt @ coeffs.V                                                   # [(C+1), D+4]
     R = coeffs.P @ T
     B, bias = be.wide_scale(R, T, partial, C)                           # [Mn | u | 0 0 0], [cn | cd | 0 0 0] (float32)
+    if max(C, D) <= 128 and not EXACT_FP32 and hasattr(be, "simple_layer_wide"):
+        # hidden 128 (node classification/run.sh:42-44): both row products, the division, the combine, the residual and the
+        # LayerNorm in ONE pass over the rows (csrc/simple_layer_wide.hip) -- no library GEMM, no [n, D + 4] intermediate
+        ax = rs = None
+        if csr is not None:
+            ax = gcn_aggregate(csr, x3, None, 1.0, 1.0).reshape(n, C)
+            rs = csr.row_sums() if Wv is not None else None
+        return be.simple_layer_wide(x, B, bias, D, attn_scale, ax, Wv if csr is not None else None,
+                                    bv if csr is not None else None, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps)
     Z = torch.addmm(bias, x, B)                                         # [n, D + 4]: numerator | denominator
     gcn = rs = None
     if csr is not None:

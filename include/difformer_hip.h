@@ -453,6 +453,16 @@ int dif_wide_gram_f64(const float* record, int C, int64_t n_global, const double
                       dif_stream_t stream);
 int dif_wide_scale_f64(const double* R, const double* T, const double* partial, int C, int DV, float* B, float* bias,
                        dif_stream_t stream);
+/* Closed-form `simple` layer at hidden 65..128 (node classification/run.sh:42-44) in ONE pass over the rows
+ * (csrc/simple_layer_wide.hip): out = LN(alpha (a_s (x Mn + cn) / (x.u + cd) + g_s ((A_hat x) Wv^T + (A_hat 1) bv^T) [+ x0]) +
+ * (1 - alpha) x).  bmat [C][dv] / bias [dv] are dif_wide_scale_f64's outputs (columns [0, D) = Mn, column D = u; cn | cd);
+ * ax = A_hat x unscaled or NULL (no graph); Wv / bv / row_sums NULL together for use_weight = False (then C == D).  C, D <= 128,
+ * multiples of 4, 16-byte aligned rows.  Both products run on split-bfloat16 operands (fp32 accumulation, ~4e-6). */
+int dif_simple_layer_wide_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* bmat, int dv,
+                              const float* bias, float attn_scale, const float* ax, int64_t ldax, const float* Wv,
+                              const float* bv, const float* row_sums, float gcn_scale, const float* x0, int64_t ldx0,
+                              int residual, float alpha, const float* ln_weight, const float* ln_bias, float ln_eps,
+                              int relu, float* out, int64_t ldo, dif_stream_t stream);
 int dif_layer_tail_mix_f32(const float* conv, int64_t ldc, const float* den, int64_t ldden, float conv_scale,
                            const float* add, int64_t lda, float add_scale, const float* rs, const float* bv,
                            int64_t n_rows, int D, const float* x0, int64_t ldx0, const float* prev, int64_t ldp,
