@@ -545,7 +545,7 @@ def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
     # and the vendor GEMM wins on big inputs (100,000 x 128 -> 256: 91 vs 68 us; -> 128: 46 vs 62 us;
     # scripts/exp_linear_wide_out.py); small inputs stay on the one-launch kernel (host-bound there)
     narrow_ok = x.dim() == 2 and (x.shape[1] <= 64 or weight.shape[0] <= 128 or x.shape[0] < 16384)
-    if not grad and x.dim() == 2 and x.shape[1] <= 128 and narrow_ok and (ln_weight is None or weight.shape[0] <= 64):
+    if not grad and x.dim() == 2 and x.shape[1] <= 128 and narrow_ok and (ln_weight is None or weight.shape[0] <= 128):
         return ops.linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
     if (not grad and x.dim() == 2 and 128 < x.shape[1] <= 8192 and weight.shape[0] <= 64 and bias is not None and
             (x.dtype == torch.float32 or (x.shape[1] % 4 == 0 and x.shape[0] >= 16384))):

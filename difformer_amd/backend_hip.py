@@ -1118,6 +1118,14 @@ class HipBackend:
         n, C = x.shape
         x, ldx = _row_major(x, C)
         rec = torch.empty(self.lib.dif_simple_reduced_len(1, C, C), dtype=torch.float32, device=dev)
+        if 64 < C <= 128 and C % 4 == 0 and ldx % 4 == 0 and x.data_ptr() % 16 == 0:
+            # hidden 128: one pass over x with the whole upper half of X^T X in a wave's registers (csrc/simple_layer_wide.hip)
+            ws_bytes = self.lib.dif_gram128_workspace_bytes(n, C)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            with _timed(self, "dif_gram_sym_f32", dev):
+                rc = self.lib.dif_gram128_f32(_ptr(x), ldx, n, C, _ptr(rec), _ptr(ws), ws_bytes, _stream(dev))
+            _lib.check(rc, "dif_gram128_f32")
+            return rec
         ws_bytes = self.lib.dif_simple_workspace_bytes(n, 1, C, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _timed(self, "dif_gram_sym_f32", dev):

@@ -233,7 +233,145 @@ __global__ __launch_bounds__(64 * kWideWaves, 4) void simple_layer_wide_kernel(W
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Gram record X^T X | sum x for 64 < C <= 128 (the record of the closed form at hidden 128).  csrc/simple_layer.hip's
+// gram_kernel widened: a wave reads four whole rows per step (lane (lg, l15): row base + lg, columns 4 l15 .. + 3 and
+// 64 + 4 l15 .. + 3), which is the coalesced stream AND the A / B operand of v_mfma_f32_16x16x4_f32 contracting over rows
+// -- the lane's eight components p select the 16-column group {4 i + p % 4 + 64 (p / 4)}; the 36 products with pa <= pb
+// cover the upper half of X^T X, the record write mirrors them.  One pass over x on the exact fp32 MFMA (the coefficient
+// algebra downstream cancels large terms: no split operands here).  Round 3's form for this width (stage 1 of the
+// attention reduce over three 64 x 64 blocks, x read three times) took 49 us at 100,000 rows.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kG128Waves = 8;
+
+__global__ __launch_bounds__(64 * kG128Waves, 2) void gram128_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C,
+                                                                     float* __restrict__ ws, int64_t ws_stride) {
+    __shared__ float sm_f[4 * 36 * 64];               // fold buffer: 9 accumulators (36 registers) x 64 lanes for up to 4 waves
+    __shared__ float sm_s[kG128Waves][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const bool ok0 = 4 * l15 < C, ok1 = 64 + 4 * l15 < C;
+    f32x4 acc[36];
+#pragma unroll
+    for (int a = 0; a < 36; ++a) acc[a] = zero4();
+    f32x4 sx0 = zero4(), sx1 = zero4();
+    const int64_t n16 = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kG128Waves + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kG128Waves;
+    auto load16 = [&](f32x4 (&xv)[4][2], int64_t tile) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = tile * 16 + 4 * u + lg;
+            const float* p = x + row * ldx + 4 * l15;
+            xv[u][0] = (row < n_rows && ok0) ? *reinterpret_cast<const f32x4*>(p) : zero4();
+            xv[u][1] = (row < n_rows && ok1) ? *reinterpret_cast<const f32x4*>(p + 64) : zero4();
+        }
+    };
+    f32x4 nxt[4][2];
+    if (first < n16) load16(nxt, first);
+    for (int64_t tile = first; tile < n16; tile += stride) {
+        f32x4 xv[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xv[u][0] = nxt[u][0]; xv[u][1] = nxt[u][1]; }
+        if (tile + stride < n16) load16(nxt, tile + stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sx0 += xv[u][0];
+            sx1 += xv[u][1];
+            const float p[8] = {xv[u][0][0], xv[u][0][1], xv[u][0][2], xv[u][0][3], xv[u][1][0], xv[u][1][1], xv[u][1][2], xv[u][1][3]};
+            int a = 0;
+#pragma unroll
+            for (int pa = 0; pa < 8; ++pa)
+#pragma unroll
+                for (int pb = pa; pb < 8; ++pb, ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[pa], p[pb], acc[a], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float a0 = sx0[t], a1 = sx1[t];
+        a0 += __shfl_xor(a0, 16, 64); a0 += __shfl_xor(a0, 32, 64);
+        a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+        if (lg == 0) { sm_s[wave][4 * l15 + t] = a0; sm_s[wave][64 + 4 * l15 + t] = a1; }
+    }
+    // fold the eight waves in registers, nine accumulators at a time: ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
+#pragma unroll
+    for (int half = kG128Waves / 2; half >= 1; half >>= 1) {
+#pragma unroll
+        for (int c0 = 0; c0 < 36; c0 += 9) {
+            if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) sm_f[((wave - half) * 36 + i * 4 + reg) * 64 + lane] = acc[c0 + i][reg];
+            }
+            __syncthreads();
+            if (wave < half) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[c0 + i][reg] += sm_f[(wave * 36 + i * 4 + reg) * 64 + lane];
+            }
+            __syncthreads();
+        }
+    }
+    float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
+    if (wave == 0) {
+        int a = 0;
+#pragma unroll
+        for (int pa = 0; pa < 8; ++pa)
+#pragma unroll
+            for (int pb = pa; pb < 8; ++pb, ++a)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int gi = 4 * (4 * lg + reg) + (pa & 3) + 64 * (pa >> 2), gj = 4 * l15 + (pb & 3) + 64 * (pb >> 2);
+                    if (gi < C && gj < C) {
+                        rec[gi * C + gj] = acc[a][reg];
+                        if (pa != pb) rec[gj * C + gi] = acc[a][reg];
+                    }
+                }
+    } else if (wave == 1) {
+        for (int c = lane; c < C; c += 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < kG128Waves; ++w2) a += sm_s[w2][c];
+            rec[C * C + c] = a;
+        }
+    }
+}
+
+int gram128_chunks(int64_t n_rows) {
+    const int64_t tiles = (n_rows + 15) / 16;
+    int64_t p = (tiles + 2 * kG128Waves - 1) / (2 * kG128Waves);       // at least two tiles per wave, every CU busy from ~65,000 rows
+    if (p > dif::kCUs) p = dif::kCUs;
+    return static_cast<int>(p < 1 ? 1 : p);
+}
+
 }  // namespace
+
+extern "C" size_t dif_gram128_workspace_bytes(int64_t n_rows, int C) {
+    if (n_rows <= 0 || C <= 64 || C > 128) return 0;
+    const size_t rec = (static_cast<size_t>(C) * C + C + 3) & ~size_t(3);
+    return rec * sizeof(float) * static_cast<size_t>(gram128_chunks(n_rows));
+}
+
+// record = [X^T X: C x C row-major, all of it][sum x: C] (+ whatever the caller's record holds beyond): the layout
+// dif_gram_sym_f32 leaves, for 64 < C <= 128, C % 4 == 0, rows 16-byte aligned.
+extern "C" int dif_gram128_f32(const float* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
+                               size_t workspace_bytes, dif_stream_t stream) {
+    DIF_REQUIRE(x && record && workspace && n_rows > 0, DIF_E_BADARG, "dif_gram128: null pointer or no rows");
+    DIF_REQUIRE(C > 64 && C <= 128 && C % 4 == 0, DIF_E_SHAPE, "dif_gram128: covers 64 < C <= 128, C %% 4 == 0 (got %d)", C);
+    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned16(x) && dif::aligned16(workspace), DIF_E_BADARG,
+                "dif_gram128: rows of x and the workspace must be 16-byte aligned");
+    DIF_REQUIRE(workspace_bytes >= dif_gram128_workspace_bytes(n_rows, C), DIF_E_WORKSPACE, "dif_gram128: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int P = gram128_chunks(n_rows);
+    const int64_t rec = (static_cast<int64_t>(C) * C + C + 3) & ~int64_t(3);
+    float* ws = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(gram128_kernel, dim3(P), dim3(64 * kG128Waves), 0, st, x, ldx, n_rows, C, ws, rec);
+    if (int rc = dif::launch_status("gram128_kernel")) return rc;
+    return dif::launch_record_finalize(ws, P, rec, C * C + C, 0, record, st);
+}
 
 // Closed-form `simple` layer for 64 < max(C, D) <= 128 (C % 4 == 0, D % 4 == 0) in one pass; see the head of this file.
 //   bmat [C][dv] (dv >= D + 1; the host's dif_wide_scale_f64 output: columns [0, D) = s Mn, column D = s u), bias [dv] = cn | cd;

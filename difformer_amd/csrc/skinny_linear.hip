@@ -685,9 +685,62 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
     f32x4 xa[KQ], xn[KQ];
     if (first < n_tiles) load_x(first, xa);
+    // LayerNorm over 65..128 output features (the input layer at the scripts' hidden 128, run.sh:42-44): both 64-feature blocks
+    // of a row tile are formed first, normalised together, then stored (the host guarantees one workgroup column: f0 == 0)
+    const bool wide_ln = ln_w != nullptr && C_out > 64;
+    f32x4 lw2 = {0.f, 0.f, 0.f, 0.f}, lb2 = {0.f, 0.f, 0.f, 0.f};
+    if (wide_ln) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f = 64 + 4 * l15 + ft;
+            if (f < C_out) { lw2[ft] = Elem<T>::ld(ln_w + f); lb2[ft] = Elem<T>::ld(ln_b + f); }
+        }
+    }
     for (int64_t tile = first; tile < n_tiles; tile += stride) {
         const int64_t r0 = tile * 16;
         if (tile + stride < n_tiles) load_x(tile + stride, xn);               // in flight under this tile's work
+        if (wide_ln) {
+            f32x4 y2[2][4];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const float* wrow = sm_w + (64 * blk + l15) * kLinStride + 4 * lg;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sm_b + 64 * blk + 4 * l15);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) y2[blk][ft] = f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
+#pragma unroll
+                for (int cq = 0; cq < KQ; ++cq)
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft) {
+                        const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + 16 * ft * kLinStride + 16 * cq);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            y2[blk][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cq][t], wf[t], y2[blk][ft], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float sm = 0.f;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) sm += y2[0][ft][reg] + ((64 + 4 * l15 + ft < C_out) ? y2[1][ft][reg] : 0.f);
+                sm = dif::row16_sum(sm);
+                const float mu = sm * inv_c;
+                float v = 0.f;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    const float d0 = y2[0][ft][reg] - mu, d1 = (64 + 4 * l15 + ft < C_out) ? y2[1][ft][reg] - mu : 0.f;
+                    v += d0 * d0 + d1 * d1;
+                }
+                v = dif::row16_sum(v);
+                const float rstd = 1.0f / sqrtf(v * inv_c + eps);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    y2[0][ft][reg] = (y2[0][ft][reg] - mu) * rstd * lw[ft] + lb[ft];
+                    y2[1][ft][reg] = (y2[1][ft][reg] - mu) * rstd * lw2[ft] + lb2[ft];
+                }
+            }
+            finish_tile<T>(y2[0], r0, 0, l15, lg, C_out, false, lw, lb, inv_c, eps, relu, out, ldo, n_rows, ovec);
+            finish_tile<T>(y2[1], r0, 64, l15, lg, C_out, false, lw2, lb2, inv_c, eps, relu, out, ldo, n_rows, ovec);
+        } else
         for (int blk = 0; blk < nblk; ++blk) {
             const int fb = f0 + 64 * blk;
             const float* wrow = sm_w + (64 * blk + l15) * kLinStride + 4 * lg;
@@ -765,7 +818,7 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
     }
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG,
                 "dif_linear: ln_weight and ln_bias must be given together");
-    DIF_REQUIRE(!ln_weight || C_out <= 64, DIF_E_SHAPE, "dif_linear: fused LayerNorm needs C_out <= 64");
+    DIF_REQUIRE(!ln_weight || C_out <= 128, DIF_E_SHAPE, "dif_linear: fused LayerNorm needs C_out <= 128");
     DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear: leading dimension smaller than a row");
     const int kq = (C_in + 15) / 16;
     const int kLinMaxBlocks = lin_max_blocks(kq), kLinStride = lin_stride(kq);

@@ -453,6 +453,12 @@ int dif_wide_gram_f64(const float* record, int C, int64_t n_global, const double
                       dif_stream_t stream);
 int dif_wide_scale_f64(const double* R, const double* T, const double* partial, int C, int DV, float* B, float* bias,
                        dif_stream_t stream);
+/* Gram record of the closed form for 64 < C <= 128 (hidden 128): record [X^T X (C x C, ALL of it) | sum x (C) | ...] in the
+ * layout of dif_gram_sym_f32, from ONE pass over x on the fp32 MFMA (csrc/simple_layer_wide.hip).  C % 4 == 0, 16-byte aligned
+ * rows; workspace: dif_gram128_workspace_bytes, 16-byte aligned. */
+size_t dif_gram128_workspace_bytes(int64_t n_rows, int C);
+int dif_gram128_f32(const float* x, int64_t ldx, int64_t n_rows, int C, float* record, void* workspace,
+                    size_t workspace_bytes, dif_stream_t stream);
 /* Closed-form `simple` layer at hidden 65..128 (node classification/run.sh:42-44) in ONE pass over the rows
  * (csrc/simple_layer_wide.hip): out = LN(alpha (a_s (x Mn + cn) / (x.u + cd) + g_s ((A_hat x) Wv^T + (A_hat 1) bv^T) [+ x0]) +
  * (1 - alpha) x).  bmat [C][dv] / bias [dv] are dif_wide_scale_f64's outputs (columns [0, D) = Mn, column D = u; cn | cd);

@@ -651,3 +651,19 @@ def test_model_takes_the_fused_input_kernel_on_a_dense_graph(dev):
                use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
     p = {k: v.detach().cpu().double().numpy() for k, v in model.state_dict().items()}
     assert rel_err(y, orc.difformer_forward(p, x.double().numpy(), ei.numpy(), None, cfg)) < 1e-4
+
+
+@pytest.mark.parametrize("n,c", [(100000, 128), (5003, 96), (17, 68), (40000, 100)])
+def test_gram_record_at_hidden_65_to_128(n, c, dev):
+    """dif_gram128_f32 (the record of the closed form at hidden 128): X^T X and the column sums against float64, and the
+    layout the wide coefficient stage reads (dif_gram_sym_f32's)."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) + 0.3).to(dev)
+    rec = be.gram_sym(x)
+    x64 = x.double().cpu().numpy()
+    got = rec[: c * c].cpu().numpy().reshape(c, c)
+    assert rel_err(got, x64.T @ x64) < 1e-5 and rel_err(rec[c * c: c * c + c].cpu().numpy(), x64.sum(0)) < 1e-5
+    assert np.array_equal(got, got.T)                                # mirrored exactly
+    assert torch.equal(rec[: c * c + c], be.gram_sym(x)[: c * c + c])           # deterministic

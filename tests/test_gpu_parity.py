@@ -1650,3 +1650,21 @@ def test_packed_weight_cache_does_not_confuse_tensors_at_a_recycled_address(dev)
         out = be.linear(x, W, b)
         assert rel_err(out.cpu().numpy(), x.double().cpu().numpy() @ W.double().cpu().numpy().T) < 1e-5, trial
         del W
+
+
+@pytest.mark.parametrize("n,ci,co", [(100000, 65, 128), (3000, 128, 96), (5001, 8, 68), (700, 40, 128)])
+def test_narrow_linear_with_layernorm_over_up_to_128_features(n, ci, co, dev):
+    """The input layer at the scripts' hidden 128 (run.sh:42-44: Pokec, 65 -> 128, LayerNorm, ReLU) in one launch: both
+    64-feature blocks of a row tile are normalised together."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + co)
+    x = torch.randn(n, ci, generator=g)
+    W, b = torch.randn(co, ci, generator=g) / np.sqrt(ci), torch.randn(co, generator=g)
+    lw, lb = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
+    be = ops.get_backend()
+    for relu in (True, False):
+        out = be.linear(x.to(dev), W.to(dev), b.to(dev), lw.to(dev), lb.to(dev), 1e-5, relu)
+        ref = orc.layer_norm(x.double().numpy() @ W.double().numpy().T + b.double().numpy(), lw.double().numpy(), lb.double().numpy())
+        if relu:
+            ref = np.maximum(ref, 0)
+        assert rel_err(out.cpu().numpy(), ref) < 1e-5
