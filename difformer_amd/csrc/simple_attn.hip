@@ -106,16 +106,31 @@ __global__ __launch_bounds__(256) void simple_reduce_kernel(
     const int64_t first = static_cast<int64_t>(blockIdx.x) * kRedWaves + wave;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kRedWaves;
 
-    for (int64_t it = first; it < n_iters; it += stride) {
-        f32x4 kx[kRedUnroll], vx[kRedUnroll], qx[kRedUnroll];
+    // the next iteration's rows are requested before this iteration's 64 MFMAs (round 4: without the prefetch a wave sat out
+    // the whole load latency between two MFMA bursts -- the Gram pass of the wide closed form ran at 25 % of the fp32 MFMA peak)
+    f32x4 nk[kRedUnroll], nv[kRedUnroll], nq[kRedUnroll];
+    auto fetch = [&](int64_t it) {
 #pragma unroll
         for (int s = 0; s < kRedUnroll; ++s) {
             const int64_t r = (it * kRedUnroll + s) * 4 + lg;
-            kx[s] = load_row4<VEC>(k, ldk, r, n_rows, h * sh.M, mc, sh.M);
-            if (SYM && dt == mt) vx[s] = kx[s];
-            else vx[s] = load_row4<VEC>(v, ldv, r, n_rows, h * sh.D, dc, sh.D);
-            if (do_q) qx[s] = load_row4<VEC>(q, ldq, r, n_rows, h * sh.M, mc, sh.M);
+            nk[s] = load_row4<VEC>(k, ldk, r, n_rows, h * sh.M, mc, sh.M);
+            if (!(SYM && dt == mt)) nv[s] = load_row4<VEC>(v, ldv, r, n_rows, h * sh.D, dc, sh.D);
+            if (do_q) nq[s] = load_row4<VEC>(q, ldq, r, n_rows, h * sh.M, mc, sh.M);
         }
+    };
+    // (the Gram pass only -- SYM: one or two streams.  With three streams the second register set costs a wave per SIMD and
+    // the attention's own reduce ran 20 % slower: it keeps the plain loop.)
+    if (SYM && first < n_iters) fetch(first);
+    for (int64_t it = first; it < n_iters; it += stride) {
+        f32x4 kx[kRedUnroll], vx[kRedUnroll], qx[kRedUnroll];
+        if (!SYM) fetch(it);
+#pragma unroll
+        for (int s = 0; s < kRedUnroll; ++s) {
+            kx[s] = nk[s];
+            vx[s] = (SYM && dt == mt) ? nk[s] : nv[s];
+            if (do_q) qx[s] = nq[s];
+        }
+        if (SYM && it + stride < n_iters) fetch(it + stride);
 #pragma unroll
         for (int s = 0; s < kRedUnroll; ++s) {
 #pragma unroll
