@@ -275,6 +275,17 @@ def main():
             model(x, edge_index)
         torch.cuda.synchronize()
         fwd_ms = sorted(a.elapsed_time(b) for a, b in fwd_events)
+    ag = getattr(model, "_ag_state", None)
+    if use_graph_replay:
+        launch_mode = "hipGraph replay"
+    elif ag is not None and ag[2] is not None:
+        # plain model(x, edge_index) calls: DIFFormer.forward captured itself as one hipGraph on the third identical call
+        # (warm-up) and the timed steps replayed it; DIFFORMER_AUTO_GRAPH=0 gives the kernel-by-kernel launches
+        launch_mode = "model(x, edge_index): auto-captured hipGraph replay"
+    else:
+        launch_mode = "eager"
+    ktimes = be.kernel_times_ms()
+    be.kernel_events = None
     # N > 1: where a rank's forward goes -- exposed collective waits (events on the compute stream around every exchange
     # step, difformer_amd/dist.py) beside the kernels by group -- so that the first run on real xGMI links is diagnostic
     per_rank = None
@@ -302,17 +313,6 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         per_rank = gathered
-    ag = getattr(model, "_ag_state", None)
-    if use_graph_replay:
-        launch_mode = "hipGraph replay"
-    elif ag is not None and ag[2] is not None:
-        # plain model(x, edge_index) calls: DIFFormer.forward captured itself as one hipGraph on the third identical call
-        # (warm-up) and the timed steps replayed it; DIFFORMER_AUTO_GRAPH=0 gives the kernel-by-kernel launches
-        launch_mode = "model(x, edge_index): auto-captured hipGraph replay"
-    else:
-        launch_mode = "eager"
-    ktimes = be.kernel_times_ms()
-    be.kernel_events = None
     elapsed = max_over_ranks(elapsed, dev)
 
     def dominant_alone(entry):

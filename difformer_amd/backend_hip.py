@@ -1224,6 +1224,72 @@ class HipBackend:
         _lib.check(rc, "dif_simple_layer_wide_f32")
         return out
 
+    def xwide_pack(self, src, transposed, C, D, cache=False):
+        """dif_xwide_pack_f32: src [C, ld] (transposed: the [Mn | u] operand) or [D, C] (an nn.Linear weight) -> packed MFMA
+        fragments.  cache=True keeps the packing per weight tensor (identity + version, as _packed_weight)."""
+        import weakref
+        from . import ops
+        dev = src.device
+        key = None
+        if cache:
+            ver = ops.tensor_version(src)
+            key = (id(src), src.data_ptr(), ver, C, D, bool(transposed), str(dev))
+            store = self.__dict__.setdefault("_packed", {})
+            hit = store.get(key)
+            if hit is not None and ver >= 0 and hit[0]() is src:
+                return hit[1]
+        src_c = src.contiguous()
+        packed = torch.empty(self.lib.dif_xwide_packed_bytes(C, D), dtype=torch.uint8, device=dev)
+        with _timed(self, "dif_xwide_pack_f32", dev):
+            rc = self.lib.dif_xwide_pack_f32(_ptr(src_c), int(src_c.shape[1]), int(bool(transposed)), C, D, _ptr(packed), _stream(dev))
+        _lib.check(rc, "dif_xwide_pack_f32")
+        if cache and key[2] >= 0:
+            for k in [k for k, v in store.items() if v[0]() is None]:
+                del store[k]
+            if len(store) >= 16:
+                store.clear()
+            store[key] = (weakref.ref(src), packed)
+        return packed
+
+    def simple_layer_xwide(self, x, B, bias, D, attn_scale, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias,
+                           eps, relu=False):
+        """Closed-form `simple` layer for 128 < max(C, D) <= 416 in one pass (csrc/simple_layer_xwide.hip); arguments as
+        simple_layer_wide.  Mn is packed per call (it changes with the Gram record), Wv once per parameter version."""
+        dev = _require_device(x, B, bias, ax, Wv, bv, rs, x0, ln_weight, ln_bias)
+        n, C = x.shape
+        for t_, nm in ((x, "x"), (B, "B"), (bias, "bias"), (ax, "ax"), (Wv, "Wv"), (x0, "x0")):
+            if t_ is not None:
+                _f32(t_, nm)
+        x, ldx = _row_major(x, C)
+        if ldx % 4 or x.data_ptr() % 16:
+            x, ldx = x.contiguous(), C
+        B, bias = B.contiguous(), bias.contiguous()
+        ldax = ldx0 = 0
+        if ax is not None:
+            ax, ldax = _row_major(ax, C)
+            if ldax % 4 or ax.data_ptr() % 16:
+                ax, ldax = ax.contiguous(), C
+        if x0 is not None:
+            x0, ldx0 = _row_major(x0, D)
+            if ldx0 % 4 or x0.data_ptr() % 16:
+                x0, ldx0 = x0.contiguous(), D
+        pm = self.xwide_pack(B, True, C, D)
+        pv = None
+        if Wv is not None:
+            pv, bv = self.xwide_pack(Wv, False, C, D, cache=True), bv.contiguous()
+        if rs is not None:
+            rs = rs.contiguous()
+        if ln_weight is not None:
+            ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        with _timed(self, "dif_simple_layer_f32", dev):
+            rc = self.lib.dif_simple_layer_xwide_f32(_ptr(x), ldx, n, C, D, _ptr(pm), _ptr(pv), _ptr(B), int(B.shape[1]), _ptr(bias),
+                                                     float(attn_scale), _ptr(ax), ldax, _ptr(bv), _ptr(rs), float(gcn_scale), _ptr(x0),
+                                                     ldx0, int(bool(residual)), float(alpha), _ptr(ln_weight), _ptr(ln_bias), float(eps),
+                                                     int(bool(relu)), _ptr(out), D, _stream(dev))
+        _lib.check(rc, "dif_simple_layer_xwide_f32")
+        return out
+
     def layer_tail(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu=False):
         dev = _require_device(conv, x0, prev, ln_weight, ln_bias)
         n, H, D = conv.shape

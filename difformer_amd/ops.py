@@ -900,6 +900,7 @@ def closed_form_coeffs_backward(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, 
     return out
 
 
+XWIDE_MAX = int(os.environ.get("DIFFORMER_XWIDE_MAX", "416"))   # widest layer of the one-pass kernel with streamed weights (0: library GEMMs)
 CLOSED_FORM_WIDE_MAX = 512      # widest layer the Gram-record formulation is used for (record = C x C floats)
 # Layers wider than this take the Gram-record formulation at the scripts' widths: from 65 columns with the one-pass layer kernel
 # of csrc/simple_layer_wide.hip (up to 128 columns: pokec-batch-h128 0.95 -> see profiles/r04_experiments.md); under
@@ -963,6 +964,15 @@ def simple_layer_closed_form_wide(x, coeffs: WideCoefficients, Wv, bv, csr, attn
             rs = csr.row_sums() if Wv is not None else None
         return be.simple_layer_wide(x, B, bias, D, attn_scale, ax, Wv if csr is not None else None,
                                     bv if csr is not None else None, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps)
+    if max(C, D) <= XWIDE_MAX and not EXACT_FP32 and hasattr(be, "simple_layer_xwide"):
+        # hidden 300 / 400 (image and text/run.sh:27): the same one pass with the rows in registers and the weights streamed
+        # through LDS (csrc/simple_layer_xwide.hip) instead of a library GEMM per product around a tail pass
+        ax = rs = None
+        if csr is not None:
+            ax = gcn_aggregate(csr, x3, None, 1.0, 1.0).reshape(n, C)
+            rs = csr.row_sums() if Wv is not None else None
+        return be.simple_layer_xwide(x, B, bias, D, attn_scale, ax, Wv if csr is not None else None,
+                                     bv if csr is not None else None, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps)
     Z = torch.addmm(bias, x, B)                                         # [n, D + 4]: numerator | denominator
     gcn = rs = None
     if csr is not None:

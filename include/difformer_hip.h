@@ -453,6 +453,19 @@ int dif_wide_gram_f64(const float* record, int C, int64_t n_global, const double
                       dif_stream_t stream);
 int dif_wide_scale_f64(const double* R, const double* T, const double* partial, int C, int DV, float* B, float* bias,
                        dif_stream_t stream);
+/* Closed-form `simple` layer at hidden 129..416 (image and text/run.sh:27 trains at 300, two lines at 400) in ONE pass over the
+ * rows (csrc/simple_layer_xwide.hip): same result as dif_simple_layer_wide_f32, with the rows kept in registers as split-bf16
+ * fragments and the weights streamed through LDS in chunks of 64 output features.  The weights come PACKED:
+ * dif_xwide_pack_f32(src, ld, transposed, C, D, packed) writes dif_xwide_packed_bytes(C, D) bytes of MFMA A fragments
+ * ([chunk][hi | lo][k-block][feature tile][lane] x 16 B) from src = bmat ([C][ld], transposed = 1: Mn sits in columns [0, D))
+ * or src = Wv ([D][ld], transposed = 0).  packed_v NULL: no graph term, or use_weight = False (then C == D). */
+int64_t dif_xwide_packed_bytes(int C, int D);
+int dif_xwide_pack_f32(const float* src, int64_t ld, int transposed, int C, int D, void* packed, dif_stream_t stream);
+int dif_simple_layer_xwide_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const void* packed_m,
+                               const void* packed_v, const float* bmat, int dv, const float* bias, float attn_scale,
+                               const float* ax, int64_t ldax, const float* bv, const float* row_sums, float gcn_scale,
+                               const float* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,
+                               const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo, dif_stream_t stream);
 /* Gram record of the closed form for 64 < C <= 128 (hidden 128): record [X^T X (C x C, ALL of it) | sum x (C) | ...] in the
  * layout of dif_gram_sym_f32, from ONE pass over x on the fp32 MFMA (csrc/simple_layer_wide.hip).  C % 4 == 0, 16-byte aligned
  * rows; workspace: dif_gram128_workspace_bytes, 16-byte aligned. */

@@ -2,6 +2,7 @@
 # Measurement builds of the feature-sliced product (profiles/r04_experiments.md): one shared library per variant under
 # scripts/bin/ (git-ignored, shipped to the GPU box), identical to the product's except for csrc/gcn_sliced.hip's macros.
 #   scripts/build_sliced_variants.sh name="flags" ...   then   scripts/run_sliced_variants.sh name ...   on the GPU box
+#   (OBJ=<source stem> rebuilds another object with the flags, e.g. OBJ=simple_layer_xwide)
 set -e
 cd "$(dirname "$0")/.."
 make -C difformer_amd/csrc -j8 >/dev/null
@@ -9,7 +10,7 @@ mkdir -p scripts/bin
 for spec in "$@"; do
     name=${spec%%=*}; flags=${spec#*=}
     obj=/tmp/dif_obj_$name
-    rm -rf $obj && cp -r difformer_amd/lib/obj $obj && rm -f $obj/gcn_sliced.o
+    rm -rf $obj && cp -r difformer_amd/lib/obj $obj && rm -f $obj/${OBJ:-gcn_sliced}.o
     make -C difformer_amd/csrc OBJDIR=$obj OUT=../../scripts/bin/libdifformer_hip_$name.so EXTRA="$flags" >/dev/null
     echo "built scripts/bin/libdifformer_hip_$name.so ($flags)"
 done

@@ -169,5 +169,9 @@ def test_bench_with_two_ranks_runs_end_to_end(workload, product):
     if workload == "ogbn-proteins-s":
         assert d["scaling"] == "strong" and d["config"]["parallelism"] == "row-shard x2"
         assert d["roofline"]["kernel"].startswith("sliced_spmm_kernel") and d["roofline"]["avg_launch_ms"] > 0
+        # per-rank diagnostics of a sharded run: exposed collective waits beside the kernel groups (round 4)
+        phases = d["per_rank_phases"]
+        assert [p["rank"] for p in phases] == [0, 1] and all(p["kernels_ms"].get("product", 0) > 0 for p in phases)
+        assert all(any(k.startswith("all_") for k in p["collectives_ms"]) for p in phases), phases
     else:
         assert d["scaling"] == "weak" and d["config"]["parallelism"] == "replicas x2"
