@@ -3,7 +3,7 @@ keep working: the FORWARD of every operator is the HIP kernel; the BACKWARD of t
 attention, the aggregation (adjoint product on the same SpMM kernels), the layer tail (LayerNorm / residual /
 head mean) and the weight gradients of the Linear layers are HIP kernels too (SURVEY.md section 8f, row 3);
 the batched (v2) attentions too (simple: raw mode of the forward kernel; sigmoid: the sweep kernels per position group); only
-heads wider than 64 re-derive their gradient on the device with tensor ops.
+`simple` heads wider than 512 and `sigmoid` heads wider than 64 re-derive their gradient on the device with tensor ops.
 Under torch.no_grad() / eval these wrappers are pass-throughs to ops.py.  Nothing here touches the CPU.
 """
 from __future__ import annotations
@@ -97,8 +97,8 @@ def _tail_expr(alpha, eps, has_ln):
 
 
 class _SimpleAttention(torch.autograd.Function):
-    """Forward and (for fp32, M, D <= 64) backward on the HIP kernels; other shapes re-derive the gradient with
-    differentiable device ops."""
+    """Forward and (for fp32, M, D <= 512: every head width of the reference's scripts) backward on the HIP kernels; other
+    shapes re-derive the gradient with differentiable device ops."""
 
     @staticmethod
     def forward(ctx, q, k, v, shard=None):
@@ -118,7 +118,7 @@ class _SimpleAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         q, k, v, reduced, out = ctx.saved_tensors
-        hip_ok = (q.dtype == torch.float32 and q.shape[2] <= 64 and v.shape[2] <= 64 and
+        hip_ok = (q.dtype == torch.float32 and q.shape[2] <= 512 and v.shape[2] <= 512 and
                   hasattr(ops.get_backend(), "simple_backward"))
         if hip_ok:
             # row-sharded: two small all-reduces inside (the sums over nodes of the backward, then the scalar T)
@@ -248,7 +248,7 @@ class _Linear(torch.autograd.Function):
 
 
 def _row_gemm(be, A, mat, bias=None, accumulate=None):
-    """A mat (+ bias) (+ accumulate) on many rows: one pass on the row-GEMM kernel where the backend has it (K, C <= 64)."""
+    """A mat (+ bias) (+ accumulate) on many rows: one pass on the row-GEMM kernel where the backend has it (K <= 512)."""
     got = be.row_gemm(A, mat, bias, accumulate) if hasattr(be, "row_gemm") else None
     if got is not None:
         return got

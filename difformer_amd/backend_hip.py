@@ -204,7 +204,7 @@ class HipBackend:
 
     # ---- a1 backward ------------------------------------------------------------------------
     def simple_backward(self, q, k, v, reduced, out, g, shard=None):
-        """(dq, dk, dv) of the simple kernel for fp32 q,k [n,H,M], v/out/g [n,H,D] with M, D <= 64.  Row-sharded
+        """(dq, dk, dv) of the simple kernel for fp32 q,k [n,H,M], v/out/g [n,H,D] with M, D <= 512.  Row-sharded
         (`shard`, `reduced` already summed over the ranks): the sums over nodes of the backward -- q^T gn, sum gn, the
         ks-gradient -- are all-reduced in one buffer, then the scalar T: two small exchange steps."""
         dev = _require_device(q, k, v, reduced, out, g)
@@ -709,12 +709,12 @@ class HipBackend:
         return coef
 
     def row_gemm(self, A, mat, bias=None, accumulate=None):
-        """A [n, K] @ mat [K, C] (+ bias [C]) (+ accumulate [n, C]) in one pass over the rows (dif_rowgemm_f32; K, C <= 64,
+        """A [n, K] @ mat [K, C] (+ bias [C]) (+ accumulate [n, C]) in one pass over the rows (dif_rowgemm_f32; K <= 512,
         float32) -> [n, C], or None when the shape is not covered (the caller then uses the vendor GEMM)."""
         dev = _require_device(A, mat, bias, accumulate)
         n, K = A.shape
         C = mat.shape[1]
-        if K > 64 or C > 64 or any(t_ is not None and t_.dtype != torch.float32 for t_ in (A, mat, bias, accumulate)):
+        if K > 512 or any(t_ is not None and t_.dtype != torch.float32 for t_ in (A, mat, bias, accumulate)):
             return None
         A, lda = _row_major(A, K)
         mat = mat.contiguous()

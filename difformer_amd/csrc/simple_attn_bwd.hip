@@ -57,11 +57,13 @@ __global__ __launch_bounds__(256) void simple_bwd_prep_kernel(const float* __res
     for (int i = threadIdx.x; i <= H * M; i += 256) part[static_cast<int64_t>(blockIdx.x) * part_stride + i] = sm[i];
 }
 
-// The same pass for M, D <= 64 with 16-byte aligned rows (every shape the reference's scripts reach): a 16-lane group owns
-// ONE head and walks rows, a lane holds four fixed columns of q / g / out (one 16-byte load each), keeps its share of
-// sum_n q * gd in registers, and the 16 groups of a workgroup fold through LDS in a fixed order -- deterministic, and no
-// LDS atomics (the generic kernel above issues M of them per row: 98 us at C4 against 34 us for this one).
-// grid.x * 16 must be a multiple of H, so that a group's head never changes.
+// The same pass for M, D <= 64 W (W = 1, 2: every width the reference's scripts reach with `simple` in one head up to 128)
+// with 16-byte aligned rows: a 16-lane group owns ONE head and walks rows, a lane holds four fixed columns per 64-column
+// chunk of q / g / out (one 16-byte load each), keeps its share of sum_n q * gd in registers, and the 16 groups of a
+// workgroup fold through LDS in a fixed order -- deterministic, and no LDS atomics (the generic kernel above issues M of
+// them per row: 98 us at C4 against 34 us for this one).  grid.x * 16 must be a multiple of H, so that a group's head never
+// changes.
+template <int W>
 __global__ __launch_bounds__(256) void simple_bwd_prep_vec_kernel(const float* __restrict__ q, int64_t ldq,
                                                                   const float* __restrict__ g, int64_t ldg,
                                                                   const float* __restrict__ out, int64_t ldo,
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void simple_bwd_prep_vec_kernel(const float* _
                                                                   float n_global, int H, int M, int D,
                                                                   float* __restrict__ gn, float* __restrict__ gd,
                                                                   float* __restrict__ part, int part_stride) {
-    __shared__ float sm[16][68];
+    __shared__ float sm[16][64 * W + 4];
     const int t_ks = H * M * D, t_main = H * M * D + H * M + H * D;
     const float s = 1.0f / (sqrtf(reduced[t_main]) * sqrtf(reduced[t_main + 1]));
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -77,33 +79,52 @@ __global__ __launch_bounds__(256) void simple_bwd_prep_vec_kernel(const float* _
     const int64_t gstride = static_cast<int64_t>(gridDim.x) * 16;
     const int64_t g0 = static_cast<int64_t>(blockIdx.x) * 16 + grp;
     const int h = static_cast<int>(g0 % H);
-    const bool mq = 4 * l16 < M, md = 4 * l16 < D;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 ks = mq ? *reinterpret_cast<const f32x4*>(reduced + t_ks + h * M + 4 * l16) : z4;
-    f32x4 acc = z4;
+    bool mq[W], md[W];
+    f32x4 ks[W], acc[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        mq[w] = 64 * w + 4 * l16 < M;
+        md[w] = 64 * w + 4 * l16 < D;
+        ks[w] = mq[w] ? *reinterpret_cast<const f32x4*>(reduced + t_ks + h * M + 64 * w + 4 * l16) : z4;
+        acc[w] = z4;
+    }
     float gd_acc = 0.f;
     for (int64_t gi = g0; gi < groups; gi += gstride) {
         const int64_t n = gi / H;
-        const f32x4 q4 = mq ? *reinterpret_cast<const f32x4*>(q + n * ldq + h * M + 4 * l16) : z4;
-        const f32x4 g4 = md ? *reinterpret_cast<const f32x4*>(g + n * ldg + h * D + 4 * l16) : z4;
-        const f32x4 o4 = md ? *reinterpret_cast<const f32x4*>(out + n * ldo + h * D + 4 * l16) : z4;
-        float dot = (q4[0] * ks[0] + q4[1] * ks[1]) + (q4[2] * ks[2] + q4[3] * ks[3]);
-        float go = (g4[0] * o4[0] + g4[1] * o4[1]) + (g4[2] * o4[2] + g4[3] * o4[3]);
+        f32x4 q4[W], g4[W], o4[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int c = 64 * w + 4 * l16;
+            q4[w] = mq[w] ? *reinterpret_cast<const f32x4*>(q + n * ldq + h * M + c) : z4;
+            g4[w] = md[w] ? *reinterpret_cast<const f32x4*>(g + n * ldg + h * D + c) : z4;
+            o4[w] = md[w] ? *reinterpret_cast<const f32x4*>(out + n * ldo + h * D + c) : z4;
+        }
+        float dot = 0.f, go = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            dot += (q4[w][0] * ks[w][0] + q4[w][1] * ks[w][1]) + (q4[w][2] * ks[w][2] + q4[w][3] * ks[w][3]);
+            go += (g4[w][0] * o4[w][0] + g4[w][1] * o4[w][1]) + (g4[w][2] * o4[w][2] + g4[w][3] * o4[w][3]);
+        }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { dot += __shfl_xor(dot, o, 64); go += __shfl_xor(go, o, 64); }
         const float rden = 1.0f / (s * dot + n_global);
         const float gdv = -go * rden;
-        if (md) *reinterpret_cast<f32x4*>(gn + (n * H + h) * D + 4 * l16) = g4 * rden;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            if (md[w]) *reinterpret_cast<f32x4*>(gn + (n * H + h) * D + 64 * w + 4 * l16) = g4[w] * rden;
+            acc[w] += q4[w] * gdv;
+        }
         if (l16 == 0) { gd[n * H + h] = gdv; gd_acc += gdv; }
-        acc += q4 * gdv;
     }
-    *reinterpret_cast<f32x4*>(&sm[grp][4 * l16]) = acc;
-    if (l16 == 0) sm[grp][64] = gd_acc;
+#pragma unroll
+    for (int w = 0; w < W; ++w) *reinterpret_cast<f32x4*>(&sm[grp][64 * w + 4 * l16]) = acc[w];
+    if (l16 == 0) sm[grp][64 * W] = gd_acc;
     __syncthreads();
     // groups with the same head: grp = h', h' + H, ... when 16 % H == 0; in general (block * 16 + grp) % H
     for (int i = threadIdx.x; i <= H * M; i += 256) {
         const bool scalar = i == H * M;
-        const int hh = scalar ? -1 : i / M, m = scalar ? 64 : i % M;
+        const int hh = scalar ? -1 : i / M, m = scalar ? 64 * W : i % M;
         float a = 0.f;
         for (int g2 = 0; g2 < 16; ++g2) {
             const int h2 = static_cast<int>((static_cast<int64_t>(blockIdx.x) * 16 + g2) % H);
@@ -217,6 +238,121 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float* __restrict__ 
     }
 }
 
+// ---- wide row-GEMM: the same contraction for heads wider than 64 (hidden 128 / 300 of the reference's scripts) ----
+// A workgroup owns 64 output columns of one head (blockIdx.y) and keeps the whole [K x 64] slab of Mat in LDS, transposed
+// (smT[c][k], so that a lane's four k-consecutive multipliers are one ds_read_b128); its eight waves walk 16-row steps,
+// the next 64 channels of A arriving under the MFMAs of the current ones.  K <= 512 (132 KiB of LDS at 512).
+constexpr int kRgWaves = 8;
+
+template <bool VEC>
+__global__ __launch_bounds__(64 * kRgWaves) void rowgemm_wide_kernel(const float* __restrict__ A, int64_t lda, int a_head_stride,
+                                                                     const float* __restrict__ Mat, int ldm, int mat_head_stride,
+                                                                     int mat_t, float mat_scale, const float* __restrict__ bias,
+                                                                     const float* __restrict__ r, int H,
+                                                                     const float* __restrict__ u, float u_scale,
+                                                                     const float* __restrict__ Cin, int64_t ldc,
+                                                                     const float* __restrict__ beta_dev, int64_t n_rows, int K,
+                                                                     int C, float* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float sm_dyn[];
+    const int h = blockIdx.z, ct = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int KT = (K + 63) >> 6, Kp = KT * 64, ldt = Kp + 4;
+    const float* mat = Mat + static_cast<int64_t>(h) * mat_head_stride;
+    const int total = Kp * 64;
+    for (int base = threadIdx.x; base < total; base += 64 * kRgWaves * 8) {           // eight loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = base + 64 * kRgWaves * i;
+            const int k = mat_t ? e % Kp : e >> 6, c = ct * 64 + (mat_t ? e / Kp : e & 63);        // coalesced either way
+            v[i] = (e < total && k < K && c < C) ? mat_scale * (mat_t ? mat[static_cast<int64_t>(c) * ldm + k]
+                                                                      : mat[static_cast<int64_t>(k) * ldm + c]) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = base + 64 * kRgWaves * i;
+            if (e < total) sm_dyn[(mat_t ? e / Kp : e & 63) * ldt + (mat_t ? e % Kp : e >> 6)] = v[i];
+        }
+    }
+    __syncthreads();
+
+    const float beta = (Cin && beta_dev) ? *beta_dev : 1.0f;
+    const int64_t n_steps = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kRgWaves + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kRgWaves;
+    auto load_a = [&](f32x4 (&av)[4], int64_t st, int kt) {
+        const int64_t row = st * 16 + l15;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const int k0 = kt * 64 + 16 * c + 4 * lg;
+            if (row < n_rows) {
+                const float* p = A + row * lda + h * a_head_stride + k0;
+                if (VEC) {
+                    if (k0 < K) z = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (k0 + i < K) z[i] = p[i];
+                }
+            }
+            av[c] = z;
+        }
+    };
+    f32x4 an[4];
+    if (first < n_steps) load_a(an, first, 0);
+    for (int64_t st = first; st < n_steps; st += stride) {
+        const int64_t row = st * 16 + l15;
+        f32x4 acc[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 av[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) av[c] = an[c];
+            if (kt + 1 < KT) load_a(an, st, kt + 1);
+            else if (st + stride < n_steps) load_a(an, st + stride, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k0 = kt * 64 + 16 * c + 4 * lg;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&sm_dyn[(16 * t4 + l15) * ldt + k0]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[t], av[c][t], acc[t4], 0, 0, 0);
+                }
+            }
+        }
+        if (row >= n_rows) continue;
+        const float rv = r ? r[row * H + h] * u_scale : 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int c0 = ct * 64 + 16 * t4 + 4 * lg;              // the lane holds out^T[c0 .. c0 + 3][row]
+            if (VEC) {
+                if (c0 >= C) continue;
+                f32x4 o = acc[t4];
+                if (bias) o += *reinterpret_cast<const f32x4*>(bias + h * C + c0);
+                if (r) o += rv * *reinterpret_cast<const f32x4*>(u + h * C + c0);
+                if (Cin) o += beta * *reinterpret_cast<const f32x4*>(Cin + row * ldc + h * C + c0);
+                *reinterpret_cast<f32x4*>(out + row * ldo + h * C + c0) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + i;
+                    if (c >= C) continue;
+                    float o = acc[t4][i];
+                    if (bias) o += bias[h * C + c];
+                    if (r) o += rv * u[h * C + c];
+                    if (Cin) o += beta * Cin[row * ldc + h * C + c];
+                    out[row * ldo + h * C + c] = o;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t dif_simple_bwd_workspace_bytes(int64_t n_rows, int H, int M, int D) {
@@ -244,15 +380,19 @@ extern "C" int dif_simple_bwd_prep_f32(const float* q, int64_t ldq, const float*
     float* part = static_cast<float*>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto row4 = [](const float* p, int64_t ld) { return ld % 4 == 0 && dif::aligned16(p); };
-    const bool vec = M <= 64 && D <= 64 && M % 4 == 0 && D % 4 == 0 && row4(q, ldq) && row4(g, ldg) && row4(out, ldo) &&
+    const bool vec = M <= 128 && D <= 128 && M % 4 == 0 && D % 4 == 0 && row4(q, ldq) && row4(g, ldg) && row4(out, ldo) &&
                      dif::aligned16(gn) && dif::aligned16(reduced) && (static_cast<int64_t>(H) * M * D + H * M) % 4 == 0 && H <= 512;
     if (vec) {
         // a group keeps its head: the stride over (row, head) pairs, 16 * P, must be a multiple of H
         int64_t Pv = P;
         while ((Pv * 16) % H != 0) --Pv;
         if (Pv < 1) Pv = H;                                  // (H * 16) % H == 0; at most 512 partial records
-        hipLaunchKernelGGL(simple_bwd_prep_vec_kernel, dim3(static_cast<unsigned>(Pv)), dim3(256), 0, st, q, ldq, g, ldg, out, ldo,
-                           reduced, n_rows, static_cast<float>(n_global), H, M, D, gn, gd, part, stride);
+        if (M <= 64 && D <= 64)
+            hipLaunchKernelGGL(simple_bwd_prep_vec_kernel<1>, dim3(static_cast<unsigned>(Pv)), dim3(256), 0, st, q, ldq, g, ldg, out,
+                               ldo, reduced, n_rows, static_cast<float>(n_global), H, M, D, gn, gd, part, stride);
+        else
+            hipLaunchKernelGGL(simple_bwd_prep_vec_kernel<2>, dim3(static_cast<unsigned>(Pv)), dim3(256), 0, st, q, ldq, g, ldg, out,
+                               ldo, reduced, n_rows, static_cast<float>(n_global), H, M, D, gn, gd, part, stride);
         if (int rc = dif::launch_status("simple_bwd_prep_vec_kernel")) return rc;
         return dif::launch_record_finalize(part, static_cast<int>(Pv), stride, len, -1, sums, st);
     }
@@ -263,14 +403,14 @@ extern "C" int dif_simple_bwd_prep_f32(const float* q, int64_t ldq, const float*
     return dif::launch_record_finalize(part, static_cast<int>(P), stride, len, -1, sums, st);
 }
 
-// out[n,h,:C] = A[n,h,:K] Mat_h + bias_h + r[n,h] * u_scale * u_h + (*beta_dev) * Cin[n,h,:C]    (K, C <= 64)
+// out[n,h,:C] = A[n,h,:K] Mat_h + bias_h + r[n,h] * u_scale * u_h + (*beta_dev) * Cin[n,h,:C]    (K <= 512)
 // beta_dev: DEVICE scalar (the backward's coefficients are computed on the device; no host round trip); NULL = 1.
 extern "C" int dif_rowgemm_f32(const float* A, int64_t lda, const float* Mat, int ldm, int mat_head_stride, int mat_t,
                                float mat_scale, const float* bias, const float* r, const float* u, float u_scale,
                                const float* Cin, int64_t ldc, const float* beta_dev, int64_t n_rows, int H, int K,
                                int C, float* out, int64_t ldo, dif_stream_t stream) {
     DIF_REQUIRE(n_rows > 0 && H > 0 && K > 0 && C > 0, DIF_E_BADARG, "dif_rowgemm_f32: sizes must be positive");
-    DIF_REQUIRE(K <= 64 && C <= 64, DIF_E_SHAPE, "dif_rowgemm_f32: covers K, C <= 64 (got %d, %d)", K, C);
+    DIF_REQUIRE(K <= 512 && C <= 65535 * 64, DIF_E_SHAPE, "dif_rowgemm_f32: covers K <= 512 (got %d, %d)", K, C);
     DIF_REQUIRE(A && Mat && out && ((r == nullptr) == (u == nullptr)), DIF_E_BADARG, "dif_rowgemm_f32: null pointer");
     DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_rowgemm_f32: too many heads");
     const int64_t n_steps = (n_rows + 15) / 16;
@@ -279,6 +419,29 @@ extern "C" int dif_rowgemm_f32(const float* A, int64_t lda, const float* Mat, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto ok4 = [](const void* p, int64_t ld) { return !p || (ld % 4 == 0 && dif::aligned16(p)); };
     const int vec = (K % 4 == 0) && (C % 4 == 0) && ok4(A, lda) && ok4(out, ldo) && ok4(Cin, ldc) && ok4(bias, 4) && ok4(u, 4);
+    if (K > 64 || C > 64) {
+        const int KT = (K + 63) / 64, CT = (C + 63) / 64;
+        const size_t lds = static_cast<size_t>(64) * (KT * 64 + 4) * sizeof(float);
+        constexpr int kLdsMax = 64 * (8 * 64 + 4) * static_cast<int>(sizeof(float));
+        static const hipError_t allowed[2] = {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_wide_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_wide_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax)};
+        if (allowed[vec] != hipSuccess)
+            return dif::fail(static_cast<int>(allowed[vec]), "dif_rowgemm_f32: LDS attribute: %s", hipGetErrorString(allowed[vec]));
+        int64_t gw = (n_steps + 2 * kRgWaves - 1) / (2 * kRgWaves);          // >= 2 steps per wave: the staging is amortised
+        const int64_t cap = (lds <= 80 * 1024 ? 2 : 1) * dif::kCUs;
+        if (gw > cap) gw = cap;
+        const dim3 grid(static_cast<unsigned>(gw), CT, H), block(64 * kRgWaves);
+        if (vec)
+            hipLaunchKernelGGL(rowgemm_wide_kernel<true>, grid, block, lds, st, A, lda, K, Mat, ldm, mat_head_stride, mat_t,
+                               mat_scale, bias, r, H, u, u_scale, Cin, ldc, beta_dev, n_rows, K, C, out, ldo);
+        else
+            hipLaunchKernelGGL(rowgemm_wide_kernel<false>, grid, block, lds, st, A, lda, K, Mat, ldm, mat_head_stride, mat_t,
+                               mat_scale, bias, r, H, u, u_scale, Cin, ldc, beta_dev, n_rows, K, C, out, ldo);
+        return dif::launch_status("rowgemm_wide_kernel");
+    }
     hipLaunchKernelGGL(rowgemm_kernel, dim3(static_cast<unsigned>(gx), H), dim3(256), 0, st, A, lda, K, Mat, ldm,
                        mat_head_stride, mat_t, mat_scale, bias, C, r, H, u, C, u_scale, Cin, ldc, beta_dev, n_rows, K, C, out,
                        ldo, vec);

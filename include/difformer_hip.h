@@ -543,7 +543,7 @@ int dif_linear_packed_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in,
  * loss.backward() (main.py:130) needs; the reference leaves it to autograd.  With gn = g/den and
  * gd = -(g.out)/den per (row, head):  dif_simple_bwd_prep_f32 writes gn [n,H,D], gd [n,H] and
  * sums [H*M+1] = { sum_n q*gd per (h,m), sum gd };  dif_simple_reduce_f32(q, q, gn) then gives q^T gn and
- * sum gn;  dif_rowgemm_f32 (out = A Mat + bias + r (x) u + beta Cin per head, K, C <= 64, beta a DEVICE scalar)
+ * sum gn;  dif_rowgemm_f32 (out = A Mat + bias + r (x) u + beta Cin per head, K <= 512, beta a DEVICE scalar)
  * forms dq, dk, dv (formulas in csrc/simple_attn_bwd.hip).
  * ------------------------------------------------------------------------------------- */
 size_t dif_simple_bwd_workspace_bytes(int64_t n_rows, int H, int M, int D);

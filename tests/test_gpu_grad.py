@@ -231,6 +231,33 @@ def test_training_step_through_the_record_every_flag(hidden, use_graph, use_weig
         assert "dif_sliced_spmm_f32" in launched
 
 
+@pytest.mark.parametrize("hidden,heads,n,deg", [(128, 1, 6000, 6), (128, 1, 9000, 60), (300, 1, 2000, 5), (64, 2, 5000, 8)])
+def test_training_step_with_wide_heads(hidden, heads, n, deg, dev):
+    """--hidden_channels 128 / 300 (run.sh's large-graph and image lines): a training step whose attention gradient runs on
+    the HIP backward for heads wider than 64 (128-column prep, wide row-GEMM; no tensor-op re-derivation), against float64
+    autograd of the oracle."""
+    from difformer_amd import DIFFormer, ops
+    g = torch.Generator().manual_seed(hidden + n)
+    pairs = torch.randint(0, n, (2, n * deg // 2), generator=g)
+    ei = torch.cat([pairs, pairs.flip(0), torch.arange(n).repeat(2, 1)], dim=1).to(dev)
+    torch.manual_seed(9)
+    kw = dict(num_layers=2, num_heads=heads, kernel="simple", alpha=0.5, use_bn=True, use_residual=True, use_weight=True,
+              use_graph=True, graph_weight=-1, use_source=False)
+    model = DIFFormer(30, hidden, 5, dropout=0.0, **kw).to(dev).train()
+    cfg = dict(hidden_channels=hidden, **kw)
+    x = torch.randn(n, 30, generator=g).to(dev).requires_grad_(True)
+    y = torch.randint(0, 5, (n,), generator=g).to(dev)
+    idx = torch.randperm(n, generator=g)[: n // 2].to(dev)
+    be = ops.get_backend()
+    be.kernel_events = {}
+    try:
+        _check_step(model, x, ei, cfg, y, idx)
+        launched = set(be.kernel_events)
+    finally:
+        be.kernel_events = None
+    assert {"dif_simple_bwd_prep_f32", "dif_rowgemm_f32"} <= launched, launched
+
+
 def test_training_step_at_cora_size(dev):
     """BASELINE config C1 as a training step (main.py:117-131 on Cora: 2,708 nodes, 1,433 features, 7 classes)."""
     from difformer_amd import DIFFormer

@@ -880,21 +880,47 @@ def test_row_sharded_kernels_match_unsharded(world, dev):
         assert rel_err(out_r.cpu().numpy(), full[lo:hi].cpu().numpy()) < 1e-5, (world, r)
 
 
-@pytest.mark.parametrize("n,h,d", [(300, 1, 64), (1000, 2, 32), (257, 3, 20), (50000, 1, 64)])
+@pytest.mark.parametrize("n,h,d", [(300, 1, 64), (1000, 2, 32), (257, 3, 20), (50000, 1, 64), (3000, 1, 128), (40000, 1, 128),
+                                   (700, 2, 100), (900, 1, 300), (333, 1, 130), (64, 1, 512)])
 def test_simple_attention_backward_kernels(n, h, d, dev):
     """dq, dk, dv from the HIP backward (bwd_prep + reduce + row-GEMMs) against float64 autograd of the closed form
-    of difformer.py:18-39 (the reference itself relies on autograd)."""
-    from difformer_amd import autograd_ops as ag
+    of difformer.py:18-39 (the reference itself relies on autograd).  Heads wider than 64 (hidden 128 / 300 of the
+    reference's scripts): the 128-column prep kernel or the generic one, and the wide row-GEMM with the [K x 64] slab in LDS."""
+    from difformer_amd import autograd_ops as ag, ops
     g = torch.Generator().manual_seed(n + d)
     q, k, v = (torch.randn(n, h, d, generator=g) for _ in range(3))
     go = torch.randn(n, h, d, generator=g)
     qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
-    out = ag.simple_attention(qd, kd, vd)
-    out.backward(go.to(dev))
+    be = ops.get_backend()
+    be.kernel_events = {}
+    try:
+        out = ag.simple_attention(qd, kd, vd)
+        out.backward(go.to(dev))
+        launched = set(be.kernel_events)
+    finally:
+        be.kernel_events = None
+    assert {"dif_simple_bwd_prep_f32", "dif_rowgemm_f32"} <= launched, launched
     q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
     ag._simple_expr(q64, k64, v64).backward(go.double())
     for got, ref, name in ((qd.grad, q64.grad, "dq"), (kd.grad, k64.grad, "dk"), (vd.grad, v64.grad, "dv")):
         assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-4, name
+
+
+@pytest.mark.parametrize("n,K,C,acc", [(5000, 128, 128, True), (777, 300, 300, False), (3000, 64, 192, True), (1000, 130, 7, True),
+                                       (20, 512, 64, False), (4000, 40, 40, True)])
+def test_row_gemm_wide(n, K, C, acc, dev):
+    """dif_rowgemm_f32 beyond 64 columns (the [K x 64] slab of the matrix resident in LDS, K <= 512): A mat + bias
+    (+ accumulate) against float64, odd widths included (scalar loads / stores)."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(K + C)
+    A, mat, bias, prev = torch.randn(n, K, generator=g), torch.randn(K, C, generator=g), torch.randn(C, generator=g), torch.randn(n, C, generator=g)
+    got = ops.get_backend().row_gemm(A.to(dev), mat.to(dev), bias.to(dev), prev.to(dev) if acc else None)
+    ref = A.double() @ mat.double() + bias.double() + (prev.double() if acc else 0)
+    assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
+    # a column slice of a wider tensor as A (leading dimension != K)
+    wide = torch.randn(n, K + 8, generator=g).to(dev)
+    got = ops.get_backend().row_gemm(wide[:, 4:4 + K], mat.to(dev))
+    assert rel_err(got.cpu().numpy(), (wide[:, 4:4 + K].cpu().double() @ mat.double()).numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("n,l,h,m,d", [(300, 300, 1, 64, 64), (100, 257, 2, 32, 32), (2708, 2708, 1, 64, 64), (65, 65, 1, 7, 7),
