@@ -709,6 +709,9 @@ __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], c
     }
 }
 
+#ifndef DIF_LAYER_PROBE
+#define DIF_LAYER_PROBE 0         // measurement builds (scripts/exp_layer_probes.py): 1 no products, 2 no weight staging,
+#endif                            // 3 no slice-major copy, 4 no row-major store, 5 the graph rows are not read
 #ifndef DIF_GATHER_WG
 #define DIF_GATHER_WG 4           // measurement builds: workgroups per CU the GATHER variants are compiled for
 #endif
@@ -732,7 +735,8 @@ void simple_layer_kernel(LayerArgsT<T> a) {
     const int64_t n_tiles = (a.n_rows + 15) / 16;
     const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * NW + wave, stride = static_cast<int64_t>(gridDim.x) * NW;
-    if (EXACT && (reinterpret_cast<uintptr_t>(a.coef) & 15u) == 0 && (!GRAPH_W || (reinterpret_cast<uintptr_t>(a.Wv) & 15u) == 0)) {
+    if (DIF_LAYER_PROBE == 2) {        // measurement build: no weight staging (the LDS holds whatever it holds)
+    } else if (EXACT && (reinterpret_cast<uintptr_t>(a.coef) & 15u) == 0 && (!GRAPH_W || (reinterpret_cast<uintptr_t>(a.Wv) & 15u) == 0)) {
         // dense 64 x 64 blocks: all eight 16-byte loads of a thread are in flight before the first LDS store (an
         // element-wise loop runs 32 load -> store round trips back to back: ~30 us of prologue per workgroup)
         // Thread -> fragment map of the staging: a wave instruction reads eight ROWS x 128 contiguous bytes (whole cache
@@ -822,7 +826,12 @@ void simple_layer_kernel(LayerArgsT<T> a) {
         f32x4 y[4];
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) y[ft] = *reinterpret_cast<const f32x4*>(&sm_cn[16 * ft + 4 * lg]);
+#if DIF_LAYER_PROBE == 1           // measurement build: no products (the rows stand in for them)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] += xa[ft];
+#else
         project_t(y, xa, sm_w[0], l15, lg);
+#endif
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) y[ft] *= rden;
         if (GATHER || a.ax) {
@@ -833,13 +842,23 @@ void simple_layer_kernel(LayerArgsT<T> a) {
 #pragma unroll
                 for (int cq = 0; cq < 4; ++cq) ga[cq] *= a.gcn_scale;          // ax = g_s A_hat x; the bias term scales below
             } else {
+#if DIF_LAYER_PROBE == 5
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) ga[cq] = xa[cq];
+#else
                 load_rows<G>(ga, a.ax, a.ldax, row, a.n_rows, lg, C);
+#endif
                 rsv = (a.rs && row_ok) ? a.rs[row] : 0.f;
             }
             if (GRAPH_W) {        // the second product accumulates on top of the attention term
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft) y[ft] += *reinterpret_cast<const f32x4*>(&sm_bv[16 * ft + 4 * lg]) * rsv;
+#if DIF_LAYER_PROBE == 1
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) y[ft] += ga[ft];
+#else
                 project_t(y, ga, sm_w[1], l15, lg);
+#endif
             } else {          // use_weight = False: the aggregated rows are the graph term (C == D), same layout
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft) y[ft] += ga[ft];
@@ -944,12 +963,12 @@ void simple_layer_kernel(LayerArgsT<T> a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (a.out && row_ok && (EXACT || f < D)) {
+            if (a.out && row_ok && (EXACT || f < D) && DIF_LAYER_PROBE != 4) {
                 if (EXACT || ((a.ldo & 3) == 0 && f + 3 < D)) Elem<T>::st4(a.out + row * a.ldo + f, v);
                 else
                     for (int r = 0; r < 4; ++r) if (f + r < D) Elem<T>::st(a.out + row * a.ldo + f + r, v[r]);
             }
-            if (!NEXT && a.ys_next) {
+            if (!NEXT && a.ys_next && DIF_LAYER_PROBE != 3) {
                 // slice-major pre-scaled copy for the next layer's SpMM straight from the registers: this lane holds
                 // slice 4ft + lg of its row, the 16 lanes of a group 16 consecutive rows -> 256 contiguous bytes
                 if (row_ok && (EXACT || f < D)) a.ys_next[static_cast<int64_t>(4 * ft + lg) * a.npad + row] = v * dscale;
