@@ -537,8 +537,8 @@ def norm_relu(x, ln_weight, ln_bias, eps):
 
 def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
     """nn.Linear (-> LayerNorm) (-> ReLU).  Narrow inputs (C_in <= 128) and long rows into a narrow layer (C_in up to 8192 ->
-    C_out <= 64: 512 -> 64 at CIFAR scale, 1,433 -> 64 on Cora) run the fused HIP kernels when no gradient is needed; the
-    rest uses the vendor GEMM (rocBLAS via F.linear) followed by the fused LayerNorm/ReLU kernel."""
+    C_out <= 64: 512 -> 64 at CIFAR scale, 1,433 -> 64 on Cora) and wide rows into a wide layer (up to 832 -> 416: 512 -> 300 of
+    the image scripts) run the fused HIP kernels when no gradient is needed; the rest uses the vendor GEMM (rocBLAS via F.linear) followed by the fused LayerNorm/ReLU kernel."""
     fn = torch.nn.functional
     grad = _needs_grad(x, weight, bias, ln_weight, ln_bias)
     # 65-128 input columns keep only 128 output features per workgroup in LDS: beyond that x is re-read per 128 features
@@ -551,6 +551,10 @@ def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
             (x.dtype == torch.float32 or (x.shape[1] % 4 == 0 and x.shape[0] >= 16384))):
         # float32: any row count and any width (Cora's 1,433 features: rows only 4-byte aligned) -- few or unaligned rows take
         # the kernel that splits K over the waves of a workgroup; bfloat16 storage: the chunked kernel's shapes only
+        return ops.linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
+    if not grad and x.dim() == 2 and bias is not None and ops.linear_xwide_covers(x, weight):
+        # wide rows into a wide layer (image and text/run.sh:27: 512 -> 300): the hidden-300 layer kernel with the two halves of
+        # the input channels as its two accumulating products, LayerNorm / ReLU in the same pass
         return ops.linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
     y = _row_linear(x, weight, bias) if grad else fn.linear(x, weight, bias)
     if ln_weight is not None:

@@ -1003,6 +1003,20 @@ class HipBackend:
             ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
         out = torch.empty((n, Co), dtype=dt, device=dev)
         from . import ops
+        if sfx == "f32" and Co > 64 and ops.linear_xwide_covers(x, weight):
+            # wide rows into a wide layer: one product (C <= 416) or the two halves of the input channels as the two accumulating
+            # products of the hidden-300 layer kernel; weights packed once per parameter version
+            if ldx % 4 or x.data_ptr() % 16:
+                x, ldx = x.contiguous(), C
+            two = C > ops.XWIDE_MAX
+            Ch = C // 2 if two else C
+            pa = self.xwide_pack(weight, False, Ch, Co, cache=True)
+            pb = self.xwide_pack(weight, False, Ch, Co, cache=True, col0=Ch) if two else None
+            with _timed(self, "dif_linear_f32", dev):
+                rc = self.lib.dif_linear_xwide_f32(_ptr(x), ldx, n, C, _ptr(pa), _ptr(pb), _ptr(bias), Co, _ptr(ln_weight), _ptr(ln_bias),
+                                                   float(eps), int(bool(relu)), _ptr(out), Co, _stream(dev))
+            _lib.check(rc, "dif_linear_xwide_f32")
+            return out
         if (sfx == "f32" and C > 128 and Co <= 64 and C <= 8192 and not ops.EXACT_FP32 and
                 (n < 16384 or C % 4 or ldx % 4 or x.data_ptr() % 16 or weight.data_ptr() % 16)):
             # few rows, or rows that are only 4-byte aligned (Cora: 2,708 x 1,433): K split over the waves of a workgroup,
@@ -1224,16 +1238,17 @@ class HipBackend:
         _lib.check(rc, "dif_simple_layer_wide_f32")
         return out
 
-    def xwide_pack(self, src, transposed, C, D, cache=False):
-        """dif_xwide_pack_f32: src [C, ld] (transposed: the [Mn | u] operand) or [D, C] (an nn.Linear weight) -> packed MFMA
-        fragments.  cache=True keeps the packing per weight tensor (identity + version, as _packed_weight)."""
+    def xwide_pack(self, src, transposed, C, D, cache=False, col0=0):
+        """dif_xwide_pack_f32: src [C, ld] (transposed: the [Mn | u] operand) or [D, ld] (an nn.Linear weight; col0: the C
+        input channels start at that column) -> packed MFMA fragments.  cache=True keeps the packing per weight tensor
+        (identity + version, as _packed_weight)."""
         import weakref
         from . import ops
         dev = src.device
         key = None
         if cache:
             ver = ops.tensor_version(src)
-            key = (id(src), src.data_ptr(), ver, C, D, bool(transposed), str(dev))
+            key = (id(src), src.data_ptr(), ver, C, D, bool(transposed), str(dev), col0)
             store = self.__dict__.setdefault("_packed", {})
             hit = store.get(key)
             if hit is not None and ver >= 0 and hit[0]() is src:
@@ -1241,7 +1256,8 @@ class HipBackend:
         src_c = src.contiguous()
         packed = torch.empty(self.lib.dif_xwide_packed_bytes(C, D), dtype=torch.uint8, device=dev)
         with _timed(self, "dif_xwide_pack_f32", dev):
-            rc = self.lib.dif_xwide_pack_f32(_ptr(src_c), int(src_c.shape[1]), int(bool(transposed)), C, D, _ptr(packed), _stream(dev))
+            rc = self.lib.dif_xwide_pack_f32(src_c.data_ptr() + 4 * col0, int(src_c.shape[1]), int(bool(transposed)), C, D, _ptr(packed),
+                                             _stream(dev))
         _lib.check(rc, "dif_xwide_pack_f32")
         if cache and key[2] >= 0:
             for k in [k for k, v in store.items() if v[0]() is None]:

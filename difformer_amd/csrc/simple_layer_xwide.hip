@@ -91,14 +91,16 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void simple_layer_xwide_kernel(XAr
     const int l15 = lane & 15, lg = lane >> 4;
     const int C = a.C, D = a.D;
     constexpr int KB = KBMAX;                      // the geometry is the template's: packed weights are zero-padded up to it
-    for (int i = threadIdx.x; i < KBMAX * 32; i += 64 * kXWaves) sm_u[i] = i < C ? a.bmat[static_cast<int64_t>(i) * a.dv + D] : 0.f;
+    // bmat == NULL (dif_linear_xwide_f32): no denominator -- u = 0, cd = 1
+    for (int i = threadIdx.x; i < KBMAX * 32; i += 64 * kXWaves)
+        sm_u[i] = (a.bmat && i < C) ? a.bmat[static_cast<int64_t>(i) * a.dv + D] : 0.f;
     for (int i = threadIdx.x; i < FCMAX * 32; i += 64 * kXWaves) {
         sm_cn[i] = i < D ? a.bias[i] : 0.f;
         sm_bv[i] = (a.pv && a.rs && i < D) ? a.bv[i] * a.gcn_scale : 0.f;
         sm_lw[i] = (a.ln_w && i < D) ? a.ln_w[i] : 1.f;
         sm_lb[i] = (a.ln_b && i < D) ? a.ln_b[i] : 0.f;
     }
-    if (threadIdx.x == 0) sm_cd = a.bias[D];
+    if (threadIdx.x == 0) sm_cd = a.bmat ? a.bias[D] : 1.0f;
     __syncthreads();
     const float cd = sm_cd;
     const float inv_d = 1.0f / static_cast<float>(D);
@@ -284,19 +286,46 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void simple_layer_xwide_kernel(XAr
 
 bool xwide_covers(int C, int D) { return C > 0 && D > 0 && C <= 416 && D <= 416 && C % 4 == 0 && D % 4 == 0; }
 
-// k-blocks (of 32 channels) = feature chunks (of 32) the kernel is instantiated for: the smallest that holds max(C, D); the
-// packed weights are laid out (and zero-padded) for it
-int xwide_geometry(int C, int D) {
-    const int need = ((C > D ? C : D) + 31) / 32;
-    return need <= 6 ? 6 : (need <= 8 ? 8 : (need <= 10 ? 10 : 13));
+// k-blocks (of 32 channels) x feature chunks (of 32) the kernel is instantiated for: squares that hold max(C, D) (the layer:
+// C == D), and two oblong ones for the input Linear's halves (256 channels -> 300 / 400 features: a square would multiply
+// 25 % / 62 % zero padding).  The packed weights are laid out (and zero-padded) for the geometry.
+struct XGeo { int kb, fc; };
+XGeo xwide_geometry(int C, int D) {
+    auto bucket = [](int v) { const int need = (v + 31) / 32; return need <= 6 ? 6 : (need <= 8 ? 8 : (need <= 10 ? 10 : 13)); };
+    const int kb = bucket(C), fc = bucket(D);
+    if (kb == 8 && (fc == 10 || fc == 13)) return {kb, fc};
+    const int g = kb > fc ? kb : fc;
+    return {g, g};
+}
+
+template <int KB, int FC>
+int xwide_launch(const XArgs& a, unsigned P, hipStream_t st) {
+    constexpr int lds = 2 * KB * 2 * 128 * 16;             // two chunk buffers
+    static const hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_layer_xwide_kernel<KB, FC>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_simple_layer_xwide: LDS attribute: %s", hipGetErrorString(he));
+    hipLaunchKernelGGL((simple_layer_xwide_kernel<KB, FC>), dim3(P), dim3(64 * kXWaves), lds, st, a);
+    return dif::launch_status("simple_layer_xwide_kernel");
+}
+int xwide_dispatch(const XArgs& a, hipStream_t st) {
+    const int64_t blocks = (a.n_rows + 16 * kXWaves - 1) / (16 * kXWaves);
+    const unsigned P = static_cast<unsigned>(blocks < dif::kCUs ? blocks : dif::kCUs);
+    switch (a.KB * 100 + a.FC) {
+        case 606: return xwide_launch<6, 6>(a, P, st);
+        case 808: return xwide_launch<8, 8>(a, P, st);
+        case 810: return xwide_launch<8, 10>(a, P, st);
+        case 813: return xwide_launch<8, 13>(a, P, st);
+        case 1010: return xwide_launch<10, 10>(a, P, st);
+        default: return xwide_launch<13, 13>(a, P, st);
+    }
 }
 
 }  // namespace
 
 extern "C" int64_t dif_xwide_packed_bytes(int C, int D) {
     if (!xwide_covers(C, D)) return 0;
-    const int64_t G = xwide_geometry(C, D);
-    return G * 2 * G * 128 * 16;
+    const XGeo g = xwide_geometry(C, D);
+    return static_cast<int64_t>(g.fc) * 2 * g.kb * 128 * 16;
 }
 
 // src: [C][ld] with the matrix in columns [0, D) when transposed (the [Mn | u] operand of dif_wide_scale_f64), else [D][ld]
@@ -305,9 +334,9 @@ extern "C" int dif_xwide_pack_f32(const float* src, int64_t ld, int transposed, 
     DIF_REQUIRE(src && packed && xwide_covers(C, D) && dif::aligned16(packed), DIF_E_BADARG,
                 "dif_xwide_pack: needs src, a 16-byte aligned buffer and C, D <= 416, multiples of 4");
     DIF_REQUIRE(ld >= (transposed ? D : C), DIF_E_BADARG, "dif_xwide_pack: leading dimension smaller than a row");
-    const int G = xwide_geometry(C, D);
-    hipLaunchKernelGGL(xwide_pack_kernel, dim3(static_cast<unsigned>((G * G + 1) / 2)), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld,
-                       transposed, C, D, G, G, static_cast<bf16x8*>(packed));
+    const XGeo g = xwide_geometry(C, D);
+    hipLaunchKernelGGL(xwide_pack_kernel, dim3(static_cast<unsigned>((g.kb * g.fc + 1) / 2)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       src, ld, transposed, C, D, g.kb, g.fc, static_cast<bf16x8*>(packed));
     return dif::launch_status("xwide_pack_kernel");
 }
 
@@ -332,22 +361,33 @@ extern "C" int dif_simple_layer_xwide_f32(const float* x, int64_t ldx, int64_t n
                 (!ax || (ldax >= C && ldax % 4 == 0 && dif::aligned16(ax))) && (!x0 || (ldx0 >= D && ldx0 % 4 == 0 && dif::aligned16(x0))) &&
                 dif::aligned16(packed_m) && dif::aligned16(packed_v), DIF_E_BADARG,
                 "dif_simple_layer_xwide: rows and packed weights must be 16-byte aligned with ld >= the row length");
-    const int G = xwide_geometry(C, D);
-    const int64_t blocks = (n_rows + 16 * kXWaves - 1) / (16 * kXWaves);
-    const unsigned P = static_cast<unsigned>(blocks < dif::kCUs ? blocks : dif::kCUs);
-    const size_t lds = 2 * static_cast<size_t>(G) * 2 * 128 * 16;             // two chunk buffers
+    const XGeo g = xwide_geometry(C, D);
     const XArgs a = {x, ldx, static_cast<const bf16x8*>(packed_m), static_cast<const bf16x8*>(packed_v), bmat, dv, bias, attn_scale,
                      ax, ldax, bv, row_sums, gcn_scale, x0, ldx0, residual, alpha, ln_weight, ln_bias, ln_eps, relu, out, ldo,
-                     n_rows, C, D, G, G};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-#define DIF_XW(GG)                                                                                                                  \
-    do {                                                                                                                            \
-        static const hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_layer_xwide_kernel<GG, GG>),          \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GG * 2 * 128 * 16);             \
-        if (he != hipSuccess) return dif::fail(static_cast<int>(he), "dif_simple_layer_xwide: LDS attribute: %s", hipGetErrorString(he)); \
-        hipLaunchKernelGGL((simple_layer_xwide_kernel<GG, GG>), dim3(P), dim3(64 * kXWaves), lds, st, a);                            \
-    } while (0)
-    if (G == 6) DIF_XW(6); else if (G == 8) DIF_XW(8); else if (G == 10) DIF_XW(10); else DIF_XW(13);
-#undef DIF_XW
-    return dif::launch_status("simple_layer_xwide_kernel");
+                     n_rows, C, D, g.kb, g.fc};
+    return xwide_dispatch(a, static_cast<hipStream_t>(stream));
+}
+
+// nn.Linear (-> LayerNorm) (-> ReLU) with a WIDE result (64 < D <= 416; image and text/run.sh:27: the 512 -> 300 input layer of
+// difformer.py:188-191) on the same kernel: the layer's two accumulating products are the two halves of the input channels,
+//   out = LN( x[:, :Ch] Wa^T + x[:, Ch:] Wb^T + bias ),   Ch = C_in / 2 <= 416,   or one product for C_in <= 416 (packed_b NULL)
+// packed_a / packed_b = dif_xwide_pack_f32(W + 0 / + Ch, ld = C_in, transposed = 0, Ch, D).  Replaces the library GEMM + tail
+// pass (143 + 26 us at 50,000 x 512 -> 300).
+extern "C" int dif_linear_xwide_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const void* packed_a, const void* packed_b,
+                                    const float* bias, int D, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                                    float* out, int64_t ldo, dif_stream_t stream) {
+    DIF_REQUIRE(x && packed_a && bias && out && n_rows > 0, DIF_E_BADARG, "dif_linear_xwide: null pointer or no rows");
+    const int Ch = packed_b ? C_in / 2 : C_in;
+    DIF_REQUIRE(C_in > 0 && (!packed_b || C_in % 2 == 0) && xwide_covers(Ch, D), DIF_E_SHAPE,
+                "dif_linear_xwide: covers D <= 416 and C_in <= 416 (one product) or C_in / 2 <= 416 (two), multiples of 4 (got %d -> %d)",
+                C_in, D);
+    DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), DIF_E_BADARG, "dif_linear_xwide: ln_weight and ln_bias must be given together");
+    DIF_REQUIRE(ldx >= C_in && ldx % 4 == 0 && dif::aligned16(x) && ldo >= D && ldo % 4 == 0 && dif::aligned16(out) &&
+                dif::aligned16(packed_a) && dif::aligned16(packed_b), DIF_E_BADARG,
+                "dif_linear_xwide: rows and packed weights must be 16-byte aligned with ld >= the row length");
+    const XGeo g = xwide_geometry(Ch, D);
+    const XArgs a = {x, ldx, static_cast<const bf16x8*>(packed_a), static_cast<const bf16x8*>(packed_b), nullptr, 0, bias, 1.0f,
+                     packed_b ? x + Ch : nullptr, ldx, bias, nullptr, 1.0f, nullptr, 0, 0, 1.0f, ln_weight, ln_bias, ln_eps, relu,
+                     out, ldo, n_rows, Ch, D, g.kb, g.fc};
+    return xwide_dispatch(a, static_cast<hipStream_t>(stream));
 }

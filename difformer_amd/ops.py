@@ -1078,5 +1078,22 @@ def layer_tail(conv, x0=None, prev=None, alpha=0.5, ln_weight=None, ln_bias=None
 
 
 def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
-    """x W^T + b (-> LayerNorm) (-> ReLU) for C_in <= 128 (difformer.py:188-191, :208; csrc/skinny_linear.hip)."""
+    """x W^T + b (-> LayerNorm) (-> ReLU) (difformer.py:188-191, :208; csrc/skinny_linear.hip: C_in <= 128, long rows into
+    <= 64 features; csrc/simple_layer_xwide.hip: wide rows into 65..416 features, see linear_xwide_covers)."""
     return get_backend().linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
+
+
+LINEAR_XWIDE_MIN_ROWS = 16384       # below: too few 128-row blocks for the chip (15,000 x 512 -> 300: 64 us against 62 for GEMM + tail)
+
+
+def linear_xwide_covers(x, weight):
+    """Shapes dif_linear_xwide_f32 takes (float32, split-bf16 products: not under DIFFORMER_EXACT_FP32): more than 128 input
+    channels in one product (<= 416) or two halves (C_in % 8 == 0, C_in / 2 <= 416), 65..416 output features, both multiples
+    of 4, enough rows to fill the chip (a workgroup owns 128 rows)."""
+    if EXACT_FP32 or x.dtype != torch.float32 or weight.dtype != torch.float32 or x.dim() != 2:
+        return False
+    n, c_in = x.shape
+    d = weight.shape[0]
+    if n < LINEAR_XWIDE_MIN_ROWS or not (64 < d <= XWIDE_MAX) or d % 4 or c_in <= 128 or c_in % 4:
+        return False
+    return c_in <= XWIDE_MAX or (c_in % 8 == 0 and c_in // 2 <= XWIDE_MAX)

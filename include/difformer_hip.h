@@ -466,6 +466,13 @@ int dif_simple_layer_xwide_f32(const float* x, int64_t ldx, int64_t n_rows, int 
                                const float* ax, int64_t ldax, const float* bv, const float* row_sums, float gcn_scale,
                                const float* x0, int64_t ldx0, int residual, float alpha, const float* ln_weight,
                                const float* ln_bias, float ln_eps, int relu, float* out, int64_t ldo, dif_stream_t stream);
+/* nn.Linear (-> LayerNorm) (-> ReLU) with a wide result, difformer.py:188-191 at image and text/run.sh:27 (512 -> 300), on the
+ * same kernel: out = LN(x[:, :Ch] Wa^T + x[:, Ch:] Wb^T + bias) with Ch = C_in / 2 <= 416 and packed_a / packed_b =
+ * dif_xwide_pack_f32(W + 0 / + Ch, ld = C_in, transposed = 0, Ch, D); packed_b NULL: one product, C_in <= 416.  D <= 416;
+ * C_in / Ch and D multiples of 4; rows of x and out 16-byte aligned. */
+int dif_linear_xwide_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in, const void* packed_a, const void* packed_b,
+                         const float* bias, int D, const float* ln_weight, const float* ln_bias, float ln_eps, int relu,
+                         float* out, int64_t ldo, dif_stream_t stream);
 /* Gram record of the closed form for 64 < C <= 128 (hidden 128): record [X^T X (C x C, ALL of it) | sum x (C) | ...] in the
  * layout of dif_gram_sym_f32, from ONE pass over x on the fp32 MFMA (csrc/simple_layer_wide.hip).  C % 4 == 0, 16-byte aligned
  * rows; workspace: dif_gram128_workspace_bytes, 16-byte aligned. */

@@ -482,6 +482,50 @@ def test_long_linear_vs_numpy(n, ci, co, ln, relu, dev):
         assert ob.dtype == torch.bfloat16 and rel_err(ob.float().cpu().numpy(), refb) < 1e-2
 
 
+@pytest.mark.parametrize("n,ci,co,ln,relu", [(50000, 512, 300, True, True),          # image and text/run.sh:27 (CIFAR embeddings)
+                                              (17000, 256, 128, True, False), (16384, 832, 416, True, True),
+                                              (16385, 300, 68, False, True), (20001, 136, 100, True, True),
+                                              (20000, 384, 400, False, False)])
+def test_wide_linear_vs_numpy(n, ci, co, ln, relu, dev):
+    """Wide rows into a wide layer (the input MLP at hidden 300 / 400, difformer.py:188-191): dif_linear_xwide_f32 -- one product
+    up to 416 input channels, the two halves of the channels as two accumulating products beyond; split-bf16 terms (~4e-6 of the
+    float64 result), LayerNorm / ReLU in the same pass.  The model path (autograd_ops.linear, no gradient) takes it too."""
+    from difformer_amd import autograd_ops as ag, ops
+    g = torch.Generator().manual_seed(ci * 100 + co)
+    x = torch.randn(n, ci, generator=g)
+    W, b = torch.randn(co, ci, generator=g) / np.sqrt(ci), torch.randn(co, generator=g)
+    lw, lb = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
+    be = ops.get_backend()
+    xd, Wd, bd = x.to(dev), W.to(dev), b.to(dev)
+    lwd, lbd = (lw.to(dev), lb.to(dev)) if ln else (None, None)
+    assert ops.linear_xwide_covers(xd, Wd)
+    be.kernel_events = {}
+    try:
+        out = be.linear(xd, Wd, bd, lwd, lbd, 1e-5, relu)
+        with torch.no_grad():
+            out_model = ag.linear(xd, Wd, bd, lwd, lbd, 1e-5, relu)
+        launched = set(be.kernel_events)
+    finally:
+        be.kernel_events = None
+    assert "dif_xwide_pack_f32" in launched, launched
+    ref = x.double().numpy() @ W.double().numpy().T + b.double().numpy()
+    if ln:
+        ref = orc.layer_norm(ref, lw.double().numpy(), lb.double().numpy())
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert rel_err(out.cpu().numpy(), ref) < 2e-5
+    assert torch.equal(out, out_model)
+    # a parameter update (version bump) re-packs the weights
+    with torch.no_grad():
+        Wd.mul_(2.0)
+    out2 = be.linear(xd, Wd, bd, None, None, 1e-5, False)
+    assert rel_err(out2.cpu().numpy(), 2 * (x.double().numpy() @ W.double().numpy().T) + b.double().numpy()) < 2e-5
+    # a column slice of a wider tensor as x (leading dimension != C_in)
+    wide = torch.randn(n, ci + 8, generator=g).to(dev)
+    out3 = be.linear(wide[:, 4:4 + ci], Wd, bd, None, None, 1e-5, False)
+    assert rel_err(out3.cpu().numpy(), wide[:, 4:4 + ci].cpu().double().numpy() @ (2 * W.double().numpy()).T + b.double().numpy()) < 2e-5
+
+
 def test_layer_tail_relu(dev):
     from difformer_amd import ops
     g = torch.Generator().manual_seed(2)
