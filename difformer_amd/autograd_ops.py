@@ -118,7 +118,7 @@ class _SimpleAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         q, k, v, reduced, out = ctx.saved_tensors
-        hip_ok = (q.dtype == torch.float32 and q.shape[2] <= 512 and v.shape[2] <= 512 and
+        hip_ok = (q.dtype == torch.float32 and q.shape[2] <= 512 and v.shape[2] <= 512 and q.shape[1] * q.shape[2] < 12000 and
                   hasattr(ops.get_backend(), "simple_backward"))
         if hip_ok:
             # row-sharded: two small all-reduces inside (the sums over nodes of the backward, then the scalar T)
