@@ -148,7 +148,12 @@ class DIFFormerConv(nn.Module):
                 w, b = self._fused_wb[1], self._fused_wb[2]
             # [n, (2|3)*H*D]; q/k/v are column slices.  Narrow inputs take the hand-written Linear kernel (one launch,
             # x read once), wide ones the vendor GEMM (autograd_ops.linear decides).
-            qkv = ag.linear(source_input, w, b) if w.shape[0] <= 256 else F.linear(source_input, w, b)
+            if w.shape[0] <= 256:
+                qkv = ag.linear(source_input, w, b)
+            elif ag._needs_grad(source_input, w, b):
+                qkv = ag._row_linear(source_input, w, b)       # training at hidden 128: weight gradient on the streaming reduce
+            else:
+                qkv = F.linear(source_input, w, b)
             cols = ag.split_columns(qkv, *([H * D] * (3 if self.use_weight else 2)))
             q, k = cols[0].reshape(-1, H, D), cols[1].reshape(-1, H, D)
             v = cols[2].reshape(-1, H, D) if self.use_weight else None

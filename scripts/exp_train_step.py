@@ -1,6 +1,6 @@
 """Training step on the C4 shape as node classification/main.py:117-131 runs it: forward (HIP kernels), BCE-with-logits
 loss on a training split, backward (HIP adjoint SpMM + simple-attention backward kernels, torch autograd elsewhere), Adam.
-    python scripts/exp_train_step.py [cora|c4]
+    python scripts/exp_train_step.py [cora|c4|h128]
 """
 import sys, os, time
 import torch
@@ -10,9 +10,15 @@ from bench import make_graph
 
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "c4"
-n, pairs, f_in, classes, layers = (132534, 39561252, 8, 112, 3) if which == "c4" else (2708, 5278, 1433, 7, 2)
+hidden = 64
+if which == "c4":
+    n, pairs, f_in, classes, layers = 132534, 39561252, 8, 112, 3
+elif which == "h128":          # node classification/run.sh:42-44: a Pokec mini-batch at hidden 128
+    n, pairs, f_in, classes, layers, hidden = 100000, 115000, 65, 2, 3, 128
+else:
+    n, pairs, f_in, classes, layers = 2708, 5278, 1433, 7, 2
 torch.manual_seed(0)
-model = DIFFormer(f_in, 64, classes, num_layers=layers, kernel="simple", dropout=0.0 if which == "c4" else 0.2).to(dev)
+model = DIFFormer(f_in, hidden, classes, num_layers=layers, kernel="simple", dropout=0.0 if which != "cora" else 0.2).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=0.0)
 x = torch.randn(n, f_in, device=dev)
 ei = make_graph(n, pairs, dev)
