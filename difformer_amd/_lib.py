@@ -124,6 +124,8 @@ SIGNATURES = {
     "dif_xwide_pack_f32": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "dif_simple_layer_xwide_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp,
                                            c_f32, c_vp, c_i64, c_int, c_f32, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
+    "dif_gram_coeffs_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp,
+                                    c_sz, c_vp]),
     "dif_linear_xwide_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp]),
     "dif_gram128_workspace_bytes": (c_sz, [c_i64, c_int]),
     "dif_gram128_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),

@@ -708,6 +708,26 @@ class HipBackend:
         _lib.check(rc, "dif_simple_coeffs_f32")
         return coef
 
+    def gram_coeffs(self, x, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale):
+        """gram(x) + simple_coeffs in one call (dif_gram_coeffs_f32): x [n, C] float32 -> (record, coef).  Up to 48 partial
+        records of the Gram pass (<= 24,576 rows) are summed inside the coefficient kernel: two launches instead of three."""
+        dev = _require_device(x, Wq, bq, Wk, bk, Wv, bv)
+        _f32(x, "x")
+        n = x.shape[0]
+        x, ldx = _row_major(x, C)
+        if ldx % 4 or x.data_ptr() % 16:
+            x, ldx = x.contiguous(), C
+        ws_ = [None if t is None else _f32(t, "weight").contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
+        record = torch.empty(C * C + C + 2, dtype=torch.float32, device=dev)
+        coef = torch.empty(self.lib.dif_simple_coeffs_len(C, D), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.dif_gram_workspace_bytes(n, C)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        with _timed(self, "dif_gram_coeffs_f32", dev):
+            rc = self.lib.dif_gram_coeffs_f32(_ptr(x), ldx, n, C, D, *[_ptr(t) for t in ws_], int(n_global), float(attn_scale),
+                                              _ptr(coef), _ptr(record), _ptr(ws), ws_bytes, _stream(dev))
+        _lib.check(rc, "dif_gram_coeffs_f32")
+        return record, coef
+
     def row_gemm(self, A, mat, bias=None, accumulate=None):
         """A [n, K] @ mat [K, C] (+ bias [C]) (+ accumulate [n, C]) in one pass over the rows (dif_rowgemm_f32; K <= 512,
         float32) -> [n, C], or None when the shape is not covered (the caller then uses the vendor GEMM)."""

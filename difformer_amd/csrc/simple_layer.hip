@@ -555,6 +555,61 @@ __global__ __launch_bounds__(1024) void coeffs_kernel(const float* __restrict__ 
     coeffs_compute(m, n_global, C, D, attn_scale, coef);
 }
 
+// The same with the Gram pass's PARTIAL records folded here (small graphs: Cora 6, PubMed 39 partial records): the chain
+// Gram -> finalize -> coefficients -> layer of a small configuration is four dependent launches of 5-12 us each, and the
+// finalize launch (4.6 us + its gap) only adds up a few 16.6-KB records.  Partials are summed in ascending chunk order
+// (fixed: deterministic), P independent loads per thread in flight; `record` (nullable) receives the summed record.
+constexpr int kFoldedPartsMax = 48;
+__global__ __launch_bounds__(1024) void coeffs_parts_kernel(const float* __restrict__ parts, int P, int64_t stride, float n_global,
+                                                            int C, int D, const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                            const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                            const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                            float attn_scale, float* __restrict__ coef, float* __restrict__ record) {
+    __shared__ __attribute__((aligned(16))) float smem[kCoefSmemFloats];
+    const CoefSmem m = carve_coef_smem(smem);
+    coeffs_stage(m, nullptr, C, D, Wq, bq, Wk, bk, Wv, bv);
+    const int tid = threadIdx.x;
+    if (C == 64 && (stride & 3) == 0 && (reinterpret_cast<uintptr_t>(parts) & 15u) == 0) {
+        const int e = 4 * tid;
+        f32x4 a = zero4();
+        for (int p0 = 0; p0 < P; p0 += 8) {          // eight partial records in flight per thread, summed in ascending order
+            f32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = p0 + i < P ? *reinterpret_cast<const f32x4*>(parts + (p0 + i) * stride + e) : zero4();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += v[i];
+        }
+        *reinterpret_cast<f32x4*>(&m.sG[(e >> 6) * kLd + (e & 63)]) = a;
+        if (record) *reinterpret_cast<f32x4*>(record + e) = a;
+    } else {
+        for (int e = tid; e < 64 * 64; e += 1024) {
+            const int a = e >> 6, b = e & 63;
+            float v = 0.f;
+            if (a < C && b < C) {
+                for (int p = 0; p < P; ++p) v += parts[p * stride + a * C + b];
+                if (record) record[a * C + b] = v;
+            }
+            m.sG[a * kLd + b] = v;
+        }
+    }
+    if (tid < 64) {
+        float v = 0.f;
+        if (tid < C) {
+            for (int p0 = 0; p0 < P; p0 += 8) {
+                float w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w[i] = p0 + i < P ? parts[(p0 + i) * stride + C * C + tid] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v += w[i];
+            }
+            if (record) record[C * C + tid] = v;
+        }
+        m.s_sx[tid] = v;
+    }
+    __syncthreads();
+    coeffs_compute(m, n_global, C, D, attn_scale, coef);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // The layer: per 16-row tile and wave, two 64 x 64 MFMA products (x Mn, ax Wv^T), computed TRANSPOSED
 //   D[i = feature][j = row] = sum_c W[feature][c] X[row][c]
@@ -1365,6 +1420,40 @@ extern "C" int dif_simple_coeffs_f32(const float* record, int64_t n_global, int 
     DIF_REQUIRE(Wv != nullptr || C == D, DIF_E_SHAPE, "dif_simple_coeffs: without a value projection C must equal D (difformer.py:120)");
     hipLaunchKernelGGL(coeffs_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), record,
                        static_cast<float>(n_global), C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale, coef);
+    return dif::launch_status("coeffs_kernel");
+}
+
+// dif_gram_f32 (no slice-major copy) + dif_simple_coeffs_f32 for one layer input: coef from x in two launches when the Gram
+// pass leaves at most 48 partial records (<= 24,576 rows: the folded kernel above), three otherwise.  record (nullable)
+// receives the Gram record.  workspace: dif_gram_workspace_bytes(n_rows, C).
+extern "C" int dif_gram_coeffs_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* Wq, const float* bq,
+                                   const float* Wk, const float* bk, const float* Wv, const float* bv, int64_t n_global,
+                                   float attn_scale, float* coef, float* record, void* workspace, size_t workspace_bytes,
+                                   dif_stream_t stream) {
+    DIF_REQUIRE(x && Wq && bq && Wk && bk && coef && workspace && n_rows > 0 && n_global >= n_rows, DIF_E_BADARG,
+                "dif_gram_coeffs: null pointer or no rows");
+    DIF_REQUIRE(C > 0 && C <= 64 && C % 4 == 0 && D > 0 && D <= 64, DIF_E_SHAPE,
+                "dif_gram_coeffs: covers C <= 64 (C %% 4 == 0), D <= 64 (got %d, %d)", C, D);
+    DIF_REQUIRE((Wv == nullptr) == (bv == nullptr), DIF_E_BADARG, "dif_gram_coeffs: Wv and bv go together");
+    DIF_REQUIRE(Wv != nullptr || C == D, DIF_E_SHAPE, "dif_gram_coeffs: without a value projection C must equal D (difformer.py:120)");
+    DIF_REQUIRE(ldx >= C && ldx % 4 == 0 && dif::aligned16(x), DIF_E_BADARG, "dif_gram_coeffs: rows of x must be 16-byte aligned");
+    DIF_REQUIRE(workspace_bytes >= dif_gram_workspace_bytes(n_rows, C), DIF_E_WORKSPACE, "dif_gram_coeffs: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int P = gram_chunks(n_rows);
+    const int64_t rec = (static_cast<int64_t>(C) * C + C + 3) & ~int64_t(3);
+    float* ws = static_cast<float*>(workspace);
+    DIF_REQUIRE(P <= kFoldedPartsMax || record, DIF_E_BADARG, "dif_gram_coeffs: more than 48 partial records need `record` as the finalize target");
+    hipLaunchKernelGGL((gram_kernel<false, float>), dim3(P), dim3(64 * kGramWaves), 0, st, x, ldx, n_rows, C, nullptr, nullptr,
+                       int64_t(0), ws, rec);
+    if (int rc = dif::launch_status("gram_kernel")) return rc;
+    if (P <= kFoldedPartsMax) {
+        hipLaunchKernelGGL(coeffs_parts_kernel, dim3(1), dim3(1024), 0, st, ws, P, rec, static_cast<float>(n_global), C, D, Wq, bq, Wk,
+                           bk, Wv, bv, attn_scale, coef, record);
+        return dif::launch_status("coeffs_parts_kernel");
+    }
+    if (int rc = dif::launch_record_finalize(ws, P, rec, C * C + C, 0, record, st)) return rc;
+    hipLaunchKernelGGL(coeffs_kernel, dim3(1), dim3(1024), 0, st, record, static_cast<float>(n_global), C, D, Wq, bq, Wk, bk, Wv, bv,
+                       attn_scale, coef);
     return dif::launch_status("coeffs_kernel");
 }
 

@@ -787,13 +787,19 @@ def simple_layer_closed_form(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_sca
         join = (main, side)                        # ... but is ENQUEUED after the product (below): its workgroups then take the
                                                    # wave slot the product leaves free on every CU instead of delaying its start
     else:
-        if record is None:
-            need_ys = sl is not None and ys is None and not sharded
-            record, ys2 = be.gram(x, csr.rowptr if need_ys else None, sl.plan if need_ys else None)
-            ys = ys2 if need_ys else ys
-        if sharded:
-            shard.all_reduce_sum(record)
-        coef = be.simple_coeffs(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
+        need_ys = sl is not None and ys is None and not sharded
+        if (record is None and not need_ys and not sharded and x.dtype == torch.float32 and C % 4 == 0 and
+                n <= GRAM_COEFFS_MAX_ROWS and hasattr(be, "gram_coeffs")):
+            # small graphs (node classification/run.sh: Cora ... PubMed): the few partial records of the Gram pass are summed
+            # inside the coefficient kernel -- one launch (and one host call) less in a chain of four dependent ones
+            record, coef = be.gram_coeffs(x, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
+        else:
+            if record is None:
+                record, ys2 = be.gram(x, csr.rowptr if need_ys else None, sl.plan if need_ys else None)
+                ys = ys2 if need_ys else ys
+            if sharded:
+                shard.all_reduce_sum(record)
+            coef = be.simple_coeffs(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
     ax = rs = gather = None
     want_next = (carry is not None and not sharded and carry.get("want_next", False) and D % 4 == 0 and D == C and
                  x.dtype == torch.float32)
@@ -1083,6 +1089,7 @@ def linear(x, weight, bias, ln_weight=None, ln_bias=None, eps=1e-5, relu=False):
     return get_backend().linear(x, weight, bias, ln_weight, ln_bias, eps, relu)
 
 
+GRAM_COEFFS_MAX_ROWS = 24576        # 48 partial Gram records: beyond, the separate finalize launch is the cheaper sum
 LINEAR_XWIDE_MIN_ROWS = 16384       # below: too few 128-row blocks for the chip (15,000 x 512 -> 300: 64 us against 62 for GEMM + tail)
 
 

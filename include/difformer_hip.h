@@ -241,6 +241,14 @@ size_t dif_simple_coeffs_len(int C, int D);
 int dif_simple_coeffs_f32(const float* record, int64_t n_global, int C, int D, const float* Wq, const float* bq,
                           const float* Wk, const float* bk, const float* Wv, const float* bv, float attn_scale,
                           float* coef, dif_stream_t stream);
+/* dif_gram_f32 (without the slice-major copy) + dif_simple_coeffs_f32 of one layer input in one call: record (nullable up to
+ * 24,576 rows) and coef from x.  Up to 48 partial records of the Gram pass are summed inside the coefficient kernel (ascending
+ * chunk order): two launches instead of three on the small graphs of node classification/run.sh (Cora: 6 partials).
+ * workspace: dif_gram_workspace_bytes(n_rows, C). */
+int dif_gram_coeffs_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* Wq, const float* bq,
+                        const float* Wk, const float* bk, const float* Wv, const float* bv, int64_t n_global,
+                        float attn_scale, float* coef, float* record, void* workspace, size_t workspace_bytes,
+                        dif_stream_t stream);
 int dif_simple_layer_f32(const float* x, int64_t ldx, int64_t n_rows, int C, int D, const float* coef,
                          const float* ax, int64_t ldax, const float* Wv, const float* bv, const float* row_sums,
                          float gcn_scale, const float* x0, int64_t ldx0, int residual, float alpha,

@@ -32,6 +32,33 @@ def test_gram_record_vs_numpy(n, c, dev):
     assert rel_err(rec[: c * c].reshape(c, c), G) < 1e-5 and rel_err(rec[c * c: c * c + c], sx) < 1e-5
 
 
+@pytest.mark.parametrize("n,c,d,use_weight", [(2708, 64, 64, True), (1, 64, 64, True), (300, 32, 64, True), (19717, 64, 64, True),
+                                              (24576, 64, 64, False), (24577, 64, 64, True), (50000, 64, 64, True), (4000, 48, 20, True),
+                                              (777, 8, 8, False)])
+def test_gram_and_coefficients_in_one_call(n, c, d, use_weight, dev):
+    """dif_gram_coeffs_f32 against dif_gram_f32 + dif_simple_coeffs_f32: up to 48 partial Gram records (24,576 rows) are summed
+    inside the coefficient kernel (ascending chunk order; the finalize kernel sums in slices: the two differ in rounding only),
+    beyond that the call runs the three launches itself.  Record against float64, coefficients against the two-call path, and
+    the same bits on a second call."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + c + d)
+    x = (torch.randn(n, c, generator=g) + 0.2).to(dev)
+    W = [(torch.randn(d, c, generator=g) / np.sqrt(c)).to(dev) for _ in range(3)]
+    b = [(torch.randn(d, generator=g) * 0.1).to(dev) for _ in range(3)]
+    Wv, bv = (W[2], b[2]) if use_weight else (None, None)
+    be = ops.get_backend()
+    rec0, _ = be.gram(x)
+    coef0 = be.simple_coeffs(rec0, n, c, d, W[0], b[0], W[1], b[1], Wv, bv, 0.7)
+    rec1, coef1 = be.gram_coeffs(x, n, c, d, W[0], b[0], W[1], b[1], Wv, bv, 0.7)
+    x64 = x.cpu().double().numpy()
+    assert rel_err(rec1[: c * c].cpu().numpy().reshape(c, c), x64.T @ x64) < 1e-5
+    assert rel_err(rec1[c * c: c * c + c].cpu().numpy(), x64.sum(0)) < 1e-5
+    k = d * c + d + c + 1
+    assert rel_err(coef1[:k].cpu().numpy(), coef0[:k].cpu().numpy()) < 1e-5
+    rec2, coef2 = be.gram_coeffs(x, n, c, d, W[0], b[0], W[1], b[1], Wv, bv, 0.7)
+    assert torch.equal(rec1[: c * c + c], rec2[: c * c + c]) and torch.equal(coef1[:k], coef2[:k])
+
+
 def test_gram_writes_the_scaled_slice_major_copy(dev):
     from difformer_amd import ops
     n, c = 12000, 64

@@ -226,7 +226,8 @@ def test_training_step_through_the_record_every_flag(hidden, use_graph, use_weig
         launched = set(be.kernel_events)
     finally:
         be.kernel_events = None
-    assert "dif_gram_f32" in launched and "dif_simple_coeffs_f32" in launched and "dif_simple_apply_f32" not in launched, launched
+    assert (({"dif_gram_f32", "dif_simple_coeffs_f32"} <= launched or "dif_gram_coeffs_f32" in launched) and
+            "dif_simple_apply_f32" not in launched), launched
     if deg >= 48:
         assert "dif_sliced_spmm_f32" in launched
 
