@@ -98,6 +98,10 @@ template <> struct Elem<float> {
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
     static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    // four elements from an address that is only ELEMENT-aligned (rows of 65 or 1,433 columns): still one global_load_dwordx4
+    // (the target runs in unaligned access mode; the type's alignment tells the compiler not to assume more)
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    static __device__ __forceinline__ f32x4 ld4u(const float* p) { const f32x4u v = *reinterpret_cast<const f32x4u*>(p); return f32x4{v[0], v[1], v[2], v[3]}; }
 };
 template <> struct Elem<bf16> {
     static constexpr int kBytes = 2;
@@ -109,6 +113,11 @@ template <> struct Elem<bf16> {
         v[0] = bf16_to_f32(static_cast<uint16_t>(r.x & 0xffffu)); v[1] = bf16_to_f32(static_cast<uint16_t>(r.x >> 16));
         v[2] = bf16_to_f32(static_cast<uint16_t>(r.y & 0xffffu)); v[3] = bf16_to_f32(static_cast<uint16_t>(r.y >> 16));
         return v;
+    }
+    typedef uint16_t u16x4u __attribute__((ext_vector_type(4), aligned(2)));
+    static __device__ __forceinline__ f32x4 ld4u(const bf16* p) {      // one 8-byte load from a 2-byte aligned address
+        const u16x4u r = *reinterpret_cast<const u16x4u*>(p);
+        return f32x4{bf16_to_f32(r[0]), bf16_to_f32(r[1]), bf16_to_f32(r[2]), bf16_to_f32(r[3])};
     }
     static __device__ __forceinline__ void st4(bf16* p, f32x4 v) {     // one 8-byte store
         uint2 r;

@@ -668,8 +668,8 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
             const int c = 16 * cq + 4 * lg;
             if (r < n_rows) {
                 const T* p = x + r * ldx + c;
-                if (vec && c + 3 < C_in) {
-                    z = Elem<T>::ld4(p);
+                if (c + 3 < C_in) {            // rows that are only element-aligned (65 columns: Pokec): still one load
+                    z = vec ? Elem<T>::ld4(p) : Elem<T>::ld4u(p);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
