@@ -144,6 +144,11 @@ class OracleBackend:
                                s * (Wq.T @ ksum), [s * bq @ ksum + N, s, q2, k2]])
         return torch.from_numpy(coef.astype(np.float32))
 
+    def gram_coeffs(self, x, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale):
+        self.gram_coeffs_calls = getattr(self, "gram_coeffs_calls", 0) + 1
+        record, _ = self.gram(x)
+        return record, self.simple_coeffs(record, n_global, C, D, Wq, bq, Wk, bk, Wv, bv, attn_scale)
+
     def simple_layer(self, x, coef, D, ax=None, Wv=None, bv=None, row_sums=None, gcn_scale=1.0, x0=None, residual=False,
                      alpha=0.5, ln_weight=None, ln_bias=None, eps=1e-5, relu=False, next_rowptr=None, next_plan=None,
                      next_record=False, head=None, gather=None):

@@ -530,6 +530,36 @@ def test_closed_form_layer_backward_matches_the_operator_path(use_graph, use_wei
         assert grad_err(g_c[k].numpy(), g_o[k].numpy(), gmax) < 1e-4, k
 
 
+def test_small_graphs_take_the_one_call_gram_and_coefficients(fake_backend, monkeypatch):
+    """ops.simple_layer_closed_form: up to GRAM_COEFFS_MAX_ROWS float32 rows, no row shard, no slice-major copy wanted -> the
+    backend's gram_coeffs (record and coefficients from one call); beyond the limit the two-call path.  Same result."""
+    from difformer_amd import DIFFormerConv, ops
+    torch.manual_seed(3)
+    conv = DIFFormerConv(16, 16, 1, kernel="simple", use_graph=True).eval()
+    g = torch.Generator().manual_seed(4)
+    x, ei = torch.randn(90, 16, generator=g), torch.randint(0, 90, (2, 400), generator=g)
+    with torch.no_grad():
+        fake_backend.gram_coeffs_calls = 0
+        out_one = conv._layer(x, x, ei, None, None, x, 0.5, None, None, 1e-5)[0]
+        assert fake_backend.gram_coeffs_calls == 1
+        monkeypatch.setattr(ops, "GRAM_COEFFS_MAX_ROWS", 10)
+        out_two = conv._layer(x, x, ei, None, None, x, 0.5, None, None, 1e-5)[0]
+        assert fake_backend.gram_coeffs_calls == 1
+    assert torch.allclose(out_one, out_two, rtol=1e-6, atol=1e-6)
+
+
+def test_wide_linear_dispatch_rule():
+    """ops.linear_xwide_covers: float32, 65..416 output features, more than 128 input channels in one product (<= 416) or two
+    equal halves (<= 832), multiples of 4, at least LINEAR_XWIDE_MIN_ROWS rows; never under DIFFORMER_EXACT_FP32."""
+    from difformer_amd import ops
+    n = ops.LINEAR_XWIDE_MIN_ROWS
+    ok = lambda rows, ci, co, dt=torch.float32: ops.linear_xwide_covers(torch.empty(rows, ci, dtype=dt), torch.empty(co, ci, dtype=dt))
+    assert ok(n, 512, 300) and ok(n, 832, 416) and ok(n, 300, 68) and ok(n, 132, 400)
+    assert not ok(n - 1, 512, 300) and not ok(n, 128, 300) and not ok(n, 512, 64) and not ok(n, 512, 420)
+    assert not ok(n, 836, 300) and not ok(n, 510, 300) and not ok(n, 420, 300) and not ok(n, 512, 302)
+    assert not ok(n, 512, 300, torch.bfloat16)
+
+
 def test_closed_form_training_keeps_a_temporary_edge_index_alive(fake_backend):
     """`model(x, ei.to(dev))`: the edge tensor is a temporary that dies with the call, while the adjoint CSR of the backward
     pass is built from it on first use -- the autograd node of the record path holds it (as the aggregation's node does)."""
