@@ -60,24 +60,27 @@ def main():
         ("sigmoid_n33_h1_d10", "sigmoid", 33, 33, 1, 10),
         ("sigmoid_n70_l20_h1_d64", "sigmoid", 70, 20, 1, 64),
     ]
-    for tag, kern, n, l, h, m in attn_shapes:
-        q = torch.randn(n, h, m, generator=g)
-        k = torch.randn(l, h, m, generator=g)
-        v = torch.randn(l, h, m, generator=g)
-        go = torch.randn(n, h, m, generator=g)
+    def attn_cases(shapes, g):
+        for tag, kern, n, l, h, m in shapes:
+            q = torch.randn(n, h, m, generator=g)
+            k = torch.randn(l, h, m, generator=g)
+            v = torch.randn(l, h, m, generator=g)
+            go = torch.randn(n, h, m, generator=g)
 
-        def run(dt):
-            qq, kk, vv = leaf(q, dt), leaf(k, dt), leaf(v, dt)
-            out = ref.full_attention_conv(qq, kk, vv, kern)
-            out.backward(go.to(dt))
-            return [t.detach().numpy() for t in (out, qq.grad, kk.grad, vv.grad)]
+            def run(dt):
+                qq, kk, vv = leaf(q, dt), leaf(k, dt), leaf(v, dt)
+                out = ref.full_attention_conv(qq, kk, vv, kern)
+                out.backward(go.to(dt))
+                return [t.detach().numpy() for t in (out, qq.grad, kk.grad, vv.grad)]
 
-        r = both(run)
-        c = dict(q=q.numpy(), k=k.numpy(), v=v.numpy(), g=go.numpy(), kernel=np.array(kern))
-        for p in ("f32", "f64"):
-            for name, a in zip(("out", "dq", "dk", "dv"), r[p]):
-                c[f"{name}_{p}"] = a
-        put("attn/" + tag, c)
+            r = both(run)
+            c = dict(q=q.numpy(), k=k.numpy(), v=v.numpy(), g=go.numpy(), kernel=np.array(kern))
+            for p in ("f32", "f64"):
+                for name, a in zip(("out", "dq", "dk", "dv"), r[p]):
+                    c[f"{name}_{p}"] = a
+            put("attn/" + tag, c)
+
+    attn_cases(attn_shapes, g)
 
     # ---- a3: gcn_conv ----------------------------------------------------------------------------
     gcn_shapes = [  # (tag, N, E, H, D, weighted, isolated)
@@ -130,67 +133,70 @@ def main():
         dict(tag="a_nobn_src", n=44, f_in=9, hidden=32, c=3, num_layers=2, num_heads=1, kernel="sigmoid",
              use_bn=False, use_source=True, graph_weight=0.6),
     ]
-    for mc in model_cfgs:
-        mc = dict(mc)
-        tag, n, f_in, hidden, c = (mc.pop(k) for k in ("tag", "n", "f_in", "hidden", "c"))
-        weighted = mc.pop("weighted", False)
-        loss_kind = mc.pop("loss", "nll")
-        x = torch.randn(n, f_in, generator=g)
-        ei = rand_graph(g, n, 6 * n, isolated=2)
-        ei = torch.cat([ei, torch.arange(n - 2).repeat(2, 1)], dim=1)            # self loops as main.py:76 adds
-        w = (torch.rand(ei.shape[1], generator=g) + 0.05) if weighted else None
-        use_graph = mc.get("use_graph", True)
-        train_idx = torch.randperm(n, generator=g)[: n // 2]
-        if loss_kind == "bce":
-            y = (torch.rand(n, c, generator=g) < 0.3).float()                    # multi-label (ogbn-proteins, main.py:121-127)
-        else:
-            y = torch.randint(0, c, (n,), generator=g)
-
-        def run(dt):
-            torch.set_default_dtype(torch.float32)
-            torch.manual_seed(123)
-            model = ref.DIFFormer(f_in, hidden, c, dropout=0.0, **mc)
-            model.reset_parameters()
-            with torch.no_grad():
-                for bn in model.bns:
-                    bn.weight.add_(0.1 * torch.randn(bn.weight.shape, generator=torch.Generator().manual_seed(7)))
-                    bn.bias.add_(0.1 * torch.randn(bn.bias.shape, generator=torch.Generator().manual_seed(8)))
-            torch.set_default_dtype(dt)
-            model = model.to(dt).train()                                         # main.py:115
-            xx = leaf(x, dt)
-            ww = None if w is None else leaf(w, dt)
-            out = model(xx, ei if use_graph else None, ww)                       # main.py:118
+    def model_cases(cfgs, g):
+        for mc in cfgs:
+            mc = dict(mc)
+            tag, n, f_in, hidden, c = (mc.pop(k) for k in ("tag", "n", "f_in", "hidden", "c"))
+            weighted = mc.pop("weighted", False)
+            loss_kind = mc.pop("loss", "nll")
+            x = torch.randn(n, f_in, generator=g)
+            ei = rand_graph(g, n, 6 * n, isolated=2)
+            ei = torch.cat([ei, torch.arange(n - 2).repeat(2, 1)], dim=1)            # self loops as main.py:76 adds
+            w = (torch.rand(ei.shape[1], generator=g) + 0.05) if weighted else None
+            use_graph = mc.get("use_graph", True)
+            train_idx = torch.randperm(n, generator=g)[: n // 2]
             if loss_kind == "bce":
-                loss = F.binary_cross_entropy_with_logits(out[train_idx], y[train_idx].to(dt))      # main.py:124-125
+                y = (torch.rand(n, c, generator=g) < 0.3).float()                    # multi-label (ogbn-proteins, main.py:121-127)
             else:
-                loss = F.nll_loss(F.log_softmax(out, dim=1)[train_idx], y[train_idx])                # main.py:127-129
-            loss.backward()                                                      # main.py:130
-            grads = {k: (torch.zeros_like(p) if p.grad is None else p.grad).float().numpy() if dt == torch.float32
-                     else (torch.zeros_like(p) if p.grad is None else p.grad).numpy() for k, p in model.named_parameters()}
-            sd = {k: v.detach().float().numpy() for k, v in model.state_dict().items()}
-            return dict(out=out.detach().numpy(), loss=loss.detach().numpy(), dx=xx.grad.numpy(),
-                        dw=None if ww is None else ww.grad.numpy(), grads=grads, sd=sd)
+                y = torch.randint(0, c, (n,), generator=g)
 
-        r = both(run)
-        case = dict(x=x.numpy(), edge_index=ei.numpy(), train_idx=train_idx.numpy(), y=y.numpy(),
-                    loss_kind=np.array(loss_kind))
-        if w is not None:
-            case["edge_weight"] = w.numpy()
-        for p in ("f32", "f64"):
-            case[f"out_{p}"], case[f"loss_{p}"], case[f"dx_{p}"] = r[p]["out"], r[p]["loss"], r[p]["dx"]
-            if r[p]["dw"] is not None:
-                case[f"dw_{p}"] = r[p]["dw"]
-            for k, v in r[p]["grads"].items():
-                case[f"grad_{p}/" + k] = v
-        for k, v in r["f32"]["sd"].items():
-            case["sd/" + k] = v
-        cfg = dict(hidden_channels=hidden, out_channels=c, in_channels=f_in, num_layers=2, num_heads=1,
-                   kernel="simple", alpha=0.5, use_bn=True, use_residual=True, use_weight=True, use_graph=True,
-                   graph_weight=-1, use_source=False)
-        cfg.update(mc)
-        for k, v in cfg.items():
-            case["cfg/" + k] = np.array(v)
-        put("model/" + tag, case)
+            def run(dt):
+                torch.set_default_dtype(torch.float32)
+                torch.manual_seed(123)
+                model = ref.DIFFormer(f_in, hidden, c, dropout=0.0, **mc)
+                model.reset_parameters()
+                with torch.no_grad():
+                    for bn in model.bns:
+                        bn.weight.add_(0.1 * torch.randn(bn.weight.shape, generator=torch.Generator().manual_seed(7)))
+                        bn.bias.add_(0.1 * torch.randn(bn.bias.shape, generator=torch.Generator().manual_seed(8)))
+                torch.set_default_dtype(dt)
+                model = model.to(dt).train()                                         # main.py:115
+                xx = leaf(x, dt)
+                ww = None if w is None else leaf(w, dt)
+                out = model(xx, ei if use_graph else None, ww)                       # main.py:118
+                if loss_kind == "bce":
+                    loss = F.binary_cross_entropy_with_logits(out[train_idx], y[train_idx].to(dt))      # main.py:124-125
+                else:
+                    loss = F.nll_loss(F.log_softmax(out, dim=1)[train_idx], y[train_idx])                # main.py:127-129
+                loss.backward()                                                      # main.py:130
+                grads = {k: (torch.zeros_like(p) if p.grad is None else p.grad).float().numpy() if dt == torch.float32
+                         else (torch.zeros_like(p) if p.grad is None else p.grad).numpy() for k, p in model.named_parameters()}
+                sd = {k: v.detach().float().numpy() for k, v in model.state_dict().items()}
+                return dict(out=out.detach().numpy(), loss=loss.detach().numpy(), dx=xx.grad.numpy(),
+                            dw=None if ww is None else ww.grad.numpy(), grads=grads, sd=sd)
+
+            r = both(run)
+            case = dict(x=x.numpy(), edge_index=ei.numpy(), train_idx=train_idx.numpy(), y=y.numpy(),
+                        loss_kind=np.array(loss_kind))
+            if w is not None:
+                case["edge_weight"] = w.numpy()
+            for p in ("f32", "f64"):
+                case[f"out_{p}"], case[f"loss_{p}"], case[f"dx_{p}"] = r[p]["out"], r[p]["loss"], r[p]["dx"]
+                if r[p]["dw"] is not None:
+                    case[f"dw_{p}"] = r[p]["dw"]
+                for k, v in r[p]["grads"].items():
+                    case[f"grad_{p}/" + k] = v
+            for k, v in r["f32"]["sd"].items():
+                case["sd/" + k] = v
+            cfg = dict(hidden_channels=hidden, out_channels=c, in_channels=f_in, num_layers=2, num_heads=1,
+                       kernel="simple", alpha=0.5, use_bn=True, use_residual=True, use_weight=True, use_graph=True,
+                       graph_weight=-1, use_source=False)
+            cfg.update(mc)
+            for k, v in cfg.items():
+                case["cfg/" + k] = np.array(v)
+            put("model/" + tag, case)
+
+    model_cases(model_cfgs, g)
 
     # ---- f4: TransConv.full_attention of the batched model -------------------------------------------
     v2_shapes = [  # (tag, kernel, n_nodes, H, D)
@@ -267,6 +273,14 @@ def main():
         for k, v in cfg.items():
             case["cfg/" + k] = np.array(v)
         put("v2model/" + tag, case)
+
+    # ---- round 4: heads wider than 64 columns (run.sh trains at hidden 128 / 300) -- drawn from a generator of their own,
+    # AFTER everything above, so that the arrays of the earlier cases keep their bits
+    g_wide = torch.Generator().manual_seed(20260926)
+    attn_cases([("simple_n70_h1_d128", "simple", 70, 70, 1, 128),
+                ("simple_n40_h1_d300", "simple", 40, 40, 1, 300),
+                ("simple_n33_h2_d100", "simple", 33, 33, 2, 100)], g_wide)
+    model_cases([dict(tag="s_h128", n=100, f_in=20, hidden=128, c=5, num_layers=2, num_heads=1, kernel="simple")], g_wide)
 
     np.savez_compressed(os.path.join(OUT, "golden_grad.npz"), **flat)
     print("wrote golden_grad.npz:", len(flat), "arrays")
