@@ -141,6 +141,11 @@ def main():
              weighted=True),
         dict(tag="s_d10_weighted", n=40, f_in=6, hidden=10, c=2, num_layers=2, num_heads=1, kernel="simple",
              weighted=True, use_source=True),
+        # round 4 (appended: the draws of the cases above are unchanged): the widths run.sh trains at -- hidden 128 takes the
+        # one-pass wide layer kernel, 132 the streamed-weight kernel of hidden 300 / 400 (rows >= 4 x columns: closed form)
+        dict(tag="s_h128_wide", n=560, f_in=30, hidden=128, c=6, num_layers=2, num_heads=1, kernel="simple"),
+        dict(tag="s_h132_nograph", n=600, f_in=16, hidden=132, c=4, num_layers=2, num_heads=1, kernel="simple",
+             use_graph=False),
     ]
     for mc in model_cfgs:
         mc = dict(mc)

@@ -552,12 +552,22 @@ def test_model_forward_golden(name, dev):
     ei = t(c["edge_index"], dev) if cfg["use_graph"] else None
     w = c.get("edge_weight")
     wt = None if w is None else t(w, dev)
-    with torch.no_grad():
-        out = model(t(c["x"], dev), ei, wt)
-        h0 = model._input_layer(t(c["x"], dev), False)
-        conv0 = model.convs[0](h0, h0, ei, wt, h0)
+    from difformer_amd import ops
+    be = ops.get_backend()
+    be.kernel_events = {}
+    try:
+        with torch.no_grad():
+            out = model(t(c["x"], dev), ei, wt)
+            launched = set(be.kernel_events)
+            h0 = model._input_layer(t(c["x"], dev), False)
+            conv0 = model.convs[0](h0, h0, ei, wt, h0)
+    finally:
+        be.kernel_events = None
     assert rel_err(out.cpu().numpy(), c["out_f64"]) < TOL
     assert rel_err(conv0.cpu().numpy(), c["conv0_f64"]) < TOL
+    if int(cfg["hidden_channels"]) > 64:       # the scripts' widths: the wide closed form (Gram record of 65+ columns, one-pass
+        # layer kernels of csrc/simple_layer_wide.hip / simple_layer_xwide.hip), not the operator path
+        assert "dif_gram_sym_f32" in launched and "dif_simple_apply_f32" not in launched, launched
 
 
 @pytest.mark.parametrize("kernel,n,f_in,layers,use_graph", [("simple", 2708, 1433, 2, True),     # C1
