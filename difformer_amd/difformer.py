@@ -194,8 +194,8 @@ class DIFFormerConv(nn.Module):
             return False
         if prev is not None and (prev is not x or x.shape[1] != self.out_channels):
             return False
-        if not hasattr(ops.get_backend(), "gram"):
-            return False
+        if not hasattr(ops.get_backend(), "gram") or (wide and not hasattr(ops.get_backend(), "gram_sym")):
+            return False          # (a host-side test backend without the record passes: operator path)
         params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias]
         if self.use_weight:
             params += [self.Wv.weight, self.Wv.bias]
