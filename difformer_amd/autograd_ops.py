@@ -373,6 +373,35 @@ def closed_form_layer(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0,
                                   alpha, eps)
 
 
+def _adjacent_columns(grads, n, sizes):
+    """The contiguous [n, sum(sizes)] tensor whose column blocks the gradients are, or None.  backend.simple_backward writes
+    dq | dk | dv as views of one such buffer; a slice whose gradient was accumulated with another consumer's (v also feeds the
+    aggregation: autograd hands over a new tensor for dv) is copied into its block -- a third of the concatenation."""
+    base = None
+    for g in grads:
+        b = None if g is None else g._base
+        if b is not None and b.dim() == 2 and tuple(b.shape) == (n, sum(sizes)) and b.is_contiguous():
+            base = b
+            break
+    if base is None:
+        return None
+    off, fill = base.storage_offset(), []
+    for g, w in zip(grads, sizes):
+        if g is None or g.dim() != 2 or tuple(g.shape) != (n, w) or g.dtype != base.dtype or g.device != base.device:
+            return None
+        in_place = g._base is base and g.stride() == (base.stride(0), 1) and g.storage_offset() == off
+        if not in_place:
+            if g._base is base:          # another view of the same buffer: not the layout this shortcut is for
+                return None
+            fill.append((off - base.storage_offset(), w, g))
+        off += w
+    if len(fill) == len(sizes):
+        return None
+    for o, w, g in fill:
+        base[:, o: o + w].copy_(g)
+    return base
+
+
 class _SplitColumns(torch.autograd.Function):
     """q | k | v as column slices of the fused projection [n, (2|3) H D].  Plain slicing would have autograd build one
     zero-filled [n, 3 H D] buffer per slice gradient and add them up (three fills, three copies, two adds of 102 MB at
@@ -385,6 +414,9 @@ class _SplitColumns(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        whole = _adjacent_columns(grads, ctx.n, ctx.sizes)
+        if whole is not None:            # the backward kernels wrote the slices side by side already (backend.simple_backward)
+            return (whole,) + (None,) * len(ctx.sizes)
         ref = next(g for g in grads if g is not None)
         parts = [g if g is not None else ref.new_zeros((ctx.n, w)) for g, w in zip(grads, ctx.sizes)]
         return (torch.cat(parts, dim=1),) + (None,) * len(ctx.sizes)

@@ -241,12 +241,21 @@ class HipBackend:
         dktv = (rec2[:hmd] * s).contiguous()                     # s q^T gn       [H,M,D]
         dvs = rec2[hmd + H * M: hmd + H * M + H * D].contiguous()
         dks = (sums[: H * M] * s).contiguous()
-        dq, dk, dv = torch.empty((n, H, M), **f32), torch.empty((n, H, M), **f32), torch.empty((n, H, D), **f32)
+        if M == D and (H * M) % 4 == 0:
+            # dq | dk | dv as the column blocks of ONE [n, 3 H D] buffer: when q, k, v were the column slices of a fused
+            # projection, the gradient of that projection is this buffer as it stands (autograd_ops._SplitColumns finds the
+            # views adjacent and skips its concatenation: 308 MB of copy per layer at 100,000 x 128)
+            fused = torch.empty((n, 3 * H * M), **f32)
+            dq, dk, dv = (fused[:, i * H * M: (i + 1) * H * M].view(n, H, M) for i in range(3))
+            ldg = 3 * H * M
+        else:
+            dq, dk, dv = torch.empty((n, H, M), **f32), torch.empty((n, H, M), **f32), torch.empty((n, H, D), **f32)
+            ldg = None
 
         def rowgemm(A, K, mat, mat_t, bias, r, u, cin, beta, C, dst, lda=None, ldc=None):
             with _timed(self, "dif_rowgemm_f32", dev):
                 rc_ = self.lib.dif_rowgemm_f32(_ptr(A), lda or H * K, _ptr(mat), D, M * D, mat_t, 1.0, _ptr(bias), _ptr(r), _ptr(u),
-                                               1.0, _ptr(cin), ldc or H * C, _ptr(beta), n, H, K, C, _ptr(dst), H * C,
+                                               1.0, _ptr(cin), ldc or H * C, _ptr(beta), n, H, K, C, _ptr(dst), ldg or H * C,
                                                _stream(dev))
             _lib.check(rc_, "dif_rowgemm_f32")
 
