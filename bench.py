@@ -15,13 +15,17 @@ sharded (strong scaling: total work fixed): one all-reduce of the 4,226-float re
 all-gather of the value rows per layer over RCCL.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel -- the C-ABI entry point with the largest
-share of the forward (the gcn_conv product on the headline workload): algorithmic bytes per launch =
-8*nnz + 4*(N+1) + 2*n_rows*H*D*4 over its mean duration from HIP events recorded on
-the launching stream in a short pass right after the timed region (the timed region holds nothing but the
-K steps).  For the feature-sliced product the primary figure is the LDS fraction (`"bound": "lds"`: its
-floor is above the HBM roofline, profiles/r04_experiments.md), the HBM fraction rides in `roofline.hbm`;
-the sigmoid kernel is priced against the fp32 MFMA peak.  `cpu_baseline` times the whole forward of the oracle port
-(numpy + OpenMP C) on the host cores, 1 warm-up + 3 runs, median (rank 0, N=1 only).
+share of the forward (the gcn_conv product on the headline workload) -- and is FLAT: `frac` is always SURVEY.md section
+8(d)'s quantity, algorithmic bytes per launch = 8*nnz + 4*(N+1) + 2*n_rows*H*D*4 over its mean duration from HIP events
+recorded on the launching stream in a short pass right after the timed region (the timed region holds nothing but the K
+steps), over 8 TB/s (`bound: "hbm"`); the sigmoid kernel is priced against the fp32 MFMA peak (`bound: "mfma"`).  For the
+feature-sliced product the keys `limiter: "lds"`, `lds_achieved_tbs`, `lds_peak_tbs`, `lds_frac` say what actually stops it
+(its LDS floor is above the HBM floor, profiles/r04_experiments.md).  `ms_per_step_exact_fp32`: a short second pass with
+every product on the fp32 MFMA (`config.exact_fp32` says which mode `value` was measured in: false = the default, two
+products on split-bfloat16 operands, ~4e-6).  `cpu_baseline` times the whole forward of the oracle port (numpy + OpenMP C)
+on the host cores, 1 warm-up + 3 runs, median (rank 0, N=1 only).  N > 1: when the hidden width splits into 16-byte slices
+over the ranks both shard products (rows / feature slices, difformer_amd/dist.py) are timed with K steps each; `value` is the
+faster one, named in `config.parallelism`, both in `ms_per_step_by_shard_product`.
 """
 import argparse
 import json
@@ -40,6 +44,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.0   # fp32-input MFMA, dense (same guide)
 LDS_PEAK_TBS = 256 * 256 * 2.4e9 / 1e12   # 256 CUs x 256 B/clk (ds_read_b128 / b64) at 2.4 GHz = 157 TB/s (same guide, LDS table)
+LDS_MEASURED_TBS = 150.0                   # the same guide's MEASURED aggregate LDS read rate
 
 WORKLOADS = {
     # name: (N, undirected pairs, F_in, classes, hidden, layers, kernel, use_graph)
@@ -179,9 +184,14 @@ def main():
                     help="replay the whole forward as one hipGraph (single GPU); per-kernel events then come from a "
                          "short eager pass after the timed region instead of from the timed region itself")
     ap.add_argument("--per-kernel", action="store_true", help="also print mean ms per C-ABI entry point (stderr)")
-    ap.add_argument("--shard-product", choices=["row", "slice"], default=os.environ.get("DIFFORMER_SHARD_PRODUCT", "row"),
+    ap.add_argument("--shard-product", choices=["auto", "row", "slice"], default=os.environ.get("DIFFORMER_SHARD_PRODUCT", "auto"),
                     help="N > 1: how closed-form layers split the aggregation -- by destination rows (all-gather of the "
-                         "layer input; default) or by feature slices (two all-to-alls of 1/N of it; difformer_amd/dist.py)")
+                         "layer input) or by feature slices (two all-to-alls of 1/N of it; difformer_amd/dist.py).  auto "
+                         "(default): when the hidden width splits into 16-byte slices over the ranks (C %% (4 N) == 0) BOTH are "
+                         "timed back to back with K steps each and the faster one is the reported value (DESIGN.md section 4 "
+                         "predicts the slice shard: 7.4 MB against 30 MB per rank and layer at C4 on 8 ranks); else rows")
+    ap.add_argument("--no-exact-pass", action="store_true",
+                    help="skip the short second pass with every product on the fp32 MFMA (ms_per_step_exact_fp32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,8 +231,14 @@ def main():
     shard = RowShard.from_process_group(n) if (world > 1 and not replicas) else None
     assert shard is None or (shard.row_begin, shard.n_local) == (plan["row_begin"], plan["n_local"])
     x = x_full if shard is None else shard.local_rows(x_full).contiguous()
+    slice_ok = (shard is not None and kernel == "simple" and hidden <= 64 and hidden % (4 * world) == 0 and store == torch.float32)
+    products = [None]
     if shard is not None:
-        shard.product = args.shard_product
+        if args.shard_product == "auto":
+            products = ["slice", "row"] if slice_ok else ["row"]
+        else:
+            products = [args.shard_product]
+        shard.product = products[0]
         model.set_row_shard(shard)
     n_local = x.shape[0]
 
@@ -242,24 +258,40 @@ def main():
             cold_build()           # timed: what every new graph / mini-batch costs
             torch.cuda.synchronize()
             cold_ms = (time.perf_counter() - t0) * 1e3
-        for _ in range(args.warmup):
-            model(x, edge_index)
-        # --graph: the whole forward is captured once and replayed as one hipGraph launch per step
         use_graph_replay = (world == 1) and args.graph
-        step = GraphedForward(model, x, edge_index) if use_graph_replay else (lambda: model(x, edge_index))
-        if use_graph_replay:
-            for _ in range(2):
+
+        def timed_region():
+            """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides -> (seconds, step)."""
+            for _ in range(args.warmup):
+                model(x, edge_index)
+            # --graph: the whole forward is captured once and replayed as one hipGraph launch per step
+            step = GraphedForward(model, x, edge_index) if use_graph_replay else (lambda: model(x, edge_index))
+            if use_graph_replay:
+                for _ in range(2):
+                    step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
                 step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            return time.perf_counter() - t0, step
+
+        by_product = {}
+        for prod in products:                  # N > 1 with a width that splits into slices: both shard products, K steps each
+            if prod is not None:
+                shard.product = prod
+            sec, step = timed_region()
+            by_product[prod] = max_over_ranks(sec, dev)
+        best = min(by_product, key=by_product.get)
+        if best is not products[-1]:           # leave the model in the faster configuration for the passes below
+            shard.product = best
+            for _ in range(2):
+                model(x, edge_index)
+        elapsed = by_product[best]
         # Separate short pass right after the timed region (nothing but the K steps sits inside it): per-forward HIP
         # events on the launching stream -> median / spread, and per-entry-point events -> the dominant kernel's mean
         # launch duration for the roofline.
@@ -313,8 +345,6 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         per_rank = gathered
-    elapsed = max_over_ranks(elapsed, dev)
-
     def dominant_alone(entry):
         # Second event pass with ONLY the dominant entry point bracketed: two events around every C-ABI call cost the
         # host enough that, on a slow host, the GPU queue runs dry in the pass above and the brackets then include the
@@ -332,6 +362,30 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = job_value(n, args.steps, elapsed, world, replicas)
+
+    # The default f32 forward runs two products on split-bfloat16 operands (hi + lo parts, three bf16 MFMAs, ~4e-6 of the
+    # float64 result: the last layer's output Linear, long-row input Linears, the hidden 65-416 layer kernels).  A short second
+    # pass with EVERY product on the fp32 MFMA (DIFFORMER_EXACT_FP32=1 / ops.set_exact_fp32) says what that buys.
+    ms_exact = None
+    if not args.no_exact_pass and store == torch.float32:
+        was = ops.set_exact_fp32(True)
+        model.invalidate_caches()
+        reps = max(5, min(args.steps, 20))
+        with torch.no_grad():
+            for _ in range(5):
+                model(x, edge_index)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                model(x, edge_index)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            ms_exact = max_over_ranks(time.perf_counter() - t0, dev) / reps * 1e3
+        ops.set_exact_fp32(was)
+        model.invalidate_caches()
 
     # roofline of the dominant kernel on this rank: the C-ABI entry point with the largest share of the forward (event
     # brackets of the eager pass above), priced with the algorithmic bytes / FLOP of SURVEY.md section 8d
@@ -367,7 +421,7 @@ def main():
     # correction + WRITE_SIZE, calibrated; scripts/pmc_traffic.sh) stored under profiles/ -- a counter run cannot
     # share a process with this timed run.  Only valid for the single-GPU workload it was collected on.
     traffic = tsrc = None
-    for tfile in ("r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
+    for tfile in ("r05_pmc_traffic_c4.json", "r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
         tpath = os.path.join(ROOT, "profiles", tfile)
         if world == 1 and use_graph and os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -376,32 +430,35 @@ def main():
                 tsrc = f"profiles/{tfile} (rocprofv3 PMC, separate passes)"
                 break
     src = "HIP events on the launching stream, only this entry point bracketed (bench.py::dominant_alone)"
-    hbm = {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
-           "algorithmic_bytes_per_launch": alg_bytes}
-    roofline = {"bound": bound, "kernel": dom_name, "entry_point": dom,
+    # FLAT record (the driver's `parsed` keeps no nested dicts).  `frac` is ALWAYS the SURVEY 8(d) quantity of the dominant
+    # kernel: algorithmic bytes / launch time / 8 TB/s for the HBM-bound rows (a1, a3, a4/a5), algorithmic FLOP / launch time
+    # / 157 TFLOP/s for a2.  What actually limits the sliced product (LDS array + vector-ALU issue, profiles/r04_experiments.md
+    # section 1) rides beside it in the lds_* siblings and in `limiter`.
+    roofline = {"bound": "mfma" if bound == "mfma" else "hbm", "kernel": dom_name, "entry_point": dom,
                 "share_of_forward": (share[dom] / sum(share.values())) if dom else None,
                 "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": dom_ms, "avg_launch_ms_source": src}
-    if bound == "hbm":
-        roofline.update(hbm)
-    elif bound == "mfma" and dom_ms:
+    if bound == "mfma" and dom_ms:
         tf = alg_flop / (dom_ms * 1e-3) / 1e12
         roofline.update({"achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                         "algorithmic_flop_per_launch": alg_flop, "hbm": hbm})
-    elif bound == "lds" and dom_ms:
-        # What limits the sliced product is the LDS array together with the vector ALU (profiles/r04_experiments.md section 1):
-        # every entry is one 16-byte LDS read per 16-byte feature slice -- nnz x F x 4 bytes per launch whatever the padding --
-        # against 256 B/clk/CU; no fp32 gather-from-LDS design can reach 60 % of the HBM roofline on this graph (the LDS floor
-        # is above it), so the LDS fraction is the primary figure and the HBM fraction the metric asks for rides beside it.
+                         "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
+                         "hbm_achieved_gbs": hbm_gbs, "hbm_frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None})
+    else:
+        roofline.update({"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None, "algorithmic_bytes_per_launch": alg_bytes})
+    if bound == "lds" and dom_ms:
+        # every entry is one 16-byte LDS read per 16-byte feature slice -- nnz x F x 4 bytes per launch whatever the padding
         lds_bytes = 1.0 * nnz * (n_local / n) * hidden * 4
         lds_tbs = lds_bytes / (dom_ms * 1e-3) / 1e12
-        roofline.update({"achieved": lds_tbs, "peak": LDS_PEAK_TBS, "unit": "TB/s", "frac": lds_tbs / LDS_PEAK_TBS,
-                         "algorithmic_bytes_per_launch": lds_bytes, "hbm": hbm,
-                         "note": "one ds_read_b128 per (entry, 16-byte slice); peak = 256 CUs x 256 B/clk x 2.4 GHz; the step's "
-                                 "budget (adds, LDS-return register writes, entry stream) is measured in profiles/r04_experiments.md"})
+        roofline.update({"limiter": "lds", "lds_achieved_tbs": lds_tbs, "lds_peak_tbs": LDS_PEAK_TBS, "lds_frac": lds_tbs / LDS_PEAK_TBS,
+                         "lds_frac_of_measured_peak": lds_tbs / LDS_MEASURED_TBS, "lds_bytes_per_launch": lds_bytes,
+                         "limiter_note": "one ds_read_b128 per (entry, 16-byte slice); lds_peak_tbs = 256 CUs x 256 B/clk x 2.4 GHz "
+                                         "(spec), lds_frac_of_measured_peak against the guide's measured ~150 TB/s; the LDS floor of any "
+                                         "fp32 gather-from-LDS design (129-147 us) is above the HBM floor (88 us): frac is the contract's "
+                                         "HBM figure, the lds_* keys say why it stops there (profiles/r04_experiments.md section 1)"})
     # the rocprofv3 figure the event bracket is checked against (same workload, tracked summary of this round if present)
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r04_*{args.workload}*kernel_stats.csv")), reverse=True) + \
-        sorted(glob.glob(os.path.join(ROOT, "profiles", f"r03_*{args.workload}*kernel_stats.csv")), reverse=True)
+    cands = [c for r in ("r05", "r04", "r03") for c in
+             sorted(glob.glob(os.path.join(ROOT, "profiles", f"{r}_*{args.workload}*kernel_stats.csv")), reverse=True)]
     for cand in cands:
         try:
             import csv
@@ -436,16 +493,18 @@ def main():
     if rank == 0:
         print(json.dumps({
             "metric": "DIFFormer-layer forward nodes/sec", "value": value, "unit": "nodes/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_exact_fp32": ms_exact,
             "ms_per_step_events": {"median": fwd_ms[len(fwd_ms) // 2], "min": fwd_ms[0], "max": fwd_ms[-1], "n": len(fwd_ms)},
             "higher_is_better": True,
             "scaling": plan["scaling"], "vs_baseline": None, "dtype": "bf16" if store == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "nodes": n, "csr_entries": nnz, "in_channels": f_in,
                        "hidden": hidden, "heads": 1, "layers": layers, "kernel": kernel, "use_graph": use_graph,
-                       "parallelism": plan["parallelism"],
+                       "parallelism": plan["parallelism"] + (f", closed-form aggregation split by {'feature slices (two all-to-alls per layer)' if best == 'slice' else 'destination rows (one all-gather per layer)'}" if best is not None else ""),
+                       "exact_fp32": bool(ops.EXACT_FP32),
                        "csr": "warm (cached); cold build reported in cold_csr_build_ms",
                        "launch": launch_mode},
             "cold_csr_build_ms": cold_ms, "roofline": roofline, "cpu_baseline": cpu,
+            **({"ms_per_step_by_shard_product": {k: v / args.steps * 1e3 for k, v in by_product.items()}} if shard is not None else {}),
             **({"per_rank_phases": per_rank} if per_rank is not None else {}),
         }))
     if world > 1:

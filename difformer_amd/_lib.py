@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DIFFORMER_HIP_LIB: another build of the SAME ABI (A/B kernel experiments); the default is the in-tree build
 LIB_PATH = os.environ.get("DIFFORMER_HIP_LIB") or os.path.join(_HERE, "lib", "libdifformer_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i64, c_int, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

@@ -380,7 +380,8 @@ def _adjacent_columns(grads, n, sizes):
     base = None
     for g in grads:
         b = None if g is None else g._base
-        if b is not None and b.dim() == 2 and tuple(b.shape) == (n, sum(sizes)) and b.is_contiguous():
+        if (b is not None and getattr(b, "_difformer_fused_grad", False) and b.dim() == 2 and tuple(b.shape) == (n, sum(sizes))
+                and b.is_contiguous()):      # the tag: never a tensor that autograd or the caller owns (retain_grad, hooks)
             base = b
             break
     if base is None:

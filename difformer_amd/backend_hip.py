@@ -246,6 +246,7 @@ class HipBackend:
             # projection, the gradient of that projection is this buffer as it stands (autograd_ops._SplitColumns finds the
             # views adjacent and skips its concatenation: 308 MB of copy per layer at 100,000 x 128)
             fused = torch.empty((n, 3 * H * M), **f32)
+            fused._difformer_fused_grad = True      # only a buffer made HERE may be completed in place by _SplitColumns
             dq, dk, dv = (fused[:, i * H * M: (i + 1) * H * M].view(n, H, M) for i in range(3))
             ldg = 3 * H * M
         else:
@@ -1074,17 +1075,33 @@ class HipBackend:
         cache = self.__dict__.setdefault("_packed", {})
         hit = cache.get(key)
         if hit is not None and ver >= 0 and hit[0]() is weight:
-            return hit[1]
+            return self._pin(hit[1])
         packed = torch.empty(self.lib.dif_linear_packed_bytes(C), dtype=torch.uint8, device=dev)
         with _timed(self, "dif_linear_pack_f32", dev):
             rc = self.lib.dif_linear_pack_f32(_ptr(weight), C, Co, _ptr(packed), _stream(dev))
         _lib.check(rc, "dif_linear_pack_f32")
         if ver >= 0:
-            for k in [k for k, v in cache.items() if v[0]() is None]:
-                del cache[k]
-            if len(cache) >= 16:
-                cache.clear()
-            cache[key] = (weakref.ref(weight), packed)
+            self._packed_insert(cache, key, weight, packed)
+        return self._pin(packed)
+
+    @staticmethod
+    def _packed_insert(cache, key, tensor, packed):
+        """Insert into a packed-weight cache.  Evicted: entries of freed tensors and OLDER VERSIONS of this tensor (an optimiser
+        step per epoch would otherwise add an entry per epoch); beyond 64 live entries the oldest.  Never everything at once:
+        a captured hipGraph bakes raw pointers to these buffers in (it pins the ones it used itself, `capture_pins`)."""
+        import weakref
+        for k in [k for k, v in cache.items() if v[0]() is None or (v[0]() is tensor and k[:2] == key[:2] and k[3:] == key[3:])]:
+            del cache[k]
+        while len(cache) >= 64:
+            del cache[next(iter(cache))]
+        cache[key] = (weakref.ref(tensor), packed)
+
+    def _pin(self, packed):
+        """While a forward is being captured, the capture keeps every packed buffer it was handed alive (DIFFormer.
+        _forward_graphed / graphs.GraphedForward set `capture_pins` to a list around the capture)."""
+        pins = getattr(self, "capture_pins", None)
+        if pins is not None:
+            pins.append(packed)
         return packed
 
     # ---- a4 / a5 tail ----------------------------------------------------------------------
@@ -1281,7 +1298,7 @@ class HipBackend:
             store = self.__dict__.setdefault("_packed", {})
             hit = store.get(key)
             if hit is not None and ver >= 0 and hit[0]() is src:
-                return hit[1]
+                return self._pin(hit[1])
         src_c = src.contiguous()
         packed = torch.empty(self.lib.dif_xwide_packed_bytes(C, D), dtype=torch.uint8, device=dev)
         with _timed(self, "dif_xwide_pack_f32", dev):
@@ -1289,12 +1306,8 @@ class HipBackend:
                                              _stream(dev))
         _lib.check(rc, "dif_xwide_pack_f32")
         if cache and key[2] >= 0:
-            for k in [k for k, v in store.items() if v[0]() is None]:
-                del store[k]
-            if len(store) >= 16:
-                store.clear()
-            store[key] = (weakref.ref(src), packed)
-        return packed
+            self._packed_insert(store, key, src, packed)
+        return self._pin(packed)
 
     def simple_layer_xwide(self, x, B, bias, D, attn_scale, ax, Wv, bv, rs, gcn_scale, x0, residual, alpha, ln_weight, ln_bias,
                            eps, relu=False):

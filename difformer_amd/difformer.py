@@ -29,6 +29,12 @@ __all__ = ["full_attention_conv", "gcn_conv", "DIFFormerConv", "DIFFormer"]
 _CHAIN_GRAM = os.environ.get("DIFFORMER_CHAIN_GRAM", "0") == "1"
 _AUTO_GRAPH = os.environ.get("DIFFORMER_AUTO_GRAPH", "1") != "0"
 _CLOSED_FORM_TRAINING = os.environ.get("DIFFORMER_CLOSED_FORM_TRAINING", "1") != "0"
+# A forward is captured and replayed as one hipGraph only while it is LAUNCH-bound: the capture keeps a private pool with one
+# forward's intermediates for the model's lifetime (~0.5 GB at the ogbn-proteins size, ~3 GB on the full Pokec graph) and
+# replay buys <= 2 % there (profiles/r04_e_bench_small_configs.json), against 2x at Cora size.  The gate is the forward's
+# estimated HBM traffic, layers x (4 N hidden s + 8 nnz) bytes: 1.5 GB is ~0.4 ms of kernels -- Cora, CIFAR-50k and Pokec
+# mini-batches (also at hidden 128 / 300) replay, the ogbn-proteins graph and the full Pokec graph run kernel by kernel.
+_AUTO_GRAPH_MAX_BYTES = float(os.environ.get("DIFFORMER_AUTO_GRAPH_MAX_BYTES", "1.5e9"))
 
 
 def _dense_attention(qs, ks, kernel):
@@ -103,6 +109,16 @@ class DIFFormerConv(nn.Module):
         state = dict(state)
         state.update(_fused_wb=None, _wide=None, _narrow=None, row_shard=None)
         return state
+
+    def __deepcopy__(self, memo):
+        # a best-checkpoint / EMA copy of a row-sharded model keeps the shard BY REFERENCE (it describes the process group,
+        # not the parameters); pickling (torch.save(model)) still drops it -- a process group does not travel
+        import copy as _copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__dict__.update(_copy.deepcopy(self.__getstate__(), memo))
+        new.row_shard = self.row_shard
+        return new
 
     def reset_parameters(self):
         self.Wk.reset_parameters()
@@ -428,6 +444,10 @@ class DIFFormer(nn.Module):
         # module swapped in after the first call does not leave a stale list behind)
         mods = self._modules
         convs = mods["convs"]._modules.values()
+        hidden = mods["fcs"]._modules["0"].weight.shape[0]
+        nnz = edge_index.shape[1] if edge_index is not None else 0
+        if len(convs) * (4.0 * x.shape[0] * hidden * x.element_size() + 8.0 * nnz) > _AUTO_GRAPH_MAX_BYTES:
+            return None                  # GPU-bound: nothing to gain from a replay, gigabytes to hold for it
         key = [x.data_ptr(), x.shape, x.stride(), x.dtype, torch.cuda.current_stream(x.device).cuda_stream,
                self.alpha, self.use_bn, self.residual, ops.SIDE_CHAIN, len(convs)]
         lin = []
@@ -457,8 +477,10 @@ class DIFFormer(nn.Module):
         shard, a flag of the model or of a layer flipped, a sub-module replaced) runs eagerly and drops the capture.
         Derived caches (concatenated projections, weight-only factors, float32 copies of bfloat16 parameters) are frozen
         into the capture; they are keyed on the same parameter versions as the capture itself.  The capture keeps a private
-        memory pool with every intermediate of one forward for as long as it lives (about a second forward's worth of HBM:
-        ~0.5 GB at C4, ~3 GB on the full Pokec graph).  DIFFORMER_AUTO_GRAPH=0 or `model.auto_graph = False` turns it off;
+        memory pool with every intermediate of one forward for as long as it lives (about a second forward's worth of HBM),
+        so only launch-bound forwards are captured (`_AUTO_GRAPH_MAX_BYTES`: the ogbn-proteins graph and the full Pokec graph
+        run kernel by kernel) and a capture whose key no longer matches is dropped, pool included, at the next call.
+        DIFFORMER_AUTO_GRAPH=0 or `model.auto_graph = False` turns it off;
         `invalidate_caches()` drops it (needed after parameter writes through `.data`, as for the other caches)."""
         key = self._graph_key(x, edge_index, edge_weight)
         if key is None:
@@ -476,7 +498,10 @@ class DIFFormer(nn.Module):
             st[1] += 1
             if st[1] < 3:
                 return None
+            be = ops._BACKEND
+            pins = []
             try:
+                be.capture_pins = pins      # packed weight buffers the captured kernels read: kept alive with the capture
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out = self._forward_eager(x, edge_index, edge_weight)
@@ -486,9 +511,11 @@ class DIFFormer(nn.Module):
                 import warnings
                 warnings.warn(f"difformer_amd: hipGraph capture of the forward failed ({e}); running eagerly")
                 return None
+            finally:
+                be.capture_pins = None
             # the captured kernels hold raw pointers into the cached CSR / formats: they live as long as the capture
             st[2], st[3] = graph, out
-            st[4] = [v[2] for v in ops.csr_cache.entries.values()] if edge_index is not None else []
+            st[4] = ([v[2] for v in ops.csr_cache.entries.values()] if edge_index is not None else []) + pins
         st[2].replay()
         return st[3].clone()
 

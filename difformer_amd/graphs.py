@@ -49,9 +49,19 @@ class GraphedForward:
             torch.cuda.current_stream(dev).wait_stream(side)
             # the captured kernels hold raw pointers into the CSR: keep it alive with this object
             self._csr = [v[2] for v in ops.csr_cache.entries.values()] if edge_index is not None else []
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = model(self.x, edge_index, edge_weight)
+            be = ops.get_backend()
+            self._pins = []                  # ... and into packed weight buffers (backend `capture_pins`)
+            be.capture_pins = self._pins
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out = model(self.x, edge_index, edge_weight)
+            finally:
+                be.capture_pins = None
+            # the other derived tensors the captured kernels read: concatenated projections, weight-only factors, float32
+            # copies of bfloat16 parameters -- a later eager call with changed parameters replaces them in their caches
+            self._pins.append([(c._fused_wb, c._wide, c._narrow) for c in getattr(model, "convs", [])])
+            self._pins.append([v[1] for v in ops._F32_PARAMS.values()])
 
     def __call__(self, x=None):
         if x is not None:

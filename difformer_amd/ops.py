@@ -915,6 +915,16 @@ CLOSED_FORM_WIDE_MAX = 512      # widest layer the Gram-record formulation is us
 CLOSED_FORM_WIDE_MIN = 128 if EXACT_FP32 else 64
 
 
+def set_exact_fp32(flag):
+    """Switch DIFFORMER_EXACT_FP32 at run time (bench.py's second pass) -> the previous setting.  Callers drop what they
+    cached under the old setting (`DIFFormer.invalidate_caches()`: a captured forward bakes the kernel choice in)."""
+    global EXACT_FP32, CLOSED_FORM_WIDE_MIN
+    was = EXACT_FP32
+    EXACT_FP32 = bool(flag)
+    CLOSED_FORM_WIDE_MIN = 128 if EXACT_FP32 else 64
+    return was
+
+
 class WideCoefficients:
     """Weight-only factors of the closed form at the scripts' widths, float64, rebuilt when a parameter changes.
     With the augmented matrices  X~ = [X | 1],  W~ = [W | b]  (so q = X~ W~q^T etc.) and  G~ = X~^T X~ = [[G, sx], [sx^T, N]]:

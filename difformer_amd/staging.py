@@ -67,12 +67,14 @@ class _OperandCache:
             return t
         ver = ops.tensor_version(t)
         key = (id(t), t.data_ptr(), tuple(t.shape), t.dtype, ver, str(dev))
+        # on EVERY call: the device copy of a freed host tensor (a full-graph x can be hundreds of MB) goes at once, not at
+        # the next miss
+        for k in [k for k, v in self.entries.items() if v[0]() is None]:
+            del self.entries[k]
         hit = self.entries.get(key)
         if ver >= 0 and hit is not None and hit[0]() is t:
             self.entries.move_to_end(key)
             return hit[1]
-        for k in [k for k, v in self.entries.items() if v[0]() is None]:
-            del self.entries[k]
         d = t.detach().to(dev)
         if ver >= 0:
             self.entries[key] = (weakref.ref(t), d)
@@ -107,6 +109,13 @@ class _Twin:
                 for t, h in zip(tp, hp):
                     t.copy_(h)                          # in place: bumps the twin's versions, so its caches refresh
             self.key = key
+        for t, h in zip(tp, hp):                        # a host parameter frozen / unfrozen after the twin was made
+            if t.requires_grad != h.requires_grad:
+                t.requires_grad_(h.requires_grad)
+        for (_, tb), (_, hb) in zip(self.module.named_buffers(), host.named_buffers()):
+            if tb is not None and hb is not None:
+                with torch.no_grad():
+                    tb.copy_(hb)
         for name in _FLAGS:
             if hasattr(host, name):
                 setattr(self.module, name, getattr(host, name))

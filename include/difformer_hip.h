@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIF_ABI_VERSION 1
+#define DIF_ABI_VERSION 2   /* 2: dif_csr_build's status is int32[2] (status[1] = longest row): a caller that allocates one int must be rebuilt */
 
 #define DIF_E_BADARG   (-1)  /* null pointer, non-positive size, misaligned pointer */
 #define DIF_E_SHAPE    (-2)  /* shape the kernels do not cover */

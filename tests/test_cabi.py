@@ -40,7 +40,7 @@ def test_python_binding_covers_the_header_exactly():
 
 
 def test_version_and_size_helpers(lib):
-    assert lib.dif_version() == 1
+    assert lib.dif_version() == 2
     assert lib.dif_simple_reduced_len(1, 64, 64) == 64 * 64 + 64 + 64 + 2          # 4,226 floats
     assert lib.dif_simple_reduced_len(2, 16, 16) == 2 * (256 + 32) + 2
     assert lib.dif_simple_workspace_bytes(132534, 1, 64, 64) >= 4226 * 4
