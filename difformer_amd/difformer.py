@@ -77,7 +77,7 @@ def gcn_conv(x, edge_index, edge_weight):
         return gcn_conv(x.to(dev), staging.operands.get(edge_index, dev), ew).to(x.device)
     csr = ops.csr_cache.get(edge_index, edge_weight, x.shape[0], x.shape[1] * x.shape[2] * x.element_size(),
                             elem_size=x.element_size())
-    return ag.gcn_aggregate(csr, x)
+    return ag.gcn_aggregate(csr, x, None, 1.0, csr.weight_scale)
 
 
 class DIFFormerConv(nn.Module):
@@ -244,6 +244,8 @@ class DIFFormerConv(nn.Module):
             a_s, g_s = (1.0 - self.graph_weight, float(self.graph_weight)) if self.graph_weight > 0 else (1.0, 1.0)
             if not self.use_graph:
                 a_s = 1.0                                       # difformer.py:130-136: the mix only exists with a graph
+            else:
+                g_s *= csr.weight_scale                         # a constant edge_weight (ops._CSRCache.get)
             Wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
             if x.shape[1] > 64 or self.out_channels > 64:          # the scripts' widths (hidden 128 / 300 / 400)
                 params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias] + ([Wv, bv] if self.use_weight else [])
@@ -309,6 +311,7 @@ class DIFFormerConv(nn.Module):
             a_s, g_s = 1.0 - self.graph_weight, float(self.graph_weight)
         else:                                                  # difformer.py:134
             a_s, g_s = 1.0, 1.0
+        g_s *= csr.weight_scale                                # a constant edge_weight (ops._CSRCache.get)
         if v.shape[1] == H:
             out = ag.gcn_aggregate_tail(csr, v, attn, a_s, g_s, shard, x0, prev, alpha, ln_weight, ln_bias, eps)
         else:  # use_weight=False with several heads: the [n,1,D] aggregate broadcasts over heads

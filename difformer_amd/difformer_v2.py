@@ -127,6 +127,7 @@ class TransConv(nn.Module):
             a_s, g_s = 1.0 - self.graph_weight, float(self.graph_weight)
         else:                                                                            # :154
             a_s, g_s = 1.0, 1.0
+        g_s *= csr.weight_scale                                                          # a constant edge_weight
         return ag.gcn_aggregate_tail(csr, v, attn, a_s, g_s, None, None, prev, alpha, ln_weight, ln_bias, eps, relu)
 
     def forward(self, query_input, source_input, n_nodes, edge_index=None, edge_weight=None):

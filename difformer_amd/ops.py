@@ -13,6 +13,7 @@ import weakref
 from collections import OrderedDict
 from typing import Optional
 
+import math
 import os
 
 import torch
@@ -250,6 +251,9 @@ class GraphCSR:
         self._sliced = {}           # (row_begin, n_rows, F) -> SlicedAdjacency | None
         self._row_sums = None
         self._format_checked = False # csr_cache.get(build_format=True) has built (or ruled out) the sliced format for this CSR
+        self.weight_scale = 1.0      # a CONSTANT edge_weight (every entry equal: `--special_treat dense` / knn, spatial-temporal/
+                                     # main.py:99,103) is not in `val`: the CSR is the unweighted one and every caller multiplies
+                                     # its gcn_scale by this (csr_cache.get)
         self._max_degree = None      # longest row: known from the build (status[1] of dif_csr_build) ...
         self._max_source = None      # ... or (graph_utils._LongestRows, batch) for the batches of one subgraph_batches call
 
@@ -409,13 +413,21 @@ class _CSRCache:
             raise NotImplementedError("difformer_amd: gradients with respect to edge_weight are not implemented for "
                                       "row-sharded runs; detach() it or keep it a constant of the graph")
         self._purge()
+        # every weight equal (one reduction, read with the host read a build has anyway): value_e = w d_in d_out
+        # (difformer.py:73) = w x the unweighted value, so the graph takes every UNWEIGHTED kernel (feature-sliced product,
+        # in-layer aggregation) and w rides in the callers' gcn_scale.  Keyed like a weighted graph, built like an unweighted one.
+        given_weight, scale = edge_weight, 1.0
+        if edge_weight is not None:
+            u = self._uniform_weight(edge_weight, edge_index.shape[1])
+            if u is not None:
+                edge_weight, scale = None, u
         n_blocks, block_rows = self.blocking(edge_index, edge_weight, num_nodes, row_bytes, shard, elem_size)
-        key = self._key(edge_index, edge_weight, num_nodes, n_blocks, block_rows)
+        key = self._key(edge_index, given_weight, num_nodes, n_blocks, block_rows)
         hit = self.entries.get(key)
         csr = None
         if hit is not None:
             ei_ref, ew_ref, csr = hit
-            if ei_ref() is edge_index and (edge_weight is None or ew_ref() is edge_weight):
+            if ei_ref() is edge_index and (given_weight is None or ew_ref() is given_weight):
                 self.entries.move_to_end(key)
                 if csr._format_checked or not build_format:
                     return csr
@@ -424,6 +436,7 @@ class _CSRCache:
                 csr = None
         if csr is None:
             csr = GraphCSR.build(edge_index, edge_weight, num_nodes, n_blocks, block_rows=block_rows)
+            csr.weight_scale = scale
         F = row_bytes // elem_size
         if build_format:
             # (also the first `build_format` request for a CSR that a pointers-only probe left here: _MixCache.get)
@@ -446,11 +459,42 @@ class _CSRCache:
                                       "GraphCSR._build_sliced); using the gather kernels on their own blocking")
                     csr = GraphCSR.build(edge_index, edge_weight, num_nodes, nb2, block_rows=br2)
                     csr._format_checked = True
-        self.entries[key] = (weakref.ref(edge_index), weakref.ref(edge_weight) if edge_weight is not None else None,
+                    csr.weight_scale = scale
+        self.entries[key] = (weakref.ref(edge_index), weakref.ref(given_weight) if given_weight is not None else None,
                              csr)
         while len(self.entries) > max(self.capacity, getattr(self, "_floor", 0)):
             self.entries.popitem(last=False)
         return csr
+
+    UNIFORM_MIN_EDGES = 4096     # below this the CSR build is a handful of launches and the check would double its host cost
+
+    def _uniform_weight(self, edge_weight, n_edges):
+        """The constant all entries of `edge_weight` are equal to (0.0 when that constant is not finite: nan_to_num,
+        difformer.py:74), or None: weights that vary, that want a gradient, or a graph too small for the check to pay.
+        Remembered per weight tensor (identity + version)."""
+        if n_edges < self.UNIFORM_MIN_EDGES or edge_weight.numel() != n_edges or not edge_weight.is_floating_point():
+            return None
+        if edge_weight.requires_grad and torch.is_grad_enabled():
+            return None
+        memo = self.__dict__.setdefault("_uniform", OrderedDict())
+        key = (id(edge_weight), edge_weight.data_ptr(), tensor_version(edge_weight), n_edges)
+        hit = memo.get(key)
+        if hit is not None and hit[0]() is edge_weight and key[2] >= 0:
+            return hit[1]
+        for k in [k for k, v in memo.items() if v[0]() is None]:
+            del memo[k]
+        w = edge_weight.detach()
+        lo, hi = torch.stack([w.min(), w.max()]).tolist()            # NaN anywhere -> both NaN -> lo == hi is False
+        if lo == hi:
+            u = float(lo) if math.isfinite(lo) else 0.0
+        elif math.isnan(lo) and bool(torch.isnan(w).all()):
+            u = 0.0
+        else:
+            u = None
+        memo[key] = (weakref.ref(edge_weight), u)
+        while len(memo) > 64:
+            memo.popitem(last=False)
+        return u
 
     @staticmethod
     def blocking(edge_index, edge_weight, num_nodes, row_bytes=256, shard=None, elem_size=4):

@@ -209,14 +209,44 @@ def test_sliced_product_with_attention_combine_and_tail(dev):
     assert rel_err(got.cpu().numpy(), old.cpu().numpy()) < 1e-5
 
 
-def test_sliced_is_declined_for_weights_and_sparse_graphs(dev):
+def test_sliced_is_declined_for_varying_weights_and_sparse_graphs(dev):
     from difformer_amd import ops
     n = 12000
     ei = _dense_graph(n, 64, seed=1).to(dev)
     w = torch.rand(ei.shape[1]).to(dev)
-    assert ops.csr_cache.get(ei, w, n, 256).sliced(0, n, 64) is None             # edge weights
+    assert ops.csr_cache.get(ei, w, n, 256).sliced(0, n, 64) is None             # edge weights that vary
     sparse = torch.randint(0, n, (2, 5 * n)).to(dev)
     assert ops.csr_cache.get(sparse, None, n, 256).sliced(0, n, 64) is None      # ~5 entries per row
+
+
+@pytest.mark.parametrize("const", [1.0, 0.37, -2.5, 0.0, float("nan"), float("inf")])
+def test_constant_weights_take_the_unweighted_product(const, dev):
+    """`edge_attr = torch.ones(E)` (spatial-temporal/main.py:99,103) or any other constant: value_e = w d_in d_out is w times
+    the unweighted value (difformer.py:70-74; a non-finite w: nan_to_num -> 0), so the graph takes the feature-sliced product
+    and w rides in gcn_scale -- against the float64 oracle WITH the weights, forward and the gradient of x."""
+    from difformer_amd import gcn_conv, ops
+    n = 12000
+    ei = _dense_graph(n, 64, seed=2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 1, 64, generator=g)
+    w = torch.full((ei.shape[1],), const)
+    eid, wd = ei.to(dev), w.to(dev)
+    csr = ops.csr_cache.get(eid, wd, n, 256)
+    assert not csr.weighted and csr.sliced(0, n, 64) is not None
+    assert csr.weight_scale == (const if np.isfinite(const) else 0.0)
+    ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), w.double().numpy())
+    xd = x.to(dev).requires_grad_(True)
+    out = gcn_conv(xd, eid, wd)
+    assert rel_err(out.detach().cpu().numpy(), ref) < 1e-5 or (not np.abs(ref).max() and not out.abs().max())
+    go = torch.randn(n, 1, 64, generator=g)
+    out.backward(go.to(dev))
+    # the adjoint through the identity <A x, g> = <x, A^T g>
+    lhs = float((out.detach().double().cpu() * go.double()).sum())
+    rhs = float((x.double() * xd.grad.double().cpu()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1e-3)
+    # weights that are constant but WANT a gradient keep the weighted operator (difformer.py:73 is differentiable in them)
+    wg = wd.clone().requires_grad_(True)
+    assert ops.csr_cache.get(eid, wg, n, 256).weighted
 
 
 @pytest.mark.parametrize("n,deg,hubs", [(12000, 64, 40), (30000, 80, 7), (64000, 50, 2000), (20000, 100, 2)])

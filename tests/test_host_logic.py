@@ -572,3 +572,36 @@ def test_closed_form_training_keeps_a_temporary_edge_index_alive(fake_backend):
     gc.collect()
     out.sum().backward()
     assert fake_backend.closed_form_calls > 0 and all(p.grad is not None for p in model.parameters())
+
+
+def test_constant_edge_weights_build_the_unweighted_csr(fake_backend):
+    """`edge_attr = torch.ones(E)` of `--special_treat dense` / knn (spatial-temporal/main.py:99,103), or any constant: the CSR
+    is the unweighted one and the constant rides in gcn_scale (ops._CSRCache.get); model output = the oracle's WITH weights."""
+    import numpy as np
+    from difformer_amd import DIFFormer, gcn_conv, ops
+    from oracle import difformer_oracle as orc
+    n = 80
+    row = torch.arange(n).unsqueeze(1).repeat(1, n).reshape(-1)
+    col = torch.arange(n).unsqueeze(0).repeat(n, 1).reshape(-1)
+    ei = torch.stack([row, col])                                          # 6,400 entries: above UNIFORM_MIN_EDGES
+    x = torch.randn(n, 1, 8)
+    for const in (1.0, 0.25, float("nan")):
+        w = torch.full((ei.shape[1],), const)
+        csr = ops.csr_cache.get(ei, w, n, 32)
+        assert not csr.weighted and csr.weight_scale == (const if np.isfinite(const) else 0.0)
+        ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), w.double().numpy())
+        assert np.abs(gcn_conv(x, ei, w).numpy() - ref).max() < 1e-5
+    wv = torch.rand(ei.shape[1]) + 0.5
+    assert ops.csr_cache.get(ei, wv, n, 32).weighted                      # weights that vary: the weighted CSR
+    torch.manual_seed(0)
+    for kernel, use_weight in (("simple", False), ("sigmoid", True)):
+        model = DIFFormer(6, 8, 3, num_layers=2, kernel=kernel, use_weight=use_weight).eval()
+        xin = torch.randn(n, 6)
+        w = torch.full((ei.shape[1],), 0.5)
+        with torch.no_grad():
+            out = model(xin, ei, w)
+        cfg = dict(hidden_channels=8, num_layers=2, num_heads=1, kernel=kernel, alpha=0.5, use_bn=True, use_residual=True,
+                   use_weight=use_weight, use_graph=True, graph_weight=-1, use_source=False)
+        p = {k: v.detach().numpy().astype(np.float64) for k, v in model.state_dict().items()}
+        ref = orc.difformer_forward(p, xin.double().numpy(), ei.numpy(), w.double().numpy(), cfg)
+        assert np.abs(out.numpy() - ref).max() / np.abs(ref).max() < 1e-4
