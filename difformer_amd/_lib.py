@@ -152,6 +152,23 @@ SIGNATURES["dif_gcn_spmm_tail_bf16"] = (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c
                                                 c_int, c_vp, c_i64, c_f32, c_f32, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_i64, c_f32,
                                                 c_vp, c_vp, c_f32, c_int, c_vp, c_i64, c_vp])
 
+
+
+class TinyCfg(ctypes.Structure):
+    """dif_tiny_cfg of include/difformer_hip.h."""
+    _fields_ = [(k, ctypes.c_int32) for k in ("n", "in_channels", "hidden", "out_channels", "num_layers", "kernel", "use_bn",
+                                               "use_residual", "use_weight", "use_graph", "use_source", "training")] + \
+               [(k, ctypes.c_float) for k in ("alpha", "attn_scale", "gcn_scale", "dropout", "eps")] + [("nnz", ctypes.c_int64)]
+
+
+SIGNATURES["dif_tiny_tape_floats"] = (c_sz, [c_int, c_int, c_int])
+SIGNATURES["dif_tiny_scratch_floats"] = (c_sz, [c_int, c_int])
+SIGNATURES["dif_tiny_graph_workspace_bytes"] = (c_sz, [c_i64, c_i64])
+SIGNATURES["dif_tiny_graph_build"] = (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp])
+SIGNATURES["dif_tiny_forward_f32"] = (c_int, [ctypes.POINTER(TinyCfg), c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])
+SIGNATURES["dif_tiny_backward_f32"] = (c_int, [ctypes.POINTER(TinyCfg), c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                               c_vp, c_vp, c_vp])
+
 _lib = None
 
 

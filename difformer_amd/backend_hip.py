@@ -138,6 +138,7 @@ def _timed(backend, name, dev):
 
 
 class HipBackend:
+    has_tiny = True          # the whole-model kernels for tiny graphs (tiny.py; csrc/tiny_model.hip) are in this library
     name = "hip"
 
     def __init__(self):

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 from . import ops
 from . import autograd_ops as ag
 from . import staging
+from . import tiny
 
 __all__ = ["full_attention_conv", "gcn_conv", "DIFFormerConv", "DIFFormer"]
 
@@ -526,6 +527,9 @@ class DIFFormer(nn.Module):
         dev = staging.staging_device(self, (x, edge_index, edge_weight))
         if dev is not None:      # model and operands in host memory (test_large_dataset.py:91-93, eval.py:38-41)
             return staging.staged_forward(self, dev, lambda m, *a: m.forward(*a), x, edge_index, edge_weight)
+        out = tiny.forward(self, x, edge_index, edge_weight)      # tiny graphs (spatial-temporal/): the whole model in one launch
+        if out is not None:
+            return out
         out = self._forward_graphed(x, edge_index, edge_weight)
         return out if out is not None else self._forward_eager(x, edge_index, edge_weight)
 

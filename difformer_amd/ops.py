@@ -418,7 +418,7 @@ class _CSRCache:
         # in-layer aggregation) and w rides in the callers' gcn_scale.  Keyed like a weighted graph, built like an unweighted one.
         given_weight, scale = edge_weight, 1.0
         if edge_weight is not None:
-            u = self._uniform_weight(edge_weight, edge_index.shape[1])
+            u = self._uniform_weight(edge_weight, edge_index.shape[1], num_nodes)
             if u is not None:
                 edge_weight, scale = None, u
         n_blocks, block_rows = self.blocking(edge_index, edge_weight, num_nodes, row_bytes, shard, elem_size)
@@ -466,13 +466,19 @@ class _CSRCache:
             self.entries.popitem(last=False)
         return csr
 
+    UNIFORM_ALWAYS = False       # tests: run the check on graphs of any size
     UNIFORM_MIN_EDGES = 4096     # below this the CSR build is a handful of launches and the check would double its host cost
+    # ... and it only buys something where the unweighted graph takes kernels the weighted one cannot: the feature-sliced
+    # product (SLICED_MIN_ROWS nodes, SLICED_MIN_DEGREE entries per row).  A 1,068-node snapshot with fresh tensors per forward
+    # (spatial-temporal/main.py:96-105) would pay two reductions and a host read per snapshot for the same gather kernels.
 
-    def _uniform_weight(self, edge_weight, n_edges):
+    def _uniform_weight(self, edge_weight, n_edges, num_nodes=None):
         """The constant all entries of `edge_weight` are equal to (0.0 when that constant is not finite: nan_to_num,
         difformer.py:74), or None: weights that vary, that want a gradient, or a graph too small for the check to pay.
         Remembered per weight tensor (identity + version)."""
         if n_edges < self.UNIFORM_MIN_EDGES or edge_weight.numel() != n_edges or not edge_weight.is_floating_point():
+            return None
+        if num_nodes is not None and (num_nodes < SLICED_MIN_ROWS or n_edges < SLICED_MIN_DEGREE * num_nodes) and not self.UNIFORM_ALWAYS:
             return None
         if edge_weight.requires_grad and torch.is_grad_enabled():
             return None

@@ -666,6 +666,55 @@ int dif_layer_tail_bf16(const void* conv, int64_t ldc, int64_t n_rows, int H, in
                         float alpha, const void* ln_weight, const void* ln_bias, float ln_eps,
                         int relu, void* out, int64_t ldo, dif_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Whole model on TINY graphs (csrc/tiny_model.hip): the `spatial-temporal/` folder trains DIFFormer(d, 4, 1, num_layers=2,
+ * num_heads=1, use_weight=False) on 20 / 129 / 1,068-node snapshots, hundreds of forwards per epoch on tensors fresh from
+ * `snapshot.to(device)` (spatial-temporal/run.sh:5-40, main.py:94-121).  Three launches replace the ~110 of the
+ * layer-by-layer path: the graph preparation, the forward, the backward.  One head, float32, n <= 4,096 nodes,
+ * hidden <= 8, <= 64 input features, <= 8 outputs, <= 8 layers.
+ *
+ * dif_tiny_graph_build   replaces gcn_conv's graph side (node classification/difformer.py:64-75 =
+ *   spatial-temporal/difformer.py:64-75: degree(col), d_norm_in / d_norm_out, value = w * d_in * d_out, nan_to_num,
+ *   SparseTensor(row=col, col=row)) for E <= 65,535 entries: rowptr / src / val = destination-major CSR (a row's entries
+ *   in edge order; val bit-identical to dif_csr_build's), rowptr_t / dst_t / val_t = its transpose (the backward's
+ *   operand).  status int32 [2]: [0] != 0 an index outside [0, N) (the entry is then filed under node 0), [1] = longest
+ *   destination row.  All buffers caller-owned; one workgroup per direction, no host synchronisation.
+ * dif_tiny_forward_f32   replaces DIFFormer.forward (difformer.py:184-209) with everything below it (DIFFormerConv.forward
+ *   :113-145, full_attention_conv :10-61 for 'simple' (kernel = 0) and 'sigmoid' (kernel = 1), gcn_conv :63-79).
+ *   params: 6 + 8 * num_layers device pointers (host array) in the order fcs.0.weight, fcs.0.bias, bns.0.weight,
+ *   bns.0.bias, fcs.1.weight, fcs.1.bias, then per layer Wk.weight, Wk.bias, Wq.weight, Wq.bias, Wv.weight, Wv.bias,
+ *   bns.{l+1}.weight, bns.{l+1}.bias (NULL where the configuration has none: use_bn = 0, use_weight = 0), row-major as
+ *   nn.Linear stores them.  attn_scale / gcn_scale: 1 / 1, or (1 - graph_weight) / graph_weight (:130-134), times a
+ *   constant edge weight.  rnd: [(num_layers + 1), n, hidden] uniforms in [0, 1) for the dropouts of :192 and :204
+ *   (an element is kept iff its uniform >= dropout and scaled by 1 / (1 - dropout)), or NULL (eval, dropout = 0).
+ *   tape: dif_tiny_tape_floats(...) floats, 16-byte aligned: the layer inputs, pre-LayerNorm values, attention outputs
+ *   and sums the backward reads.  y [n, out_channels].
+ * dif_tiny_backward_f32  what autograd derives for `cost.backward()` (spatial-temporal/main.py:112,119) from that
+ *   forward: grads = pointers in the order of params (each the size of its parameter), dx [n, in_channels] or NULL;
+ *   rowptr_t / dst_t / val_t = the transposed CSR; scratch: dif_tiny_scratch_floats(...) floats.  The tape is only read:
+ *   `backward(retain_graph=True)` may run again.  Bitwise reproducible (sums over nodes in a fixed order).
+ */
+typedef struct {
+    int32_t n, in_channels, hidden, out_channels, num_layers;
+    int32_t kernel;                 /* 0 = 'simple', 1 = 'sigmoid' */
+    int32_t use_bn, use_residual, use_weight, use_graph, use_source, training;
+    float alpha, attn_scale, gcn_scale, dropout, eps;
+    int64_t nnz;
+} dif_tiny_cfg;
+size_t dif_tiny_tape_floats(int n, int hidden, int num_layers);
+size_t dif_tiny_scratch_floats(int n, int hidden);
+size_t dif_tiny_graph_workspace_bytes(int64_t E, int64_t N);
+int dif_tiny_graph_build(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N, int32_t* rowptr,
+                         int32_t* src, float* val, int32_t* rowptr_t, int32_t* dst_t, float* val_t, int32_t* status,
+                         void* workspace, size_t workspace_bytes, dif_stream_t stream);
+int dif_tiny_forward_f32(const dif_tiny_cfg* cfg, const float* x, int64_t ldx, const void* const* params,
+                         const int32_t* rowptr, const int32_t* src, const float* val, const float* rnd, float* tape,
+                         float* y, dif_stream_t stream);
+int dif_tiny_backward_f32(const dif_tiny_cfg* cfg, const float* x, int64_t ldx, const void* const* params,
+                          const int32_t* rowptr_t, const int32_t* dst_t, const float* val_t, const float* rnd,
+                          float* tape, const float* grad_y, void* const* grads, float* dx, float* scratch,
+                          dif_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

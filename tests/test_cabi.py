@@ -25,7 +25,7 @@ def lib():
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and "dif_sliced_spmm_f32" in names and "dif_simple_layer_f32" in names and "dif_subgraph_batches_group" in names and "dif_graph_prepare" in names and "dif_gcn_edge_weight_grad_f32" in names and "dif_batched_sigmoid_attn_bwd_f32" in names and len(names) == 95
+    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and "dif_sliced_spmm_f32" in names and "dif_simple_layer_f32" in names and "dif_subgraph_batches_group" in names and "dif_graph_prepare" in names and "dif_gcn_edge_weight_grad_f32" in names and "dif_batched_sigmoid_attn_bwd_f32" in names and "dif_tiny_forward_f32" in names and "dif_tiny_backward_f32" in names and "dif_tiny_graph_build" in names and len(names) == 101
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -132,3 +132,23 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU / eager fallback"):
         _lib.load()
+
+
+def test_tiny_model_entry_points_check_their_arguments(lib):
+    """dif_tiny_*: size helpers are host arithmetic; the configuration is validated before any HIP call."""
+    from difformer_amd import _lib
+    assert lib.dif_tiny_tape_floats(20, 4, 2) == 20 * 4 * (2 * 3 + 2 + 3) + 2 * 20 + 2 * 96
+    assert lib.dif_tiny_tape_floats(20, 5, 2) == 20 * 8 * (2 * 3 + 2 + 3) + 2 * 20 + 2 * 96       # hidden 5..8: padded to 8
+    assert lib.dif_tiny_scratch_floats(1068, 4) == 1068 * 4 * 14 + 3 * 1068
+    assert lib.dif_tiny_graph_workspace_bytes(100, 20) >= 4 * 100 * 4
+    cfg = _lib.TinyCfg(n=5000, in_channels=4, hidden=4, out_channels=1, num_layers=2, kernel=0, use_bn=1, use_residual=1,
+                       use_weight=0, use_graph=0, use_source=0, training=0, alpha=0.5, attn_scale=1.0, gcn_scale=1.0, dropout=0.0,
+                       eps=1e-5, nnz=0)
+    assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -2
+    assert b"nodes" in lib.dif_last_error()
+    cfg.n, cfg.hidden = 20, 9
+    assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -2
+    cfg.hidden = 4
+    assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -1
+    assert lib.dif_tiny_graph_build(None, None, 70000, 20, None, None, None, None, None, None, None, None, 0, None) == -2
+    assert lib.dif_tiny_graph_build(None, None, 10, 20, None, None, None, None, None, None, None, None, 0, None) == -1

@@ -585,6 +585,8 @@ def test_constant_edge_weights_build_the_unweighted_csr(fake_backend):
     col = torch.arange(n).unsqueeze(0).repeat(n, 1).reshape(-1)
     ei = torch.stack([row, col])                                          # 6,400 entries: above UNIFORM_MIN_EDGES
     x = torch.randn(n, 1, 8)
+    ops.csr_cache.UNIFORM_ALWAYS = True                                    # (the check is reserved for sliced-eligible sizes)
+    request_finalizer = lambda: setattr(ops.csr_cache, "UNIFORM_ALWAYS", False)
     for const in (1.0, 0.25, float("nan")):
         w = torch.full((ei.shape[1],), const)
         csr = ops.csr_cache.get(ei, w, n, 32)
@@ -605,3 +607,5 @@ def test_constant_edge_weights_build_the_unweighted_csr(fake_backend):
         p = {k: v.detach().numpy().astype(np.float64) for k, v in model.state_dict().items()}
         ref = orc.difformer_forward(p, xin.double().numpy(), ei.numpy(), w.double().numpy(), cfg)
         assert np.abs(out.numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    request_finalizer()
+    assert ops.csr_cache.get(ei, torch.full((ei.shape[1],), 2.0), n, 32).weighted    # 80 nodes: not worth the check by default
