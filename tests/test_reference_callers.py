@@ -370,3 +370,60 @@ def test_reference_test_large_dataset_body_runs_staged(staged_on_host, tmp_path,
         finally:
             staging.FORCE_DEVICE = staging_dev
         assert torch.allclose(out, plain, atol=1e-6)
+
+
+def test_spatial_temporal_training_loop_executed_from_the_reference_source(fake_backend):
+    """`spatial-temporal/main.py:81-123` -- reset_parameters, Adam, retain_grad on the parameters, the snapshot loop with
+    `snapshot.to(device)`, `model(snapshot.x, snapshot.edge_index, snapshot.edge_attr)`, the summed cost with ONE
+    `cost_tr.backward(retain_graph=True)` (chickenpox, covid) or a backward + step per snapshot (wikimath), then
+    `evaluate(model, val_dataset, device, args)` from the folder's own eval.py -- EXECUTED from the reference files on the drop-in,
+    for every `--method difformer` line of run.sh of the chickenpox and wikimath blocks (the two branches of the loop)."""
+    import numpy as np
+    parse, dropin = _load("spatial-temporal", "difformer.py", extra=("gnns",))
+    src = open(os.path.join(REF, "spatial-temporal", "main.py")).read().splitlines()
+    body = "\n".join(src[80:123])                                      # lines 81-123
+    assert body.startswith("for run in range(args.runs):") and "cost_tr.backward(retain_graph=True)" in body
+    assert "y_hat = model(snapshot.x, snapshot.edge_index, snapshot.edge_attr)" in body and body.rstrip().endswith(
+        "cost_val = evaluate(model, val_dataset, device, args)")
+    saved = {k: sys.modules.get(k) for k in ("torch_geometric", "torch_geometric.nn")}
+    sys.modules["torch_geometric"] = _stub("torch_geometric", nn=_stub("torch_geometric.nn", knn_graph=None))
+    sys.modules["torch_geometric.nn"] = sys.modules["torch_geometric"].nn
+    try:
+        spec = importlib.util.spec_from_file_location("ref_st_eval", os.path.join(REF, "spatial-temporal", "eval.py"))
+        ref_eval = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref_eval)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    class Snapshot:                                                     # torch_geometric.data.Data as the loop uses it
+        def __init__(self, x, edge_index, edge_attr, y):
+            self.x, self.edge_index, self.edge_attr, self.y = x, edge_index, edge_attr, y
+
+        def to(self, device):                                           # main.py:95: NEW tensors every time
+            return Snapshot(*(t.clone().to(device) for t in (self.x, self.edge_index, self.edge_attr, self.y)))
+
+    g = torch.Generator().manual_seed(3)
+    n, c = 20, 1
+    cmds = [a for a in _difformer_commands("spatial-temporal") if a[a.index("--dataset") + 1] in ("chickenpox", "wikimath")]
+    assert len(cmds) == 8
+    for argv in cmds:
+        args = _args(parse, argv)
+        d = 4 if args.dataset == "chickenpox" else 14
+        ei = _graph(n, 60, seed=4)
+        data = [Snapshot(torch.randn(n, d, generator=g), ei, torch.rand(ei.shape[1], generator=g) + 0.1, torch.randn(n, generator=g))
+                for _ in range(7)]
+        args.runs, args.epochs = 1, 2
+        device = torch.device("cpu")
+        torch.manual_seed(args.seed)
+        model, _ = parse.parse_method(args, n, c, d, device)
+        ns = dict(args=args, model=model, torch=torch, np=np, train_dataset=data[:5], val_dataset=data[5:], device=device,
+                  evaluate=ref_eval.evaluate, knn_graph=None)
+        before = [p.detach().clone() for p in model.parameters()]
+        exec(compile(body, "spatial-temporal/main.py", "exec"), ns)
+        assert np.isfinite(ns["cost_val"]) and np.isfinite(float(ns["cost_tr"]))
+        assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))      # the optimiser moved them
+        assert all(p.grad is None or not p.grad.any() for p in model.parameters())         # zero_grad() after the last step
