@@ -114,10 +114,20 @@ template <> struct Elem<bf16> {
         v[2] = bf16_to_f32(static_cast<uint16_t>(r.y & 0xffffu)); v[3] = bf16_to_f32(static_cast<uint16_t>(r.y >> 16));
         return v;
     }
-    typedef uint16_t u16x4u __attribute__((ext_vector_type(4), aligned(2)));
-    static __device__ __forceinline__ f32x4 ld4u(const bf16* p) {      // one 8-byte load from a 2-byte aligned address
-        const u16x4u r = *reinterpret_cast<const u16x4u*>(p);
-        return f32x4{bf16_to_f32(r[0]), bf16_to_f32(r[1]), bf16_to_f32(r[2]), bf16_to_f32(r[3])};
+    // four elements from an address that is only 2-byte aligned (rows of 65 bfloat16: every other row starts in the middle of a
+    // dword).  A misaligned 8-byte load is split by the memory pipeline (skinny_linear_kernel<5, bf16>: 37 us against 26 us for
+    // its float32 twin at 100,000 x 65); instead: the three ALIGNED dwords that cover the eight bytes, shifted into place by
+    // v_alignbit (two VALU instructions).  Reads up to two bytes past the four elements -- inside the same allocation for any
+    // tensor whose storage is a multiple of four bytes (the allocator's granularity is 512).
+    typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+    static __device__ __forceinline__ f32x4 ld4u(const bf16* p) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        const u32x3a r = *reinterpret_cast<const u32x3a*>(a & ~static_cast<uintptr_t>(3));
+        const uint32_t sh = static_cast<uint32_t>(a & 2u) * 8u;           // 0 or 16 bits
+        const uint32_t lo = __builtin_amdgcn_alignbit(r[1], r[0], sh);    // ({r1, r0} >> sh) & 0xffffffff
+        const uint32_t hi = __builtin_amdgcn_alignbit(r[2], r[1], sh);
+        return f32x4{bf16_to_f32(static_cast<uint16_t>(lo & 0xffffu)), bf16_to_f32(static_cast<uint16_t>(lo >> 16)),
+                     bf16_to_f32(static_cast<uint16_t>(hi & 0xffffu)), bf16_to_f32(static_cast<uint16_t>(hi >> 16))};
     }
     static __device__ __forceinline__ void st4(bf16* p, f32x4 v) {     // one 8-byte store
         uint2 r;

@@ -72,6 +72,62 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const T* __res
             xv[u] = (row < n_rows && col_ok) ? Elem<T>::ld4(x + row * ldx + 4 * l15) : zero4();
         }
     };
+    if constexpr (sizeof(T) == 2 && !WRITE_YS) {
+        // bfloat16 rows: the products of two bfloat16 numbers are exact in float32, so the record can come straight off the
+        // bf16 matrix core -- v_mfma_f32_16x16x32_bf16 contracts 32 ROWS per instruction (two 16-row tiles) where the float32
+        // path needs eight v_mfma_f32_16x16x4_f32, and no element is converted.  A lane's eight raw loads hold rows 4 u + lg
+        // (u = 0..7) of the 32, columns 4 l15 .. + 3; its operand for column offset t is the t-th element of each of them
+        // (k = 8 lg + u <-> row 4 u + lg: the same map on both sides of the product), packed by v_perm_b32.  The column sums
+        // are one more product, against ones.  Float32-converted rows made this pass issue-bound at every size
+        // (1,600,000 x 64: 131 us against 91 us for float32 rows, profiles/r05_experiments.md).
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        auto load32 = [&](uint2 (&raw)[8], int64_t tile) {        // tile: index of a 32-row block
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t row = tile * 32 + 4 * u + lg;
+                raw[u] = (row < n_rows && col_ok) ? *reinterpret_cast<const uint2*>(x + row * ldx + 4 * l15) : make_uint2(0u, 0u);
+            }
+        };
+        const int64_t n32 = (n_rows + 31) / 32;
+        const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+        f32x4 accs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accs[t] = zero4();
+        uint2 nraw[8];
+        if (first < n32) load32(nraw, first);
+        for (int64_t tile = first; tile < n32; tile += stride) {
+            uint2 raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw[u] = nraw[u];
+            if (tile + stride < n32) load32(nraw, tile + stride);
+            bf16x8_t op[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                u32x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a0 = (t < 2) ? raw[2 * j].x : raw[2 * j].y, a1 = (t < 2) ? raw[2 * j + 1].x : raw[2 * j + 1].y;
+                    // low halves (t even) or high halves (t odd) of the two dwords, row 2 j below row 2 j + 1
+                    w[j] = __builtin_amdgcn_perm(a1, a0, (t & 1) ? 0x07060302u : 0x05040100u);
+                }
+                op[t] = __builtin_bit_cast(bf16x8_t, w);
+            }
+            int a = 0;
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta) {
+                accs[ta] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[ta], ones, accs[ta], 0, 0, 0);
+#pragma unroll
+                for (int tb = ta; tb < 4; ++tb, ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op[ta], op[tb], acc[a], 0, 0, 0);
+            }
+        }
+        // accs[ta][reg] = column sum of column 4 (4 lg + reg) + ta, the same in every l15: the lanes with l15 == 0 file them
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (l15 == 0) sm_s[wave][4 * (4 * lg + reg) + ta] = accs[ta][reg];
+    } else {
     f32x4 nxt[4];
     if (first < n16) load16(nxt, first);
     for (int64_t tile = first; tile < n16; tile += stride) {
@@ -94,6 +150,7 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const T* __res
                     acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][ta], xv[u][tb], acc[a], 0, 0, 0);
         }
     }
+    }
     if (WRITE_YS) {          // rows n_rows .. npad-1 of the copy are read by the last tile of the sweep: zero them
         const int64_t pad = npad - n_rows;
         for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pad * 16;
@@ -102,12 +159,14 @@ __global__ __launch_bounds__(64 * kGramWaves, 2) void gram_kernel(const T* __res
             if (4 * sl < C) ys[sl * npad + r] = zero4();
         }
     }
+    if constexpr (!(sizeof(T) == 2 && !WRITE_YS)) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         float a = sx[t];
         a += __shfl_xor(a, 16, 64);
         a += __shfl_xor(a, 32, 64);
         if (lg == 0) sm_s[wave][4 * l15 + t] = a;
+    }
     }
     // fold the eight waves in registers, halving the live set three times through LDS (fixed order):
     // ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))

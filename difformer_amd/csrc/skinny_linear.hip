@@ -683,8 +683,11 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
     const int64_t n_tiles = (n_rows + 15) / 16;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
-    f32x4 xa[KQ], xn[KQ];
+    // bfloat16 rows: half the bytes per load instruction -> two tiles ahead (see gram_kernel)
+    constexpr bool kTwoAhead = sizeof(T) == 2;
+    f32x4 xa[KQ], xn[KQ], xn2[KQ];
     if (first < n_tiles) load_x(first, xa);
+    if (kTwoAhead && first + stride < n_tiles) load_x(first + stride, xn);
     // LayerNorm over 65..128 output features (the input layer at the scripts' hidden 128, run.sh:42-44): both 64-feature blocks
     // of a row tile are formed first, normalised together, then stored (the host guarantees one workgroup column: f0 == 0)
     const bool wide_ln = ln_w != nullptr && C_out > 64;
@@ -698,7 +701,9 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
     }
     for (int64_t tile = first; tile < n_tiles; tile += stride) {
         const int64_t r0 = tile * 16;
-        if (tile + stride < n_tiles) load_x(tile + stride, xn);               // in flight under this tile's work
+        if (kTwoAhead) {
+            if (tile + 2 * stride < n_tiles) load_x(tile + 2 * stride, xn2);
+        } else if (tile + stride < n_tiles) load_x(tile + stride, xn);        // in flight under this tile's work
         if (wide_ln) {
             f32x4 y2[2][4];
 #pragma unroll
@@ -760,7 +765,10 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
             finish_tile<T>(y, r0, fb, l15, lg, C_out, ln_w != nullptr, lw, lb, inv_c, eps, relu, out, ldo, n_rows, ovec);
         }
 #pragma unroll
-        for (int cq = 0; cq < KQ; ++cq) xa[cq] = xn[cq];
+        for (int cq = 0; cq < KQ; ++cq) {
+            xa[cq] = xn[cq];
+            if (kTwoAhead) xn[cq] = xn2[cq];
+        }
     }
 }
 
