@@ -772,6 +772,101 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const T* __restrict_
     }
 }
 
+// bfloat16 storage, C_in <= 128 -> C_out <= 64 (the input layer of a Pokec mini-batch in bf16: 100,000 x 65 -> 64, BASELINE
+// config C5): x and W are bfloat16, so their products are exact in float32 and the product can run on
+// v_mfma_f32_16x16x32_bf16 -- 32 input channels per instruction where the converted-to-float32 path above needs eight
+// v_mfma_f32_16x16x4_f32 and four conversions per load (that path is issue-bound at every size: 1.3 TB/s at 1.6 M rows
+// against 3.2 TB/s for float32 storage, profiles/r05_experiments.md).  A lane (row l15, k-group lg) reads the 16 contiguous
+// bytes of channels 32 kb + 8 lg .. + 7 of its row: rows of 65 elements start on odd 2-byte boundaries, so the load is five
+// ALIGNED dwords shifted into place (v_alignbit).  W sits in LDS as ready-made B fragments [kb][ft][lane] (feature
+// 4 l15 + ft: the epilogue's layout), zero beyond C_in.  The LAST 16-row tile reads element by element (no read past the
+// end of the tensor).
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+template <int KB>
+__global__ __launch_bounds__(256) void skinny_linear_bf16_kernel(const dif::bf16* __restrict__ x, int64_t ldx, int64_t n_rows, int C_in,
+                                                                 const dif::bf16* __restrict__ W, const dif::bf16* __restrict__ bias,
+                                                                 int C_out, const dif::bf16* __restrict__ ln_w,
+                                                                 const dif::bf16* __restrict__ ln_b, float eps, int relu,
+                                                                 dif::bf16* __restrict__ out, int64_t ldo, int ovec) {
+    using B = dif::bf16;
+    __shared__ __attribute__((aligned(16))) uint16_t sm_w[KB * 4 * 64 * 8];
+    __shared__ __attribute__((aligned(16))) float sm_b[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    for (int e = threadIdx.x; e < KB * 4 * 64 * 8; e += 256) {
+        const int s_ = e & 7, ln_ = (e >> 3) & 63, ft = (e >> 9) & 3, kb = e >> 11;
+        const int f = 4 * (ln_ & 15) + ft, c = 32 * kb + 8 * (ln_ >> 4) + s_;
+        sm_w[e] = (f < C_out && c < C_in) ? W[static_cast<int64_t>(f) * C_in + c].bits : uint16_t(0);
+    }
+    if (threadIdx.x < 64) sm_b[threadIdx.x] = threadIdx.x < C_out ? Elem<B>::ld(bias + threadIdx.x) : 0.f;
+    __syncthreads();
+    f32x4 lw = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};
+    if (ln_w) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f = 4 * l15 + ft;
+            if (f < C_out) { lw[ft] = Elem<B>::ld(ln_w + f); lb[ft] = Elem<B>::ld(ln_b + f); }
+        }
+    }
+    const float inv_c = 1.0f / static_cast<float>(C_out);
+    const int64_t n_tiles = (n_rows + 15) / 16;
+
+    auto load_x = [&](int64_t tile, u32x4v (&xa)[KB]) {
+        const int64_t r = tile * 16 + l15;
+        const bool careful = tile == n_tiles - 1;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            u32x4v z = {0u, 0u, 0u, 0u};
+            const int c = 32 * kb + 8 * lg;
+            if (r < n_rows && c < C_in) {
+                const B* p = x + r * ldx + c;
+                if (c + 7 < C_in && !careful) {
+                    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~static_cast<uintptr_t>(3));
+                    typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+                    const u32x4a lo = *reinterpret_cast<const u32x4a*>(q);
+                    const uint32_t hi = q[4];
+                    const uint32_t sh = static_cast<uint32_t>(a & 2u) * 8u;
+                    z[0] = __builtin_amdgcn_alignbit(lo[1], lo[0], sh);
+                    z[1] = __builtin_amdgcn_alignbit(lo[2], lo[1], sh);
+                    z[2] = __builtin_amdgcn_alignbit(lo[3], lo[2], sh);
+                    z[3] = __builtin_amdgcn_alignbit(hi, lo[3], sh);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (c + i < C_in) z[i >> 1] |= static_cast<uint32_t>(p[i].bits) << (16 * (i & 1));
+                }
+            }
+            xa[kb] = z;
+        }
+    };
+
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
+    u32x4v xa[KB], xn[KB];
+    if (first < n_tiles) load_x(first, xa);
+    const bf16x8v* wfrag = reinterpret_cast<const bf16x8v*>(sm_w);
+    for (int64_t tile = first; tile < n_tiles; tile += stride) {
+        if (tile + stride < n_tiles) load_x(tile + stride, xn);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sm_b + 4 * l15);
+        f32x4 y[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] = f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const bf16x8v av = __builtin_bit_cast(bf16x8v, xa[kb]);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+                y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wfrag[(kb * 4 + ft) * 64 + lane], y[ft], 0, 0, 0);
+        }
+        finish_tile<B>(y, tile * 16, 0, l15, lg, C_out, ln_w != nullptr, lw, lb, inv_c, eps, relu, out, ldo, n_rows, ovec);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) xa[kb] = xn[kb];
+    }
+}
+
 template <typename T>
 int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, const T* bias, int C_out,
                  const T* ln_weight, const T* ln_bias, float ln_eps, int relu, T* out, int64_t ldo, dif_stream_t stream) {
@@ -828,6 +923,27 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
                 "dif_linear: ln_weight and ln_bias must be given together");
     DIF_REQUIRE(!ln_weight || C_out <= 128, DIF_E_SHAPE, "dif_linear: fused LayerNorm needs C_out <= 128");
     DIF_REQUIRE(ldx >= C_in && ldo >= C_out, DIF_E_BADARG, "dif_linear: leading dimension smaller than a row");
+    if constexpr (std::is_same<T, dif::bf16>::value) {
+        if (C_out <= 64 && C_in <= 128 && !dif::exact_fp32()) {
+            const int64_t n_tiles = (n_rows + 15) / 16;
+            int64_t gx = (n_tiles + 15) / 16;
+            const int64_t one_each = (n_tiles + 3) / 4;
+            if (gx < dif::kCUs) gx = one_each < dif::kCUs ? one_each : dif::kCUs;
+            if (gx > 4 * dif::kCUs) gx = 4 * dif::kCUs;
+            const int ovec = (ldo % 4 == 0) && dif::aligned_v4<T>(out);
+            const int kb = (C_in + 31) / 32;
+            hipStream_t st = static_cast<hipStream_t>(stream);
+#define DIF_LINB(KB) \
+            hipLaunchKernelGGL((skinny_linear_bf16_kernel<KB>), dim3(static_cast<unsigned>(gx)), dim3(256), 0, st, x, ldx, n_rows, C_in, W, \
+                               bias, C_out, ln_weight, ln_bias, ln_eps, relu, out, ldo, ovec)
+            if (kb == 1) DIF_LINB(1);
+            else if (kb == 2) DIF_LINB(2);
+            else if (kb == 3) DIF_LINB(3);
+            else DIF_LINB(4);
+#undef DIF_LINB
+            return dif::launch_status("skinny_linear_bf16_kernel");
+        }
+    }
     const int kq = (C_in + 15) / 16;
     const int kLinMaxBlocks = lin_max_blocks(kq), kLinStride = lin_stride(kq);
     const int gy = (C_out + 64 * kLinMaxBlocks - 1) / (64 * kLinMaxBlocks);
