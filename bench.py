@@ -286,12 +286,12 @@ def main():
                 shard.product = prod
             sec, step = timed_region()
             by_product[prod] = max_over_ranks(sec, dev)
-        best = min(by_product, key=by_product.get)
-        if best is not products[-1]:           # leave the model in the faster configuration for the passes below
-            shard.product = best
+        best_product = min(by_product, key=by_product.get)
+        if best_product is not products[-1]:   # leave the model in the faster configuration for the passes below
+            shard.product = best_product
             for _ in range(2):
                 model(x, edge_index)
-        elapsed = by_product[best]
+        elapsed = by_product[best_product]
         # Separate short pass right after the timed region (nothing but the K steps sits inside it): per-forward HIP
         # events on the launching stream -> median / spread, and per-entry-point events -> the dominant kernel's mean
         # launch duration for the roofline.
@@ -499,7 +499,7 @@ def main():
             "scaling": plan["scaling"], "vs_baseline": None, "dtype": "bf16" if store == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "nodes": n, "csr_entries": nnz, "in_channels": f_in,
                        "hidden": hidden, "heads": 1, "layers": layers, "kernel": kernel, "use_graph": use_graph,
-                       "parallelism": plan["parallelism"] + (f", closed-form aggregation split by {'feature slices (two all-to-alls per layer)' if best == 'slice' else 'destination rows (one all-gather per layer)'}" if best is not None else ""),
+                       "parallelism": plan["parallelism"] + (f", closed-form aggregation split by {'feature slices (two all-to-alls per layer)' if best_product == 'slice' else 'destination rows (one all-gather per layer)'}" if best_product is not None else ""),
                        "exact_fp32": bool(ops.EXACT_FP32),
                        "csr": "warm (cached); cold build reported in cold_csr_build_ms",
                        "launch": launch_mode},

@@ -223,19 +223,29 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     const int li = lane % G;
     const int col = blockIdx.y * (G * W) + li * W;
     const bool active = col < F;
-    const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const int64_t gw = static_cast<int64_t>(blockIdx.x) * 4 + wave;
     const int64_t nw = static_cast<int64_t>(gridDim.x) * 4;
     const E* xcol = x + col;
+    // HUB ROWS.  A wave walks its row 64 entries per index load, 8 gathers in flight: ~1 us per 32 entries, so the 14,854-entry
+    // hub of the real Pokec graph would hold one wave for ~0.5 ms of a 1.3-ms launch and a 120,000-entry row for 4 ms
+    // (scripts/exp_regional_order.py, round 5).  Rows beyond kWaveLong entries are left out of the walk and noted in LDS; when the
+    // block has finished its ordinary rows its four waves take a noted row together, a quarter of the entries each (cut at
+    // multiples of 64), and wave 0 adds the four partial rows in wave order (deterministic) and finishes the row.
+    constexpr int kWaveLong = 1024, kNoted = 16;
+    __shared__ int64_t s_row[kNoted];
+    __shared__ int s_count;
+    __shared__ V s_part[3][64];
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
 
-    for (int64_t row = gw; row < n_rows; row += nw) {
-        const int64_t r = row_begin + row;
-        const int32_t e0 = rowptr[r], e1 = rowptr[r + 1];
+    auto walk = [&](int32_t a0, int32_t a1) {
         V acc = vzero<W>();
-        for (int32_t base = e0; base < e1; base += 64) {
+        for (int32_t base = a0; base < a1; base += 64) {
             const int32_t idx = base + lane;
-            const int32_t my_src = (idx < e1) ? src[idx] : 0;
-            const float my_val = (idx < e1) ? val[idx] : 0.f;
-            const int cnt = (e1 - base < 64) ? (e1 - base) : 64;
+            const int32_t my_src = (idx < a1) ? src[idx] : 0;
+            const float my_val = (idx < a1) ? val[idx] : 0.f;
+            const int cnt = (a1 - base < 64) ? (a1 - base) : 64;
             const int steps = (cnt + EPW - 1) / EPW;
             for (int j0 = 0; j0 < steps; j0 += kGatherUnroll) {
                 V xv[kGatherUnroll];
@@ -254,11 +264,48 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
         // fold the EPW partial rows (fixed tree)
 #pragma unroll
         for (int m = G; m < 64; m <<= 1) acc += vshfl_xor<W>(acc, m);
+        return acc;
+    };
+    auto finish = [&](V acc, int64_t row) {
         const bool ok = (sub == 0 && active);
         V o = gcn_scale * acc;
         if (ok && attn) o += attn_scale * gload<W, E>(attn + row * lda + col);
         if (tail.enabled) o = apply_tail<G, W, E>(o, tail, row, col, ok, F);
         if (ok) gstore<W, E>(out + row * ldo + col, o);
+    };
+
+    for (int64_t row = gw; row < n_rows; row += nw) {
+        const int64_t r = row_begin + row;
+        const int32_t e0 = rowptr[r], e1 = rowptr[r + 1];
+        if (e1 - e0 > kWaveLong) {                       // wave-uniform
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(&s_count, 1);
+            slot = __shfl(slot, 0, 64);
+            if (slot < kNoted) {
+                if (lane == 0) s_row[slot] = row;
+                continue;
+            }
+        }
+        finish(walk(e0, e1), row);
+    }
+    __syncthreads();
+    const int noted = s_count < kNoted ? s_count : kNoted;
+    for (int k = 0; k < noted; ++k) {
+        const int64_t row = s_row[k];
+        const int64_t r = row_begin + row;
+        const int32_t e0 = rowptr[r], e1 = rowptr[r + 1];
+        const int32_t chunk = (((e1 - e0 + 3) / 4) + 63) & ~63;
+        const int32_t a0 = e0 + wave * chunk < e1 ? e0 + wave * chunk : e1;
+        const int32_t a1 = a0 + chunk < e1 ? a0 + chunk : e1;
+        V acc = walk(a0, a1);
+        if (wave > 0) s_part[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w2 = 0; w2 < 3; ++w2) acc += s_part[w2][lane];
+            finish(acc, row);
+        }
+        __syncthreads();
     }
 }
 

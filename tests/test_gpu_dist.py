@@ -149,7 +149,8 @@ def test_two_ranks_on_one_gpu_slice_sharded_product(n, deg):
         assert sliced and 32 in widths, (rank, widths)
 
 
-@pytest.mark.parametrize("workload,product", [("ogbn-proteins-s", "row"), ("pokec-batch-s-bf16", "row"), ("ogbn-proteins-s", "slice")])
+@pytest.mark.parametrize("workload,product", [("ogbn-proteins-s", "row"), ("pokec-batch-s-bf16", "row"), ("ogbn-proteins-s", "slice"),
+                                              ("ogbn-proteins-s", "auto")])
 def test_bench_with_two_ranks_runs_end_to_end(workload, product):
     """The command the driver launches for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), with both ranks
     on this box's one GPU and the collectives over gloo: the row-sharded headline workload (closed-form layers, the
@@ -167,7 +168,13 @@ def test_bench_with_two_ranks_runs_end_to_end(workload, product):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["unit"] == "nodes/s"
     if workload == "ogbn-proteins-s":
-        assert d["scaling"] == "strong" and d["config"]["parallelism"] == "row-shard x2"
+        assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("row-shard x2, closed-form aggregation split by ")
+        by = d["ms_per_step_by_shard_product"]
+        assert set(by) == ({"slice", "row"} if product == "auto" else {product}) and all(v > 0 for v in by.values())
+        chosen = "feature slices" if min(by, key=by.get) == "slice" else "destination rows"
+        assert chosen in d["config"]["parallelism"] and abs(d["ms_per_step"] - min(by.values())) < 1e-9
+        assert d["ms_per_step_exact_fp32"] > 0 and d["config"]["exact_fp32"] is False and d["roofline"]["bound"] == "hbm"
+        assert 0 < d["roofline"]["frac"] < 1 and "lds_frac" in d["roofline"] and not any(isinstance(v, dict) for v in d["roofline"].values())
         assert d["roofline"]["kernel"].startswith("sliced_spmm_kernel") and d["roofline"]["avg_launch_ms"] > 0
         # per-rank diagnostics of a sharded run: exposed collective waits beside the kernel groups (round 4)
         phases = d["per_rank_phases"]

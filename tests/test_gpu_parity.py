@@ -1748,3 +1748,27 @@ def test_narrow_linear_with_layernorm_over_up_to_128_features(n, ci, co, dev):
         if relu:
             ref = np.maximum(ref, 0)
         assert rel_err(out.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("n,deg,hubs,F", [(120000, 20, (15000, 1025, 1024), 64), (90000, 24, (130000, 3000), 64), (70000, 18, (5000,) * 20, 32)])
+def test_gcn_conv_hub_rows_of_a_mid_degree_graph(n, deg, hubs, F, dev):
+    """spmm_wave_row_kernel (graphs of ~20 entries per row: the full Pokec graph, eval.py:40-43) gives a row to ONE wave; a social
+    graph's hubs (Pokec: 14,854 entries) are noted and taken by the block's four waves together at the end (round 5; before: a
+    120,000-entry row held one wave for 4 ms of a 1.3-ms launch).  Rows just below / above the threshold, more hubs than a block
+    can note, one giant row: against the float64 oracle, bitwise equal from call to call."""
+    from difformer_amd import gcn_conv
+    g = torch.Generator().manual_seed(n + deg)
+    ei = torch.randint(0, n, (2, n * deg), generator=g)
+    at = 0
+    for k, h in enumerate(hubs):                       # hub k: the first entries of the list point at node 7 k + 3
+        ei[1, at: at + h] = 7 * k + 3
+        at += h
+    x = torch.randn(n, 1, F, generator=g)
+    ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), None)
+    eid, xd = ei.to(dev), x.to(dev)
+    out = gcn_conv(xd, eid, None)
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5
+    assert torch.equal(gcn_conv(xd, eid, None), out)
+    w = torch.rand(ei.shape[1], generator=g) + 0.1
+    refw = orc.gcn_conv(x.double().numpy(), ei.numpy(), w.double().numpy())
+    assert rel_err(gcn_conv(xd, eid, w.to(dev)).cpu().numpy(), refw) < 1e-5

@@ -233,7 +233,7 @@ def test_constant_weights_take_the_unweighted_product(const, dev):
     eid, wd = ei.to(dev), w.to(dev)
     csr = ops.csr_cache.get(eid, wd, n, 256)
     assert not csr.weighted and csr.sliced(0, n, 64) is not None
-    assert csr.weight_scale == (const if np.isfinite(const) else 0.0)
+    assert csr.weight_scale == (float(np.float32(const)) if np.isfinite(const) else 0.0)
     ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), w.double().numpy())
     xd = x.to(dev).requires_grad_(True)
     out = gcn_conv(xd, eid, wd)
