@@ -823,16 +823,45 @@ __device__ __forceinline__ void project_t(f32x4 (&y)[4], const f32x4 (&xa)[4], c
     }
 }
 
+// Split-bfloat16 form of project_t for the 64 x 64 float32 layers (round 5): x = xh + xl, W = wh + wl, three terms
+// xl.wh + xh.wl + xh.wh on v_mfma_f32_16x16x32_bf16 -- 24 instructions of 16 cycles per product where project_t issues 64 of 32
+// (the 128 fp32 MFMAs per tile were 9 of the kernel's 34 us at the ogbn-proteins size, profiles/r04_experiments.md section 7);
+// the dropped xl.wl term is 2^-16 of the product (~4e-6 on the layer's rows, as the output Linear and the hidden-128 kernel).
+// W fragments [hi | lo][ft * 2 + kb][lane] in LDS: lane (lg, l15) holds feature 16 ft + l15, columns 16 (2 kb) + 4 lg .. + 3 and
+// 16 (2 kb + 1) + 4 lg .. + 3 -- the k order of a row piece.  DIFFORMER_EXACT_FP32=1 keeps project_t.
+__device__ __forceinline__ void project_split(f32x4 (&y)[4], const f32x4 (&xa)[4], const bf16x8* __restrict__ wh,
+                                              const bf16x8* __restrict__ wl, int lane) {
+    bf16x8 xh[2], xl[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        bf16x4 h0, l0, h1, l1;
+        split_bf16(xa[2 * kb], h0, l0);
+        split_bf16(xa[2 * kb + 1], h1, l1);
+        xh[kb] = cat8(h0, h1);
+        xl[kb] = cat8(l0, l1);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const bf16x8 ah = wh[(ft * 2 + kb) * 64 + lane], al = wl[(ft * 2 + kb) * 64 + lane];
+            y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[kb], y[ft], 0, 0, 0);      // small terms first
+            y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[kb], y[ft], 0, 0, 0);
+            y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[kb], y[ft], 0, 0, 0);
+        }
+}
+
 #ifndef DIF_LAYER_PROBE
 #define DIF_LAYER_PROBE 0         // measurement builds (scripts/exp_layer_probes.py): 1 no products, 2 no weight staging,
 #endif                            // 3 no slice-major copy, 4 no row-major store, 5 the graph rows are not read
 #ifndef DIF_GATHER_WG
 #define DIF_GATHER_WG 4           // measurement builds: workgroups per CU the GATHER variants are compiled for
 #endif
-template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float, bool HEAD = false, bool GATHER = false>
+template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float, bool HEAD = false, bool GATHER = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * (HEAD ? kHeadWaves : kWaves),
                              HEAD ? (2 * kHeadWaves + 3) / 4 : (NEXT ? 2 : (GATHER ? DIF_GATHER_WG : 4)))
 void simple_layer_kernel(LayerArgsT<T> a) {
+    static_assert(!SPLIT || (EXACT && !NEXT), "split-bf16 products: the dense 64 x 64 float32 layers");
     constexpr int NW = HEAD ? kHeadWaves : kWaves;          // waves per workgroup
     __shared__ __attribute__((aligned(16))) float sm_w[2][kWBlock];   // MnT, Wv (zero padded; widx layout)
     // HEAD: up to 128 output classes as split-bf16 A fragments, [hi | lo][(blk * 4 + ft) * 2 + kb][lane]: lane (lg, l15) holds
@@ -869,8 +898,23 @@ void simple_layer_kernel(LayerArgsT<T> a) {
         for (int i = 0; i < NL; ++i) {
             const int idx = wave + NW * i;
             const int f = 8 * (idx & 7) + (lane & 7), c = 32 * (idx >> 3) + 4 * (lane >> 3);
-            *reinterpret_cast<f32x4*>(&sm_w[0][widx(f, c)]) = wreg[0][i];
-            if (GRAPH_W) *reinterpret_cast<f32x4*>(&sm_w[1][widx(f, c)]) = wreg[1][i];
+            if constexpr (SPLIT) {
+                // the same 16-byte pieces, split into hi | lo halves of the MFMA fragment they belong to: piece (f, c) is half
+                // (c / 16) % 2 of fragment (f / 16) * 2 + c / 32, lane 16 ((c / 4) % 4) + f % 16; the 64 lanes of a store
+                // instruction fill 512 contiguous bytes (no bank conflicts)
+                bf16x4* frag = reinterpret_cast<bf16x4*>(&sm_w[0][0]);      // [matrix][hi | lo][fragment][lane][half] x 8 bytes
+                const int slot = ((((f >> 4) * 2 + (c >> 5)) * 64 + 16 * ((c >> 2) & 3) + (f & 15)) << 1) + ((c >> 4) & 1);
+#pragma unroll
+                for (int m = 0; m < (GRAPH_W ? 2 : 1); ++m) {
+                    bf16x4 h, l;
+                    split_bf16(wreg[m][i], h, l);
+                    frag[(m * 2 + 0) * 1024 + slot] = h;
+                    frag[(m * 2 + 1) * 1024 + slot] = l;
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(&sm_w[0][widx(f, c)]) = wreg[0][i];
+                if (GRAPH_W) *reinterpret_cast<f32x4*>(&sm_w[1][widx(f, c)]) = wreg[1][i];
+            }
         }
     } else {
         for (int e = threadIdx.x; e < 64 * 64; e += 64 * NW) {         // e = LDS dword: [ft][cq][lg][l15][t]
@@ -944,7 +988,8 @@ void simple_layer_kernel(LayerArgsT<T> a) {
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) y[ft] += xa[ft];
 #else
-        project_t(y, xa, sm_w[0], l15, lg);
+        if constexpr (SPLIT) project_split(y, xa, reinterpret_cast<const bf16x8*>(&sm_w[0][0]), reinterpret_cast<const bf16x8*>(&sm_w[0][0]) + 512, lane);
+        else project_t(y, xa, sm_w[0], l15, lg);
 #endif
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) y[ft] *= rden;
@@ -971,7 +1016,8 @@ void simple_layer_kernel(LayerArgsT<T> a) {
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft) y[ft] += ga[ft];
 #else
-                project_t(y, ga, sm_w[1], l15, lg);
+                if constexpr (SPLIT) project_split(y, ga, reinterpret_cast<const bf16x8*>(&sm_w[0][0]) + 1024, reinterpret_cast<const bf16x8*>(&sm_w[0][0]) + 1536, lane);
+                else project_t(y, ga, sm_w[1], l15, lg);
 #endif
             } else {          // use_weight = False: the aggregated rows are the graph term (C == D), same layout
 #pragma unroll
@@ -1570,6 +1616,21 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
     const bool gw = (ax != nullptr || gather) && Wv != nullptr;
+    // dense 64 x 64 float32 layers (the headline shape): both products on split-bfloat16 operands unless DIFFORMER_EXACT_FP32=1
+    const bool split = exact && f32 && !next && !gather && !dif::exact_fp32() && DIF_LAYER_PROBE == 0 &&
+                       (reinterpret_cast<uintptr_t>(coef) & 15u) == 0 && (!gw || (reinterpret_cast<uintptr_t>(Wv) & 15u) == 0);
+    if (split) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (head) {
+                if (gw) hipLaunchKernelGGL((simple_layer_kernel<true, true, false, T, true, false, true>), dim3(P), dim3(64 * kHeadWaves), 0, st, a);
+                else hipLaunchKernelGGL((simple_layer_kernel<true, false, false, T, true, false, true>), dim3(P), dim3(64 * kHeadWaves), 0, st, a);
+            } else {
+                if (gw) hipLaunchKernelGGL((simple_layer_kernel<true, true, false, T, false, false, true>), dim3(P), dim3(64 * kWaves), 0, st, a);
+                else hipLaunchKernelGGL((simple_layer_kernel<true, false, false, T, false, false, true>), dim3(P), dim3(64 * kWaves), 0, st, a);
+            }
+            return dif::launch_status("simple_layer_kernel");
+        }
+    }
 #define DIF_LAYER(E, G, N) hipLaunchKernelGGL((simple_layer_kernel<E, G, N, T>), dim3(P), dim3(64 * kWaves), 0, st, a)
 #define DIF_LAYER_HEAD(E, G) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, true>), dim3(P), dim3(64 * kHeadWaves), 0, st, a)
 #define DIF_LAYER_GATHER(E, G, H) hipLaunchKernelGGL((simple_layer_kernel<E, G, false, T, H, true>), dim3(P), dim3(64 * (H ? kHeadWaves : kWaves)), 0, st, a)

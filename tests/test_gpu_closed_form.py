@@ -225,9 +225,16 @@ def test_layer_kernel_leaves_the_next_layers_products(n, deg, c, dev):
     out2 = ops.simple_layer_closed_form(x, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
                                         lw, lb, 1e-5, carry=carry2)
     # (sparse graphs without the record: the layer kernel aggregates itself -- another summation order than the SpMM kernel's)
-    assert torch.equal(out2, out) if (sl is not None or csr is None) else rel_err(out2.cpu().numpy(), out.cpu().numpy()) < 1e-5
+    # (dense 64-column layers: the default kernel multiplies on split-bfloat16 operands, ~4e-6, the record-writing variant on the
+    # fp32 matrix core -- bit-equal only where both take the same products)
+    same_products = ops.EXACT_FP32 or c != 64
+    assert torch.equal(out2, out) if ((sl is not None or csr is None) and same_products) else rel_err(out2.cpu().numpy(), out.cpu().numpy()) < 2e-5
     if sl is not None:
-        assert carry2["products"]["record"] is None and torch.equal(carry2["products"]["ys"], ys)
+        assert carry2["products"]["record"] is None
+        if same_products:
+            assert torch.equal(carry2["products"]["ys"], ys)
+        else:       # the copy of THIS pass's rows: bit for bit the slice-major copy dif_gram_f32 makes of out2
+            assert torch.equal(carry2["products"]["ys"], be.gram(out2, csr.rowptr, sl.plan)[1])
     else:
         assert carry2["products"] is None
     # and the next layer uses them: same result as a fresh call without the carry
@@ -235,7 +242,7 @@ def test_layer_kernel_leaves_the_next_layers_products(n, deg, c, dev):
                                      lw, lb, 1e-5, carry=carry)
     b = ops.simple_layer_closed_form(out, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], csr, 1.0, 1.0, None, True, 0.5,
                                      lw, lb, 1e-5)
-    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < (1e-5 if same_products else 2e-5)
 
 
 class _EmulatedShard:
