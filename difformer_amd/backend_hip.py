@@ -1187,7 +1187,7 @@ class HipBackend:
                 rc = self.lib.dif_gram128_f32(_ptr(x), ldx, n, C, _ptr(rec), _ptr(ws), ws_bytes, _stream(dev))
             _lib.check(rc, "dif_gram128_f32")
             return rec
-        ws_bytes = self.lib.dif_simple_workspace_bytes(n, 1, C, C)
+        ws_bytes = self.lib.dif_gram_sym_workspace_bytes(n, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _timed(self, "dif_gram_sym_f32", dev):
             rc = self.lib.dif_gram_sym_f32(_ptr(x), ldx, n, C, _ptr(rec), _ptr(ws), ws_bytes, _stream(dev))
