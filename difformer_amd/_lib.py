@@ -161,6 +161,7 @@ class TinyCfg(ctypes.Structure):
                [(k, ctypes.c_float) for k in ("alpha", "attn_scale", "gcn_scale", "dropout", "eps")] + [("nnz", ctypes.c_int64)]
 
 
+SIGNATURES["dif_wide_coeffs_f64"] = (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp])
 SIGNATURES["dif_gram_sym_workspace_bytes"] = (c_sz, [c_i64, c_int])
 SIGNATURES["dif_tiny_tape_floats"] = (c_sz, [c_int, c_int, c_int])
 SIGNATURES["dif_tiny_scratch_floats"] = (c_sz, [c_int, c_int])

@@ -1204,6 +1204,21 @@ class HipBackend:
         _lib.check(rc, "dif_wide_gram_f64")
         return Gt, partial
 
+    def wide_coeffs(self, rec, C, n_global, S, V, P):
+        """Record of gram_sym -> (B float32 [C, DV], bias float32 [DV]), the row GEMM's operands [Mn | u], [cn | cd]: both
+        float64 products and their bookkeeping in two launches (dif_wide_coeffs_f64; no library GEMM)."""
+        dev = _require_device(rec, S, V, P)
+        DV = V.shape[1]
+        T = torch.empty((C + 1, DV), dtype=torch.float64, device=dev)
+        partial = torch.empty(2 * ((C + 16) // 16), dtype=torch.float64, device=dev)
+        B = torch.empty((C, DV), dtype=torch.float32, device=dev)
+        bias = torch.empty(DV, dtype=torch.float32, device=dev)
+        with _timed(self, "dif_wide_coeffs_f64", dev):
+            rc = self.lib.dif_wide_coeffs_f64(_ptr(rec), C, int(n_global), _ptr(S), _ptr(V), _ptr(P), DV, _ptr(T), _ptr(partial),
+                                              _ptr(B), _ptr(bias), _stream(dev))
+        _lib.check(rc, "dif_wide_coeffs_f64")
+        return B, bias
+
     def wide_scale(self, R, T, partial, C):
         """R, T float64 [(C+1), DV] -> (B float32 [C, DV], bias float32 [DV]) = (s R[:C], s R[C] + T[C]) -- dif_wide_scale_f64."""
         dev = _require_device(R, T, partial)

@@ -64,7 +64,126 @@ __global__ __launch_bounds__(kWideThreads) void wide_scale_kernel(const double* 
     else bias[c] = static_cast<float>(s * R[idx] + T[idx]);
 }
 
+// ---- round 5: the two float64 products themselves, no library GEMM left in the forward ---------------------------------
+// T = G~ V~ and R = P~ T are (C + 1)-square times (C + 1) x (D + 4): 55 MFLOP at hidden 300 -- nothing for the chip, but as
+// two library GEMMs between two bookkeeping kernels they were four dependent launches of 5-10 us each (33 us per layer, 17 %
+// of the cifar50k-h300 forward).  Two launches do all of it:
+//   wide_gemm_kernel<0>   T = G~ V~ with G~ read straight from the Gram record (float32 -> float64, lower blocks mirrored,
+//                         sum x and N appended) and, in the workgroups of the first column of tiles, the partial sums of
+//                         <W~q^T W~q, G~> and <W~k^T W~k, G~> for their 32 rows
+//   wide_gemm_kernel<1>   R = P~ T, then the row GEMM's operands in float32: B = s R[0..C), bias = s R[C] + T[C], with
+//                         s = 1 / (|Q| |K|) from the partial sums (added in index order by every workgroup: deterministic)
+// The work is tiny and the chain is dependent, so the kernels are built for LATENCY: one 1,024-thread workgroup per 16 x 16
+// output tile, its 16 waves split K (a wave's <= 5 steps of v_mfma_f64_16x16x4_f64 need <= 10 loads, all issued before the
+// first product -- one memory round trip per kernel), the 16 partial tiles meet in LDS and are added in wave order.
+// (A first version that walked K in 32-wide LDS tiles paid one round trip per tile: 40 us per product.)
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kWT = 16;
+constexpr int kWWaves = 16;
+
+__device__ __forceinline__ double gt_entry(const float* __restrict__ rec, int C, double n_global, int i, int j) {
+    if (i < C && j < C) return ((i >> 6) <= (j >> 6)) ? rec[static_cast<int64_t>(i) * C + j] : rec[static_cast<int64_t>(j) * C + i];
+    if (i < C) return rec[static_cast<int64_t>(C) * C + i];
+    if (j < C) return rec[static_cast<int64_t>(C) * C + j];
+    return n_global;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kWWaves) void wide_gemm_kernel(const float* __restrict__ rec, int C, double n_global,
+                                                                 const double* __restrict__ S, const double* __restrict__ A,
+                                                                 const double* __restrict__ Bm, int DV, double* __restrict__ T,
+                                                                 double* __restrict__ partial, int n_partial,
+                                                                 float* __restrict__ Bout, float* __restrict__ bias) {
+    __shared__ double sRed[kWWaves][256];
+    __shared__ double smw[kWWaves], smb[kWWaves];
+    const int C1 = C + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int i0 = blockIdx.y * kWT, j0 = blockIdx.x * kWT;
+    const int steps = (C1 + 3) / 4;
+    constexpr int kMaxSteps = 8;                       // per wave: C + 1 <= 512 columns
+    const int64_t tot = static_cast<int64_t>(C1) * C1;
+    double av[kMaxSteps], bv[kMaxSteps];
+    double na = 0.0, nb = 0.0;
+#pragma unroll
+    for (int q = 0; q < kMaxSteps; ++q) {
+        const int st = wave + kWWaves * q;
+        const int k = 4 * st + kg, i = i0 + l15, j = j0 + l15;
+        av[q] = 0.0;
+        bv[q] = 0.0;
+        if (st < steps && k < C1) {
+            if (i < C1) {
+                if (MODE == 0) {
+                    av[q] = gt_entry(rec, C, n_global, i, k);
+                    if (blockIdx.x == 0) {
+                        na += S[static_cast<int64_t>(i) * C1 + k] * av[q];
+                        nb += S[tot + static_cast<int64_t>(i) * C1 + k] * av[q];
+                    }
+                } else {
+                    av[q] = A[static_cast<int64_t>(i) * C1 + k];
+                }
+            }
+            if (j < DV) bv[q] = Bm[static_cast<int64_t>(k) * DV + j];
+        }
+    }
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < kMaxSteps; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[wave][64 * r + lane] = acc[r];
+    double q2 = 0.0, k2 = 0.0;
+    if (MODE == 0 && blockIdx.x == 0) {                // norm partials of this row block: wave sums, then the waves in order
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { na += __shfl_xor(na, m, 64); nb += __shfl_xor(nb, m, 64); }
+        if (lane == 0) { smw[wave] = na; smb[wave] = nb; }
+    }
+    __syncthreads();
+    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        double sa = 0.0, sb = 0.0;
+        for (int w = 0; w < kWWaves; ++w) { sa += smw[w]; sb += smb[w]; }
+        partial[2 * blockIdx.y] = sa;
+        partial[2 * blockIdx.y + 1] = sb;
+    }
+    if (MODE == 1) {
+        for (int p = 0; p < n_partial; ++p) { q2 += partial[2 * p]; k2 += partial[2 * p + 1]; }      // same order in every thread
+    }
+    if (threadIdx.x < 256) {
+        const int e = threadIdx.x;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWWaves; ++w) v += sRed[w][e];
+        const int r = e >> 6, ln = e & 63;
+        const int i = i0 + 4 * r + (ln >> 4), j = j0 + (ln & 15);          // v_mfma_f64_16x16x4_f64: register r of lane l holds
+                                                                           // D[4 r + l / 16][l % 16] (NOT the float32 layout)
+        if (MODE == 0) {
+            if (i < C1 && j < DV) T[static_cast<int64_t>(i) * DV + j] = v;
+        } else {
+            const double s = 1.0 / (sqrt(q2) * sqrt(k2));
+            if (i < C && j < DV) Bout[static_cast<int64_t>(i) * DV + j] = static_cast<float>(s * v);
+            else if (i == C && j < DV) bias[j] = static_cast<float>(s * v + T[static_cast<int64_t>(C) * DV + j]);
+        }
+    }
+}
+
 }  // namespace
+
+// Gram record -> the row GEMM's operands in two launches (see above).  record: dif_gram_sym_f32's; S double [2][(C+1)^2],
+// V double [(C+1)][DV], P double [(C+1)][(C+1)]: the weight-only factors (ops.WideCoefficients); T double [(C+1)][DV] and
+// partial double [2 * ceil((C+1) / 16)]: scratch; B float [C][DV], bias float [DV]: out.
+extern "C" int dif_wide_coeffs_f64(const float* record, int C, int64_t n_global, const double* S, const double* V, const double* P,
+                                   int DV, double* T, double* partial, float* B, float* bias, dif_stream_t stream) {
+    DIF_REQUIRE(record && S && V && P && T && partial && B && bias && C > 0 && C <= 8192 && DV > 0 && n_global > 0, DIF_E_BADARG,
+                "dif_wide_coeffs: bad argument");
+    const int C1 = C + 1;
+    DIF_REQUIRE(C1 <= 512, DIF_E_SHAPE, "dif_wide_coeffs: C + 1 <= 512");
+    const int gy = (C1 + kWT - 1) / kWT, gx = (DV + kWT - 1) / kWT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(wide_gemm_kernel<0>, dim3(gx, gy), dim3(64 * kWWaves), 0, st, record, C, static_cast<double>(n_global), S, nullptr, V, DV, T,
+                       partial, gy, nullptr, nullptr);
+    if (int rc = dif::launch_status("wide_gemm_kernel<0>")) return rc;
+    hipLaunchKernelGGL(wide_gemm_kernel<1>, dim3(gx, gy), dim3(64 * kWWaves), 0, st, nullptr, C, 0.0, nullptr, P, T, DV, T, partial, gy, B, bias);
+    return dif::launch_status("wide_gemm_kernel<1>");
+}
 
 extern "C" int64_t dif_wide_partials(int C) {
     const int64_t total = static_cast<int64_t>(C + 1) * (C + 1);

@@ -1001,6 +1001,9 @@ class WideCoefficients:
         self.V = V
 
 
+WIDE_COEFFS_OWN = os.environ.get("DIFFORMER_WIDE_COEFFS_LIBRARY", "0") != "1"      # 1: the two float64 library GEMMs of round 4
+
+
 def simple_layer_closed_form_wide(x, coeffs: WideCoefficients, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha,
                                   ln_weight, ln_bias, eps):
     """The closed form of simple_layer_closed_form at the widths the reference's scripts train with (hidden 128 / 300 /
@@ -1017,10 +1020,13 @@ def simple_layer_closed_form_wide(x, coeffs: WideCoefficients, Wv, bv, csr, attn
     D = coeffs.D
     x3 = x.reshape(n, 1, C)
     rec = be.gram_sym(x)                                                # [X^T X (upper blocks) | sum x | ...]
-    Gt, partial = be.wide_gram(rec, C, n, coeffs.S)                     # G~ (float64) and the partial sums of |Q|^2, |K|^2
-    T = Gt @ coeffs.V                                                   # [(C+1), D+4]
-    R = coeffs.P @ T
-    B, bias = be.wide_scale(R, T, partial, C)                           # [Mn | u | 0 0 0], [cn | cd | 0 0 0] (float32)
+    if hasattr(be, "wide_coeffs") and WIDE_COEFFS_OWN:
+        B, bias = be.wide_coeffs(rec, C, n, coeffs.S, coeffs.V, coeffs.P)   # both float64 products + bookkeeping: two launches
+    else:
+        Gt, partial = be.wide_gram(rec, C, n, coeffs.S)                 # G~ (float64) and the partial sums of |Q|^2, |K|^2
+        T = Gt @ coeffs.V                                               # [(C+1), D+4]
+        R = coeffs.P @ T
+        B, bias = be.wide_scale(R, T, partial, C)                       # [Mn | u | 0 0 0], [cn | cd | 0 0 0] (float32)
     if max(C, D) <= 128 and not EXACT_FP32 and hasattr(be, "simple_layer_wide"):
         # hidden 128 (node classification/run.sh:42-44): both row products, the division, the combine, the residual and the
         # LayerNorm in ONE pass over the rows (csrc/simple_layer_wide.hip) -- no library GEMM, no [n, D + 4] intermediate

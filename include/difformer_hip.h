@@ -465,6 +465,13 @@ int dif_wide_gram_f64(const float* record, int C, int64_t n_global, const double
                       dif_stream_t stream);
 int dif_wide_scale_f64(const double* R, const double* T, const double* partial, int C, int DV, float* B, float* bias,
                        dif_stream_t stream);
+/* Round 5: the same coefficients WITHOUT the two library GEMMs -- record (dif_gram_sym_f32 / dif_gram128_f32) -> B float [C][DV] =
+   s R[0..C) and bias float [DV] = s R[C] + T[C] in two launches (T = G~ V~ straight from the record with the partial norm
+   products; R = P~ T with the scaling).  S double [2][(C+1)^2], V double [(C+1)][DV], P double [(C+1)][(C+1)]: weight-only factors;
+   T double [(C+1)][DV], partial double [2 * ceil((C+1) / 16)]: scratch; C + 1 <= 512.  Replaces ops.simple_layer_closed_form_wide's
+   dif_wide_gram_f64 -> GEMM -> GEMM -> dif_wide_scale_f64 chain (difformer.py:20-38 in closed form). */
+int dif_wide_coeffs_f64(const float* record, int C, int64_t n_global, const double* S, const double* V, const double* P, int DV,
+                        double* T, double* partial, float* B, float* bias, dif_stream_t stream);
 /* Closed-form `simple` layer at hidden 129..416 (image and text/run.sh:27 trains at 300, two lines at 400) in ONE pass over the
  * rows (csrc/simple_layer_xwide.hip): same result as dif_simple_layer_wide_f32, with the rows kept in registers as split-bf16
  * fragments and the weights streamed through LDS in chunks of 64 output features.  The weights come PACKED:

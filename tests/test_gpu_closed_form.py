@@ -701,3 +701,34 @@ def test_gram_record_at_hidden_65_to_128(n, c, dev):
     assert rel_err(got, x64.T @ x64) < 1e-5 and rel_err(rec[c * c: c * c + c].cpu().numpy(), x64.sum(0)) < 1e-5
     assert np.array_equal(got, got.T)                                # mirrored exactly
     assert torch.equal(rec[: c * c + c], be.gram_sym(x)[: c * c + c])           # deterministic
+
+
+@pytest.mark.parametrize("C,D,n", [(300, 300, 5000), (68, 68, 3000), (128, 128, 4000), (400, 400, 6000), (132, 96, 5000)])
+def test_wide_coefficients_kernels_vs_float64_definition(C, D, n, dev):
+    """dif_wide_coeffs_f64 (round 5: both float64 products of the wide closed form on own kernels) against the same algebra
+    in float64 tensor ops, entry by entry -- the model-level parity metric barely sees [Mn | u] (the attention of the `simple`
+    kernel is mean(V) + O(1 / N)), so the operands themselves are held to 1e-6 here."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(C + n)
+    x = torch.randn(n, C, generator=g).to(dev)
+    Wq, Wk = (torch.randn(D, C, generator=g) / C ** 0.5).to(dev), (torch.randn(D, C, generator=g) / C ** 0.5).to(dev)
+    Wv = (torch.randn(D, C, generator=g) / C ** 0.5).to(dev)
+    bq, bk, bv = (torch.randn(D, generator=g) * 0.1).to(dev), (torch.randn(D, generator=g) * 0.1).to(dev), (torch.randn(D, generator=g) * 0.1).to(dev)
+    co = ops.WideCoefficients(Wq, bq, Wk, bk, Wv, bv)
+    rec = be.gram_sym(x)
+    B, bias = be.wide_coeffs(rec, C, n, co.S, co.V, co.P)
+    Gt, partial = be.wide_gram(rec, C, n, co.S)
+    T = Gt @ co.V
+    R = co.P @ T
+    B0, bias0 = be.wide_scale(R, T, partial, C)
+    assert rel_err(B.cpu().numpy(), B0.cpu().numpy()) < 1e-6 and rel_err(bias.cpu().numpy(), bias0.cpu().numpy()) < 1e-6
+    # and against the definition from x itself, in float64
+    X = torch.cat([x.double(), torch.ones(n, 1, dtype=torch.float64, device=dev)], dim=1)
+    Gd = X.t() @ X
+    q2, k2 = (co.S[0].view(C + 1, C + 1) * Gd).sum(), (co.S[1].view(C + 1, C + 1) * Gd).sum()
+    s = 1.0 / (q2.sqrt() * k2.sqrt())
+    Td = Gd @ co.V
+    Rd = co.P @ Td
+    assert rel_err(B.cpu().numpy(), (s * Rd[:C]).cpu().numpy()) < 2e-5          # (the Gram record itself is float32 / split-bf16)
+    assert rel_err(bias.cpu().numpy(), (s * Rd[C] + Td[C]).cpu().numpy()) < 2e-5
