@@ -1179,7 +1179,8 @@ class HipBackend:
         n, C = x.shape
         x, ldx = _row_major(x, C)
         rec = torch.empty(self.lib.dif_simple_reduced_len(1, C, C), dtype=torch.float32, device=dev)
-        if 64 < C <= 128 and C % 4 == 0 and ldx % 4 == 0 and x.data_ptr() % 16 == 0:
+        from . import ops
+        if 64 < C <= 128 and C % 4 == 0 and ldx % 4 == 0 and x.data_ptr() % 16 == 0 and (ops.EXACT_FP32 or n < 4096):
             # hidden 128: one pass over x with the whole upper half of X^T X in a wave's registers (csrc/simple_layer_wide.hip)
             ws_bytes = self.lib.dif_gram128_workspace_bytes(n, C)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -719,9 +719,13 @@ __global__ __launch_bounds__(512) void gram_slab_kernel(const float* __restrict_
 }
 }  // namespace
 
-static int gram_slab_chunks(int64_t n_rows) {
+static int gram_slab_chunks(int64_t n_rows, int C) {
+    // partial records of C^2 floats each: ~35 MB in all (96 at C = 300; 256 -- every CU -- from C = 185 down)
     const int64_t slabs = (n_rows + kSlabRows - 1) / kSlabRows;
-    return static_cast<int>(slabs < 96 ? slabs : 96);       // 96 partial records of C^2 floats: 35 MB at C = 300
+    int64_t p = (int64_t(35) << 20) / (static_cast<int64_t>(C) * C * 4);
+    if (p < 64) p = 64;
+    if (p > 256) p = 256;
+    return static_cast<int>(slabs < p ? slabs : p);
 }
 
 // Gram record of the closed form at the scripts' widths: record = [X^T X (C x C) | sum x (C) | unused (C) | 2 unused];
@@ -741,9 +745,9 @@ extern "C" int dif_gram_sym_f32(const float* x, int64_t ldx, int64_t n_rows, int
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && dif::aligned16(x);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* ws = static_cast<float*>(workspace);
-    // 129..320 columns, enough rows to fill the chip, a workspace sized by dif_gram_sym_workspace_bytes: the one-read slab kernel
-    const int Ps = gram_slab_chunks(n_rows);
-    if (vec && C > 128 && sh.MT <= kSlabMaxMT && n_rows >= 4096 && !dif::exact_fp32() &&
+    // 65..320 columns, enough rows to fill the chip, a workspace sized by dif_gram_sym_workspace_bytes: the one-read slab kernel
+    const int Ps = gram_slab_chunks(n_rows, C);
+    if (vec && C > 64 && sh.MT <= kSlabMaxMT && n_rows >= 4096 && !dif::exact_fp32() &&
         workspace_bytes >= static_cast<size_t>(rec) * sizeof(float) * static_cast<size_t>(Ps)) {
         hipLaunchKernelGGL(gram_slab_kernel, dim3(Ps, (tiles_sym + 7) / 8), dim3(512), 0, st, x, ldx, n_rows, C, sh.MT, ws, rec);
         if (int rc = dif::launch_status("gram_slab_kernel")) return rc;
@@ -761,7 +765,7 @@ extern "C" size_t dif_gram_sym_workspace_bytes(int64_t n_rows, int C) {
     const Shape sh = make_shape(1, C, C);
     const size_t rec = (static_cast<size_t>(sh.t_main) + 2 * static_cast<size_t>(sh.tiles) + 3) & ~size_t(3);
     const size_t a = rec * sizeof(float) * static_cast<size_t>(reduce_chunks(n_rows, sh.tiles));
-    const size_t b = rec * sizeof(float) * static_cast<size_t>(gram_slab_chunks(n_rows));
+    const size_t b = rec * sizeof(float) * static_cast<size_t>(gram_slab_chunks(n_rows, C));
     return a > b ? a : b;
 }
 

@@ -447,7 +447,7 @@ int dif_simple_coeffs_bg_f32(const float* gt, const float* pt, const float* vtt,
                              float attn_scale, float* scratch, float* coef, dif_stream_t stream);
 /* Gram record of that closed form: record float[dif_simple_reduced_len(1, C, C)] = [X^T X (C x C, row-major) | sum x (C) |
  * C + 2 unused]; of X^T X only the 64 x 64 blocks on and above the diagonal are written (symmetric: the caller mirrors).
- * One streaming pass on the fp32 MFMA -- or, for 129..320 columns and >= 4,096 rows (round 5), ONE read of x with split-bfloat16
+ * One streaming pass on the fp32 MFMA -- or, for 65..320 columns and >= 4,096 rows (round 5), ONE read of x with split-bfloat16
  * operands staged in LDS (csrc/simple_attn.hip, gram_slab_kernel; DIFFORMER_EXACT_FP32=1 keeps the fp32 pass).  workspace:
  * dif_gram_sym_workspace_bytes(n_rows, C) (a smaller one of dif_simple_workspace_bytes(n_rows, 1, C, C) bytes selects the fp32
  * pass), 16-byte aligned. */
