@@ -28,10 +28,12 @@ shutil.copy(os.path.join(src, "bench_zipf.json"), os.path.join(dst, f"{prefix}_b
 if os.path.exists(os.path.join(src, "zipf_kernel_stats.csv")):
     shutil.copy(os.path.join(src, "zipf_kernel_stats.csv"), os.path.join(dst, f"{prefix}_ogbn-proteins-zipf-s_kernel_stats.csv"))
 for name, out in (("pokec_epoch.log", "pokec_epoch.txt"), ("train_step.log", "train_step.txt"), ("sigmoid_bwd.log", "sigmoid_bwd.txt"),
-                  ("sliced_shard.log", "row_shard_per_rank.txt")):
+                  ("sliced_shard.log", "row_shard_per_rank.txt"), ("st_epoch_tiny.log", "st_epoch_tiny.txt"),
+                  ("st_epoch_layers.log", "st_epoch_layers.txt"), ("c5_bf16.log", "c5_bf16.txt"), ("bf16_scaling.log", "bf16_scaling.txt"),
+                  ("regional_order.log", "regional_order.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p):
-        lines = [l for l in open(p) if "amdgpu.ids" not in l]
+        lines = [l for l in open(p) if "amdgpu.ids" not in l and "UserWarning" not in l and "Consider using tensor.detach" not in l and "return float(cost_tr)" not in l]
         open(os.path.join(dst, f"{prefix}_{out}"), "w").writelines(lines)
 small = {}
 for p in sorted(glob.glob(os.path.join(cfg, "bench_*.json"))):
