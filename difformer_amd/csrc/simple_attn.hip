@@ -9,6 +9,7 @@
 // contraction step of that shape matches a wave reading 4 whole 256-B rows with one
 // global_load_dwordx4 (16 lanes x 16 B per row), so the HBM stream stays fully coalesced and
 // no LDS transpose is needed.  HBM-bound: 4*N*H*D*4 bytes per layer.
+#include <type_traits>
 #include "dif_common.h"
 
 namespace {
@@ -503,6 +504,11 @@ int check_shape(int64_t n_rows, int H, int M, int D) {
     return 0;
 }
 
+constexpr int kSlabRows = 32;          // rows of a slab of the one-read kernels below (gram_slab_kernel, reduce_slab_kernel)
+__global__ __launch_bounds__(256, 2) void reduce_slab_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                          int64_t ldk, const float* __restrict__ v, int64_t ldv, int64_t n_rows,
+                                                          int M, int D, float* __restrict__ ws, int64_t ws_stride, int t_main);
+
 template <typename T>
 int simple_reduce_entry(const T* q, int64_t ldq, const T* k, int64_t ldk, const T* v, int64_t ldv, int64_t n_rows, int H,
                         int M, int D, float* reduced, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
@@ -521,6 +527,17 @@ int simple_reduce_entry(const T* q, int64_t ldq, const T* k, int64_t ldk, const 
                      dif::aligned_v4<T>(q) && dif::aligned_v4<T>(k) && dif::aligned_v4<T>(v);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* ws = static_cast<float*>(workspace);
+    if constexpr (std::is_same<T, float>::value) {
+        // one head of 65..128 columns (training at hidden 128): every operand read once, products on split-bf16 (reduce_slab_kernel)
+        if (H == 1 && vec && sh.tiles >= 2 && sh.MT <= 8 && sh.DT <= 2 && n_rows >= 4096 && !dif::exact_fp32()) {
+            const int64_t slabs = (n_rows + kSlabRows - 1) / kSlabRows;
+            const int Ps = static_cast<int>(slabs < P ? slabs : P);
+            hipLaunchKernelGGL(reduce_slab_kernel, dim3(Ps, (sh.MT + 1) / 2), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, n_rows, M, D, ws, rec,
+                               sh.t_main);
+            if (int rc = dif::launch_status("reduce_slab_kernel")) return rc;
+            return dif::launch_record_finalize(ws, Ps, rec, sh.t_main, sh.tiles, reduced, st);
+        }
+    }
     dim3 grid(P, sh.tiles), block(256);
     if (vec)
         hipLaunchKernelGGL((simple_reduce_kernel<true, T>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, n_rows, sh, ws, rec);
@@ -602,7 +619,6 @@ int simple_apply_entry(const T* q, int64_t ldq, const float* reduced, int64_t n_
 namespace {
 typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gs_bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int kSlabRows = 32;
 constexpr int kSlabMaxMT = 5;
 
 __global__ __launch_bounds__(512) void gram_slab_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int C, int MT,
@@ -716,6 +732,138 @@ __global__ __launch_bounds__(512) void gram_slab_kernel(const float* __restrict_
     // (the record's two Frobenius slots per tile are not used by the Gram record; zero them so that the finalize sums zeros)
     const int tiles_all = MT * MT;
     for (int i = threadIdx.x; i < 2 * tiles_all; i += 512) rec[static_cast<int64_t>(C) * C + 2 * C + i] = 0.f;
+}
+}  // namespace
+
+// The same one-read scheme for the GENERAL record K^T V | sum k | sum v | sum q^2 | sum k^2 at one head of 65..128 columns
+// (training at hidden 128, node classification/run.sh:42-44: the attention's forward record, q^T gn in its backward and every
+// Linear weight gradient g^T x go through dif_simple_reduce_f32 -- nine launches of 88 us per step on the fp32 matrix core, each
+// of the four tiles streaming its two column blocks).  Waves 0..3 multiply the (<= 2 x 2) tiles, 128 + 128 + 128 threads stage
+// the k slab, the v slab and square the q rows.
+namespace {
+__global__ __launch_bounds__(256, 2) void reduce_slab_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                          int64_t ldk, const float* __restrict__ v, int64_t ldv, int64_t n_rows,
+                                                          int M, int D, float* __restrict__ ws, int64_t ws_stride, int t_main) {
+    __shared__ __attribute__((aligned(16))) gs_bf16x8 sm_k[2 * 2 * 4 * 64], sm_v[2 * 2 * 4 * 64];      // [hi | lo][block][t][lane]
+    __shared__ float sm_sx[2][4][128];
+    __shared__ float sm_sq[2][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    // blockIdx.y: which 128 columns of k (two 64-blocks) this workgroup multiplies against ALL of v (<= 128 columns): the fused
+    // q | k | v projection's weight gradient is k = g [n, 384], v = x [n, 128] -- three workgroups per row chunk, one partial record
+    const int m0 = blockIdx.y * 128;
+    const int Ml = min(128, M - m0);                                  // k columns of this workgroup
+    const int MTl = (Ml + 63) / 64, DT = (D + 63) / 64, MT = (M + 63) / 64;
+    // 256 threads = four waves, two workgroups per CU (~220 VGPRs: two waves per SIMD): twice the loads in flight of one
+    // 512-thread workgroup -- the pass is paced by the latency of a slab's loads, not by its 768 matrix cycles.
+    // staging roles: threads [0, 128): k, and the squares of the q columns beside them (q has M columns like k: every one is
+    // squared exactly once); [128, 256): v.  Thread (slg, cq) of a role reads rows 8 slg .. + 7 of the slab, columns 4 cq .. + 3.
+    const int role = threadIdx.x >> 7, rt = threadIdx.x & 127;
+    const int width = role == 1 ? D : Ml;
+    const int nq = width / 4;
+    const int slg = rt / nq, cq = rt % nq;
+    const bool stager = rt < 4 * nq;
+    const float* src = role == 0 ? k + m0 : v;
+    const int64_t lds_ = role == 0 ? ldk : ldv;
+    const bool with_q = role == 0 && q != k;                          // (q == k: the squares are the k squares)
+    const bool worker = wave < MTl * DT;
+    const int mt = wave / DT, dt = wave % DT;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 sx = {0.f, 0.f, 0.f, 0.f};
+    float sq = 0.f;
+    const int64_t n_slabs = (n_rows + kSlabRows - 1) / kSlabRows;
+    f32x4 nxt[8], nxq[8];
+    float sqq = 0.f;
+    auto fetch = [&](int64_t slab) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t r = slab * kSlabRows + 8 * slg + j;
+            nxt[j] = (stager && r < n_rows) ? *reinterpret_cast<const f32x4*>(src + r * lds_ + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (with_q) nxq[j] = (stager && r < n_rows) ? *reinterpret_cast<const f32x4*>(q + m0 + r * ldq + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    if (first < n_slabs) fetch(first);
+    for (int64_t slab = first; slab < n_slabs; slab += stride) {
+        if (stager) {
+            gs_bf16x4 h[8], l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sx += nxt[j];
+                sq += nxt[j][0] * nxt[j][0] + nxt[j][1] * nxt[j][1] + nxt[j][2] * nxt[j][2] + nxt[j][3] * nxt[j][3];
+                if (with_q) sqq += nxq[j][0] * nxq[j][0] + nxq[j][1] * nxq[j][1] + nxq[j][2] * nxq[j][2] + nxq[j][3] * nxq[j][3];
+                h[j] = __builtin_convertvector(nxt[j], gs_bf16x4);
+                const f32x4 back = __builtin_convertvector(h[j], f32x4);
+                l[j] = __builtin_convertvector(nxt[j] - back, gs_bf16x4);
+            }
+            {
+                gs_bf16x8* op = role == 0 ? sm_k : sm_v;
+                const int b = cq >> 4, ln = 16 * slg + (cq & 15);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    op[((0 * 2 + b) * 4 + t) * 64 + ln] = gs_bf16x8{h[0][t], h[1][t], h[2][t], h[3][t], h[4][t], h[5][t], h[6][t], h[7][t]};
+                    op[((1 * 2 + b) * 4 + t) * 64 + ln] = gs_bf16x8{l[0][t], l[1][t], l[2][t], l[3][t], l[4][t], l[5][t], l[6][t], l[7][t]};
+                }
+            }
+        }
+        __syncthreads();
+        if (slab + stride < n_slabs) fetch(slab + stride);
+        if (worker) {
+            gs_bf16x8 bh[4], bl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bh[u] = sm_v[((0 * 2 + dt) * 4 + u) * 64 + lane];
+                bl[u] = sm_v[((1 * 2 + dt) * 4 + u) * 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const gs_bf16x8 ah = sm_k[((0 * 2 + mt) * 4 + t) * 64 + lane];
+                const gs_bf16x8 al = sm_k[((1 * 2 + mt) * 4 + t) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[u], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[u], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[u], acc[t][u], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
+    if (worker) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = m0 + 64 * mt + 16 * lg + 4 * reg + t, d0 = 64 * dt + 4 * l15;
+                if (m < M && d0 < D)
+                    *reinterpret_cast<f32x4*>(&rec[static_cast<int64_t>(m) * D + d0]) =
+                        f32x4{acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+            }
+    }
+    if (stager) *reinterpret_cast<f32x4*>(&sm_sx[role][slg][4 * cq]) = sx;
+    if (role == 0) {                                                        // [0]: q squares, [1]: k squares
+        sm_sq[1][rt] = stager ? sq : 0.f;
+        sm_sq[0][rt] = stager ? (with_q ? sqq : sq) : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Ml; c += 256) rec[static_cast<int64_t>(M) * D + m0 + c] = ((sm_sx[0][0][c] + sm_sx[0][1][c]) + sm_sx[0][2][c]) + sm_sx[0][3][c];
+    if (blockIdx.y == 0)
+        for (int c = threadIdx.x; c < D; c += 256) rec[static_cast<int64_t>(M) * D + M + c] = ((sm_sx[1][0][c] + sm_sx[1][1][c]) + sm_sx[1][2][c]) + sm_sx[1][3][c];
+    // the Frobenius pairs (one per tile of the record): this workgroup owns the pairs of ITS tiles, puts its sums of squares (in
+    // thread order) into the first and zeros into the others -- the finalize adds all pairs
+    const int pair0 = 2 * blockIdx.y * DT, pairs = MTl * DT;
+    if (threadIdx.x < 2) {
+        float a = 0.f;
+        for (int i = 0; i < 128; ++i) a += sm_sq[threadIdx.x][i];
+        rec[t_main + 2 * pair0 + threadIdx.x] = a;
+    }
+    for (int i = 2 + threadIdx.x; i < 2 * pairs; i += 256) rec[t_main + 2 * pair0 + i] = 0.f;
+    (void)MT;
 }
 }  // namespace
 

@@ -118,7 +118,9 @@ def test_simple_attention_vs_oracle(n, h, d, dev):
 
 
 SIMPLE_SHAPES = [(1, 1, 64), (15, 1, 64), (17, 2, 32), (2708, 1, 64), (50000, 1, 64), (4099, 1, 128), (1000, 1, 300),
-                 (777, 3, 20), (333, 1, 7), (132534, 1, 64), (513, 2, 100)]
+                 (777, 3, 20), (333, 1, 7), (132534, 1, 64), (513, 2, 100),
+                 # one head of 65..128 columns from 4,096 rows: the one-read slab kernel on split-bf16 operands (round 5)
+                 (100000, 1, 128), (20000, 1, 100), (9000, 1, 72), (4096, 1, 68)]
 
 
 @pytest.mark.parametrize("n,h,d", SIMPLE_SHAPES)
@@ -1772,3 +1774,46 @@ def test_gcn_conv_hub_rows_of_a_mid_degree_graph(n, deg, hubs, F, dev):
     w = torch.rand(ei.shape[1], generator=g) + 0.1
     refw = orc.gcn_conv(x.double().numpy(), ei.numpy(), w.double().numpy())
     assert rel_err(gcn_conv(xd, eid, w.to(dev)).cpu().numpy(), refw) < 1e-5
+
+
+@pytest.mark.parametrize("n,m,d", [(100000, 384, 128), (6000, 256, 100), (5000, 128, 64), (4100, 72, 128), (9000, 512, 68)])
+def test_reduce_slab_kernel_with_wide_k(n, m, d, dev):
+    """g^T x for the fused q | k | v projection at hidden 128 (k = g [n, 384], v = x [n, 128]) and other k / v widths through
+    dif_simple_reduce_f32's one-read slab kernel (round 5): K^T V, both column sums and both sums of squares against float64."""
+    import ctypes
+    from difformer_amd import _lib, ops
+    from difformer_amd.backend_hip import _stream
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + m + d)
+    q = (torch.randn(n, m, generator=g) + 0.1).to(dev)
+    k = (torch.randn(n, m, generator=g) - 0.2).to(dev)
+    v = (torch.randn(n, d, generator=g) + 0.3).to(dev)
+    rec = torch.empty(lib.dif_simple_reduced_len(1, m, d), dtype=torch.float32, device=dev)
+    ws_bytes = lib.dif_simple_workspace_bytes(n, 1, m, d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rc = lib.dif_simple_reduce_f32(q.data_ptr(), m, k.data_ptr(), m, v.data_ptr(), d, n, 1, m, d, rec.data_ptr(), ws.data_ptr(), ws_bytes,
+                                   _stream(dev))
+    assert rc == 0
+    r = rec.cpu().numpy().astype(np.float64)
+    q64, k64, v64 = (t.double().cpu().numpy() for t in (q, k, v))
+    assert rel_err(r[: m * d].reshape(m, d), k64.T @ v64) < 1e-5
+    assert rel_err(r[m * d: m * d + m], k64.sum(0)) < 1e-5 and rel_err(r[m * d + m: m * d + m + d], v64.sum(0)) < 1e-5
+    assert abs(r[m * d + m + d] - (q64 ** 2).sum()) < 1e-5 * (q64 ** 2).sum()
+    assert abs(r[m * d + m + d + 1] - (k64 ** 2).sum()) < 1e-5 * (k64 ** 2).sum()
+
+
+@pytest.mark.parametrize("n,K,C", [(100000, 128, 128), (5000, 100, 128), (4096, 128, 72), (6000, 68, 96)])
+def test_rowgemm_split_kernel_vs_float64(n, K, C, dev):
+    """dif_rowgemm_f32 at one head of 65..128 x 65..128 from 4,096 rows: all output columns per workgroup, split-bfloat16 operands
+    (round 5; the fp32 kernel below that size and under DIFFORMER_EXACT_FP32=1) -- A Mat + bias + accumulate against float64."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(n + K + C)
+    A = torch.randn(n, K, generator=g).to(dev)
+    mat = (torch.randn(K, C, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    acc = torch.randn(n, C, generator=g).to(dev)
+    out = be.row_gemm(A, mat, bias, acc)
+    ref = A.double() @ mat.double() + bias.double() + acc.double()
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+    assert torch.equal(be.row_gemm(A, mat, bias, acc), out)
