@@ -442,6 +442,9 @@ def main():
         roofline.update({"achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                          "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_achieved_gbs": hbm_gbs, "hbm_frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None})
+        if dom == "dif_sigmoid_attn_f32" and hidden <= 64 and store == torch.float32 and not ops.EXACT_FP32:
+            roofline["limiter_note"] = ("heads of <= 64 channels contract on split-bfloat16 operands: 3 v_mfma_f32_16x16x32_bf16 per "
+                                        "32-deep step; frac stays algorithmic fp32 FLOP over the fp32 MFMA peak (the contract's figure)")
     else:
         roofline.update({"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None, "algorithmic_bytes_per_launch": alg_bytes})

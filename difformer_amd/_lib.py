@@ -18,6 +18,7 @@ c_i64, c_int, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, 
 # name -> (restype, argtypes); mirrors include/difformer_hip.h one to one
 SIGNATURES = {
     "dif_version": (c_int, []),
+    "dif_set_exact_fp32": (c_int, [c_int]),
     "dif_last_error": (ctypes.c_char_p, []),
     "dif_simple_reduced_len": (c_sz, [c_int, c_int, c_int]),
     "dif_simple_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int]),

@@ -147,6 +147,12 @@ class HipBackend:
         self.kernel_events = None
         self.kernel_events_only = None
         self._ones = {}                             # device -> float32 [1] = 1.0 (device-side beta of dif_rowgemm_f32)
+        from . import ops
+        self.lib.dif_set_exact_fp32(1 if ops.EXACT_FP32 else 0)      # a set_exact_fp32 made before the library was loaded
+
+    def set_exact_fp32(self, flag):
+        """The launchers' side of ops.set_exact_fp32: which matrix core their products take (dif_set_exact_fp32)."""
+        return bool(self.lib.dif_set_exact_fp32(1 if flag else 0))
 
     def kernel_times_ms(self):
         """{entry point: [ms per call]} from the collected events (synchronises)."""

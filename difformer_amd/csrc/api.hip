@@ -29,7 +29,12 @@ int launch_status(const char* what) {
 extern "C" int dif_version(void) { return DIF_ABI_VERSION; }
 extern "C" const char* dif_last_error(void) { return dif::err_buf(); }
 
-bool dif::exact_fp32() {
-    static const bool on = [] { const char* e = getenv("DIFFORMER_EXACT_FP32"); return e && e[0] == '1'; }();
-    return on;
+// DIFFORMER_EXACT_FP32 seeds the switch; dif_set_exact_fp32 flips it at run time (bench.py's second pass, the tests' A/B runs).
+// A plain int: the launchers read it on the host thread that calls them, the same one that sets it.
+static int g_exact_fp32 = [] { const char* e = getenv("DIFFORMER_EXACT_FP32"); return (e && e[0] == '1') ? 1 : 0; }();
+bool dif::exact_fp32() { return g_exact_fp32 != 0; }
+extern "C" int dif_set_exact_fp32(int on) {
+    const int was = g_exact_fp32;
+    g_exact_fp32 = on ? 1 : 0;
+    return was;
 }

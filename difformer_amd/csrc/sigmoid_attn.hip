@@ -11,6 +11,7 @@
 //   O^T[d][query]  += V^T P^T    : k-step `reg` contracts key = 4*(lane/16)+reg, which is exactly the
 //                                  register the lane already holds (B operand = P[reg]).
 // Compute-bound on the f32 matrix pipe: 4*N*L*H*D FLOP.
+#include <type_traits>
 #include "dif_common.h"
 
 namespace {
@@ -60,7 +61,23 @@ __device__ __forceinline__ float sigmoidf(float x) {
 // (descending), so those are exactly ranks 0 .. seg_cnt[p]-1 and local row r is node seg_first[r] + p
 // (seg_first[r] = first node of the r-th largest graph).  The n_graphs - seg_cnt[p] shorter graphs are the
 // reference's zero padding: sigma(0) = 0.5 each in the denominator (+1e-9), nothing in the numerator.
-template <bool VEC, bool QREG, bool SEG, typename T = float>
+// SPLIT (round 5; float32 storage, M <= 64): both contractions on split-bfloat16 operands -- every operand v = hi + lo, three
+// v_mfma_f32_16x16x32_bf16 per 32-deep step (lo.hi + hi.lo + hi.hi; the dropped lo.lo term is 2^-16 of a product) instead of
+// eight v_mfma_f32_16x16x4_f32 at twice the cycles: 5.3x less matrix-pipe time for a kernel that sat at 31-62 % of the fp32 MFMA
+// peak.  The wave takes TWO 16-key tiles per step: the second contraction runs 32 keys deep, and its B operand is still the
+// lane's own registers -- k-slot 8 lg + s <-> key 4 lg + s of the first tile (s < 4) / of the second (s >= 4), the same map on
+// the V side.  Scores ~4e-6 |q||k|, sigma is 1/4-Lipschitz.  DIFFORMER_EXACT_FP32=1 keeps the fp32 chain.
+typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sg_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sg_split8(const f32x4& a, const f32x4& b, sg_bf16x8& hi, sg_bf16x8& lo) {
+    const sg_bf16x4 h0 = __builtin_convertvector(a, sg_bf16x4), h1 = __builtin_convertvector(b, sg_bf16x4);
+    const sg_bf16x4 l0 = __builtin_convertvector(a - __builtin_convertvector(h0, f32x4), sg_bf16x4);
+    const sg_bf16x4 l1 = __builtin_convertvector(b - __builtin_convertvector(h1, f32x4), sg_bf16x4);
+    hi = sg_bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    lo = sg_bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+}
+
+template <bool VEC, bool QREG, bool SEG, typename T = float, bool SPLIT = false>
 __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const T* __restrict__ q, int64_t ldq,
                                                            const T* __restrict__ k, int64_t ldk,
                                                            const T* __restrict__ v, int64_t ldv,
@@ -123,6 +140,84 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const T* __restrict__
     const int64_t per = (n_ktiles + S - 1) / S;
     const int64_t kt0 = split * per;
     const int64_t kt1 = (kt0 + per < n_ktiles) ? kt0 + per : n_ktiles;
+    if constexpr (SPLIT) {
+        static_assert(QREG, "split-bf16 sigmoid attention keeps the query fragments in registers (M <= 64)");
+        sg_bf16x8 qh[kQT][2], ql[kQT][2];
+#pragma unroll
+        for (int t = 0; t < kQT; ++t)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sg_split8(qv[t][2 * kb], qv[t][2 * kb + 1], qh[t][kb], ql[t][kb]);
+        const int64_t key_limit = (kt1 * 16 < L) ? kt1 * 16 : L;         // the keys of THIS workgroup's range end here
+        for (int64_t kt = kt0 + 2 * wave; kt < kt1; kt += 2 * kWaves) {
+            const int64_t kbase = kt * 16;
+            f32x4 s2[2][kQT];
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+                const int64_t kb16 = kbase + 16 * tile;
+                f32x4 kx[4];
+                const int64_t kr = krow(kb16 + l15);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kx[c] = ld4<VEC>(k, ldk, kr, kb16 + l15 < key_limit, h * M, 16 * c + 4 * lg, M);
+#pragma unroll
+                for (int t = 0; t < kQT; ++t) s2[tile][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    sg_bf16x8 kh, kl;
+                    sg_split8(kx[2 * kb], kx[2 * kb + 1], kh, kl);
+#pragma unroll
+                    for (int t = 0; t < kQT; ++t) {
+                        s2[tile][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[t][kb], s2[tile][t], 0, 0, 0);      // small terms first
+                        s2[tile][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[t][kb], s2[tile][t], 0, 0, 0);
+                        s2[tile][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[t][kb], s2[tile][t], 0, 0, 0);
+                    }
+                }
+            }
+            // V fragments: A[i = l15 <-> d][k-slot 8 lg + 4 tile + reg] = V[kbase + 16 tile + 4 lg + reg][16 dtl + l15]
+            sg_bf16x8 vh[4], vl[4];
+            {
+                f32x4 va[4][2];
+#pragma unroll
+                for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int64_t key = kbase + 16 * tile + 4 * lg + reg;
+                        const bool kok = key < key_limit;
+                        const T* vrow = v + krow(key) * ldv + h * D;
+#pragma unroll
+                        for (int dtl = 0; dtl < 4; ++dtl) {
+                            const int d = dt * kDTile + 16 * dtl + l15;
+                            const bool dok = d < D;
+                            const float tv = dif::Elem<T>::ld(vrow + (dok ? d : 0));
+                            va[dtl][tile][reg] = (kok && dok) ? tv : 0.f;
+                        }
+                    }
+#pragma unroll
+                for (int dtl = 0; dtl < 4; ++dtl) sg_split8(va[dtl][0], va[dtl][1], vh[dtl], vl[dtl]);
+            }
+            // P = sigma(S) masked beyond the range (difformer.py:47), its row sums (:50-51), split for the second contraction
+            sg_bf16x8 ph[kQT], pl[kQT];
+#pragma unroll
+            for (int t = 0; t < kQT; ++t) {
+                f32x4 pp[2];
+#pragma unroll
+                for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        pp[tile][reg] = (kbase + 16 * tile + 4 * lg + reg < key_limit) ? sigmoidf(s2[tile][t][reg]) : 0.f;
+                        den[t] += pp[tile][reg];
+                    }
+                sg_split8(pp[0], pp[1], ph[t], pl[t]);
+            }
+#pragma unroll
+            for (int dtl = 0; dtl < 4; ++dtl)
+#pragma unroll
+                for (int t = 0; t < kQT; ++t) {
+                    acc_o[t][dtl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[dtl], ph[t], acc_o[t][dtl], 0, 0, 0);
+                    acc_o[t][dtl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[dtl], pl[t], acc_o[t][dtl], 0, 0, 0);
+                    acc_o[t][dtl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[dtl], ph[t], acc_o[t][dtl], 0, 0, 0);
+                }
+        }
+    } else
     for (int64_t kt = kt0 + wave; kt < kt1; kt += kWaves) {
         const int64_t kbase = kt * 16;
         // ---- S^T tiles (one per query tile) ------------------------------------------------
@@ -303,6 +398,25 @@ int sigmoid_attn(const char* who, const T* q, int64_t ldq, const T* k, int64_t l
 #define DIF_LAUNCH_SIG(V, Q) \
     hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q, false, T>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, \
                        ldo, part, pden, den, nullptr, nullptr, 0)
+    if constexpr (std::is_same<T, float>::value) {
+        if (qreg && !dif::exact_fp32()) {          // both contractions on split-bfloat16 operands (sigmoid_attn_kernel<..., SPLIT>)
+            if (vec)
+                hipLaunchKernelGGL((sigmoid_attn_kernel<true, true, false, T, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D,
+                                   out, ldo, part, pden, den, nullptr, nullptr, 0);
+            else
+                hipLaunchKernelGGL((sigmoid_attn_kernel<false, true, false, T, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D,
+                                   out, ldo, part, pden, den, nullptr, nullptr, 0);
+            if (int rc = dif::launch_status("sigmoid_attn_kernel<split>")) return rc;
+            if (S > 1) {
+                int64_t g = (N * H * D + 255) / 256;
+                if (g > 8 * dif::kCUs) g = 8 * dif::kCUs;
+                hipLaunchKernelGGL(sigmoid_combine_kernel<T>, dim3(static_cast<unsigned>(g)), dim3(256), 0, st, part, pden, N, H, D, S,
+                                   out, ldo, den);
+                return dif::launch_status("sigmoid_combine_kernel");
+            }
+            return 0;
+        }
+    }
     if (vec && qreg) DIF_LAUNCH_SIG(true, true);
     else if (vec) DIF_LAUNCH_SIG(true, false);
     else if (qreg) DIF_LAUNCH_SIG(false, true);

@@ -81,7 +81,27 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_prep_kernel(const float* __re
 // a batch, stationary and swept side are both the seg_cnt[p] nodes at position p of their graph (local row r = node
 // seg_first[r] + p, graphs ranked by size as in the forward kernel); `cinv` already holds the FULL denominators (padded
 // graphs add constants only: no gradient flows into them), so the arithmetic is the unbatched kernel's.  No splits.
-template <int MODE, bool VEC, bool SEG = false>
+// SPLIT (round 5): all five products on split-bfloat16 operands -- v = hi + lo, three v_mfma_f32_16x16x32_bf16 per 32-deep step
+// (lo.hi + hi.lo + hi.hi) instead of eight v_mfma_f32_16x16x4_f32 at twice the cycles.  The wave sweeps TWO 16-row tiles per
+// step so that the second contractions run 32 swept rows deep; their B operand is still the lane's own registers: k-slot
+// 8 lg + e <-> swept row 4 lg + e of the first tile (e < 4) / 4 lg + e - 4 of the second -- the forward kernel's map.
+// Gradients move by a few 1e-6 relative; DIFFORMER_EXACT_FP32=1 / dif_set_exact_fp32 keeps the fp32 chain.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    const bf16x4 h0 = __builtin_convertvector(a, bf16x4), h1 = __builtin_convertvector(b, bf16x4);
+    const bf16x4 l0 = __builtin_convertvector(a - __builtin_convertvector(h0, f32x4), bf16x4);
+    const bf16x4 l1 = __builtin_convertvector(b - __builtin_convertvector(h1, f32x4), bf16x4);
+    hi = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    lo = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+}
+__device__ __forceinline__ f32x4 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);          // small terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+template <int MODE, bool VEC, bool SEG = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restrict__ x1, int64_t ldx1,
                                                           const float* __restrict__ x2, int64_t ldx2,
                                                           const float* __restrict__ y1, int64_t ldy1,
@@ -137,6 +157,130 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
     const int64_t per = (n_tiles + S - 1) / S;
     const int64_t t0 = split * per;
     const int64_t t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    if constexpr (SPLIT) {
+        // The stationary fragments are the same for the 8 waves: split once, parked in LDS (16 KiB at the head of the fold
+        // buffer, free until the sweep ends) as ready B operands [x1 hi, x1 lo, x2 hi, x2 lo][t][kb][lane] -- 64 VGPRs the sweep
+        // needs for its own operands (the fp32 chain keeps them in registers: it has no hi/lo pairs to hold).
+        bf16x8* sm_x = reinterpret_cast<bf16x8*>(&sm_o[0][0]);
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < kXT; ++t)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8 hi, lo;
+                    split8(xs1[t][2 * kb], xs1[t][2 * kb + 1], hi, lo);
+                    sm_x[((0 * kXT + t) * 2 + kb) * 64 + lane] = hi;
+                    sm_x[((1 * kXT + t) * 2 + kb) * 64 + lane] = lo;
+                    split8(xs2[t][2 * kb], xs2[t][2 * kb + 1], hi, lo);
+                    sm_x[((2 * kXT + t) * 2 + kb) * 64 + lane] = hi;
+                    sm_x[((3 * kXT + t) * 2 + kb) * 64 + lane] = lo;
+                }
+        }
+        __syncthreads();
+        const int64_t y_limit = (t1 * 16 < Y) ? t1 * 16 : Y;              // the swept rows of THIS workgroup's range end here
+        for (int64_t yt = t0 + 2 * wave; yt < t1; yt += 2 * kWaves) {
+            const int64_t ybase = yt * 16;
+            f32x4 s[2][kXT], r[2][kXT];
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+                asm volatile("" ::: "memory");       // the LDS operands are re-read per tile, not hoisted into registers
+                const int64_t yr = ybase + 16 * tile + l15;
+                const bool yok = yr < y_limit;
+                const int64_t yrc = mrow(yok ? yr : Y - 1);
+                f32x4 ya1[4], ya2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ya1[c] = ld4<VEC>(y1, ldy1, yrc, yok, h * M, 16 * c + 4 * lg, M);
+                    ya2[c] = ld4<VEC>(y2, ldy2, yrc, yok, h * D, 16 * c + 4 * lg, D);
+                }
+#pragma unroll
+                for (int t = 0; t < kXT; ++t) s[tile][t] = r[tile][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8 ah, al;
+                    split8(ya1[2 * kb], ya1[2 * kb + 1], ah, al);
+#pragma unroll
+                    for (int t = 0; t < kXT; ++t)                                              // q . k
+                        s[tile][t] = mfma3(ah, al, sm_x[((0 * kXT + t) * 2 + kb) * 64 + lane], sm_x[((1 * kXT + t) * 2 + kb) * 64 + lane],
+                                           s[tile][t]);
+                    split8(ya2[2 * kb], ya2[2 * kb + 1], ah, al);
+#pragma unroll
+                    for (int t = 0; t < kXT; ++t)                                              // g . v
+                        r[tile][t] = mfma3(ah, al, sm_x[((2 * kXT + t) * 2 + kb) * 64 + lane], sm_x[((3 * kXT + t) * 2 + kb) * 64 + lane],
+                                           r[tile][t]);
+                }
+            }
+            // per-swept-row scalars (MODE 1: the queries are the swept side)
+            float cy[2][4], dy[2][4];
+            int64_t zrow[2][4];
+            bool zok[2][4];
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t yy = ybase + 16 * tile + 4 * lg + reg;
+                    zok[tile][reg] = yy < y_limit;
+                    zrow[tile][reg] = mrow(zok[tile][reg] ? yy : Y - 1);
+                    if (MODE == 1) {
+                        float c = cinv[zrow[tile][reg] * H + h], dl = delta[zrow[tile][reg] * H + h];
+                        asm volatile("" : "+v"(c), "+v"(dl));
+                        cy[tile][reg] = zok[tile][reg] ? c : 0.f;
+                        dy[tile][reg] = zok[tile][reg] ? dl : 0.f;
+                    }
+                }
+            // weights: lane holds T^T[swept row 16 tile + 4 lg + reg][stationary row l15]
+            bf16x8 dsh[kXT], dsl[kXT], pch[kXT], pcl[kXT];
+#pragma unroll
+            for (int t = 0; t < kXT; ++t) {
+                f32x4 ds[2], pc[2];
+#pragma unroll
+                for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float p = zok[tile][reg] ? sigmoidf(s[tile][t][reg]) : 0.f;
+                        const float c = (MODE == 0) ? cx[t] : cy[tile][reg];
+                        const float dl = (MODE == 0) ? dx[t] : dy[tile][reg];
+                        pc[tile][reg] = p * c;
+                        ds[tile][reg] = pc[tile][reg] * (r[tile][t][reg] - dl) * (1.0f - p);
+                    }
+                split8(ds[0], ds[1], dsh[t], dsl[t]);
+                if (MODE == 1) split8(pc[0], pc[1], pch[t], pcl[t]);
+            }
+            asm volatile("" ::: "memory");           // the transposed reads below start after the score tiles are consumed (register budget)
+            // second contraction, one 16-column tile at a time: A[i = l15 <-> column][k-slot 8 lg + 4 tile + reg] = swept row
+            // ybase + 16 tile + 4 lg + reg (the rows the ld4 above just brought through the L1)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (MODE == 1 && ct == 2) asm volatile("" ::: "memory");      // dK/dV: two column tiles of transposed reads in flight
+                const int col = 16 * ct + l15;
+                f32x4 z1[2], z2[2];
+#pragma unroll
+                for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        // (the empty asm pins the load where it is: left alone, the compiler sinks each one into its own
+                        //  `if (ok)` block -- a branch and a full memory latency per element)
+                        float a = y1[zrow[tile][reg] * ldy1 + h * M + (col < M ? col : 0)];
+                        asm volatile("" : "+v"(a));
+                        z1[tile][reg] = (zok[tile][reg] && col < M) ? a : 0.f;
+                        if (MODE == 1) {
+                            float b = y2[zrow[tile][reg] * ldy2 + h * D + (col < D ? col : 0)];
+                            asm volatile("" : "+v"(b));
+                            z2[tile][reg] = (zok[tile][reg] && col < D) ? b : 0.f;
+                        }
+                    }
+                bf16x8 zh, zl;
+                split8(z1[0], z1[1], zh, zl);
+#pragma unroll
+                for (int t = 0; t < kXT; ++t) acc1[t][ct] = mfma3(zh, zl, dsh[t], dsl[t], acc1[t][ct]);
+                if (MODE == 1) {
+                    split8(z2[0], z2[1], zh, zl);
+#pragma unroll
+                    for (int t = 0; t < kXT; ++t) acc2[t][ct] = mfma3(zh, zl, pch[t], pcl[t], acc2[t][ct]);
+                }
+            }
+        }
+    } else
     for (int64_t yt = t0 + wave; yt < t1; yt += kWaves) {
         const int64_t ybase = yt * 16;
         // ---- swept fragments (A operands of the two score products): row = ybase + l15 ----
@@ -173,16 +317,22 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
             for (int ct = 0; ct < 4; ++ct) {
                 const int col = 16 * ct + l15;
                 // dQ^T += K^T dS (MODE 0: y1 = k)   |   dK^T += Q^T dS (MODE 1: y1 = q)
-                const float a = y1[yc * ldy1 + h * M + (col < M ? col : 0)];
+                // (the empty asm pins each load: left alone the compiler sinks it into its own `if (ok)` block -- a branch and
+                //  a full memory latency per element, 30+ basic blocks per step)
+                float a = y1[yc * ldy1 + h * M + (col < M ? col : 0)];
+                asm volatile("" : "+v"(a));
                 zf1[ct][reg] = (ok && col < M) ? a : 0.f;
                 if (MODE == 1) {                 // dV^T += G^T (c P)   (y2 = g)
-                    const float b = y2[yc * ldy2 + h * D + (col < D ? col : 0)];
+                    float b = y2[yc * ldy2 + h * D + (col < D ? col : 0)];
+                    asm volatile("" : "+v"(b));
                     zf2[ct][reg] = (ok && col < D) ? b : 0.f;
                 }
             }
             if (MODE == 1) {                     // per-query scalars ride with the swept row
-                cy[reg] = ok ? cinv[yc * H + h] : 0.f;
-                dy[reg] = ok ? delta[yc * H + h] : 0.f;
+                float c = cinv[yc * H + h], dl = delta[yc * H + h];
+                asm volatile("" : "+v"(c), "+v"(dl));
+                cy[reg] = ok ? c : 0.f;
+                dy[reg] = ok ? dl : 0.f;
             }
         }
         // ---- weights: lane holds T^T[swept row 4 lg + reg][stationary row l15] ----
@@ -231,6 +381,7 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
         }
         __syncthreads();
     };
+    if constexpr (SPLIT) __syncthreads();          // every wave is done with the operands parked in the fold buffer
     fold_store(acc1, M, o1, ldo1, part1);
     if (MODE == 1) fold_store(acc2, D, o2, ldo2, part2);
 }
@@ -310,10 +461,15 @@ extern "C" int dif_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float
     if (int rc = dif::launch_status("sigmoid_bwd_prep_kernel")) return rc;
     auto al = [](const void* p, int64_t ld) { return ld % 4 == 0 && dif::aligned16(p); };
     const bool vec = (M % 4 == 0) && (D % 4 == 0) && al(q, ldq) && al(k, ldk) && al(v, ldv) && al(g, ldg);
+    const bool split = !dif::exact_fp32();          // split-bfloat16 operands on the bf16 matrix core (sigmoid_bwd_kernel<..., SPLIT>)
     // dQ: stationary queries (q, g), swept keys (k, v)
     {
         dim3 grid(static_cast<unsigned>((N + kXGroup - 1) / kXGroup), H, S0), block(512);
-        if (vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<0, true>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv, cinv, delta,
+        if (split && vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<0, true, false, true>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv,
+                                             cinv, delta, N, L, H, M, D, dq, lddq, nullptr, int64_t{0}, pq, nullptr);
+        else if (split) hipLaunchKernelGGL((sigmoid_bwd_kernel<0, false, false, true>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv,
+                                           cinv, delta, N, L, H, M, D, dq, lddq, nullptr, int64_t{0}, pq, nullptr);
+        else if (vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<0, true>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv, cinv, delta,
                                     N, L, H, M, D, dq, lddq, nullptr, int64_t{0}, pq, nullptr);
         else hipLaunchKernelGGL((sigmoid_bwd_kernel<0, false>), grid, block, 0, st, q, ldq, g, ldg, k, ldk, v, ldv, cinv, delta,
                                 N, L, H, M, D, dq, lddq, nullptr, int64_t{0}, pq, nullptr);
@@ -322,7 +478,11 @@ extern "C" int dif_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float
     // dK, dV: stationary keys (k, v), swept queries (q, g)
     {
         dim3 grid(static_cast<unsigned>((L + kXGroup - 1) / kXGroup), H, S1), block(512);
-        if (vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<1, true>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg, cinv, delta,
+        if (split && vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<1, true, false, true>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg,
+                                             cinv, delta, L, N, H, M, D, dk, lddk, dv, lddv, pk, pv);
+        else if (split) hipLaunchKernelGGL((sigmoid_bwd_kernel<1, false, false, true>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg,
+                                           cinv, delta, L, N, H, M, D, dk, lddk, dv, lddv, pk, pv);
+        else if (vec) hipLaunchKernelGGL((sigmoid_bwd_kernel<1, true>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg, cinv, delta,
                                     L, N, H, M, D, dk, lddk, dv, lddv, pk, pv);
         else hipLaunchKernelGGL((sigmoid_bwd_kernel<1, false>), grid, block, 0, st, k, ldk, v, ldv, q, ldq, g, ldg, cinv, delta,
                                 L, N, H, M, D, dk, lddk, dv, lddv, pk, pv);

@@ -899,7 +899,8 @@ int linear_entry(const T* x, int64_t ldx, int64_t n_rows, int C_in, const T* W, 
         if constexpr (std::is_same<T, float>::value) {
             // float32 storage: split-bfloat16 operands on the bf16 matrix core (DIFFORMER_LINEAR_FP32_MFMA=1: the exact
             // fp32-MFMA kernel, for A/B measurements)
-            static const bool exact = dif::exact_fp32() || [] { const char* e = getenv("DIFFORMER_LINEAR_FP32_MFMA"); return e && e[0] == '1'; }();
+            static const bool fp32_mfma = [] { const char* e = getenv("DIFFORMER_LINEAR_FP32_MFMA"); return e && e[0] == '1'; }();
+            const bool exact = dif::exact_fp32() || fp32_mfma;
             if (!exact && C_in <= 64 * kResidentChunks && n_rows >= 32768) {     // below: the chunked kernel's many small workgroups win
                 const int64_t tiles = (n_rows + 15) / 16;
                 const int64_t wg = (tiles + 15) / 16 < dif::kCUs ? (tiles + 15) / 16 : dif::kCUs;      // one 16-wave workgroup per CU

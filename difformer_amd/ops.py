@@ -971,6 +971,9 @@ def set_exact_fp32(flag):
     global EXACT_FP32, CLOSED_FORM_WIDE_MIN
     was = EXACT_FP32
     EXACT_FP32 = bool(flag)
+    be = _BACKEND
+    if be is not None and hasattr(be, "set_exact_fp32"):
+        be.set_exact_fp32(EXACT_FP32)                       # the launchers' own choices (dif_set_exact_fp32)
     CLOSED_FORM_WIDE_MIN = 128 if EXACT_FP32 else 64
     return was
 

@@ -39,6 +39,10 @@ typedef void* dif_stream_t; /* hipStream_t */
 
 int dif_version(void);
 const char* dif_last_error(void);
+/* Every product on the fp32 matrix core (on != 0) or the default choice per kernel (split-bfloat16 operands on the bf16
+ * core where the entry points below say so); seeded from DIFFORMER_EXACT_FP32, returns the previous setting.  The reference
+ * has no such switch: its products are whatever torch.matmul does on the device (difformer.py:23-58). */
+int dif_set_exact_fp32(int on);
 
 /* ---------------------------------------------------------------------------------------
  * a1  full_attention_conv(qs, ks, vs, 'simple')     node classification/difformer.py:18-39

@@ -22,9 +22,22 @@ def timeit(f, it=20):
 for n in (2708, 8192, 20000):
     q, k, v, g = (torch.randn(n, 1, 64, device=dev) * 0.5 for _ in range(4))
     out, den = be.sigmoid_attention(q, k, v, want_den=True)
-    t_f = timeit(lambda: be.sigmoid_attention(q, k, v, want_den=True))
-    t_b = timeit(lambda: be.sigmoid_backward(q, k, v, out, den, g))
-    t_r = timeit(lambda: ag._grad_by_recompute(ag._sigmoid_expr, (q, k, v), g), it=5) if n <= 8192 else float("nan")
     fl = 14.0 * n * n * 64
-    print(f"N = L = {n}: forward {t_f:.0f} us, backward kernel {t_b:.0f} us ({fl / t_b / 1e6:.1f} TFLOP/s fp32 MFMA), "
-          f"tensor-op recompute {t_r:.0f} us", flush=True)
+    ref = None
+    for exact in (True, False):              # every product on the fp32 core | split-bfloat16 operands on the bf16 core (default)
+        ops.set_exact_fp32(exact)
+        t_f = timeit(lambda: be.sigmoid_attention(q, k, v, want_den=True))
+        t_b = timeit(lambda: be.sigmoid_backward(q, k, v, out, den, g))
+        grads = be.sigmoid_backward(q, k, v, out, den, g)
+        if exact:
+            ref = grads
+            dev_s = ""
+        else:
+            dev_s = ", gradients vs the fp32 chain: " + " ".join(
+                f"{float((a - b).abs().max() / b.abs().max()):.1e}" for a, b in zip(grads, ref))
+        print(f"N = L = {n} [{'fp32 MFMA' if exact else 'split bf16'}]: forward {t_f:.0f} us ({4.0 * n * n * 64 / t_f / 1e6:.1f} TFLOP/s), "
+              f"backward kernels {t_b:.0f} us ({fl / t_b / 1e6:.1f} TFLOP/s algorithmic){dev_s}", flush=True)
+    ops.set_exact_fp32(False)
+    if n <= 8192:
+        t_r = timeit(lambda: ag._grad_by_recompute(ag._sigmoid_expr, (q, k, v), g), it=5)
+        print(f"N = L = {n}: tensor-op recompute {t_r:.0f} us", flush=True)

@@ -25,7 +25,7 @@ def lib():
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and "dif_sliced_spmm_f32" in names and "dif_simple_layer_f32" in names and "dif_subgraph_batches_group" in names and "dif_graph_prepare" in names and "dif_gcn_edge_weight_grad_f32" in names and "dif_batched_sigmoid_attn_bwd_f32" in names and "dif_tiny_forward_f32" in names and "dif_tiny_backward_f32" in names and "dif_tiny_graph_build" in names and len(names) == 103
+    assert "dif_simple_reduce_f32" in names and "dif_gcn_spmm_f32" in names and "dif_gcn_spmm_tail_f32" in names and "dif_project_reduce_f32" in names and "dif_linear_f32" in names and "dif_gcn_spmm_tail_bf16" in names and "dif_rowgemm_f32" in names and "dif_subgraph" in names and "dif_batched_simple_attn_f32" in names and "dif_row_order" in names and "dif_gcn_spmm_part_f32" in names and "dif_sliced_spmm_f32" in names and "dif_simple_layer_f32" in names and "dif_subgraph_batches_group" in names and "dif_graph_prepare" in names and "dif_gcn_edge_weight_grad_f32" in names and "dif_batched_sigmoid_attn_bwd_f32" in names and "dif_tiny_forward_f32" in names and "dif_tiny_backward_f32" in names and "dif_tiny_graph_build" in names and "dif_set_exact_fp32" in names and len(names) == 104
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -37,6 +37,15 @@ def test_library_exports_every_declared_symbol(lib):
 def test_python_binding_covers_the_header_exactly():
     from difformer_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
+
+
+def test_exact_fp32_switch_is_a_runtime_setting_of_the_library(lib):
+    """dif_set_exact_fp32 returns what was set before: the launchers read the switch per call (host state, no device work)."""
+    was = lib.dif_set_exact_fp32(1)
+    try:
+        assert lib.dif_set_exact_fp32(0) == 1 and lib.dif_set_exact_fp32(0) == 0
+    finally:
+        lib.dif_set_exact_fp32(was)
 
 
 def test_version_and_size_helpers(lib):

@@ -256,6 +256,28 @@ def test_sigmoid_attention_saturated_scores(dev):
     assert np.isfinite(out).all() and rel_err(out, ref) < TOL
 
 
+@pytest.mark.parametrize("n,l,h,d", [(70, 17, 1, 64), (300, 1000, 2, 32), (2708, 2708, 1, 64), (5000, 4111, 1, 48)])
+def test_sigmoid_attention_split_operands_against_the_fp32_chain(n, l, h, d, dev):
+    """Heads of at most 64 channels contract on split-bfloat16 operands (three 32-deep bf16 MFMAs per step, two key tiles per
+    wave step); ops.set_exact_fp32 puts the same call back on the fp32 core.  Both are measured against the float64 oracle:
+    the split path may cost a few 1e-6 -- far inside the 1e-4 of the contract -- and ragged key counts (odd tile counts, a
+    tail tile, several key ranges) are masked the same way in both."""
+    from difformer_amd import full_attention_conv, ops
+    g = torch.Generator().manual_seed(n + 3 * l + d)
+    q = torch.randn(n, h, d, generator=g) * 0.5
+    k = torch.randn(l, h, d, generator=g) * 0.5
+    v = torch.randn(l, h, d, generator=g)
+    ref = orc.sigmoid_attention(q.double().numpy(), k.double().numpy(), v.double().numpy())
+    errs = {}
+    try:
+        for exact in (False, True):
+            ops.set_exact_fp32(exact)
+            errs[exact] = rel_err(full_attention_conv(q.to(dev), k.to(dev), v.to(dev), "sigmoid").cpu().numpy(), ref)
+    finally:
+        ops.set_exact_fp32(False)
+    assert errs[True] < 5e-6 and errs[False] < 2e-5, errs
+
+
 # ------------------------------------------------------------------ a3
 def _csr_reference(edge_index, n, edge_weight, n_blocks=1):
     """numpy statement of the CSR layout: entries sorted (stably) by destination, then source block."""
