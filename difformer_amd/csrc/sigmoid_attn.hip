@@ -345,11 +345,14 @@ __global__ __launch_bounds__(256) void sigmoid_combine_kernel(const float* __res
 // S minimises rounds x per-workgroup time: it fills the chip when there are few query groups (Cora: 85 groups -> S = 6)
 // and trims the half-empty last round when there are many (N = 20,000: 625 groups, S = 1 runs 2 rounds for 1.22
 // rounds of work; S = 4 runs 5 quarter-rounds).
-int key_splits(int64_t N, int64_t L, int H, int D) {
+// The split-bfloat16 kernel (float32 storage, M <= 64) holds hi / lo pairs of every operand: 162 VGPRs, ONE workgroup per CU,
+// and a wave step is two key tiles -- its splits are priced on 256 slots and keep >= two key tiles per wave.  (Parking the
+// query fragments in LDS brings it to 124 VGPRs and two workgroups per CU: measured slower, 743 -> 800 us at N = 20,000.)
+int key_splits(int64_t N, int64_t L, int H, int D, bool split_kernel = false) {
     const int64_t groups = ((N + kQGroup - 1) / kQGroup) * H * ((D + kDTile - 1) / kDTile);
     const int64_t n_ktiles = (L + 15) / 16;
-    const int64_t slots = 2 * dif::kCUs;
-    int64_t smax = (n_ktiles + kWaves - 1) / kWaves;              // keep >= one key tile per wave
+    const int64_t slots = (split_kernel ? 1 : 2) * dif::kCUs;
+    int64_t smax = split_kernel ? (n_ktiles + 2 * kWaves - 1) / (2 * kWaves) : (n_ktiles + kWaves - 1) / kWaves;   // keep >= one step per wave
     if (smax > 16) smax = 16;
     int best = 1;
     double best_cost = -1.0;
@@ -364,9 +367,13 @@ int key_splits(int64_t N, int64_t L, int H, int D) {
 }  // namespace
 
 extern "C" size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M, int D) {
-    (void)M;
+
     if (N <= 0 || L <= 0 || H <= 0 || D <= 0) return 0;
-    const int S = key_splits(N, L, H, D);
+    int S = key_splits(N, L, H, D);
+    if (M <= 64) {                                                   // whichever kernel the exact-fp32 switch picks at launch
+        const int S2 = key_splits(N, L, H, D, true);
+        if (S2 > S) S = S2;
+    }
     if (S == 1) return 0;
     const size_t DT = (D + kDTile - 1) / kDTile;
     return static_cast<size_t>(S) * N * H * (static_cast<size_t>(D) + DT) * sizeof(float);
@@ -385,7 +392,8 @@ int sigmoid_attn(const char* who, const T* q, int64_t ldq, const T* k, int64_t l
     const int64_t gx = (N + kQGroup - 1) / kQGroup;
     const int64_t gy = static_cast<int64_t>(H) * ((D + kDTile - 1) / kDTile);
     DIF_REQUIRE(gx < (1ll << 31) && gy <= 65535, DIF_E_RANGE, "%s: grid too large", who);
-    const int S = key_splits(N, L, H, D);
+    const bool split_kernel = std::is_same<T, float>::value && M <= 64 && !dif::exact_fp32();
+    const int S = key_splits(N, L, H, D, split_kernel);
     const size_t need = dif_sigmoid_workspace_bytes(N, L, H, M, D);
     DIF_REQUIRE(S == 1 || (workspace && workspace_bytes >= need), DIF_E_WORKSPACE, "%s: workspace too small (%zu < %zu)", who,
                 workspace_bytes, need);
@@ -399,7 +407,7 @@ int sigmoid_attn(const char* who, const T* q, int64_t ldq, const T* k, int64_t l
     hipLaunchKernelGGL((sigmoid_attn_kernel<V, Q, false, T>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, \
                        ldo, part, pden, den, nullptr, nullptr, 0)
     if constexpr (std::is_same<T, float>::value) {
-        if (qreg && !dif::exact_fp32()) {          // both contractions on split-bfloat16 operands (sigmoid_attn_kernel<..., SPLIT>)
+        if (split_kernel) {                        // both contractions on split-bfloat16 operands (sigmoid_attn_kernel<..., SPLIT>)
             if (vec)
                 hipLaunchKernelGGL((sigmoid_attn_kernel<true, true, false, T, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D,
                                    out, ldo, part, pden, den, nullptr, nullptr, 0);

@@ -1032,6 +1032,35 @@ def test_sigmoid_attention_backward_kernel(n, l, h, m, d, dev):
     assert torch.equal(qd2.grad, qd.grad) and torch.equal(kd2.grad, kd.grad) and torch.equal(vd2.grad, vd.grad)
 
 
+@pytest.mark.parametrize("n,l,h,m,d", [(70, 17, 1, 64, 64), (300, 1000, 2, 32, 32), (2708, 2708, 1, 64, 64), (333, 95, 1, 20, 12)])
+def test_sigmoid_attention_backward_split_operands_against_the_fp32_chain(n, l, h, m, d, dev):
+    """The backward sweeps take TWO 16-row tiles of the swept side per step on split-bfloat16 operands (default) or one tile on
+    the fp32 core (ops.set_exact_fp32): both against float64 autograd, the split path within a few 1e-6 of the fp32 chain --
+    odd tile counts, a masked tail tile, swept-side splits and scalar-load widths included."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(n + l + d)
+    q = torch.randn(n, h, m, generator=g) * 0.5
+    k = torch.randn(l, h, m, generator=g) * 0.5
+    v = torch.randn(l, h, d, generator=g)
+    go = torch.randn(n, h, d, generator=g)
+    from difformer_amd import autograd_ops as ag
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    ag._sigmoid_expr(q64, k64, v64).backward(go.double())
+    want = [t.grad.numpy() for t in (q64, k64, v64)]
+    qd, kd, vd, gd = (t.to(dev) for t in (q, k, v, go))
+    errs = {}
+    try:
+        for exact in (False, True):
+            ops.set_exact_fp32(exact)
+            out, den = be.sigmoid_attention(qd, kd, vd, want_den=True)
+            got = be.sigmoid_backward(qd, kd, vd, out, den, gd)
+            errs[exact] = max(rel_err(a.cpu().numpy(), b) for a, b in zip(got, want))
+    finally:
+        ops.set_exact_fp32(False)
+    assert errs[True] < 1e-5 and errs[False] < 3e-5, errs
+
+
 def test_sigmoid_attention_backward_wide_heads_fall_back_to_tensor_ops(dev):
     """hidden 128: beyond the backward kernel's 64 columns -- gradient re-derived with device tensor ops."""
     from difformer_amd import autograd_ops as ag
