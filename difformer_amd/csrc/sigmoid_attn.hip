@@ -45,6 +45,31 @@ __device__ __forceinline__ f32x4 ld4(const T* __restrict__ base, int64_t ld, int
     return z;
 }
 
+// The two halves of ld4 for software-pipelined loads: the raw (clamped-address) load is issued a step ahead and NOT touched until
+// the step that uses it -- masking at load time would make the issuing step wait for the data.
+template <bool VEC, typename T>
+__device__ __forceinline__ f32x4 ld4_raw(const T* __restrict__ base, int64_t ld, int64_t rc, int col0, int c, int width) {
+    f32x4 z;
+    if (VEC) {
+        z = dif::Elem<T>::ld4(base + rc * ld + col0 + (c < width ? c : 0));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = dif::Elem<T>::ld(base + rc * ld + col0 + (c + i < width ? c + i : 0));
+    }
+    return z;
+}
+template <bool VEC>
+__device__ __forceinline__ f32x4 mask4(f32x4 z, bool rok, int c, int width) {
+    if (VEC) {
+        if (!(rok && c < width)) z = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!(rok && c + i < width)) z[i] = 0.f;
+    }
+    return z;
+}
+
 // sigma(x) with the hardware exp2 / rcp (each ~1 ulp): far inside the 1e-4 parity budget, and ~5x
 // fewer VALU instructions than expf + IEEE division next to the MFMAs.
 __device__ __forceinline__ float sigmoidf(float x) {
@@ -148,16 +173,58 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const T* __restrict__
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) sg_split8(qv[t][2 * kb], qv[t][2 * kb + 1], qh[t][kb], ql[t][kb]);
         const int64_t key_limit = (kt1 * 16 < L) ? kt1 * 16 : L;         // the keys of THIS workgroup's range end here
+        // The K and V fragments of the NEXT step are in flight under this step's products (64 VGPRs): a step is a chain
+        // loads -> products -> sigma -> products, and one workgroup per CU leaves two waves per SIMD to hide it.  Raw loads
+        // from clamped (valid) addresses, issued unconditionally -- the last step re-reads its own rows -- and masked only
+        // when used: a mask or a branch at issue time makes the issuing step wait for the data (measured: 665 -> 1,493 us).
+        // V: A[i = l15 <-> d][k-slot 8 lg + 4 tile + reg] = V[kbase + 16 tile + 4 lg + reg][16 dtl + l15].
+        f32x4 kn[2][4], vn[4][2];
+        auto prefetch = [&](int64_t kbase) {
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+                const int64_t kr = krow(kbase + 16 * tile + l15);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kn[tile][c] = ld4_raw<VEC>(k, ldk, kr, h * M, 16 * c + 4 * lg, M);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const T* vrow = v + krow(kbase + 16 * tile + 4 * lg + reg) * ldv + h * D;
+#pragma unroll
+                    for (int dtl = 0; dtl < 4; ++dtl) {
+                        const int d = dt * kDTile + 16 * dtl + l15;
+                        vn[dtl][tile][reg] = dif::Elem<T>::ld(vrow + (d < D ? d : 0));
+                    }
+                }
+            }
+        };
+        prefetch((kt0 + 2 * wave) * 16);
         for (int64_t kt = kt0 + 2 * wave; kt < kt1; kt += 2 * kWaves) {
             const int64_t kbase = kt * 16;
+            f32x4 kc[2][4];
+            sg_bf16x8 vh[4], vl[4];
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kc[tile][c] = mask4<VEC>(kn[tile][c], kbase + 16 * tile + l15 < key_limit, 16 * c + 4 * lg, M);
+#pragma unroll
+            for (int dtl = 0; dtl < 4; ++dtl) {
+                const bool dok = dt * kDTile + 16 * dtl + l15 < D;
+                f32x4 va[2];
+#pragma unroll
+                for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        va[tile][reg] = (dok && kbase + 16 * tile + 4 * lg + reg < key_limit) ? vn[dtl][tile][reg] : 0.f;
+                sg_split8(va[0], va[1], vh[dtl], vl[dtl]);
+            }
+            {
+                const int64_t nxt = kt + 2 * kWaves;
+                prefetch((nxt < kt1 ? nxt : kt) * 16);
+                __builtin_amdgcn_sched_barrier(0);       // issued HERE, ahead of the products (the scheduler sank the V reads to the end of the step)
+            }
             f32x4 s2[2][kQT];
 #pragma unroll
             for (int tile = 0; tile < 2; ++tile) {
-                const int64_t kb16 = kbase + 16 * tile;
-                f32x4 kx[4];
-                const int64_t kr = krow(kb16 + l15);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) kx[c] = ld4<VEC>(k, ldk, kr, kb16 + l15 < key_limit, h * M, 16 * c + 4 * lg, M);
+                const f32x4 (&kx)[4] = kc[tile];
 #pragma unroll
                 for (int t = 0; t < kQT; ++t) s2[tile][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -171,28 +238,6 @@ __global__ __launch_bounds__(512) void sigmoid_attn_kernel(const T* __restrict__
                         s2[tile][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[t][kb], s2[tile][t], 0, 0, 0);
                     }
                 }
-            }
-            // V fragments: A[i = l15 <-> d][k-slot 8 lg + 4 tile + reg] = V[kbase + 16 tile + 4 lg + reg][16 dtl + l15]
-            sg_bf16x8 vh[4], vl[4];
-            {
-                f32x4 va[4][2];
-#pragma unroll
-                for (int tile = 0; tile < 2; ++tile)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int64_t key = kbase + 16 * tile + 4 * lg + reg;
-                        const bool kok = key < key_limit;
-                        const T* vrow = v + krow(key) * ldv + h * D;
-#pragma unroll
-                        for (int dtl = 0; dtl < 4; ++dtl) {
-                            const int d = dt * kDTile + 16 * dtl + l15;
-                            const bool dok = d < D;
-                            const float tv = dif::Elem<T>::ld(vrow + (dok ? d : 0));
-                            va[dtl][tile][reg] = (kok && dok) ? tv : 0.f;
-                        }
-                    }
-#pragma unroll
-                for (int dtl = 0; dtl < 4; ++dtl) sg_split8(va[dtl][0], va[dtl][1], vh[dtl], vl[dtl]);
             }
             // P = sigma(S) masked beyond the range (difformer.py:47), its row sums (:50-51), split for the second contraction
             sg_bf16x8 ph[kQT], pl[kQT];
@@ -395,12 +440,13 @@ int sigmoid_attn(const char* who, const T* q, int64_t ldq, const T* k, int64_t l
     // Inference only (no row sums asked for): under loss.backward() the few 1e-6 the split operands move out / den come back
     // amplified in gradients that are sums of cancelling rows (Wk.bias of model/a_nobn_src: 2.0e-5 of itself against 4.3e-6
     // with the fp32 chain, the reference's own float32 run 3.7e-6; scripts/exp_sigmoid_grad_parity.py) -- training keeps fp32.
-    const bool split_kernel = std::is_same<T, float>::value && M <= 64 && !dif::exact_fp32() && den == nullptr;
+    // (aligned rows only: the scalar-load variant of the split kernel does not fit its hi / lo pairs and the prefetch in 256 VGPRs)
+    const bool vec = (M % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && dif::aligned_v4<T>(q) && dif::aligned_v4<T>(k);
+    const bool split_kernel = std::is_same<T, float>::value && M <= 64 && vec && !dif::exact_fp32() && den == nullptr;
     const int S = key_splits(N, L, H, D, split_kernel);
     const size_t need = dif_sigmoid_workspace_bytes(N, L, H, M, D);
     DIF_REQUIRE(S == 1 || (workspace && workspace_bytes >= need), DIF_E_WORKSPACE, "%s: workspace too small (%zu < %zu)", who,
                 workspace_bytes, need);
-    const bool vec = (M % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && dif::aligned_v4<T>(q) && dif::aligned_v4<T>(k);
     const bool qreg = (M <= 64);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(workspace);
@@ -411,12 +457,8 @@ int sigmoid_attn(const char* who, const T* q, int64_t ldq, const T* k, int64_t l
                        ldo, part, pden, den, nullptr, nullptr, 0)
     if constexpr (std::is_same<T, float>::value) {
         if (split_kernel) {                        // both contractions on split-bfloat16 operands (sigmoid_attn_kernel<..., SPLIT>)
-            if (vec)
-                hipLaunchKernelGGL((sigmoid_attn_kernel<true, true, false, T, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D,
-                                   out, ldo, part, pden, den, nullptr, nullptr, 0);
-            else
-                hipLaunchKernelGGL((sigmoid_attn_kernel<false, true, false, T, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D,
-                                   out, ldo, part, pden, den, nullptr, nullptr, 0);
+            hipLaunchKernelGGL((sigmoid_attn_kernel<true, true, false, T, true>), grid, block, 0, st, q, ldq, k, ldk, v, ldv, N, L, H, M, D,
+                               out, ldo, part, pden, den, nullptr, nullptr, 0);
             if (int rc = dif::launch_status("sigmoid_attn_kernel<split>")) return rc;
             if (S > 1) {
                 int64_t g = (N * H * D + 255) / 256;
