@@ -46,6 +46,31 @@ __device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld,
     return z;
 }
 
+// The two halves of ld4 for software-pipelined loads: the raw (clamped-address) load is issued a step ahead and NOT touched until
+// the step that uses it -- a mask (or a branch) at issue time makes the issuing step wait for the data.
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld4_raw(const float* __restrict__ base, int64_t ld, int64_t rc, int col0, int c, int width) {
+    f32x4 z;
+    if (VEC) {
+        z = *reinterpret_cast<const f32x4*>(base + rc * ld + col0 + (c < width ? c : 0));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = base[rc * ld + col0 + (c + i < width ? c + i : 0)];
+    }
+    return z;
+}
+template <bool VEC>
+__device__ __forceinline__ f32x4 mask4(f32x4 z, bool rok, int c, int width) {
+    if (VEC) {
+        if (!(rok && c < width)) z = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!(rok && c + i < width)) z[i] = 0.f;
+    }
+    return z;
+}
+
 __device__ __forceinline__ float sigmoidf(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
@@ -223,10 +248,8 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
                     zok[tile][reg] = yy < y_limit;
                     zrow[tile][reg] = mrow(zok[tile][reg] ? yy : Y - 1);
                     if (MODE == 1) {
-                        float c = cinv[zrow[tile][reg] * H + h], dl = delta[zrow[tile][reg] * H + h];
-                        asm volatile("" : "+v"(c), "+v"(dl));
-                        cy[tile][reg] = zok[tile][reg] ? c : 0.f;
-                        dy[tile][reg] = zok[tile][reg] ? dl : 0.f;
+                        cy[tile][reg] = cinv[zrow[tile][reg] * H + h] * (zok[tile][reg] ? 1.0f : 0.0f);
+                        dy[tile][reg] = delta[zrow[tile][reg] * H + h] * (zok[tile][reg] ? 1.0f : 0.0f);
                     }
                 }
             // weights: lane holds T^T[swept row 16 tile + 4 lg + reg][stationary row l15]
@@ -259,15 +282,12 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
                 for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        // (the empty asm pins the load where it is: left alone, the compiler sinks each one into its own
-                        //  `if (ok)` block -- a branch and a full memory latency per element)
-                        float a = y1[zrow[tile][reg] * ldy1 + h * M + (col < M ? col : 0)];
-                        asm volatile("" : "+v"(a));
-                        z1[tile][reg] = (zok[tile][reg] && col < M) ? a : 0.f;
+                        // (masked by multiplication: see the fp32 sweep below)
+                        const float a = y1[zrow[tile][reg] * ldy1 + h * M + (col < M ? col : 0)];
+                        z1[tile][reg] = a * ((zok[tile][reg] && col < M) ? 1.0f : 0.0f);
                         if (MODE == 1) {
-                            float b = y2[zrow[tile][reg] * ldy2 + h * D + (col < D ? col : 0)];
-                            asm volatile("" : "+v"(b));
-                            z2[tile][reg] = (zok[tile][reg] && col < D) ? b : 0.f;
+                            const float b = y2[zrow[tile][reg] * ldy2 + h * D + (col < D ? col : 0)];
+                            z2[tile][reg] = b * ((zok[tile][reg] && col < D) ? 1.0f : 0.0f);
                         }
                     }
                 bf16x8 zh, zl;
@@ -281,84 +301,120 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
                 }
             }
         }
-    } else
-    for (int64_t yt = t0 + wave; yt < t1; yt += kWaves) {
-        const int64_t ybase = yt * 16;
-        // ---- swept fragments (A operands of the two score products): row = ybase + l15 ----
-        const int64_t yr = ybase + l15;
-        const bool yok = yr < Y;
-        const int64_t yrc = mrow(yok ? yr : Y - 1);
-        f32x4 ya1[4], ya2[4];
+    } else {
+        // fp32 chain, software-pipelined (round 5).  Until then a step was loads -> wait -> products, the 16-32 transposed scalar
+        // reads each in its own exec-masked block (the compiler sinks a load under the select that masks it) or, pinned, each
+        // waiting for itself: ~14,500 cycles per step per SIMD against 4,100 of MFMA.  Now every operand of the NEXT step is in
+        // flight under this step's products: raw loads from clamped (valid) addresses, issued unconditionally (the last step
+        // re-reads its own rows), masked only when used.  The registers for that come from the stationary fragments, which are
+        // the same for the 8 waves: parked in LDS (16 KiB at the head of the fold buffer, free until the sweep ends) as B operands
+        // [x1 | x2][t][c][lane], re-read per step behind a compiler barrier.
+        f32x4* sm_x = reinterpret_cast<f32x4*>(&sm_o[0][0]);
+        if (wave == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            ya1[c] = ld4<VEC>(y1, ldy1, yrc, yok, h * M, 16 * c + 4 * lg, M);
-            ya2[c] = ld4<VEC>(y2, ldy2, yrc, yok, h * D, 16 * c + 4 * lg, D);
+            for (int t = 0; t < kXT; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sm_x[((0 * kXT + t) * 4 + c) * 64 + lane] = xs1[t][c];
+                    sm_x[((1 * kXT + t) * 4 + c) * 64 + lane] = xs2[t][c];
+                }
         }
-        f32x4 s[kXT], r[kXT];
+        __syncthreads();
+        // Two half-step prefetches into the registers their predecessors just left (no second register set): the row fragments
+        // of the next step are issued after this step's score products, the transposed scalars after its second contraction.
+        f32x4 ya1n[4], ya2n[4];
+        float z1n[4][4], z2n[4][4], cyn[4], dyn[4];
+        auto prefetch_rows = [&](int64_t ybase) {
+            const int64_t yr = ybase + l15;
+            const int64_t yrc = mrow(yr < Y ? yr : Y - 1);
 #pragma unroll
-        for (int t = 0; t < kXT; ++t) s[t] = r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < 4; ++c) {
+                ya1n[c] = ld4_raw<VEC>(y1, ldy1, yrc, h * M, 16 * c + 4 * lg, M);
+                ya2n[c] = ld4_raw<VEC>(y2, ldy2, yrc, h * D, 16 * c + 4 * lg, D);
+            }
+        };
+        auto prefetch_cols = [&](int64_t ybase) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t yy = ybase + 4 * lg + reg;
+                const int64_t yc = mrow(yy < Y ? yy : Y - 1);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int col = 16 * ct + l15;
+                    z1n[ct][reg] = y1[yc * ldy1 + h * M + (col < M ? col : 0)];
+                    if (MODE == 1) z2n[ct][reg] = y2[yc * ldy2 + h * D + (col < D ? col : 0)];
+                }
+                if (MODE == 1) {
+                    cyn[reg] = cinv[yc * H + h];
+                    dyn[reg] = delta[yc * H + h];
+                }
+            }
+        };
+        if (t0 + wave < t1) {
+            prefetch_rows((t0 + wave) * 16);
+            prefetch_cols((t0 + wave) * 16);
+        }
+        for (int64_t yt = t0 + wave; yt < t1; yt += kWaves) {
+            const int64_t ybase = yt * 16;
+            const int64_t ynext = ((yt + kWaves < t1) ? yt + kWaves : yt) * 16;
+            asm volatile("" ::: "memory");           // the LDS operands are re-read per step, not hoisted into registers
+            f32x4 s[kXT], r[kXT];
+#pragma unroll
+            for (int t = 0; t < kXT; ++t) s[t] = r[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 ya1 = mask4<VEC>(ya1n[c], ybase + l15 < Y, 16 * c + 4 * lg, M);
+                const f32x4 ya2 = mask4<VEC>(ya2n[c], ybase + l15 < Y, 16 * c + 4 * lg, D);
+                f32x4 b1[kXT], b2[kXT];
 #pragma unroll
                 for (int t = 0; t < kXT; ++t) {
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya1[c][u], xs1[t][c][u], s[t], 0, 0, 0);      // q . k
-                    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya2[c][u], xs2[t][c][u], r[t], 0, 0, 0);      // g . v
+                    b1[t] = sm_x[((0 * kXT + t) * 4 + c) * 64 + lane];
+                    b2[t] = sm_x[((1 * kXT + t) * 4 + c) * 64 + lane];
                 }
-        // ---- second-contraction A operands: A[i = l15 <-> column][k = swept row 4 lg + reg] ----
-        float zf1[4][4], zf2[4][4];              // [column tile][reg]
-        float cy[4], dy[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t yy = ybase + 4 * lg + reg;
-            const bool ok = yy < Y;
-            const int64_t yc = mrow(ok ? yy : Y - 1);
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const int col = 16 * ct + l15;
-                // dQ^T += K^T dS (MODE 0: y1 = k)   |   dK^T += Q^T dS (MODE 1: y1 = q)
-                // (the empty asm pins each load: left alone the compiler sinks it into its own `if (ok)` block -- a branch and
-                //  a full memory latency per element, 30+ basic blocks per step)
-                float a = y1[yc * ldy1 + h * M + (col < M ? col : 0)];
-                asm volatile("" : "+v"(a));
-                zf1[ct][reg] = (ok && col < M) ? a : 0.f;
-                if (MODE == 1) {                 // dV^T += G^T (c P)   (y2 = g)
-                    float b = y2[yc * ldy2 + h * D + (col < D ? col : 0)];
-                    asm volatile("" : "+v"(b));
-                    zf2[ct][reg] = (ok && col < D) ? b : 0.f;
+                    for (int t = 0; t < kXT; ++t) {
+                        s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya1[u], b1[t][u], s[t], 0, 0, 0);      // q . k
+                        r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya2[u], b2[t][u], r[t], 0, 0, 0);      // g . v
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch_rows(ynext);                    // into the registers the score products just left
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- weights: lane holds T^T[swept row 4 lg + reg][stationary row l15] ----
+            f32x4 ds[kXT], pc[kXT];
+#pragma unroll
+            for (int t = 0; t < kXT; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const bool ok = ybase + 4 * lg + reg < Y;
+                    const float p = ok ? sigmoidf(s[t][reg]) : 0.f;
+                    const float c = (MODE == 0) ? cx[t] : (ok ? cyn[reg] : 0.f);      // per-query scalars ride with the swept row
+                    const float dl = (MODE == 0) ? dx[t] : (ok ? dyn[reg] : 0.f);
+                    pc[t][reg] = p * c;
+                    ds[t][reg] = pc[t][reg] * (r[t][reg] - dl) * (1.0f - p);
                 }
-            }
-            if (MODE == 1) {                     // per-query scalars ride with the swept row
-                float c = cinv[yc * H + h], dl = delta[yc * H + h];
-                asm volatile("" : "+v"(c), "+v"(dl));
-                cy[reg] = ok ? c : 0.f;
-                dy[reg] = ok ? dl : 0.f;
-            }
-        }
-        // ---- weights: lane holds T^T[swept row 4 lg + reg][stationary row l15] ----
-        f32x4 ds[kXT], pc[kXT];
-#pragma unroll
-        for (int t = 0; t < kXT; ++t)
+            // ---- second contraction: A[i = l15 <-> column][k = swept row 4 lg + reg], masked out of the prefetch registers ----
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const bool ok = ybase + 4 * lg + reg < Y;
-                const float p = ok ? sigmoidf(s[t][reg]) : 0.f;
-                const float c = (MODE == 0) ? cx[t] : cy[reg];
-                const float dl = (MODE == 0) ? dx[t] : dy[reg];
-                pc[t][reg] = p * c;
-                ds[t][reg] = pc[t][reg] * (r[t][reg] - dl) * (1.0f - p);
-            }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int col = 16 * ct + l15;
+                    const float zf1 = (ok && col < M) ? z1n[ct][reg] : 0.f;       // dQ^T += K^T dS (MODE 0: y1 = k) | dK^T += Q^T dS (MODE 1: y1 = q)
+                    const float zf2 = (MODE == 1 && ok && col < D) ? z2n[ct][reg] : 0.f;      // dV^T += G^T (c P)   (y2 = g)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int t = 0; t < kXT; ++t) {
-                    acc1[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf1[ct][reg], ds[t][reg], acc1[t][ct], 0, 0, 0);
-                    if (MODE == 1)
-                        acc2[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf2[ct][reg], pc[t][reg], acc2[t][ct], 0, 0, 0);
+                    for (int t = 0; t < kXT; ++t) {
+                        acc1[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf1, ds[t][reg], acc1[t][ct], 0, 0, 0);
+                        if (MODE == 1) acc2[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf2, pc[t][reg], acc2[t][ct], 0, 0, 0);
+                    }
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch_cols(ynext);                    // into the registers the second contraction just left
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // fold the 8 waves through LDS; lane holds O^T[col = 16 ct + 4 lg + reg][row = 16 t + l15] -> stored as [row][col]
@@ -382,7 +438,7 @@ __global__ __launch_bounds__(512) void sigmoid_bwd_kernel(const float* __restric
         }
         __syncthreads();
     };
-    if constexpr (SPLIT) __syncthreads();          // every wave is done with the operands parked in the fold buffer
+    __syncthreads();                               // every wave is done with the operands parked in the fold buffer
     fold_store(acc1, M, o1, ldo1, part1);
     if (MODE == 1) fold_store(acc2, D, o2, ldo2, part2);
 }
