@@ -372,19 +372,29 @@ __global__ __launch_bounds__(64 * kRsWaves) void rowgemm_split_kernel(const floa
                                                                       const float* __restrict__ beta_dev, int64_t n_rows, int K, int C,
                                                                       float* __restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) rg_bf16x8 sm_frag[];          // [hi | lo][ft < 8][kb < 4][lane]
+    __shared__ __attribute__((aligned(16))) float sm_bias[128], sm_u[128];       // per-column epilogue operands (zero when absent)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
+    for (int i = threadIdx.x; i < 128; i += 64 * kRsWaves) {
+        sm_bias[i] = (bias && i < C) ? bias[i] : 0.f;
+        sm_u[i] = (r && i < C) ? u[i] : 0.f;
+    }
     for (int e = threadIdx.x; e < 8 * 4 * 64; e += 64 * kRsWaves) {
         const int ln = e & 63, kb = (e >> 6) & 3, ft = e >> 8;
         const int c = 16 * ft + (ln & 15), k0 = 32 * kb + 4 * (ln >> 4);
-        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-        if (c < C) {
+        // (eight raw loads from clamped indices in flight, masked afterwards: guarded, each was a serialised round trip)
+        f32x4 w0, w1;
+        const int cc = c < C ? c : C - 1;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ka = k0 + t, kc = k0 + 16 + t;
-                if (ka < K) w0[t] = mat_scale * (mat_t ? Mat[static_cast<int64_t>(c) * ldm + ka] : Mat[static_cast<int64_t>(ka) * ldm + c]);
-                if (kc < K) w1[t] = mat_scale * (mat_t ? Mat[static_cast<int64_t>(c) * ldm + kc] : Mat[static_cast<int64_t>(kc) * ldm + c]);
-            }
+        for (int t = 0; t < 4; ++t) {
+            const int ka = (k0 + t < K) ? k0 + t : K - 1, kc = (k0 + 16 + t < K) ? k0 + 16 + t : K - 1;
+            w0[t] = mat_t ? Mat[static_cast<int64_t>(cc) * ldm + ka] : Mat[static_cast<int64_t>(ka) * ldm + cc];
+            w1[t] = mat_t ? Mat[static_cast<int64_t>(cc) * ldm + kc] : Mat[static_cast<int64_t>(kc) * ldm + cc];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            w0[t] = (c < C && k0 + t < K) ? mat_scale * w0[t] : 0.f;
+            w1[t] = (c < C && k0 + 16 + t < K) ? mat_scale * w1[t] : 0.f;
         }
         const rg_bf16x4 h0 = __builtin_convertvector(w0, rg_bf16x4), h1 = __builtin_convertvector(w1, rg_bf16x4);
         const rg_bf16x4 l0 = __builtin_convertvector(w0 - __builtin_convertvector(h0, f32x4), rg_bf16x4);
@@ -397,29 +407,49 @@ __global__ __launch_bounds__(64 * kRsWaves) void rowgemm_split_kernel(const floa
     const int64_t n_steps = (n_rows + 15) / 16;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * kRsWaves + wave;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kRsWaves;
+    // Every global operand of a tile is requested a tile ahead (A) or before the tile's products (the accumulated-into rows,
+    // the row scalar), as RAW loads from clamped (valid) addresses that are masked only when used: a guarded load is its own
+    // exec-masked block and a masked one waits for its data where it is issued -- the first version of this kernel had 8 + 24
+    // such blocks per tile, each epilogue operand a serialised round trip.
     auto load_a = [&](f32x4 (&av)[8], int64_t st) {
         const int64_t row = st * 16 + l15;
+        const float* base = A + (row < n_rows ? row : n_rows - 1) * lda;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int k0 = 16 * c + 4 * lg;
-            av[c] = (row < n_rows && k0 < K) ? *reinterpret_cast<const f32x4*>(A + row * lda + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            av[c] = *reinterpret_cast<const f32x4*>(base + (k0 < K ? k0 : 0));
         }
     };
     f32x4 an[8];
-    if (first < n_steps) load_a(an, first);
+    load_a(an, first < n_steps ? first : n_steps - 1);
     for (int64_t st = first; st < n_steps; st += stride) {
         const int64_t row = st * 16 + l15;
+        const bool row_ok = row < n_rows;
+        const int64_t rowc = row_ok ? row : n_rows - 1;
         rg_bf16x8 xh[4], xl[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const f32x4 a0 = an[2 * kb], a1 = an[2 * kb + 1];
+            f32x4 a0 = an[2 * kb], a1 = an[2 * kb + 1];
+            if (!(row_ok && 32 * kb + 4 * lg < K)) a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(row_ok && 32 * kb + 16 + 4 * lg < K)) a1 = f32x4{0.f, 0.f, 0.f, 0.f};
             const rg_bf16x4 h0 = __builtin_convertvector(a0, rg_bf16x4), h1 = __builtin_convertvector(a1, rg_bf16x4);
             const rg_bf16x4 l0 = __builtin_convertvector(a0 - __builtin_convertvector(h0, f32x4), rg_bf16x4);
             const rg_bf16x4 l1 = __builtin_convertvector(a1 - __builtin_convertvector(h1, f32x4), rg_bf16x4);
             xh[kb] = rg_bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
             xl[kb] = rg_bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         }
-        if (st + stride < n_steps) load_a(an, st + stride);                  // the next rows arrive under this tile's products
+        load_a(an, st + stride < n_steps ? st + stride : st);               // the next rows arrive under this tile's products
+        f32x4 cin[8];
+        float rv = 0.f;
+        if (Cin) {
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft) {
+                const int c0 = 16 * ft + 4 * lg;
+                cin[ft] = *reinterpret_cast<const f32x4*>(Cin + rowc * ldc + (c0 < C ? c0 : 0));
+            }
+        }
+        if (r) rv = r[rowc];
+        __builtin_amdgcn_sched_barrier(0);   // requested HERE, ahead of the products
         asm volatile("" ::: "memory");       // the 64 weight fragments are re-read from LDS per tile (hoisted they would need 256 VGPRs)
         f32x4 acc[8];
 #pragma unroll
@@ -433,17 +463,13 @@ __global__ __launch_bounds__(64 * kRsWaves) void rowgemm_split_kernel(const floa
                 acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[kb], acc[ft], 0, 0, 0);
                 acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[kb], acc[ft], 0, 0, 0);
             }
-        if (row >= n_rows) continue;
-        const float rv = r ? r[row] * u_scale : 0.f;
+        rv *= u_scale;
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             const int c0 = 16 * ft + 4 * lg;                                 // the lane holds out^T[c0 .. c0 + 3][row]
-            if (c0 >= C) continue;
-            f32x4 o = acc[ft];
-            if (bias) o += *reinterpret_cast<const f32x4*>(bias + c0);
-            if (r) o += rv * *reinterpret_cast<const f32x4*>(u + c0);
-            if (Cin) o += beta * *reinterpret_cast<const f32x4*>(Cin + row * ldc + c0);
-            *reinterpret_cast<f32x4*>(out + row * ldo + c0) = o;
+            f32x4 o = acc[ft] + *reinterpret_cast<const f32x4*>(&sm_bias[c0]) + rv * *reinterpret_cast<const f32x4*>(&sm_u[c0]);
+            if (Cin) o += beta * cin[ft];
+            if (row_ok && c0 < C) *reinterpret_cast<f32x4*>(out + row * ldo + c0) = o;
         }
     }
 }
