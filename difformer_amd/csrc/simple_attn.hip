@@ -11,6 +11,7 @@
 // no LDS transpose is needed.  HBM-bound: 4*N*H*D*4 bytes per layer.
 #include <type_traits>
 #include "dif_common.h"
+#include "rowgemm_split.h"
 
 namespace {
 
@@ -560,6 +561,18 @@ int simple_apply_entry(const T* q, int64_t ldq, const float* reduced, int64_t n_
                      dif::aligned_v4<T>(out) && dif::aligned16(reduced) && ((H * M * D + H * M) % 4 == 0);
     const bool single = (sh.MT == 1 && sh.DT == 1);
     const int64_t n_steps = (n_rows + 15) / 16;
+    if constexpr (std::is_same<T, float>::value) {
+        // one head of 65..128 columns on >= 4,096 rows (the scripts' hidden 128): the row-GEMM kernel on split-bfloat16 operands in
+        // its APPLY mode -- q read once for all output columns, 96 bf16 MFMAs per 16 rows instead of 2 x 128 fp32 ones
+        // (csrc/rowgemm_split.h; ~4e-6 of the float64 result).  DIFFORMER_EXACT_FP32=1 keeps the fp32 kernel below.
+        if (H == 1 && !single && M <= 128 && D <= 128 && vec && n_rows >= 4096 && !dif::exact_fp32()) {
+            const float* ksum = reduced + static_cast<int64_t>(M) * D;
+            const float* vsum = ksum + M;
+            return rowgemm_split_launch("dif_simple_apply_f32", static_cast<hipStream_t>(stream), q, ldq, reduced, D, 0, 1.0f, vsum, nullptr,
+                                        nullptr, 0.f, nullptr, 0, nullptr, n_rows, M, D, out, ldo, reduced + sh.t_main, ksum,
+                                        static_cast<float>(n_global));
+        }
+    }
     if (!single && sh.MT <= 8) {              // wide heads: 64 output columns per workgroup, s * KtV^T resident in LDS
         const size_t lds = (static_cast<size_t>(kTile) * (sh.MT * kTile + 4) + sh.MT * kTile) * sizeof(float);
         int64_t gxw = (n_steps + 2 * kWideWaves - 1) / (2 * kWideWaves);       // >= 2 steps per wave: the staging is amortised
