@@ -1717,6 +1717,35 @@ def test_simple_apply_wide_heads(n, h, m, d, bf16, dev):
     assert rel_err(out, num / den[..., None]) < (2e-2 if bf16 else TOL)
 
 
+@pytest.mark.parametrize("n,m,d", [(6000, 128, 128), (4100, 96, 72), (5003, 68, 128), (4096, 128, 100), (20000, 72, 68)])
+def test_simple_apply_on_the_split_row_gemm_kernel(n, m, d, dev):
+    """Stage 2 at ONE head of 65..128 columns on >= 4,096 rows (run.sh's hidden 128): rowgemm_split_kernel in its apply mode --
+    K^T V and sum k scaled on the device by the record's norms, sum v as the bias, the division by q . sum k + N per row -- on
+    split-bfloat16 operands; ops.set_exact_fp32 puts the call back on simple_apply_wide_kernel.  Both against float64; ragged
+    row counts and M != D included."""
+    from difformer_amd import ops
+    g = torch.Generator().manual_seed(n + m + d)
+    q, k = (torch.randn(n, 1, m, generator=g) for _ in range(2))
+    v = torch.randn(n, 1, d, generator=g)
+    be = ops.get_backend()
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    rec = be.simple_reduce(qd, kd, vd)
+    q64, k64, v64 = (t.double().numpy() for t in (q, k, v))
+    s = 1.0 / (np.linalg.norm(q64) * np.linalg.norm(k64))
+    num = s * np.einsum("nhm,hmd->nhd", q64, np.einsum("lhm,lhd->hmd", k64, v64)) + v64.sum(0)
+    den = s * np.einsum("nhm,hm->nh", q64, k64.sum(0)) + n
+    want = num / den[..., None]
+    errs, outs = {}, {}
+    try:
+        for exact in (False, True):
+            ops.set_exact_fp32(exact)
+            outs[exact] = be.simple_apply(qd, rec, n, d)
+            errs[exact] = rel_err(outs[exact].cpu().numpy(), want)
+    finally:
+        ops.set_exact_fp32(False)
+    assert errs[True] < 5e-6 and errs[False] < 2e-5 and not torch.equal(outs[True], outs[False]), errs
+
+
 # ------------------------------------------------------------------ repeated inference forwards replay as one hipGraph
 def test_repeated_inference_forwards_are_captured_and_stay_correct(dev):
     """DIFFormer.forward: the third consecutive eval / no_grad call with the same operands captures the forward as a hipGraph;
