@@ -91,12 +91,20 @@ __host__ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return static_cast<uint16_t>(c.u >> 16);
 }
 
+// A pointer the compiler could not prove global (computed from loaded indices inside a loop, rebuilt from an integer, read out of
+// a struct argument) is dereferenced with FLAT instructions: slower, and they count on the LDS counter too.  Every tensor this
+// library touches is device-global memory: say so where it matters.
+#define DIF_GLOBAL __attribute__((address_space(1)))
+template <typename U>
+__device__ __forceinline__ const U DIF_GLOBAL* as_global(const U* p) { return (const U DIF_GLOBAL*)p; }
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kBytes = 4;
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
     static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ f32x4 ld4g(const float* p) { return *as_global(reinterpret_cast<const f32x4*>(p)); }   // global_load, whatever the compiler knows
     static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
     // four elements from an address that is only ELEMENT-aligned (rows of 65 or 1,433 columns): still one global_load_dwordx4
     // (the target runs in unaligned access mode; the type's alignment tells the compiler not to assume more)
@@ -107,12 +115,20 @@ template <> struct Elem<bf16> {
     static constexpr int kBytes = 2;
     static __device__ __forceinline__ float ld(const bf16* p) { return bf16_to_f32(p->bits); }
     static __device__ __forceinline__ void st(bf16* p, float v) { p->bits = f32_to_bf16(v); }
+    static __device__ __forceinline__ f32x4 unpack4(uint32_t x, uint32_t y) {
+        f32x4 v;
+        v[0] = bf16_to_f32(static_cast<uint16_t>(x & 0xffffu)); v[1] = bf16_to_f32(static_cast<uint16_t>(x >> 16));
+        v[2] = bf16_to_f32(static_cast<uint16_t>(y & 0xffffu)); v[3] = bf16_to_f32(static_cast<uint16_t>(y >> 16));
+        return v;
+    }
     static __device__ __forceinline__ f32x4 ld4(const bf16* p) {       // one 8-byte load
         const uint2 r = *reinterpret_cast<const uint2*>(p);
-        f32x4 v;
-        v[0] = bf16_to_f32(static_cast<uint16_t>(r.x & 0xffffu)); v[1] = bf16_to_f32(static_cast<uint16_t>(r.x >> 16));
-        v[2] = bf16_to_f32(static_cast<uint16_t>(r.y & 0xffffu)); v[3] = bf16_to_f32(static_cast<uint16_t>(r.y >> 16));
-        return v;
+        return unpack4(r.x, r.y);
+    }
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f32x4 ld4g(const bf16* p) {      // ... as a global_load, whatever the compiler knows
+        const u32x2 r = *as_global(reinterpret_cast<const u32x2*>(p));
+        return unpack4(r[0], r[1]);
     }
     // four elements from an address that is only 2-byte aligned (rows of 65 bfloat16: every other row starts in the middle of a
     // dword).  A misaligned 8-byte load is split by the memory pipeline (skinny_linear_kernel<5, bf16>: 37 us against 26 us for
@@ -122,7 +138,7 @@ template <> struct Elem<bf16> {
     typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
     static __device__ __forceinline__ f32x4 ld4u(const bf16* p) {
         const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-        const u32x3a r = *reinterpret_cast<const u32x3a*>(a & ~static_cast<uintptr_t>(3));
+        const u32x3a r = *(const u32x3a DIF_GLOBAL*)(a & ~static_cast<uintptr_t>(3));        // (an address rebuilt from an integer: flat without the cast)
         const uint32_t sh = static_cast<uint32_t>(a & 2u) * 8u;           // 0 or 16 bits
         const uint32_t lo = __builtin_amdgcn_alignbit(r[1], r[0], sh);    // ({r1, r0} >> sh) & 0xffffffff
         const uint32_t hi = __builtin_amdgcn_alignbit(r[2], r[1], sh);

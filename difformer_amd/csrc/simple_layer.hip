@@ -706,12 +706,12 @@ __device__ __forceinline__ void load_rows(f32x4 (&xa)[4], const T* __restrict__ 
     if (!GUARD) {
         const T* p = x + r * ldx + 4 * lg;
 #pragma unroll
-        for (int cq = 0; cq < 4; ++cq) xa[cq] = Elem<T>::ld4(p + 16 * cq);
+        for (int cq = 0; cq < 4; ++cq) xa[cq] = Elem<T>::ld4g(p + 16 * cq);        // (ld4g: flat loads in the GATHER variants otherwise)
     } else {
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
             const int c = 16 * cq + 4 * lg;
-            xa[cq] = (r < n && c < C) ? Elem<T>::ld4(x + r * ldx + c) : zero4();
+            xa[cq] = (r < n && c < C) ? Elem<T>::ld4g(x + r * ldx + c) : zero4();
         }
     }
 }
@@ -763,8 +763,8 @@ __device__ __forceinline__ void gather_rows(f32x4 (&ga)[4], float& wsum, GatherC
         for (int cq = 0; cq < 4; ++cq) {
             const int c = 16 * cq + 4 * lg;
             const bool ok = EXACT || c < C;
-            r0[cq] = ok ? Elem<T>::ld4(p0 + c) : zero4();
-            r1[cq] = ok ? Elem<T>::ld4(p1 + c) : zero4();
+            r0[cq] = ok ? Elem<T>::ld4g(p0 + c) : zero4();        // (rows addressed through loaded indices: flat loads without the hint)
+            r1[cq] = ok ? Elem<T>::ld4g(p1 + c) : zero4();
         }
         g.e += 2;
         gather_fetch(g, src, val);                 // next step's indices: in flight while this step's rows arrive
@@ -1029,7 +1029,7 @@ void simple_layer_kernel(LayerArgsT<T> a) {
             for (int ft = 0; ft < 4; ++ft) {
                 const int f = 16 * ft + 4 * lg;
                 if (row_ok && (EXACT || f < D)) {
-                    if (EXACT || ((a.ldx0 & 3) == 0 && f + 3 < D)) y[ft] += Elem<T>::ld4(a.x0 + row * a.ldx0 + f);
+                    if (EXACT || ((a.ldx0 & 3) == 0 && f + 3 < D)) y[ft] += Elem<T>::ld4g(a.x0 + row * a.ldx0 + f);
                     else
                         for (int r = 0; r < 4; ++r) if (f + r < D) y[ft][r] += Elem<T>::ld(a.x0 + row * a.ldx0 + f + r);
                 }

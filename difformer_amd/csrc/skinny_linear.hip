@@ -813,31 +813,59 @@ __global__ __launch_bounds__(256) void skinny_linear_bf16_kernel(const dif::bf16
     const float inv_c = 1.0f / static_cast<float>(C_out);
     const int64_t n_tiles = (n_rows + 15) / 16;
 
-    auto load_x = [&](int64_t tile, u32x4v (&xa)[KB]) {
+    // Rows are 2-byte aligned at best (F_in = 65: 130-byte rows): a lane's eight channels come as five aligned dwords, shifted
+    // into place.  Full tiles (every tile but the last: its 16 rows and the row after them exist, so 20 bytes from any of their
+    // channels stay inside the tensor) are fetched RAW a tile ahead and assembled -- shifted, masked beyond C_in -- only when
+    // used; the last tile takes the element-wise path.  (Assembled at issue time, and the ragged channel block element-wise on
+    // every tile, each load waited for itself: 53 of the kernel's 58 loads were serialised round trips.)
+    typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+    struct Raw { u32x4a lo; uint32_t hi; };
+    const bool fast_ok = ldx >= 9 && n_tiles > 1;
+    u32x4v cmask[KB];                           // channels of this lane that exist, per k-block
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int nv = C_in - (32 * kb + 8 * lg);           // valid channels among the lane's eight
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cmask[kb][i] = nv >= 2 * i + 2 ? 0xffffffffu : (nv == 2 * i + 1 ? 0x0000ffffu : 0u);
+    }
+    // dword view of x by pointer arithmetic only (an integer round trip of the address loses the address space: flat loads)
+    const int64_t xoff = static_cast<int64_t>((reinterpret_cast<uintptr_t>(x) >> 1) & 1u);          // x starts xoff elements into a dword
+    const uint32_t* xw = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(x) - 2 * xoff);
+    auto fetch_raw = [&](int64_t tile, Raw (&rw)[KB]) {     // tile < n_tiles - 1
         const int64_t r = tile * 16 + l15;
-        const bool careful = tile == n_tiles - 1;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int c = 32 * kb + 8 * lg;
+            const uint32_t* q = xw + ((r * ldx + (c < C_in ? c : 0) + xoff) >> 1);
+            rw[kb].lo = *reinterpret_cast<const u32x4a*>(q);
+            rw[kb].hi = q[4];
+        }
+    };
+    auto assemble = [&](int64_t tile, const Raw (&rw)[KB], u32x4v (&xa)[KB]) {
+        const int64_t r = tile * 16 + l15;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int c = 32 * kb + 8 * lg;
+            const uint32_t sh = static_cast<uint32_t>((r * ldx + (c < C_in ? c : 0) + xoff) & 1) * 16u;
+            u32x4v z;
+            z[0] = __builtin_amdgcn_alignbit(rw[kb].lo[1], rw[kb].lo[0], sh);
+            z[1] = __builtin_amdgcn_alignbit(rw[kb].lo[2], rw[kb].lo[1], sh);
+            z[2] = __builtin_amdgcn_alignbit(rw[kb].lo[3], rw[kb].lo[2], sh);
+            z[3] = __builtin_amdgcn_alignbit(rw[kb].hi, rw[kb].lo[3], sh);
+            xa[kb] = z & cmask[kb];
+        }
+    };
+    auto load_careful = [&](int64_t tile, u32x4v (&xa)[KB]) {                // the last tile: element by element
+        const int64_t r = tile * 16 + l15;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             u32x4v z = {0u, 0u, 0u, 0u};
             const int c = 32 * kb + 8 * lg;
             if (r < n_rows && c < C_in) {
                 const B* p = x + r * ldx + c;
-                if (c + 7 < C_in && !careful) {
-                    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-                    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~static_cast<uintptr_t>(3));
-                    typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
-                    const u32x4a lo = *reinterpret_cast<const u32x4a*>(q);
-                    const uint32_t hi = q[4];
-                    const uint32_t sh = static_cast<uint32_t>(a & 2u) * 8u;
-                    z[0] = __builtin_amdgcn_alignbit(lo[1], lo[0], sh);
-                    z[1] = __builtin_amdgcn_alignbit(lo[2], lo[1], sh);
-                    z[2] = __builtin_amdgcn_alignbit(lo[3], lo[2], sh);
-                    z[3] = __builtin_amdgcn_alignbit(hi, lo[3], sh);
-                } else {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (c + i < C_in) z[i >> 1] |= static_cast<uint32_t>(p[i].bits) << (16 * (i & 1));
-                }
+                for (int i = 0; i < 8; ++i)
+                    if (c + i < C_in) z[i >> 1] |= static_cast<uint32_t>(p[i].bits) << (16 * (i & 1));
             }
             xa[kb] = z;
         }
@@ -845,11 +873,19 @@ __global__ __launch_bounds__(256) void skinny_linear_bf16_kernel(const dif::bf16
 
     const int64_t first = static_cast<int64_t>(blockIdx.x) * 4 + wave;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
-    u32x4v xa[KB], xn[KB];
-    if (first < n_tiles) load_x(first, xa);
+    const int64_t last_fast = n_tiles - 2;                                  // only meaningful with fast_ok
+    Raw rw[KB];
+    if (fast_ok) fetch_raw(first <= last_fast ? first : last_fast, rw);
     const bf16x8v* wfrag = reinterpret_cast<const bf16x8v*>(sm_w);
     for (int64_t tile = first; tile < n_tiles; tile += stride) {
-        if (tile + stride < n_tiles) load_x(tile + stride, xn);
+        u32x4v xa[KB];
+        if (fast_ok && tile <= last_fast) assemble(tile, rw, xa);
+        else load_careful(tile, xa);
+        if (fast_ok) {
+            const int64_t nxt = tile + stride;
+            fetch_raw(nxt <= last_fast ? nxt : (tile <= last_fast ? tile : last_fast), rw);     // unconditional: no wait where it is issued
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const f32x4 bv = *reinterpret_cast<const f32x4*>(sm_b + 4 * l15);
         f32x4 y[4];
 #pragma unroll
@@ -862,8 +898,6 @@ __global__ __launch_bounds__(256) void skinny_linear_bf16_kernel(const dif::bf16
                 y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wfrag[(kb * 4 + ft) * 64 + lane], y[ft], 0, 0, 0);
         }
         finish_tile<B>(y, tile * 16, 0, l15, lg, C_out, ln_w != nullptr, lw, lb, inv_c, eps, relu, out, ldo, n_rows, ovec);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) xa[kb] = xn[kb];
     }
 }
 
