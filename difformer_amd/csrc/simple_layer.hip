@@ -733,10 +733,12 @@ struct GatherCursor {
 };
 
 __device__ __forceinline__ void gather_fetch(GatherCursor& g, const int32_t* __restrict__ src, const float* __restrict__ val) {
+    // four INDEPENDENT loads: `two ? src[e + 1] : s0` made the second index wait for the first -- and, the memory counter being in
+    // order, for the eight row loads issued before it: the "prefetch" of the next step's indices ran after this step's rows arrived
     const bool one = g.e < g.e1, two = g.e + 1 < g.e1;
     g.s0 = one ? src[g.e] : 0;
     g.w0 = one ? val[g.e] : 0.f;
-    g.s1 = two ? src[g.e + 1] : g.s0;
+    g.s1 = one ? src[two ? g.e + 1 : g.e] : 0;          // an odd tail re-reads its own entry (weight 0)
     g.w1 = two ? val[g.e + 1] : 0.f;
 }
 
