@@ -609,3 +609,21 @@ def test_constant_edge_weights_build_the_unweighted_csr(fake_backend):
         assert np.abs(out.numpy() - ref).max() / np.abs(ref).max() < 1e-4
     request_finalizer()
     assert ops.csr_cache.get(ei, torch.full((ei.shape[1],), 2.0), n, 32).weighted    # 80 nodes: not worth the check by default
+
+
+def test_exact_fp32_switch_reaches_the_backend(fake_backend):
+    """ops.set_exact_fp32: returns the previous setting, moves the Python-side width threshold of the closed form and tells the
+    backend (whose launchers make the per-kernel choice: dif_set_exact_fp32) -- a backend without the hook is left alone."""
+    from difformer_amd import ops
+    seen = []
+    was = ops.set_exact_fp32(True)                       # the host test backend has no hook: nothing to call
+    try:
+        assert ops.EXACT_FP32 is True and ops.CLOSED_FORM_WIDE_MIN == 128
+        fake_backend.set_exact_fp32 = seen.append
+        assert ops.set_exact_fp32(False) is True and ops.EXACT_FP32 is False and ops.CLOSED_FORM_WIDE_MIN == 64
+        assert ops.set_exact_fp32(True) is False
+        assert seen == [False, True]
+    finally:
+        if hasattr(fake_backend, "set_exact_fp32"):
+            del fake_backend.set_exact_fp32
+        ops.set_exact_fp32(was)
