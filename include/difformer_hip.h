@@ -56,6 +56,9 @@ int dif_set_exact_fp32(int on);
  * Stage 2 (`apply`):  out[n,h,:] = (s*q[n,h,:]*KtV[h] + vsum[h]) / (s*q[n,h,:]*ksum[h] + n_global)
  * with s = 1/(sqrt(sum q*q)*sqrt(sum k*k)); n_global is N of difformer.py:22,38.
  * q,k are [n_rows,H,M], v and out [n_rows,H,D]; ld* = elements between consecutive rows.
+ * Products: float32, ONE head of 65..128 channels, >= 4,096 rows, 16-byte aligned rows: both stages contract on
+ * split-bfloat16 operands (hi + lo, bf16 matrix core; ~4e-6 of the float64 result); every other shape, and
+ * dif_set_exact_fp32(1), on the fp32 matrix core.
  * ------------------------------------------------------------------------------------- */
 size_t dif_simple_reduced_len(int H, int M, int D);
 size_t dif_simple_workspace_bytes(int64_t n_rows, int H, int M, int D);
@@ -87,6 +90,10 @@ int dif_project_reduce_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in
  *     out[n,h,:] = sum_l sigmoid(q[n,h,:].k[l,h,:]) v[l,h,:] / sum_l sigmoid(q[n,h,:].k[l,h,:])
  * q [N,H,M], k [L,H,M], v [L,H,D], out [N,H,D]; N may differ from L.  The [N,L,H] score
  * tensor is never materialised.
+ * Products: float32 heads of at most 64 channels with 16-byte aligned rows contract on split-bfloat16 operands
+ * (hi + lo, bf16 matrix core; ~7e-6 of the float64 result) in dif_sigmoid_attn_f32; dif_set_exact_fp32(1) keeps the
+ * fp32 matrix core.  dif_sigmoid_attn_fwd_f32 / dif_sigmoid_attn_bwd_f32 (training) always run the fp32 chain
+ * (DIFFORMER_SIGMOID_BWD_SPLIT=1 opts the backward in): gradients made of cancelling rows amplify the operands' error.
  * ------------------------------------------------------------------------------------- */
 size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M, int D);
 int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
