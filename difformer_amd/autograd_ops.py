@@ -3,7 +3,7 @@ keep working: the FORWARD of every operator is the HIP kernel; the BACKWARD of t
 attention, the aggregation (adjoint product on the same SpMM kernels), the layer tail (LayerNorm / residual /
 head mean) and the weight gradients of the Linear layers are HIP kernels too (SURVEY.md section 8f, row 3);
 the batched (v2) attentions too (simple: raw mode of the forward kernel; sigmoid: the sweep kernels per position group); only
-`simple` heads wider than 512 and `sigmoid` heads wider than 64 re-derive their gradient on the device with tensor ops.
+heads wider than 512 columns re-derive their gradient on the device with tensor ops.
 Under torch.no_grad() / eval these wrappers are pass-throughs to ops.py.  Nothing here touches the CPU.
 """
 from __future__ import annotations
@@ -128,8 +128,9 @@ class _SimpleAttention(torch.autograd.Function):
 
 
 class _SigmoidAttention(torch.autograd.Function):
-    """Forward and (fp32, M, D <= 64) backward on the HIP kernels: the forward leaves the row sums, the backward
-    recomputes sigma tile by tile (csrc/sigmoid_attn_bwd.hip).  Other shapes re-derive the gradient with tensor ops.
+    """Forward and (fp32, M, D <= 512) backward on the HIP kernels: the forward leaves the row sums, the backward
+    recomputes sigma tile by tile (csrc/sigmoid_attn_bwd.hip up to 64 columns, csrc/sigmoid_wide.hip beyond).  Other shapes
+    (bfloat16 storage, heads wider than 512) re-derive the gradient with tensor ops.
     Row-sharded: the key / value rows are all-gathered (queries stay local); their gradients are partial sums over the
     ranks' queries and come back as the sum over ranks of this rank's rows."""
 
@@ -139,8 +140,11 @@ class _SigmoidAttention(torch.autograd.Function):
         ctx.shard = shard = _sharded(shard)
         if shard is not None:
             k, v = shard.all_gather_rows(k), shard.all_gather_rows(v)
+        # heads up to 64 columns: the fp32 sweep kernels; 65 .. 512 (image and text/run.sh: hidden 300 / 400): the split-bfloat16
+        # plane kernels of csrc/sigmoid_wide.hip -- not under ops.set_exact_fp32(True), where wide heads keep the tensor-op gradient
+        width = max(q.shape[2], v.shape[2])
         ctx.hip = (q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32 and
-                   q.shape[2] <= 64 and v.shape[2] <= 64 and hasattr(be, "sigmoid_backward"))
+                   (width <= 64 or (width <= 512 and not ops.EXACT_FP32)) and hasattr(be, "sigmoid_backward"))
         if ctx.hip:
             out, den = be.sigmoid_attention(q, k, v, want_den=True)
             ctx.save_for_backward(q, k, v, out, den)

@@ -309,7 +309,8 @@ class HipBackend:
 
     def sigmoid_backward(self, q, k, v, out, den, g):
         """(dq, dk, dv) of the sigmoid kernel for fp32 q [N,H,M], k [L,H,M], v [L,H,D], out / g [N,H,D], den [N,H];
-        M, D <= 64 (csrc/sigmoid_attn_bwd.hip: sigma recomputed tile by tile, nothing of size N x L stored)."""
+        M, D <= 512 (csrc/sigmoid_attn_bwd.hip up to 64 columns, csrc/sigmoid_wide.hip beyond: sigma recomputed tile by tile,
+        nothing of size N x L stored)."""
         dev = _require_device(q, k, v, out, den, g)
         N, H, M = q.shape
         L, D = k.shape[0], v.shape[2]

@@ -13,6 +13,7 @@
 // Compute-bound on the f32 matrix pipe: 4*N*L*H*D FLOP.
 #include <type_traits>
 #include "dif_common.h"
+#include "sigmoid_wide.h"
 
 namespace {
 
@@ -414,6 +415,13 @@ int key_splits(int64_t N, int64_t L, int H, int D, bool split_kernel = false) {
 extern "C" size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M, int D) {
 
     if (N <= 0 || L <= 0 || H <= 0 || D <= 0) return 0;
+    if (dif::sigw_covers(M, D)) {                                    // heads of 65 .. 512 columns: csrc/sigmoid_wide.hip (packed planes + partial sums)
+        const size_t wide = dif::sigw_fwd_workspace_bytes(N, L, H, M, D);
+        const int S0 = key_splits(N, L, H, D);                       // ... or this file's kernel under dif_set_exact_fp32(1) / bfloat16 storage
+        const size_t DT0 = (D + kDTile - 1) / kDTile;
+        const size_t narrow = S0 == 1 ? 0 : static_cast<size_t>(S0) * N * H * (static_cast<size_t>(D) + DT0) * sizeof(float);
+        return wide > narrow ? wide : narrow;
+    }
     int S = key_splits(N, L, H, D);
     if (M <= 64) {                                                   // whichever kernel the exact-fp32 switch picks at launch
         const int S2 = key_splits(N, L, H, D, true);
@@ -441,6 +449,13 @@ int sigmoid_attn(const char* who, const T* q, int64_t ldq, const T* k, int64_t l
     // amplified in gradients that are sums of cancelling rows (Wk.bias of model/a_nobn_src: 2.0e-5 of itself against 4.3e-6
     // with the fp32 chain, the reference's own float32 run 3.7e-6; scripts/exp_sigmoid_grad_parity.py) -- training keeps fp32.
     // (aligned rows only: the scalar-load variant of the split kernel does not fit its hi / lo pairs and the prefetch in 256 VGPRs)
+    if constexpr (std::is_same<T, float>::value) {
+        // heads of 65 .. 512 columns (image and text/run.sh:17,35,54: hidden 300 / 400): every operand as split-bfloat16 planes, packed
+        // in MFMA fragment order, scores formed once per (query, key) pair for all D columns (csrc/sigmoid_wide.hip)
+        if (dif::sigw_covers(M, D) && !dif::exact_fp32())
+            return dif::sigw_fwd(q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, ldo, den, workspace, workspace_bytes,
+                                 static_cast<hipStream_t>(stream));
+    }
     const bool vec = (M % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && dif::aligned_v4<T>(q) && dif::aligned_v4<T>(k);
     const bool split_kernel = std::is_same<T, float>::value && M <= 64 && vec && !dif::exact_fp32() && den == nullptr;
     const int S = key_splits(N, L, H, D, split_kernel);

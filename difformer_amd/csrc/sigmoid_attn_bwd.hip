@@ -17,6 +17,7 @@
 // FLOPs: 14 N L H D against the forward's 4 N L H D.
 #include <stdlib.h>
 #include "dif_common.h"
+#include "sigmoid_wide.h"
 
 namespace {
 
@@ -477,6 +478,7 @@ size_t align16(size_t b) { return (b + 15) & ~size_t(15); }
 
 extern "C" size_t dif_sigmoid_bwd_workspace_bytes(int64_t N, int64_t L, int H, int M, int D) {
     if (N <= 0 || L <= 0 || H <= 0 || M <= 0 || D <= 0) return 0;
+    if (dif::sigw_covers(M, D)) return dif::sigw_bwd_workspace_bytes(N, L, H, M, D);
     const size_t S0 = sweep_splits(N, L, H), S1 = sweep_splits(L, N, H);
     size_t b = 2 * align16(static_cast<size_t>(N) * H * sizeof(float));                        // cinv, delta
     if (S0 > 1) b += align16(S0 * N * H * M * sizeof(float));
@@ -490,11 +492,18 @@ extern "C" int dif_sigmoid_attn_bwd_f32(const float* q, int64_t ldq, const float
                                         float* dk, int64_t lddk, float* dv, int64_t lddv, void* workspace,
                                         size_t workspace_bytes, dif_stream_t stream) {
     DIF_REQUIRE(N > 0 && L > 0 && H > 0 && M > 0 && D > 0, DIF_E_BADARG, "dif_sigmoid_attn_bwd_f32: sizes must be positive");
-    DIF_REQUIRE(M <= kCols && D <= kCols, DIF_E_SHAPE, "dif_sigmoid_attn_bwd_f32: covers M, D <= 64 (got %d, %d)", M, D);
+    const bool wide = dif::sigw_covers(M, D);
+    DIF_REQUIRE((M <= kCols && D <= kCols) || wide, DIF_E_SHAPE, "dif_sigmoid_attn_bwd_f32: covers M, D <= 512 (got %d, %d)", M, D);
+    DIF_REQUIRE(!(wide && dif::exact_fp32()), DIF_E_SHAPE,
+                "dif_sigmoid_attn_bwd_f32: heads wider than 64 columns run on split-bfloat16 planes; under dif_set_exact_fp32(1) the "
+                "fp32 chain covers M, D <= 64 (got %d, %d)", M, D);
     DIF_REQUIRE(q && k && v && out && den && g && dq && dk && dv && workspace, DIF_E_BADARG,
                 "dif_sigmoid_attn_bwd_f32: null pointer");
     DIF_REQUIRE(ldq >= H * M && ldk >= H * M && ldv >= H * D && ldo >= H * D && ldg >= H * D && lddq >= H * M &&
                     lddk >= H * M && lddv >= H * D, DIF_E_BADARG, "dif_sigmoid_attn_bwd_f32: leading dimension smaller than a row");
+    if (wide)
+        return dif::sigw_bwd(q, ldq, k, ldk, v, ldv, out, ldo, den, g, ldg, N, L, H, M, D, dq, lddq, dk, lddk, dv, lddv, workspace,
+                             workspace_bytes, static_cast<hipStream_t>(stream));
     DIF_REQUIRE(H <= 65535, DIF_E_RANGE, "dif_sigmoid_attn_bwd_f32: too many heads");
     DIF_REQUIRE(workspace_bytes >= dif_sigmoid_bwd_workspace_bytes(N, L, H, M, D) && dif::aligned16(workspace), DIF_E_WORKSPACE,
                 "dif_sigmoid_attn_bwd_f32: workspace too small or not 16-byte aligned");

@@ -11,7 +11,8 @@ Parity pinning: the reference ships no golden vectors / KATs for this path
 reference *itself*, generated in the build container by importing the
 reference source verbatim (`tests/golden/make_golden.py` for
 `node classification/difformer.py`, `tests/golden/make_golden_v2.py` for
-`physical particle/difformer-v2.py`; fixtures under `tests/golden/*.npz`).  `tests/test_oracle_golden.py` checks every function
+`physical particle/difformer-v2.py`, `tests/golden/make_golden_st.py` / `make_golden_it.py` for the `spatial-temporal` and
+`image and text` copies; fixtures under `tests/golden/*.npz`).  `tests/test_oracle_golden.py` checks every function
 here against those fixtures.
 
 Every function cites the reference lines it restates.  All arithmetic runs in
@@ -103,6 +104,51 @@ def sigmoid_attention(qs, ks, vs, return_weights=False):
     att = (s / den).astype(dt)
     out = np.einsum("nlh,lhd->nhd", att, vs).astype(dt)
     return (out, att) if return_weights else out
+
+
+def sigmoid_attention_blocked(qs, ks, vs, block=2048, return_den=False):
+    """difformer.py:45-56 for sizes whose [N,L,H] score tensor does not fit (N = L = 15,000 at 300 columns: the
+    image-and-text scripts): the same lines over blocks of `block` queries, one BLAS product per head and block.
+    Identical to sigmoid_attention up to summation order (tests/test_oracle_it_golden.py holds the two together)."""
+    dt = qs.dtype
+    n, h, _ = qs.shape
+    out = np.empty((n, h, vs.shape[2]), dtype=dt)
+    dens = np.empty((n, h), dtype=dt)
+    for hh in range(h):
+        kt = np.ascontiguousarray(ks[:, hh, :].T)
+        vh = np.ascontiguousarray(vs[:, hh, :])
+        for r0 in range(0, n, block):
+            s = qs[r0:r0 + block, hh, :] @ kt                             # :47 q . k
+            s = (1.0 / (1.0 + np.exp(-s))).astype(dt)                     # :47 sigmoid
+            den = s.sum(axis=1, dtype=dt)                                 # :50-52
+            dens[r0:r0 + block, hh] = den
+            out[r0:r0 + block, hh, :] = ((s / den[:, None]).astype(dt) @ vh).astype(dt)       # :55-56
+    return (out, dens) if return_den else out
+
+
+def sigmoid_attention_grad_blocked(qs, ks, vs, g, block=2048):
+    """(dq, dk, dv) of difformer.py:45-56 under the cotangent g = dL/dout, i.e. what `loss.backward()` (main.py:113 of the
+    image-and-text folder) derives from those lines, written out and evaluated over blocks of queries:
+        P = sigmoid(q . k) (:47), den = sum_l P (:50-52), A = P / den (:55), out = A v (:56)
+        dv = A^T g,  dA = g v^T,  dP = (dA - sum_l dA A) / den,  dS = dP P (1 - P),  dq = dS k,  dk = dS^T q
+    Pinned to autograd of the reference itself through tests/golden/golden_it.npz and golden_grad.npz."""
+    dt = qs.dtype
+    n, h, _ = qs.shape
+    dq, dk, dv = np.zeros_like(qs), np.zeros_like(ks), np.zeros_like(vs)
+    for hh in range(h):
+        kh, vh = np.ascontiguousarray(ks[:, hh, :]), np.ascontiguousarray(vs[:, hh, :])
+        for r0 in range(0, n, block):
+            qb, gb = qs[r0:r0 + block, hh, :], g[r0:r0 + block, hh, :]
+            p = (1.0 / (1.0 + np.exp(-(qb @ kh.T)))).astype(dt)
+            den = p.sum(axis=1, dtype=dt)[:, None]
+            a = p / den
+            dv[:, hh, :] += a.T @ gb
+            da = gb @ vh.T
+            dp = (da - (da * a).sum(axis=1, dtype=dt)[:, None]) / den
+            ds = dp * p * (1.0 - p)
+            dq[r0:r0 + block, hh, :] = ds @ kh
+            dk[:, hh, :] += ds.T @ qb
+    return dq, dk, dv
 
 
 def full_attention_conv(qs, ks, vs, kernel, output_attn=False):

@@ -1,0 +1,242 @@
+"""`sigmoid` attention with heads of 65 .. 512 columns on the kernels of csrc/sigmoid_wide.hip: the
+image-and-text scripts' DIFFormer-a lines (`image and text/run.sh:17,35,54`: hidden 300 / 400, N = 13,000 .. 18,846).
+
+Yardsticks, all derived from the reference:
+  * tests/golden/golden_it.npz -- `image and text/difformer.py` itself at the script flags, forward and gradients;
+  * oracle.sigmoid_attention / difformer_oracle_grad (float64), pinned to those fixtures by tests/test_oracle_it_golden.py;
+  * at script size (N = L = 15,000, 300 columns) the BLOCKED float64 restatements of the same lines.
+Tolerance 1e-4 norm-wise; the split-bfloat16 planes sit around 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import grad_err, load_golden, rel_err, split_model_case
+from oracle import difformer_oracle as orc
+from oracle import difformer_oracle_grad as og
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+IT = load_golden("it")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def t(a, dev, grad=False):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return x.requires_grad_(True) if grad else x
+
+
+def launched(fn):
+    """Runs fn() with the backend's entry-point log on -> (result, set of C entry points called)."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    be.kernel_events = {}
+    try:
+        r = fn()
+    finally:
+        names, be.kernel_events = set(be.kernel_events), None
+    return r, names
+
+
+# ------------------------------------------------------------------ fixtures of image and text/difformer.py
+@pytest.mark.parametrize("name", sorted(k for k in IT if k.startswith("attn/")))
+def test_attention_golden(name, dev):
+    from difformer_amd import full_attention_conv
+    c = IT[name]
+    q, k, v = (t(c[a], dev, True) for a in "qkv")
+    out, names = launched(lambda: full_attention_conv(q, k, v, "sigmoid"))
+    _, names_b = launched(lambda: out.backward(t(c["g"], dev)))
+    assert "dif_sigmoid_attn_fwd_f32" in names and "dif_sigmoid_attn_bwd_f32" in names_b      # own kernels both ways
+    assert rel_err(out.detach().cpu().numpy(), c["out_f64"]) < TOL
+    gmax = max(np.abs(c[f"d{a}_f64"]).max() for a in "qkv")
+    for x, a in ((q, "dq"), (k, "dk"), (v, "dv")):
+        assert grad_err(x.grad.cpu().numpy(), c[a + "_f64"], gmax) < TOL, a
+
+
+@pytest.mark.parametrize("name", sorted(k for k in IT if k.startswith("step/")))
+def test_training_step_golden(name, dev):
+    """main.py:97-113 of the image-and-text folder on the drop-in model: logits, loss, every parameter gradient, dx."""
+    from difformer_amd import DIFFormer
+    c = IT[name]
+    cfg, sd = split_model_case(c)
+    model = DIFFormer(cfg["in_channels"], cfg["hidden_channels"], cfg["out_channels"], num_layers=cfg["num_layers"], alpha=0.5,
+                      dropout=0.0, num_heads=1, kernel="sigmoid", use_bn=True, use_residual=True, use_graph=False,
+                      use_weight=False).to(dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.train()
+    x = t(c["x"], dev, True)
+    y, idx = t(c["y"], dev), t(c["train_idx"], dev)
+
+    def step():
+        out = model(x, t(c["edge_index"], dev))
+        loss = torch.nn.NLLLoss()(torch.nn.functional.log_softmax(out, dim=1)[idx], y[idx])
+        loss.backward()
+        return out, loss
+    (out, loss), names = launched(step)
+    assert {"dif_sigmoid_attn_fwd_f32", "dif_sigmoid_attn_bwd_f32"} <= names
+    assert rel_err(out.detach().cpu().numpy(), c["out_f64"]) < TOL
+    assert abs(float(loss.detach()) - float(c["loss_f64"])) < TOL * abs(float(c["loss_f64"]))
+    assert rel_err(x.grad.cpu().numpy(), c["dx_f64"]) < TOL
+    gmax = max(float(np.max(np.abs(v))) for k, v in c.items() if k.startswith("grad_f64/") and v.size)
+    for k, p in model.named_parameters():
+        assert grad_err(p.grad.cpu().numpy(), c["grad_f64/" + k], gmax) < TOL, k
+
+
+# ------------------------------------------------------------------ every fragment count (KS = 3 .. 16), ragged sizes, heads
+WIDTHS = [(65, 65), (96, 96), (100, 128), (129, 160), (161, 161), (200, 192), (224, 224), (256, 250), (288, 288), (300, 300),
+          (320, 320), (352, 340), (384, 384), (400, 400), (416, 416), (448, 440), (449, 480), (512, 512)]
+
+
+@pytest.mark.parametrize("m,d", WIDTHS)
+def test_forward_and_backward_vs_oracle(m, d, dev):
+    from difformer_amd import full_attention_conv
+    n, l, h = (150, 333, 1) if (m + d) % 3 else (97, 64, 2)
+    g_ = torch.Generator().manual_seed(m * 7 + d)
+    q = torch.randn(n, h, m, generator=g_) * (4.0 / m ** 0.5)
+    k = torch.randn(l, h, m, generator=g_) * 0.5
+    v = torch.randn(l, h, d, generator=g_)
+    go = torch.randn(n, h, d, generator=g_)
+    qd, kd, vd = (x.to(dev).requires_grad_(True) for x in (q, k, v))
+    out, names = launched(lambda: full_attention_conv(qd, kd, vd, "sigmoid"))
+    _, names_b = launched(lambda: out.backward(go.to(dev)))
+    assert "dif_sigmoid_attn_fwd_f32" in names and "dif_sigmoid_attn_bwd_f32" in names_b
+    ref = orc.sigmoid_attention(q.double().numpy(), k.double().numpy(), v.double().numpy())
+    assert rel_err(out.detach().cpu().numpy(), ref) < TOL
+    q64, k64, v64 = (x.double().requires_grad_(True) for x in (q, k, v))
+    og.sigmoid_attention(q64, k64, v64).backward(go.double())
+    gmax = max(float(x.grad.abs().max()) for x in (q64, k64, v64))
+    for got, want, nm in ((qd, q64, "dq"), (kd, k64, "dk"), (vd, v64, "dv")):
+        assert grad_err(got.grad.cpu().numpy(), want.grad.numpy(), gmax) < TOL, nm
+    # inference entry point (no row sums kept): same kernels, same numbers
+    with torch.no_grad():
+        out2, names2 = launched(lambda: full_attention_conv(qd, kd, vd, "sigmoid"))
+    assert "dif_sigmoid_attn_f32" in names2 and torch.equal(out2, out.detach())
+
+
+@pytest.mark.parametrize("n,l", [(40, 9000), (3000, 31), (5000, 5000), (1, 1), (4097, 33)])
+def test_stream_splits_and_ragged_edges(n, l, dev):
+    """Few stationary rows -> the stream is cut into splits and recombined; one-row / one-key problems; both sweeps' tails."""
+    from difformer_amd import full_attention_conv
+    m = 160
+    g_ = torch.Generator().manual_seed(n + l)
+    q, k = torch.randn(n, 1, m, generator=g_) * 0.3, torch.randn(l, 1, m, generator=g_) * 0.3
+    v, go = torch.randn(l, 1, m, generator=g_), torch.randn(n, 1, m, generator=g_)
+    qd, kd, vd = (x.to(dev).requires_grad_(True) for x in (q, k, v))
+    out = full_attention_conv(qd, kd, vd, "sigmoid")
+    out.backward(go.to(dev))
+    ref = orc.sigmoid_attention_blocked(q.double().numpy(), k.double().numpy(), v.double().numpy())
+    assert rel_err(out.detach().cpu().numpy(), ref) < TOL
+    dq, dk, dv = orc.sigmoid_attention_grad_blocked(q.double().numpy(), k.double().numpy(), v.double().numpy(), go.double().numpy())
+    gmax = max(np.abs(dq).max(), np.abs(dk).max(), np.abs(dv).max())
+    # (one key: dq = dk = 0 exactly -- g.v - g.out cancels to rounding noise, which is measured against the step's largest gradient)
+    floor = 1.0 if l == 1 else 2e-6
+    for got, want, nm in ((qd, dq, "dq"), (kd, dk, "dk"), (vd, dv, "dv")):
+        assert grad_err(got.grad.cpu().numpy(), want, gmax, floor=floor) < TOL, nm
+    # bitwise reproducible (partial sums are added in split order)
+    q2, k2, v2 = (x.to(dev).requires_grad_(True) for x in (q, k, v))
+    out2 = full_attention_conv(q2, k2, v2, "sigmoid")
+    out2.backward(go.to(dev))
+    assert torch.equal(out2, out) and torch.equal(q2.grad, qd.grad) and torch.equal(k2.grad, kd.grad) and torch.equal(v2.grad, vd.grad)
+
+
+def test_saturated_scores_and_strided_inputs(dev):
+    """|q.k| up to ~40 drives sigma to 0 / 1; q, k, v as column slices of wider buffers (leading dimension > row)."""
+    from difformer_amd import full_attention_conv
+    g_ = torch.Generator().manual_seed(3)
+    big = torch.randn(500, 3 * 300, generator=g_)
+    qkv = big.to(dev)
+    q, k, v = (qkv[:, i * 300:(i + 1) * 300].reshape(500, 1, 300) for i in range(3))
+    out = full_attention_conv(q, k, v, "sigmoid").cpu().numpy()
+    b64 = big.double().numpy()
+    ref = orc.sigmoid_attention(*(b64[:, i * 300:(i + 1) * 300].reshape(500, 1, 300) for i in range(3)))
+    assert np.isfinite(out).all() and rel_err(out, ref) < TOL
+
+
+# ------------------------------------------------------------------ script size: N = 15,000 x 300 (cifar10), no N x L tensor
+def test_script_size_forward_backward(dev):
+    from difformer_amd import full_attention_conv
+    n, m = 15000, 300
+    g_ = torch.Generator().manual_seed(15)
+    x = torch.randn(n, 64, generator=g_)
+    wq, wk = (torch.randn(64, m, generator=g_) / 8.0 for _ in range(2))
+    q, k = (x @ wq).reshape(n, 1, m) * 0.3, (x @ wk).reshape(n, 1, m) * 0.3          # correlated rows: scores spread over +-10
+    v = torch.randn(n, 1, m, generator=g_)
+    go = torch.randn(n, 1, m, generator=g_)
+    qd, kd, vd = (a.to(dev).requires_grad_(True) for a in (q, k, v))
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = full_attention_conv(qd, kd, vd, "sigmoid")
+    out.backward(go.to(dev))
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 450e6, f"peak {peak / 1e6:.0f} MB: an N x L float tensor alone is {n * n * 4 / 1e6:.0f} MB"
+    q64, k64, v64, g64 = (a.double().numpy() for a in (q, k, v, go))
+    ref = orc.sigmoid_attention_blocked(q64, k64, v64)
+    assert rel_err(out.detach().cpu().numpy(), ref) < TOL
+    dq, dk, dv = orc.sigmoid_attention_grad_blocked(q64, k64, v64, g64)
+    gmax = max(np.abs(dq).max(), np.abs(dk).max(), np.abs(dv).max())
+    errs = {nm: grad_err(got.grad.cpu().numpy(), want, gmax) for got, want, nm in ((qd, dq, "dq"), (kd, dk, "dk"), (vd, dv, "dv"))}
+    assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("hidden,layers,n", [(300, 2, 3000), (400, 2, 1500), (128, 8, 700)])
+def test_model_training_step_vs_oracle(hidden, layers, n, dev):
+    """The script configuration at a size the float64 autograd oracle finishes in seconds; (128, 8): the deepest sigmoid script
+    (node classification/run.sh:10 runs 8 layers) at a wide head."""
+    from difformer_amd import DIFFormer
+    torch.manual_seed(hidden + layers)
+    f_in, c = 48, 10
+    cfg = dict(hidden_channels=hidden, num_layers=layers, num_heads=1, kernel="sigmoid", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=False, use_graph=False, graph_weight=-1, use_source=False)
+    model = DIFFormer(f_in, hidden, c, num_layers=layers, alpha=0.5, dropout=0.0, num_heads=1, kernel="sigmoid", use_bn=True,
+                      use_residual=True, use_graph=False, use_weight=False).to(dev).train()
+    x = torch.randn(n, f_in)
+    y = torch.randint(0, c, (n,))
+    idx = torch.randperm(n)[: n // 3]
+    xd = x.to(dev).requires_grad_(True)
+
+    def step():
+        out = model(xd, None)
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(out, dim=1)[idx.to(dev)], y.to(dev)[idx.to(dev)])
+        loss.backward()
+        return out, loss
+    (out, loss), names = launched(step)
+    assert {"dif_sigmoid_attn_fwd_f32", "dif_sigmoid_attn_bwd_f32"} <= names
+    pl = og.leaves({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    oref = og.difformer_forward(pl, x64, None, None, cfg)
+    lref = og.training_loss(oref, y, idx)
+    lref.backward()
+    assert rel_err(out.detach().cpu().numpy(), oref.detach().numpy()) < TOL
+    assert abs(float(loss.detach()) - float(lref.detach())) < TOL * abs(float(lref.detach()))
+    assert rel_err(xd.grad.cpu().numpy(), x64.grad.numpy()) < TOL
+    gmax = max(float(v.grad.abs().max()) for v in pl.values())
+    errs = {k: grad_err(p.grad.cpu().numpy(), pl[k].grad.numpy(), gmax) for k, p in model.named_parameters()}
+    assert max(errs.values()) < TOL, {k: f"{e:.2e}" for k, e in errs.items() if e > 2e-5}
+
+
+def test_exact_fp32_keeps_the_fp32_chain(dev):
+    """ops.set_exact_fp32(True): wide heads go back to the fp32-MFMA forward kernel and the tensor-op gradient."""
+    from difformer_amd import full_attention_conv, ops
+    g_ = torch.Generator().manual_seed(9)
+    q, k, v, go = (torch.randn(200, 1, 300, generator=g_) * 0.2 for _ in range(4))
+    was = ops.set_exact_fp32(True)
+    try:
+        qd, kd, vd = (a.to(dev).requires_grad_(True) for a in (q, k, v))
+        out, names = launched(lambda: full_attention_conv(qd, kd, vd, "sigmoid"))
+        _, names_b = launched(lambda: out.backward(go.to(dev)))
+    finally:
+        ops.set_exact_fp32(was)
+    assert "dif_sigmoid_attn_bwd_f32" not in names_b
+    ref = orc.sigmoid_attention(q.double().numpy(), k.double().numpy(), v.double().numpy())
+    assert rel_err(out.detach().cpu().numpy(), ref) < 1e-5
+    dq, dk, dv = orc.sigmoid_attention_grad_blocked(q.double().numpy(), k.double().numpy(), v.double().numpy(), go.double().numpy())
+    gmax = max(np.abs(dq).max(), np.abs(dk).max(), np.abs(dv).max())
+    for got, want in ((qd, dq), (kd, dk), (vd, dv)):
+        assert grad_err(got.grad.cpu().numpy(), want, gmax) < 1e-5
