@@ -22,8 +22,12 @@ steps), over 8 TB/s (`bound: "hbm"`); the sigmoid kernel is priced against the f
 feature-sliced product the keys `limiter: "lds"`, `lds_achieved_tbs`, `lds_peak_tbs`, `lds_frac` say what actually stops it
 (its LDS floor is above the HBM floor, profiles/r04_experiments.md).  `ms_per_step_exact_fp32`: a short second pass with
 every product on the fp32 MFMA (`config.exact_fp32` says which mode `value` was measured in: false = the default, two
-products on split-bfloat16 operands, ~4e-6).  `cpu_baseline` times the whole forward of the oracle port (numpy + OpenMP C)
-on the host cores, 1 warm-up + 3 runs, median (rank 0, N=1 only).  N > 1: when the hidden width splits into 16-byte slices
+products on split-bfloat16 operands, ~4e-6).  `cpu_baseline` times the whole forward of the oracle on the host cores in both of its
+restatements (numpy + OpenMP C; the same lines as CPU torch operations), 1 warm-up + 3 runs, median; `value` is the faster
+one, both are printed beside the reference file's own figure from the build container (rank 0, N=1 only).  `whole_forward_frac`:
+SURVEY 8(d)'s whole-forward bytes over `ms_per_step` over 8 TB/s; `roofline.share_of_forward`: the dominant entry point bracketed
+ALONE over the un-instrumented forward.  `--workload cifar15k-a-h300` / `stl13k-a-h400`: the image-and-text DIFFormer-a lines
+(sigmoid attention at 300 / 400 columns, `bound: "mfma"`).  N > 1: when the hidden width splits into 16-byte slices
 over the ranks both shard products (rows / feature slices, difformer_amd/dist.py) are timed with K steps each; `value` is the
 faster one, named in `config.parallelism`, both in `ms_per_step_by_shard_product`.
 """
@@ -43,6 +47,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.0   # fp32-input MFMA, dense (same guide)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # bf16 MFMA, dense (same guide; AMD's 5 PF headline includes 2:1 sparsity)
 LDS_PEAK_TBS = 256 * 256 * 2.4e9 / 1e12   # 256 CUs x 256 B/clk (ds_read_b128 / b64) at 2.4 GHz = 157 TB/s (same guide, LDS table)
 LDS_MEASURED_TBS = 150.0                   # the same guide's MEASURED aggregate LDS read rate
 
@@ -76,6 +81,11 @@ WORKLOADS = {
     # reduce / wide apply kernels), hidden 300 the closed form on library GEMMs around the hand-written Gram / tail passes
     "pokec-batch-h128": (100000, 115000, 65, 2, 128, 3, "simple", True),
     "cifar50k-h300": (50000, 0, 512, 10, 300, 4, "simple", False),
+    # the DIFFormer-a lines of the image-and-text scripts (image and text/run.sh:35: cifar10, 15,000 instances -- dataset.py:168 --,
+    # --kernel sigmoid --hidden_channels 300 --num_layers 2 --use_residual --use_bn, no --use_graph, no --use_weight): the
+    # O(N^2) attention at 300 columns per head, bound by the matrix pipe (csrc/sigmoid_wide.hip)
+    "cifar15k-a-h300": (15000, 0, 512, 10, 300, 2, "sigmoid", False, {"use_weight": False}),
+    "stl13k-a-h400": (13000, 0, 512, 10, 400, 2, "sigmoid", False, {"use_weight": False}),           # run.sh:17 (stl10, hidden 400)
 }
 
 
@@ -120,24 +130,49 @@ def make_graph(n, pairs, dev, zipf=False, blocks=0):
 
 
 def cpu_baseline(model, x, edge_index, cfg, repeats=3):
-    """The oracle port (numpy + OpenMP C restatement of the reference, oracle/) timed on the host cores: the WHOLE
-    forward on the full graph, one warm-up + `repeats` timed runs, median."""
+    """The oracle timed on the host cores: the WHOLE forward on the full graph, one warm-up + `repeats`
+    timed runs, median -- in BOTH restatements the oracle ships: the numpy + OpenMP C port (oracle/difformer_oracle.py) and
+    the same lines as CPU torch operations (oracle/difformer_oracle_grad.py under no_grad: what the reference file itself
+    executes, minus torch_sparse).  `value` is the FASTER of the two (the numpy einsums are not BLAS calls: on the small
+    configs the torch restatement is ~10x faster, on the C4 graph the OpenMP product wins); both are printed."""
     from oracle import difformer_oracle as orc
-    p = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    xh = x.cpu().numpy()
-    ei = None if edge_index is None else edge_index.cpu().numpy()
+    from oracle import difformer_oracle_grad as og
     cores = os.cpu_count() or 1
     os.environ["ORACLE_THREADS"] = str(cores)
-    orc.difformer_forward(p, xh, ei, None, cfg)
-    times = []
-    for _ in range(repeats):
-        t0 = time.perf_counter()
-        orc.difformer_forward(p, xh, ei, None, cfg)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": x.shape[0] / med, "unit": "nodes/s", "cores": cores, "kind": "port",
-            "sample": f"whole {cfg['num_layers']}-layer forward of the oracle port (numpy + OpenMP C gcn_conv) on the full "
-                      f"graph, 1 warm-up + {repeats} timed runs: median {med:.2f} s (min {min(times):.2f}, max {max(times):.2f})"}
+    torch.set_num_threads(cores)
+    n = x.shape[0]
+
+    def timed(fn):
+        fn()
+        times = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times)), times
+
+    runs = {}
+    dense_pairs = cfg["kernel"] == "sigmoid" and n > 4000        # np.einsum("nhm,lhm->nlh") is a scalar loop: minutes at N = 15,000
+    if not dense_pairs:
+        p = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        xh = x.cpu().numpy()
+        ei = None if edge_index is None else edge_index.cpu().numpy()
+        runs["numpy+openmp"] = timed(lambda: orc.difformer_forward(p, xh, ei, None, cfg))
+    big_graph = edge_index is not None and edge_index.shape[1] > 2_000_000      # index_add_ over 79 M entries: tens of seconds per layer
+    if not big_graph:
+        pt = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+        xt = x.cpu().float()
+        eit = None if edge_index is None else edge_index.cpu()
+        def torch_port():
+            with torch.no_grad():
+                og.difformer_forward(pt, xt, eit, None, cfg)
+        runs["torch-ops"] = timed(torch_port)
+    best = min(runs, key=lambda k: runs[k][0])
+    med, times = runs[best]
+    return {"value": n / med, "unit": "nodes/s", "cores": cores, "kind": "port", "restatement": best,
+            "by_restatement_nodes_per_s": {k: n / v[0] for k, v in runs.items()},
+            "sample": f"whole {cfg['num_layers']}-layer forward of the oracle ({best}) on the full graph, 1 warm-up + {repeats} timed "
+                      f"runs: median {med:.3f} s (min {min(times):.3f}, max {max(times):.3f})"}
 
 
 def shard_plan(workload, world, rank):
@@ -212,9 +247,11 @@ def main():
 
     from difformer_amd import DIFFormer, GraphedForward, RowShard, ops
 
-    n, pairs, f_in, classes, hidden, layers, kernel, use_graph = WORKLOADS[args.workload]
+    n, pairs, f_in, classes, hidden, layers, kernel, use_graph = WORKLOADS[args.workload][:8]
+    flags = WORKLOADS[args.workload][8] if len(WORKLOADS[args.workload]) > 8 else {}
+    use_weight = flags.get("use_weight", True)
     torch.manual_seed(123)
-    model = DIFFormer(f_in, hidden, classes, num_layers=layers, num_heads=1, kernel=kernel, use_graph=use_graph)
+    model = DIFFormer(f_in, hidden, classes, num_layers=layers, num_heads=1, kernel=kernel, use_graph=use_graph, use_weight=use_weight)
     model.reset_parameters()
     model = model.to(dev).eval()
     store = torch.bfloat16 if args.workload.endswith("-bf16") else torch.float32
@@ -401,8 +438,10 @@ def main():
                                   "hbm", gcn_bytes, None) if (use_graph and not share.get("dif_gcn_spmm_f32") and not share.get("dif_sliced_spmm_f32"))
                                  else ("simple_layer_kernel (closed-form simple layer)", "simple_layer_kernel", "hbm",
                                        (3.0 if use_graph else 2.0) * n_local * hidden * esz, None)),
-        "dif_sigmoid_attn_f32": ("sigmoid_attn_kernel", "sigmoid_attn_kernel", "mfma", 4.0 * n_local * hidden * 4,
-                                 4.0 * n_local * n * hidden),
+        "dif_sigmoid_attn_f32": (("sigw_fwd_kernel (sigmoid attention, heads of 65..512 columns: split-bfloat16 plane sweep) + its pack / combine launches",
+                                  "sigw_fwd_kernel") if (hidden > 64 and store == torch.float32 and not ops.EXACT_FP32)
+                                 else ("sigmoid_attn_kernel", "sigmoid_attn_kernel")) + ("mfma", 4.0 * n_local * hidden * 4,
+                                                                                         4.0 * n_local * n * hidden),
         "dif_gram_sym_f32": ("simple_reduce_kernel<sym> (Gram record of the wide closed form)", "simple_reduce_kernel", "mfma",
                              1.0 * n_local * hidden * 4, 1.0 * n_local * hidden * (hidden + 1)),
         "dif_linear_f32": ("linear kernels (input MLP / output Linear)", "linear_", "hbm", 1.0 * n_local * (f_in + hidden) * esz, None),
@@ -421,7 +460,7 @@ def main():
     # correction + WRITE_SIZE, calibrated; scripts/pmc_traffic.sh) stored under profiles/ -- a counter run cannot
     # share a process with this timed run.  Only valid for the single-GPU workload it was collected on.
     traffic = tsrc = None
-    for tfile in ("r05_pmc_traffic_c4.json", "r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
+    for tfile in ("r06_pmc_traffic_c4.json", "r05_pmc_traffic_c4.json", "r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
         tpath = os.path.join(ROOT, "profiles", tfile)
         if world == 1 and use_graph and os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -434,15 +473,28 @@ def main():
     # kernel: algorithmic bytes / launch time / 8 TB/s for the HBM-bound rows (a1, a3, a4/a5), algorithmic FLOP / launch time
     # / 157 TFLOP/s for a2.  What actually limits the sliced product (LDS array + vector-ALU issue, profiles/r04_experiments.md
     # section 1) rides beside it in the lds_* siblings and in `limiter`.
+    # share of the forward: the dominant entry point's launches of ONE forward (bracketed alone, so the queue stays full) over the
+    # un-instrumented forward (median of the per-forward event pairs) -- the all-entry-point pass above inflates the small kernels
+    n_alone_fwd = min(args.steps, 5)
+    share_alone = (float(np.sum(alone)) / n_alone_fwd / fwd_ms[len(fwd_ms) // 2]) if (alone and fwd_ms) else None
     roofline = {"bound": "mfma" if bound == "mfma" else "hbm", "kernel": dom_name, "entry_point": dom,
-                "share_of_forward": (share[dom] / sum(share.values())) if dom else None,
+                "share_of_forward": share_alone if share_alone is not None else ((share[dom] / sum(share.values())) if dom else None),
+                "share_of_forward_source": "dominant entry point bracketed alone / median un-instrumented forward",
                 "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": dom_ms, "avg_launch_ms_source": src}
     if bound == "mfma" and dom_ms:
         tf = alg_flop / (dom_ms * 1e-3) / 1e12
         roofline.update({"achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                          "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_achieved_gbs": hbm_gbs, "hbm_frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None})
-        if dom == "dif_sigmoid_attn_f32" and hidden <= 64 and store == torch.float32 and not ops.EXACT_FP32:
+        if dom == "dif_sigmoid_attn_f32" and hidden > 64 and store == torch.float32 and not ops.EXACT_FP32:
+            roofline.update({"mfma_bf16_peak_tflops": MFMA_BF16_PEAK_TFLOPS, "products_per_fp32_product": 3,
+                             "frac_of_split_bf16_peak": tf / (MFMA_BF16_PEAK_TFLOPS / 3.0),
+                             "limiter_note": "every operand as two bfloat16 planes (hi + lo), three v_mfma_f32_16x16x32_bf16 per 32-deep "
+                                             "step: `frac` is algorithmic fp32 FLOP (4 N L D) over the fp32 MFMA peak and may exceed 1; "
+                                             "frac_of_split_bf16_peak prices the same FLOP against the dense bf16 peak / 3.  avg_launch_ms "
+                                             "brackets the ENTRY POINT: three pack launches + the sweep + the split combine "
+                                             "(avg_launch_ms_rocprofv3 = the sweep kernel alone)"})
+        elif dom == "dif_sigmoid_attn_f32" and hidden <= 64 and store == torch.float32 and not ops.EXACT_FP32:
             roofline["limiter_note"] = ("heads of <= 64 channels contract on split-bfloat16 operands: 3 v_mfma_f32_16x16x32_bf16 per "
                                         "32-deep step; frac stays algorithmic fp32 FLOP over the fp32 MFMA peak (the contract's figure)")
     else:
@@ -460,7 +512,7 @@ def main():
                                          "HBM figure, the lds_* keys say why it stops there (profiles/r04_experiments.md section 1)"})
     # the rocprofv3 figure the event bracket is checked against (same workload, tracked summary of this round if present)
     import glob
-    cands = [c for r in ("r05", "r04", "r03") for c in
+    cands = [c for r in ("r06", "r05", "r04", "r03") for c in
              sorted(glob.glob(os.path.join(ROOT, "profiles", f"{r}_*{args.workload}*kernel_stats.csv")), reverse=True)]
     for cand in cands:
         try:
@@ -474,6 +526,16 @@ def main():
         except Exception:
             continue
 
+    # SURVEY 8(d) "whole forward": N F_in s + N C s + L (B_a1 + use_graph B_a3), B_a1 = 4 N H D s, B_a3 = 8 nnz + 4 (N + 1) + 2 N H D s
+    whole_bytes = (n_local * f_in * esz + n_local * classes * esz +
+                   layers * (4.0 * n_local * hidden * esz + (gcn_bytes if use_graph else 0.0)))
+    whole_flop = layers * 4.0 * n_local * n * hidden if kernel == "sigmoid" else None
+    whole = {"whole_forward_bytes": whole_bytes, "whole_forward_gbs": whole_bytes / (ms_per_step * 1e-3) / 1e9,
+             "whole_forward_frac": whole_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if whole_flop:
+        whole.update({"whole_forward_attention_flop": whole_flop, "whole_forward_tflops": whole_flop / (ms_per_step * 1e-3) / 1e12,
+                      "whole_forward_mfma_frac": whole_flop / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS})
+
     if args.per_kernel and rank == 0:
         for k, v in sorted(ktimes.items()):
             print(f"[per-kernel] {k}: calls={len(v)} mean={np.mean(v) * 1e3:.1f} us min={np.min(v) * 1e3:.1f} us",
@@ -482,7 +544,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and store == torch.float32:
         cfg = dict(hidden_channels=hidden, num_layers=layers, num_heads=1, kernel=kernel, alpha=0.5, use_bn=True,
-                   use_residual=True, use_weight=True, use_graph=use_graph, graph_weight=-1, use_source=False)
+                   use_residual=True, use_weight=use_weight, use_graph=use_graph, graph_weight=-1, use_source=False)
         cpu = cpu_baseline(model, x_full, edge_index, cfg)
 
     if cpu is not None:
@@ -506,7 +568,7 @@ def main():
                        "exact_fp32": bool(ops.EXACT_FP32),
                        "csr": "warm (cached); cold build reported in cold_csr_build_ms",
                        "launch": launch_mode},
-            "cold_csr_build_ms": cold_ms, "roofline": roofline, "cpu_baseline": cpu,
+            "cold_csr_build_ms": cold_ms, **whole, "roofline": roofline, "cpu_baseline": cpu,
             **({"ms_per_step_by_shard_product": {k: v / args.steps * 1e3 for k, v in by_product.items()}} if shard is not None else {}),
             **({"per_rank_phases": per_rank} if per_rank is not None else {}),
         }))

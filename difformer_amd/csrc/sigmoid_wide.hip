@@ -45,17 +45,14 @@ __device__ __forceinline__ float sigmoidf(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
-// product terms (streamed plane, stationary plane), small terms first
+// product terms (streamed plane a, stationary plane b) and the accumulator each adds to (0 = hi.hi, 1 = the small terms):
+// consecutive terms alternate accumulators, so that no MFMA waits for the one before it
 template <int NP> struct Terms;
 template <> struct Terms<2> {
-    static constexpr int n = 3;
-    static __device__ __forceinline__ constexpr int a(int i) { return i == 0 ? 1 : 0; }       // lo.hi  hi.lo  hi.hi
-    static __device__ __forceinline__ constexpr int b(int i) { return i == 1 ? 1 : 0; }
-};
-template <> struct Terms<3> {
-    static constexpr int n = 6;                                                                // mid.mid  hi.lo  lo.hi  hi.mid  mid.hi  hi.hi
-    static __device__ __forceinline__ constexpr int a(int i) { return i == 0 ? 1 : i == 2 ? 2 : i == 4 ? 1 : 0; }
-    static __device__ __forceinline__ constexpr int b(int i) { return i == 0 ? 1 : i == 1 ? 2 : i == 3 ? 1 : 0; }
+    static constexpr int n = 3;                                                                // lo.hi  hi.hi  hi.lo
+    static __device__ __forceinline__ constexpr int a(int i) { return i == 0 ? 1 : 0; }
+    static __device__ __forceinline__ constexpr int b(int i) { return i == 2 ? 1 : 0; }
+    static __device__ __forceinline__ constexpr int acc(int i) { return i == 1 ? 0 : 1; }
 };
 
 // x -> NP bf16 planes (round to nearest even; plane p + 1 holds what plane p left)
@@ -73,58 +70,106 @@ __device__ __forceinline__ void split_planes(f32x4 x0, f32x4 x1, bf16x8 (&pl)[NP
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// pack: one workgroup per (32-row tile, head).  x [R][ld] (head h at column h * creal), optional per-row divisor
-// rowdiv [R][H] (G~ = G / den).  Writes the row-packed and / or the col-packed planes of the tile.
+// pack: one workgroup per (32-row tile, head, chunk of 64 columns = 2 column steps / 4 column tiles); one fragment lane per
+// thread and orientation.  x [R][ld] (head h at column h * creal), optional per-row divisor rowdiv [R][H] (G~ = G / den),
+// optional per-column offset colsub [H][creal] that is subtracted (the centred values V - mean V).
 template <int NP>
 __global__ __launch_bounds__(256) void sigw_pack_kernel(const float* __restrict__ x, int64_t ld, int64_t R, int creal, int H,
-                                                        int KS, const float* __restrict__ rowdiv, bf16x8* __restrict__ rowp,
-                                                        bf16x8* __restrict__ colp, int T) {
-    extern __shared__ __attribute__((aligned(16))) float smf[];
-    const int C = 32 * KS, lds = C + 4;
-    const int t = blockIdx.x, h = blockIdx.y;
-    for (int e = threadIdx.x; e < 32 * C; e += 256) {
-        const int r = e / C, c = e - r * C;
+                                                        int KS, const float* __restrict__ rowdiv, const float* __restrict__ colsub,
+                                                        bf16x8* __restrict__ rowp, bf16x8* __restrict__ colp, int T) {
+    __shared__ __attribute__((aligned(16))) float smf[32][68];
+    const int t = blockIdx.x, h = blockIdx.y, c0 = 64 * blockIdx.z;
+    {   // 32 rows x 64 columns: 8 threads per row, 16 bytes each, twice
+        const int r = threadIdx.x >> 3;
         const int64_t row = 32ll * t + r;
-        float v = 0.f;
-        if (row < R && c < creal) {
-            v = x[row * ld + static_cast<int64_t>(h) * creal + c];
-            if (rowdiv) v /= rowdiv[row * H + h];
+        const float* src = x + row * ld + static_cast<int64_t>(h) * creal;
+        const bool vec = (creal % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+        float inv = 1.0f;
+        if (rowdiv && row < R) inv = rowdiv[row * H + h];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int cl = 4 * (threadIdx.x & 7) + 32 * half, c = c0 + cl;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < R) {
+                if (vec) {
+                    if (c < creal) v = *reinterpret_cast<const f32x4*>(src + c);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < creal) v[j] = src[c + j];
+                }
+                if (rowdiv) v = f32x4{v[0] / inv, v[1] / inv, v[2] / inv, v[3] / inv};
+                if (colsub) {                                  // centred values (see sigw_colmean): padded columns stay zero
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < creal) v[j] -= colsub[static_cast<int64_t>(h) * creal + c + j];
+                }
+            }
+            *reinterpret_cast<f32x4*>(&smf[r][cl]) = v;
         }
-        smf[r * lds + c] = v;
     }
     __syncthreads();
     const int FR = 2 * KS;
     const int64_t tile = (static_cast<int64_t>(h) * T + t) * NP * FR * 64;
-    for (int item = threadIdx.x; item < FR * 64; item += 256) {
-        const int f = item >> 6, lane = item & 63, l15 = lane & 15, lg = lane >> 4;
-        if (rowp) {
-            const int rt = f / KS, ks = f - rt * KS;
-            const float* s = smf + (16 * rt + l15) * lds + 32 * ks + 8 * lg;
+    const int f4 = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    if (rowp) {                                            // fragment (rt, ks): rt = f4 / 2, ks = 2 blockIdx.z + f4 % 2
+        const int rt = f4 >> 1, ksl = f4 & 1, ks = 2 * blockIdx.z + ksl;
+        if (ks < KS) {
+            const float* sp = &smf[16 * rt + l15][32 * ksl + 8 * lg];
             bf16x8 pl[NP];
-            split_planes<NP>(*reinterpret_cast<const f32x4*>(s), *reinterpret_cast<const f32x4*>(s + 4), pl);
+            split_planes<NP>(*reinterpret_cast<const f32x4*>(sp), *reinterpret_cast<const f32x4*>(sp + 4), pl);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) rowp[tile + (static_cast<int64_t>(p) * FR + f) * 64 + lane] = pl[p];
+            for (int p = 0; p < NP; ++p) rowp[tile + (static_cast<int64_t>(p) * FR + rt * KS + ks) * 64 + lane] = pl[p];
         }
-        if (colp) {
-            const int col = 16 * f + l15;
+    }
+    if (colp) {                                            // column tile ct = 4 blockIdx.z + f4
+        const int ct = 4 * blockIdx.z + f4;
+        if (ct < FR) {
+            const int col = 16 * f4 + l15;
             f32x4 v0, v1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v0[j] = smf[(4 * lg + j) * lds + col];
-                v1[j] = smf[(16 + 4 * lg + j) * lds + col];
+                v0[j] = smf[4 * lg + j][col];
+                v1[j] = smf[16 + 4 * lg + j][col];
             }
             bf16x8 pl[NP];
             split_planes<NP>(v0, v1, pl);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) colp[tile + (static_cast<int64_t>(p) * FR + f) * 64 + lane] = pl[p];
+            for (int p = 0; p < NP; ++p) colp[tile + (static_cast<int64_t>(p) * FR + ct) * 64 + lane] = pl[p];
         }
     }
 }
 
-// delta~[h][n] = (g_n . out_n) / den_n for n < N, 0 up to NPAD (one wave per (n, h))
+// Column means of v [L][H x D] -> cmean [H][D] in two deterministic stages (row blocks of 128, then the blocks in order).
+// WHY: out_n is a convex combination of the value rows, so  g.v_l - g.out_n = g.(v_l - c) - g.(out_n - c)  for any c.  The
+// backward's dS = (g~.v_l - g~.out_n) P (1 - P) takes the first product off the matrix core at ~4e-6 |g~||v| (split planes) and
+// the second from float32 row arithmetic: where the value rows resemble each other (deep layers behind LayerNorm + residual)
+// the difference is far smaller than either term and the split error came back amplified (last layer of an 8-layer model:
+// 1.5e-4 of a Wk.bias gradient).  With c = the column mean both terms shrink to the rows' spread; the forward sums
+// P (v - c) and adds c back for the same reason.
+__global__ __launch_bounds__(256) void sigw_colsum_kernel(const float* __restrict__ v, int64_t ldv, int64_t L, int HD,
+                                                          float* __restrict__ partial) {
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 128;
+    const int64_t r1 = r0 + 128 < L ? r0 + 128 : L;
+    for (int c = threadIdx.x; c < HD; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += v[r * ldv + c];
+        partial[static_cast<int64_t>(blockIdx.x) * HD + c] = s;
+    }
+}
+__global__ __launch_bounds__(256) void sigw_colmean_kernel(const float* __restrict__ partial, int blocks, int64_t L, int HD,
+                                                           float* __restrict__ cmean) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= HD) return;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += partial[static_cast<int64_t>(b) * HD + c];
+    cmean[c] = s / static_cast<float>(L);
+}
+
+// delta~[h][n] = g_n . (out_n - c) / den_n for n < N, 0 up to NPAD (one wave per (n, h)); c [H][D] = the value rows' centre
 __global__ __launch_bounds__(256) void sigw_delta_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ out,
-                                                         int64_t ldo, const float* __restrict__ den, int64_t N, int64_t NPAD, int H,
-                                                         int D, float* __restrict__ delta) {
+                                                         int64_t ldo, const float* __restrict__ den, const float* __restrict__ cmean,
+                                                         int64_t N, int64_t NPAD, int H, int D, float* __restrict__ delta) {
     const int lane = threadIdx.x & 63;
     const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (item >= NPAD * H) return;
@@ -132,7 +177,7 @@ __global__ __launch_bounds__(256) void sigw_delta_kernel(const float* __restrict
     const int h = static_cast<int>(item - n * H);
     float s = 0.f;
     if (n < N) {
-        for (int d = lane; d < D; d += 64) s += g[n * ldg + h * D + d] * out[n * ldo + h * D + d];
+        for (int d = lane; d < D; d += 64) s += g[n * ldg + h * D + d] * (out[n * ldo + h * D + d] - cmean[h * D + d]);
         s = dif::wave_sum(s) / den[n * H + h];
     }
     if (lane == 0) delta[static_cast<int64_t>(h) * NPAD + n] = s;
@@ -145,6 +190,7 @@ struct SweepOut {
     float* part; float* pden;                   // S > 1: [S][H][NXPAD][C], [S][H][NXPAD]
     int64_t NXPAD;
     int normalize;
+    const float* coladd;                        // nullable [H][cout]: added to the (normalised) rows -- the centre of the values
 };
 
 // stores the accumulators of a wave (O^T[col = 16 ct + 4 lg + r][row = l15]) -- final or partial
@@ -156,16 +202,23 @@ __device__ __forceinline__ void store_acc(const f32x4 (&o)[2 * KS], float den_to
         if (row < NX) {
             const float sc = w.normalize ? 1.0f / den_tot : 1.0f;
             float* dst = w.out + row * w.ldo + static_cast<int64_t>(h) * w.cout;
+            const float* add = w.coladd ? w.coladd + static_cast<int64_t>(h) * w.cout : nullptr;
             const bool vec = (w.cout % 4 == 0) && (w.ldo % 4 == 0) && (reinterpret_cast<uintptr_t>(w.out) & 15u) == 0;
 #pragma unroll
             for (int ct = 0; ct < 2 * KS; ++ct) {
                 const int c = 16 * ct + 4 * lg;
+                f32x4 val = o[ct] * sc;
+                if (add) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < w.cout) val[r] += add[c + r];
+                }
                 if (vec) {
-                    if (c < w.cout) *reinterpret_cast<f32x4*>(dst + c) = o[ct] * sc;
+                    if (c < w.cout) *reinterpret_cast<f32x4*>(dst + c) = val;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (c + r < w.cout) dst[c + r] = o[ct][r] * sc;
+                        if (c + r < w.cout) dst[c + r] = val[r];
                 }
             }
             if (w.den_out && lg == 0) w.den_out[row * H + h] = den_tot;
@@ -179,6 +232,117 @@ __device__ __forceinline__ void store_acc(const f32x4 (&o)[2 * KS], float den_to
     }
 }
 
+// ---- the two stage bodies shared by both sweep kernels.  `tile` = LDS tile + lane.  Fragments are fetched one step AHEAD of the
+// products that use them (two register sets): with one or two waves per SIMD nothing else hides the LDS round trip. ----
+
+// S^T[streamed row 4 lg + r of row tile rt][stationary row l15 of tile qt] = Y X^T over the KS column steps
+template <int KS, int NP, int QT>
+__device__ __forceinline__ void score_stage(const bf16x8* tile, const bf16x8 (&xs)[QT][NP][KS], f32x4 (&res)[QT][2]) {
+    constexpr int FR = 2 * KS;
+    using TT = Terms<NP>;
+    f32x4 sa[2][QT][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sa[i][qt][0] = sa[i][qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 y[2][NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) y[0][p][rt] = tile[(p * FR + rt * KS) * 64];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) y[(ks + 1) & 1][p][rt] = tile[(p * FR + rt * KS + ks + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);               // (the scheduler would sink the reads to just before their use)
+#pragma unroll
+        for (int i = 0; i < TT::n; ++i)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    sa[TT::acc(i)][qt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[ks & 1][TT::a(i)][rt], xs[qt][TT::b(i)][ks],
+                                                                                   sa[TT::acc(i)][qt][rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) res[qt][rt] = sa[1][qt][rt] + sa[0][qt][rt];
+}
+
+// O^T[col 16 ct + 4 lg + r][stationary row l15 of tile qt] += Z^T B over the 32 streamed rows (B = the planes of sigma(S^T) or dS^T)
+template <int KS, int NP, int QT>
+__device__ __forceinline__ void accumulate_stage(const bf16x8* tile, const bf16x8 (&pb)[QT][NP], f32x4 (&o)[QT][2 * KS]) {
+    constexpr int FR = 2 * KS;
+    using TT = Terms<NP>;
+    bf16x8 z[2][NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) z[0][p][i] = tile[(p * FR + i) * 64];
+#pragma unroll
+    for (int c0 = 0; c0 < FR; c0 += 2) {
+        if (c0 + 2 < FR) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) z[((c0 >> 1) + 1) & 1][p][i] = tile[(p * FR + c0 + 2 + i) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TT::n; ++tm)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    o[qt][c0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[(c0 >> 1) & 1][TT::a(tm)][i], pb[qt][TT::b(tm)], o[qt][c0 + i],
+                                                                           0, 0, 0);
+    }
+}
+
+// LDS-DMA of one tile (NP x 2 KS KiB): one KiB per wave instruction (lane l's 16 bytes land at M0 + 16 l), no registers.
+// Inline assembly on purpose: with `__builtin_amdgcn_global_load_lds` in the kernel the compiler's wait-count pass answers every
+// `ds_read` -> MFMA dependence with `s_waitcnt lgkmcnt(0)` -- the fragment reads issued one step ahead are waited for together
+// with the ones needed now, and the prefetch buys nothing (the same loop without the builtin gets `lgkmcnt(4)`).  The compiler
+// does not count these loads: every sub-stage ends with an explicit vmcnt(0) + barrier.  M0 is saved and restored inside the
+// statement (cdna_hip_programming.md 5.7).  Issued at the head of a sub-stage; the sched_barrier keeps it there.
+__device__ __forceinline__ void dma_1k(const bf16x8* gsrc, const bf16x8* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        static_cast<unsigned>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) bf16x8*)lds_dst)));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+template <int KS, int NP, int W>
+__device__ __forceinline__ void issue_tile(const bf16x8* tile, bf16x8* dst, int wave, int lane) {
+    constexpr int PIECES = NP * 2 * KS;
+#pragma unroll
+    for (int i = 0; i < (PIECES + W - 1) / W; ++i) {
+        const int piece = wave + i * W;
+        if (PIECES % W == 0 || piece < PIECES) dma_1k(tile + piece * 64 + lane, dst + piece * 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// fragments of this wave's QT stationary 16-row tiles (tile index g0 + qt, clamped to the packed rows)
+template <int KS, int NP, int QT>
+__device__ __forceinline__ void load_stationary(const bf16x8* xr, int h, int Tx, int64_t g0, int lane, bf16x8 (&xf)[QT][NP][KS]) {
+    constexpr int FR = 2 * KS;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int64_t g = g0 + qt < 2ll * Tx ? g0 + qt : 2ll * Tx - 1;
+        const bf16x8* xt = xr + ((static_cast<int64_t>(h) * Tx + (g >> 1)) * NP * FR + (g & 1) * KS) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[qt][p][ks] = xt[(p * FR + ks) * 64];
+    }
+}
+
 struct FwdArgs {
     const bf16x8* xr; const bf16x8* yr; const bf16x8* zc;
     int64_t NX, NY;
@@ -186,104 +350,60 @@ struct FwdArgs {
     SweepOut w;
 };
 
-// grid (ceil(NX / (16 W)), H, S); block 64 W; dynamic LDS 2 tiles
-template <int KS, int NP, int W>
+// grid (ceil(NX / (16 W QT)), H, S); block 64 W; dynamic LDS 2 tiles
+template <int KS, int NP, int W, int QT>
 __global__ __launch_bounds__(64 * W) void sigw_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16x8 sm[];
     constexpr int FR = 2 * KS;
     constexpr int TILE = NP * FR * 64;
-    using TT = Terms<NP>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
     const int h = blockIdx.y, S = gridDim.z, split = blockIdx.z;
-    const int64_t g = static_cast<int64_t>(blockIdx.x) * W + wave;               // this wave's 16 stationary rows
-    const int64_t gc = g < 2ll * a.Tx ? g : 2ll * a.Tx - 1;
-    bf16x8 xf[NP][KS];
-    {
-        const bf16x8* xt = a.xr + ((static_cast<int64_t>(h) * a.Tx + (gc >> 1)) * NP * FR + (gc & 1) * KS) * 64 + lane;
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xf[p][ks] = xt[(p * FR + ks) * 64];
-    }
+    const int64_t g0 = (static_cast<int64_t>(blockIdx.x) * W + wave) * QT;       // this wave's stationary 16-row tiles
+    bf16x8 xf[QT][NP][KS];
+    load_stationary<KS, NP, QT>(a.xr, h, a.Tx, g0, lane, xf);
     const int per = (a.Ty + S - 1) / S;
     const int t0 = split * per, t1 = (t0 + per < a.Ty) ? t0 + per : a.Ty;
     const bf16x8* ybase = a.yr + static_cast<int64_t>(h) * a.Ty * TILE;
     const bf16x8* zbase = a.zc + static_cast<int64_t>(h) * a.Ty * TILE;
-    auto issue = [&](const bf16x8* tile, int b) {                      // LDS-DMA: one KiB per wave instruction, no registers
+    f32x4 o[QT][FR];
+    float den[QT];
 #pragma unroll
-        for (int i = 0; i < (NP * FR + W - 1) / W; ++i) {
-            const int piece = wave + i * W;
-            if ((NP * FR) % W == 0 || piece < NP * FR)
-                __builtin_amdgcn_global_load_lds(tile + piece * 64 + lane, sm + b * TILE + piece * 64, 16, 0, 0);
-        }
-    };
-    f32x4 o[FR];
+    for (int qt = 0; qt < QT; ++qt) {
+        den[qt] = 0.f;
 #pragma unroll
-    for (int ct = 0; ct < FR; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float den = 0.f;
-    if (t0 < t1) issue(ybase + static_cast<int64_t>(t0) * TILE, 0);
+        for (int ct = 0; ct < FR; ++ct) o[qt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (t0 < t1) issue_tile<KS, NP, W>(ybase + static_cast<int64_t>(t0) * TILE, sm, wave, lane);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     for (int t = t0; t < t1; ++t) {
-        issue(zbase + static_cast<int64_t>(t) * TILE, 1);
-        // ---- S^T[streamed 4 lg + r of tile rt][stationary l15] ----
-        f32x4 sa[TT::n][2];
+        issue_tile<KS, NP, W>(zbase + static_cast<int64_t>(t) * TILE, sm + TILE, wave, lane);
+        f32x4 s[QT][2];
+        score_stage<KS, NP, QT>(sm + lane, xf, s);
+        bf16x8 pb[QT][NP];
 #pragma unroll
-        for (int i = 0; i < TT::n; ++i) sa[i][0] = sa[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16x8* b0 = sm + lane;
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 p[2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 y[NP][2];
+            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) y[p][rt] = b0[(p * FR + rt * KS + ks) * 64];
-#pragma unroll
-            for (int i = 0; i < TT::n; ++i)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-                    sa[i][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[TT::a(i)][rt], xf[TT::b(i)][ks], sa[i][rt], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = 32ll * t + 16 * rt + 4 * lg + r < a.NY;      // padded rows of the stream: sigma(0) = 1/2 stays out of den
+                    p[rt][r] = ok ? sigmoidf(s[qt][rt][r]) : 0.f;
+                    den[qt] += p[rt][r];
+                }
+            split_planes<NP>(p[0], p[1], pb[qt]);
         }
-        f32x4 p[2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            f32x4 s = sa[0][rt];
-#pragma unroll
-            for (int i = 1; i < TT::n; ++i) s += sa[i][rt];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = 32ll * t + 16 * rt + 4 * lg + r < a.NY;          // padded rows of the stream: sigma(0) = 1/2 stays out of den
-                p[rt][r] = ok ? sigmoidf(s[r]) : 0.f;
-                den += p[rt][r];
-            }
-        }
-        bf16x8 pb[NP];
-        split_planes<NP>(p[0], p[1], pb);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
-        if (t + 1 < t1) issue(ybase + static_cast<int64_t>(t + 1) * TILE, 0);
-        // ---- O^T[col 16 ct + 4 lg + r][stationary l15] += Z^T P^T ----
-        const bf16x8* b1 = sm + TILE + lane;
-#pragma unroll
-        for (int c0 = 0; c0 < FR; c0 += 4) {
-            bf16x8 z[NP][4];
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (c0 + i < FR) z[pl][i] = b1[(pl * FR + c0 + i) * 64];
-#pragma unroll
-            for (int tm = 0; tm < TT::n; ++tm)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (c0 + i < FR)
-                        o[c0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[TT::a(tm)][i], pb[TT::b(tm)], o[c0 + i], 0, 0, 0);
-        }
+        if (t + 1 < t1) issue_tile<KS, NP, W>(ybase + static_cast<int64_t>(t + 1) * TILE, sm, wave, lane);
+        accumulate_stage<KS, NP, QT>(sm + TILE + lane, pb, o);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
     }
-    const float den_tot = dif::rows4_sum(den);
-    store_acc<KS>(o, den_tot, a.w, 16 * g + l15, a.NX, h, a.H, S, split, l15, lg);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+        store_acc<KS>(o[qt], dif::rows4_sum(den[qt]), a.w, 16 * (g0 + qt) + l15, a.NX, h, a.H, S, split, l15, lg);
 }
 
 struct BwdArgs {
@@ -302,66 +422,23 @@ __global__ __launch_bounds__(64 * W) void sigw_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16x8 sm[];
     constexpr int FR = 2 * KS;
     constexpr int TILE = NP * FR * 64;
-    using TT = Terms<NP>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
     const int h = blockIdx.y, S = gridDim.z, split = blockIdx.z;
     const int64_t g = static_cast<int64_t>(blockIdx.x) * W + wave;
     const int64_t gc = g < 2ll * a.Tx ? g : 2ll * a.Tx - 1;
-    bf16x8 x1[NP][KS], x2[NP][KS];
-    {
-        const int64_t off = ((static_cast<int64_t>(h) * a.Tx + (gc >> 1)) * NP * FR + (gc & 1) * KS) * 64 + lane;
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                x1[p][ks] = a.x1r[off + (p * FR + ks) * 64];
-                x2[p][ks] = a.x2r[off + (p * FR + ks) * 64];
-            }
-    }
+    bf16x8 x1[1][NP][KS], x2[1][NP][KS];
+    load_stationary<KS, NP, 1>(a.x1r, h, a.Tx, g, lane, x1);
+    load_stationary<KS, NP, 1>(a.x2r, h, a.Tx, g, lane, x2);
     const float* dl = a.delta + static_cast<int64_t>(h) * a.NDPAD;
     const float dstat = DSTREAM ? 0.f : dl[16 * gc + l15];
     const int per = (a.Ty + S - 1) / S;
     const int t0 = split * per, t1 = (t0 + per < a.Ty) ? t0 + per : a.Ty;
     const int64_t hb = static_cast<int64_t>(h) * a.Ty * TILE;
-    auto issue = [&](const bf16x8* tile, int b) {                      // LDS-DMA: one KiB per wave instruction, no registers
+    f32x4 o[1][FR];
 #pragma unroll
-        for (int i = 0; i < (NP * FR + W - 1) / W; ++i) {
-            const int piece = wave + i * W;
-            if ((NP * FR) % W == 0 || piece < NP * FR)
-                __builtin_amdgcn_global_load_lds(tile + piece * 64 + lane, sm + b * TILE + piece * 64, 16, 0, 0);
-        }
-    };
-    // S^T or T^T of the tile in buffer b against the stationary fragments xs
-    auto scores = [&](int b, const bf16x8 (&xs)[NP][KS], f32x4 (&res)[2]) {
-        f32x4 sa[TT::n][2];
-#pragma unroll
-        for (int i = 0; i < TT::n; ++i) sa[i][0] = sa[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16x8* bb = sm + b * TILE + lane;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 y[NP][2];
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) y[p][rt] = bb[(p * FR + rt * KS + ks) * 64];
-#pragma unroll
-            for (int i = 0; i < TT::n; ++i)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-                    sa[i][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[TT::a(i)][rt], xs[TT::b(i)][ks], sa[i][rt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            res[rt] = sa[0][rt];
-#pragma unroll
-            for (int i = 1; i < TT::n; ++i) res[rt] += sa[i][rt];
-        }
-    };
-    f32x4 o[FR];
-#pragma unroll
-    for (int ct = 0; ct < FR; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < FR; ++ct) o[0][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     int q = 0;                                                          // sub-stage counter: tile q sits in buffer q & 1
-    if (t0 < t1) issue(a.y1r + hb + static_cast<int64_t>(t0) * TILE, 0);
+    if (t0 < t1) issue_tile<KS, NP, W>(a.y1r + hb + static_cast<int64_t>(t0) * TILE, sm, wave, lane);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     for (int t = t0; t < t1; ++t) {
@@ -372,57 +449,42 @@ __global__ __launch_bounds__(64 * W) void sigw_bwd_kernel(BwdArgs a) {
         } else {
             dv[0] = dv[1] = f32x4{dstat, dstat, dstat, dstat};
         }
-        f32x4 s[2], tt[2];
-        issue(a.y2r + hb + static_cast<int64_t>(t) * TILE, (q + 1) & 1);
-        scores(q & 1, x1, s);
+        f32x4 s[1][2], tt[1][2];
+        issue_tile<KS, NP, W>(a.y2r + hb + static_cast<int64_t>(t) * TILE, sm + ((q + 1) & 1) * TILE, wave, lane);
+        score_stage<KS, NP, 1>(sm + (q & 1) * TILE + lane, x1, s);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         ++q;
-        issue(a.y1c + hb + static_cast<int64_t>(t) * TILE, (q + 1) & 1);
-        scores(q & 1, x2, tt);
+        issue_tile<KS, NP, W>(a.y1c + hb + static_cast<int64_t>(t) * TILE, sm + ((q + 1) & 1) * TILE, wave, lane);
+        score_stage<KS, NP, 1>(sm + (q & 1) * TILE + lane, x2, tt);
         // dS = (T - delta~) P (1 - P); padded rows of the stream meet zero rows of Y1 in the last contraction
         f32x4 ds[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pp = sigmoidf(s[rt][r]);
-                ds[rt][r] = (tt[rt][r] - dv[rt][r]) * (pp - pp * pp);
+                const float pp = sigmoidf(s[0][rt][r]);
+                ds[rt][r] = (tt[0][rt][r] - dv[rt][r]) * (pp - pp * pp);
             }
-        bf16x8 pb[NP];
-        split_planes<NP>(ds[0], ds[1], pb);
+        bf16x8 pb[1][NP];
+        split_planes<NP>(ds[0], ds[1], pb[0]);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         ++q;
-        if (t + 1 < t1) issue(a.y1r + hb + static_cast<int64_t>(t + 1) * TILE, (q + 1) & 1);
-        const bf16x8* b1 = sm + (q & 1) * TILE + lane;
-#pragma unroll
-        for (int c0 = 0; c0 < FR; c0 += 4) {
-            bf16x8 z[NP][4];
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (c0 + i < FR) z[pl][i] = b1[(pl * FR + c0 + i) * 64];
-#pragma unroll
-            for (int tm = 0; tm < TT::n; ++tm)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (c0 + i < FR)
-                        o[c0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[TT::a(tm)][i], pb[TT::b(tm)], o[c0 + i], 0, 0, 0);
-        }
+        if (t + 1 < t1) issue_tile<KS, NP, W>(a.y1r + hb + static_cast<int64_t>(t + 1) * TILE, sm + ((q + 1) & 1) * TILE, wave, lane);
+        accumulate_stage<KS, NP, 1>(sm + (q & 1) * TILE + lane, pb, o);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         ++q;
     }
-    store_acc<KS>(o, 1.0f, a.w, 16 * g + l15, a.NX, h, a.H, S, split, l15, lg);
+    store_acc<KS>(o[0], 1.0f, a.w, 16 * g + l15, a.NX, h, a.H, S, split, l15, lg);
 }
 
 // S > 1: out = sum_s part[s] (/ sum_s pden[s]); fixed split order
 __global__ __launch_bounds__(256) void sigw_combine_kernel(const float* __restrict__ part, const float* __restrict__ pden,
                                                            int64_t NX, int64_t NXPAD, int H, int C, int cout, int S,
                                                            float* __restrict__ out, int64_t ldo, float* __restrict__ den_out,
-                                                           int normalize) {
+                                                           int normalize, const float* __restrict__ coladd) {
     const int c4 = (cout + 3) / 4;
     const int64_t total = NX * H * c4;
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
@@ -441,7 +503,7 @@ __global__ __launch_bounds__(256) void sigw_combine_kernel(const float* __restri
         float* dst = out + row * ldo + static_cast<int64_t>(h) * cout + 4 * cq;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (4 * cq + r < cout) dst[r] = acc[r];
+            if (4 * cq + r < cout) dst[r] = acc[r] + (coladd ? coladd[static_cast<int64_t>(h) * cout + 4 * cq + r] : 0.f);
         if (den_out && cq == 0) den_out[row * H + h] = dn;
     }
 }
@@ -449,7 +511,12 @@ __global__ __launch_bounds__(256) void sigw_combine_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------------------------------
 inline size_t align256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 inline int ks_of(int M, int D) { const int c = M > D ? M : D; return (c + 31) / 32; }
-inline int fwd_waves(int KS) { return KS <= 10 ? 8 : 4; }
+// forward sweep: waves per workgroup and stationary 16-row tiles per wave.  Up to 320 columns eight waves fit 256 registers (80
+// for the stationary fragments, 80 for the accumulators at KS = 10); beyond, four waves with up to 512.  (Four waves with TWO row
+// tiles each -- half the LDS reads per product, one wave per SIMD -- measured the same 0.73 ms at 15,000 x 300; kept as QT.)
+constexpr int fwd_waves_c(int KS) { return KS <= 10 ? 8 : 4; }
+constexpr int fwd_qt_c(int KS) { return 1; }
+inline int fwd_rows(int KS) { return 16 * fwd_waves_c(KS) * fwd_qt_c(KS); }
 constexpr int kBwdWaves = 4;
 constexpr int kNP = 2;
 
@@ -472,13 +539,12 @@ int sweep_splits(int64_t groups, int64_t steps) {
     return best;
 }
 
-struct SweepPlan { int W; int64_t gx; int S; int64_t NXPAD; size_t part_bytes; };
-SweepPlan plan_sweep(int64_t NX, int64_t NY, int H, int KS, int W, bool with_den) {
+struct SweepPlan { int64_t gx; int S; int64_t NXPAD; size_t part_bytes; };
+SweepPlan plan_sweep(int64_t NX, int64_t NY, int H, int KS, int rows_per_wg, bool with_den) {
     SweepPlan p;
-    p.W = W;
-    p.gx = (NX + 16 * W - 1) / (16 * W);
+    p.gx = (NX + rows_per_wg - 1) / rows_per_wg;
     p.S = sweep_splits(p.gx * H, (NY + 31) / 32);
-    p.NXPAD = p.gx * 16 * W;
+    p.NXPAD = p.gx * rows_per_wg;
     p.part_bytes = p.S > 1 ? align256(static_cast<size_t>(p.S) * H * p.NXPAD * 32 * KS * sizeof(float)) +
                                  (with_den ? align256(static_cast<size_t>(p.S) * H * p.NXPAD * sizeof(float)) : 0)
                            : 0;
@@ -492,22 +558,21 @@ int set_lds(K kernel, int bytes, const char* who) {
     return 0;
 }
 
-int launch_pack(const float* x, int64_t ld, int64_t R, int creal, int H, int KS, const float* rowdiv, bf16x8* rowp, bf16x8* colp,
-                hipStream_t st) {
+int launch_pack(const float* x, int64_t ld, int64_t R, int creal, int H, int KS, const float* rowdiv, const float* colsub, bf16x8* rowp,
+                bf16x8* colp, hipStream_t st) {
     const int T = static_cast<int>((R + 31) / 32);
-    const int lds = 32 * (32 * KS + 4) * static_cast<int>(sizeof(float));
-    static const int rc = set_lds(&sigw_pack_kernel<kNP>, 32 * (32 * kMaxKS + 4) * static_cast<int>(sizeof(float)), "sigw_pack");
-    if (rc) return rc;
-    hipLaunchKernelGGL(sigw_pack_kernel<kNP>, dim3(T, H), dim3(256), lds, st, x, ld, R, creal, H, KS, rowdiv, rowp, colp, T);
+    hipLaunchKernelGGL(sigw_pack_kernel<kNP>, dim3(T, H, (KS + 1) / 2), dim3(256), 0, st, x, ld, R, creal, H, KS, rowdiv, colsub, rowp, colp,
+                       T);
     return dif::launch_status("sigw_pack_kernel");
 }
 
-template <int KS, int W>
+template <int KS>
 int launch_fwd_t(const FwdArgs& a, const SweepPlan& p, hipStream_t st) {
     constexpr int lds = 2 * kNP * 2 * KS * 1024;
-    static const int rc = set_lds(&sigw_fwd_kernel<KS, kNP, W>, lds, "sigw_fwd");
+    constexpr int W = fwd_waves_c(KS), QT = fwd_qt_c(KS);
+    static const int rc = set_lds(&sigw_fwd_kernel<KS, kNP, W, QT>, lds, "sigw_fwd");
     if (rc) return rc;
-    hipLaunchKernelGGL((sigw_fwd_kernel<KS, kNP, W>), dim3(static_cast<unsigned>(p.gx), a.H, p.S), dim3(64 * W), lds, st, a);
+    hipLaunchKernelGGL((sigw_fwd_kernel<KS, kNP, W, QT>), dim3(static_cast<unsigned>(p.gx), a.H, p.S), dim3(64 * W), lds, st, a);
     return dif::launch_status("sigw_fwd_kernel");
 }
 template <int KS, bool DSTREAM>
@@ -522,7 +587,7 @@ int launch_bwd_t(const BwdArgs& a, const SweepPlan& p, hipStream_t st) {
 
 int launch_fwd(int KS, const FwdArgs& a, const SweepPlan& p, hipStream_t st) {
     switch (KS) {
-#define DIF_CASE(K) case K: return launch_fwd_t<K, (K <= 10 ? 8 : 4)>(a, p, st);
+#define DIF_CASE(K) case K: return launch_fwd_t<K>(a, p, st);
         DIF_CASE(3) DIF_CASE(4) DIF_CASE(5) DIF_CASE(6) DIF_CASE(7) DIF_CASE(8) DIF_CASE(9) DIF_CASE(10)
         DIF_CASE(11) DIF_CASE(12) DIF_CASE(13) DIF_CASE(14) DIF_CASE(15) DIF_CASE(16)
 #undef DIF_CASE
@@ -545,8 +610,20 @@ int launch_combine(const SweepPlan& p, const SweepOut& w, int64_t NX, int H, int
     int64_t gr = (NX * H * ((w.cout + 3) / 4) + 255) / 256;
     if (gr > 8 * dif::kCUs) gr = 8 * dif::kCUs;
     hipLaunchKernelGGL(sigw_combine_kernel, dim3(static_cast<unsigned>(gr)), dim3(256), 0, st, w.part, w.pden, NX, p.NXPAD, H, 32 * KS,
-                       w.cout, p.S, w.out, w.ldo, w.den_out, w.normalize);
+                       w.cout, p.S, w.out, w.ldo, w.den_out, w.normalize, w.coladd);
     return dif::launch_status("sigw_combine_kernel");
+}
+
+// cmean [H][D] = column means of v; partial: ceil(L / 128) x H D floats
+inline size_t colmean_bytes(int64_t L, int H, int D) {
+    return align256(static_cast<size_t>((L + 127) / 128) * H * D * sizeof(float)) + align256(static_cast<size_t>(H) * D * sizeof(float));
+}
+int launch_colmean(const float* v, int64_t ldv, int64_t L, int H, int D, float* partial, float* cmean, hipStream_t st) {
+    const int blocks = static_cast<int>((L + 127) / 128);
+    hipLaunchKernelGGL(sigw_colsum_kernel, dim3(blocks), dim3(256), 0, st, v, ldv, L, H * D, partial);
+    if (int rc = dif::launch_status("sigw_colsum_kernel")) return rc;
+    hipLaunchKernelGGL(sigw_colmean_kernel, dim3((H * D + 255) / 256), dim3(256), 0, st, partial, blocks, L, H * D, cmean);
+    return dif::launch_status("sigw_colmean_kernel");
 }
 
 // carve `bytes` out of the workspace
@@ -571,14 +648,14 @@ bool sigw_covers(int M, int D) {
 
 size_t sigw_fwd_workspace_bytes(int64_t N, int64_t L, int H, int M, int D) {
     const int KS = ks_of(M, D);
-    const SweepPlan p = plan_sweep(N, L, H, KS, fwd_waves(KS), true);
-    return 256 + packed_bytes(N, H, KS, kNP) + 2 * packed_bytes(L, H, KS, kNP) + p.part_bytes;
+    const SweepPlan p = plan_sweep(N, L, H, KS, fwd_rows(KS), true);
+    return 256 + packed_bytes(N, H, KS, kNP) + 2 * packed_bytes(L, H, KS, kNP) + colmean_bytes(L, H, D) + p.part_bytes;
 }
 
 int sigw_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int64_t N, int64_t L, int H,
              int M, int D, float* out, int64_t ldo, float* den, void* workspace, size_t workspace_bytes, hipStream_t st) {
     const int KS = ks_of(M, D);
-    const SweepPlan p = plan_sweep(N, L, H, KS, fwd_waves(KS), true);
+    const SweepPlan p = plan_sweep(N, L, H, KS, fwd_rows(KS), true);
     DIF_REQUIRE(workspace && workspace_bytes >= sigw_fwd_workspace_bytes(N, L, H, M, D), DIF_E_WORKSPACE,
                 "sigmoid attention (wide heads): workspace too small (%zu < %zu)", workspace_bytes,
                 sigw_fwd_workspace_bytes(N, L, H, M, D));
@@ -591,13 +668,16 @@ int sigw_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const flo
     bf16x8* qr = static_cast<bf16x8*>(cv.take(packed_bytes(N, H, KS, kNP)));
     bf16x8* kr = static_cast<bf16x8*>(cv.take(packed_bytes(L, H, KS, kNP)));
     bf16x8* vc = static_cast<bf16x8*>(cv.take(packed_bytes(L, H, KS, kNP)));
-    if (int rc = launch_pack(q, ldq, N, M, H, KS, nullptr, qr, nullptr, st)) return rc;
-    if (int rc = launch_pack(k, ldk, L, M, H, KS, nullptr, kr, nullptr, st)) return rc;
-    if (int rc = launch_pack(v, ldv, L, D, H, KS, nullptr, nullptr, vc, st)) return rc;
+    float* cpart = static_cast<float*>(cv.take(static_cast<size_t>((L + 127) / 128) * H * D * sizeof(float)));
+    float* cmean = static_cast<float*>(cv.take(static_cast<size_t>(H) * D * sizeof(float)));
+    if (int rc = launch_colmean(v, ldv, L, H, D, cpart, cmean, st)) return rc;
+    if (int rc = launch_pack(q, ldq, N, M, H, KS, nullptr, nullptr, qr, nullptr, st)) return rc;
+    if (int rc = launch_pack(k, ldk, L, M, H, KS, nullptr, nullptr, kr, nullptr, st)) return rc;
+    if (int rc = launch_pack(v, ldv, L, D, H, KS, nullptr, cmean, nullptr, vc, st)) return rc;       // centred values; the centre comes back in the epilogue
     FwdArgs a;
     a.xr = qr; a.yr = kr; a.zc = vc;
     a.NX = N; a.NY = L; a.Tx = static_cast<int>((N + 31) / 32); a.Ty = static_cast<int>((L + 31) / 32); a.H = H;
-    a.w = SweepOut{out, ldo, D, den, nullptr, nullptr, p.NXPAD, 1};
+    a.w = SweepOut{out, ldo, D, den, nullptr, nullptr, p.NXPAD, 1, cmean};
     if (p.S > 1) {
         a.w.part = static_cast<float*>(cv.take(static_cast<size_t>(p.S) * H * p.NXPAD * 32 * KS * sizeof(float)));
         a.w.pden = static_cast<float*>(cv.take(static_cast<size_t>(p.S) * H * p.NXPAD * sizeof(float)));
@@ -608,12 +688,13 @@ int sigw_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const flo
 
 size_t sigw_bwd_workspace_bytes(int64_t N, int64_t L, int H, int M, int D) {
     const int KS = ks_of(M, D);
-    const SweepPlan pq = plan_sweep(N, L, H, KS, kBwdWaves, false), pk = plan_sweep(L, N, H, KS, kBwdWaves, false),
-                    pv = plan_sweep(L, N, H, KS, fwd_waves(KS), false);
+    const SweepPlan pq = plan_sweep(N, L, H, KS, 16 * kBwdWaves, false), pk = plan_sweep(L, N, H, KS, 16 * kBwdWaves, false),
+                    pv = plan_sweep(L, N, H, KS, fwd_rows(KS), false);
     size_t part = pq.part_bytes > pk.part_bytes ? pq.part_bytes : pk.part_bytes;
     if (pv.part_bytes > part) part = pv.part_bytes;
     const size_t ndpad = static_cast<size_t>((N + 63) / 64 * 64 + 64);
-    return 256 + 4 * packed_bytes(N, H, KS, kNP) + 3 * packed_bytes(L, H, KS, kNP) + align256(H * ndpad * sizeof(float)) + part;
+    return 256 + 4 * packed_bytes(N, H, KS, kNP) + 3 * packed_bytes(L, H, KS, kNP) + align256(H * ndpad * sizeof(float)) +
+           colmean_bytes(L, H, D) + part;
 }
 
 int sigw_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* out, int64_t ldo,
@@ -639,33 +720,36 @@ int sigw_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const flo
     bf16x8* vr = static_cast<bf16x8*>(cv.take(pl));
     const int64_t ndpad = (N + 63) / 64 * 64 + 64;
     float* delta = static_cast<float*>(cv.take(static_cast<size_t>(H) * ndpad * sizeof(float)));
+    float* cpart = static_cast<float*>(cv.take(static_cast<size_t>((L + 127) / 128) * H * D * sizeof(float)));
+    float* cmean = static_cast<float*>(cv.take(static_cast<size_t>(H) * D * sizeof(float)));
     float* part = reinterpret_cast<float*>(cv.p);
-    hipLaunchKernelGGL(sigw_delta_kernel, dim3(static_cast<unsigned>((ndpad * H + 3) / 4)), dim3(256), 0, st, g, ldg, out, ldo, den, N,
-                       ndpad, H, D, delta);
+    if (int rc = launch_colmean(v, ldv, L, H, D, cpart, cmean, st)) return rc;
+    hipLaunchKernelGGL(sigw_delta_kernel, dim3(static_cast<unsigned>((ndpad * H + 3) / 4)), dim3(256), 0, st, g, ldg, out, ldo, den, cmean,
+                       N, ndpad, H, D, delta);
     if (int rc = dif::launch_status("sigw_delta_kernel")) return rc;
-    if (int rc = launch_pack(q, ldq, N, M, H, KS, nullptr, qr, qc, st)) return rc;
-    if (int rc = launch_pack(k, ldk, L, M, H, KS, nullptr, kr, kc, st)) return rc;
-    if (int rc = launch_pack(v, ldv, L, D, H, KS, nullptr, vr, nullptr, st)) return rc;
-    if (int rc = launch_pack(g, ldg, N, D, H, KS, den, gr, gc, st)) return rc;
+    if (int rc = launch_pack(q, ldq, N, M, H, KS, nullptr, nullptr, qr, qc, st)) return rc;
+    if (int rc = launch_pack(k, ldk, L, M, H, KS, nullptr, nullptr, kr, kc, st)) return rc;
+    if (int rc = launch_pack(v, ldv, L, D, H, KS, nullptr, cmean, vr, nullptr, st)) return rc;       // centred: T - delta~ = g~.(v - c) - g~.(out - c)
+    if (int rc = launch_pack(g, ldg, N, D, H, KS, den, nullptr, gr, gc, st)) return rc;
     const int Tn = static_cast<int>((N + 31) / 32), Tl = static_cast<int>((L + 31) / 32);
     {   // dQ: stationary = queries
-        const SweepPlan p = plan_sweep(N, L, H, KS, kBwdWaves, false);
-        BwdArgs a{qr, gr, kr, vr, kc, delta, ndpad, N, L, Tn, Tl, H, SweepOut{dq, lddq, M, nullptr, p.S > 1 ? part : nullptr, nullptr, p.NXPAD, 0}};
+        const SweepPlan p = plan_sweep(N, L, H, KS, 16 * kBwdWaves, false);
+        BwdArgs a{qr, gr, kr, vr, kc, delta, ndpad, N, L, Tn, Tl, H, SweepOut{dq, lddq, M, nullptr, p.S > 1 ? part : nullptr, nullptr, p.NXPAD, 0, nullptr}};
         if (int rc = launch_bwd<false>(KS, a, p, st)) return rc;
         if (int rc = launch_combine(p, a.w, N, H, KS, st)) return rc;
     }
     {   // dK: stationary = keys, delta~ rides on the streamed queries
-        const SweepPlan p = plan_sweep(L, N, H, KS, kBwdWaves, false);
-        BwdArgs a{kr, vr, qr, gr, qc, delta, ndpad, L, N, Tl, Tn, H, SweepOut{dk, lddk, M, nullptr, p.S > 1 ? part : nullptr, nullptr, p.NXPAD, 0}};
+        const SweepPlan p = plan_sweep(L, N, H, KS, 16 * kBwdWaves, false);
+        BwdArgs a{kr, vr, qr, gr, qc, delta, ndpad, L, N, Tl, Tn, H, SweepOut{dk, lddk, M, nullptr, p.S > 1 ? part : nullptr, nullptr, p.NXPAD, 0, nullptr}};
         if (int rc = launch_bwd<true>(KS, a, p, st)) return rc;
         if (int rc = launch_combine(p, a.w, L, H, KS, st)) return rc;
     }
     {   // dV = P^T G~: the forward sweep with the roles of Q and K exchanged, raw sums
-        const SweepPlan p = plan_sweep(L, N, H, KS, fwd_waves(KS), false);
+        const SweepPlan p = plan_sweep(L, N, H, KS, fwd_rows(KS), false);
         FwdArgs a;
         a.xr = kr; a.yr = qr; a.zc = gc;
         a.NX = L; a.NY = N; a.Tx = Tl; a.Ty = Tn; a.H = H;
-        a.w = SweepOut{dv, lddv, D, nullptr, p.S > 1 ? part : nullptr, nullptr, p.NXPAD, 0};
+        a.w = SweepOut{dv, lddv, D, nullptr, p.S > 1 ? part : nullptr, nullptr, p.NXPAD, 0, nullptr};
         if (int rc = launch_fwd(KS, a, p, st)) return rc;
         if (int rc = launch_combine(p, a.w, L, H, KS, st)) return rc;
     }

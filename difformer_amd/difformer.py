@@ -388,6 +388,13 @@ class DIFFormer(nn.Module):
         self.invalidate_caches()
         return out
 
+    def train(self, mode=True):
+        """model.train() / model.eval() (once per epoch in the reference's loops): also the point where the whole-model path for
+        tiny graphs reads its deferred edge_index checks (tiny._poll_status): a node id outside [0, n) seen by an earlier forward
+        raises ValueError here at the latest (DIFFORMER_DEBUG=1: at the offending call)."""
+        tiny._poll_status(wait=True)
+        return super().train(mode)
+
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self.invalidate_caches()

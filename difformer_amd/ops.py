@@ -428,9 +428,15 @@ class _CSRCache:
         if hit is not None:
             ei_ref, ew_ref, csr = hit
             if ei_ref() is edge_index and (given_weight is None or ew_ref() is given_weight):
-                self.entries.move_to_end(key)
-                if csr._format_checked or not build_format:
-                    return csr
+                if edge_weight is not None and not csr.weighted:
+                    # built through the uniform-weight shortcut (an eval pass before the first step of learnable weights
+                    # initialised to a constant): this call wants the weighted CSR, whose values autograd differentiates
+                    del self.entries[key]
+                    csr = None
+                else:
+                    self.entries.move_to_end(key)
+                    if csr._format_checked or not build_format:
+                        return csr
             else:
                 del self.entries[key]
                 csr = None

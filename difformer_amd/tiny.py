@@ -51,8 +51,14 @@ class _GraphCache:
         self.capacity, self.entries = capacity, OrderedDict()
 
     def get(self, edge_index, edge_weight, n):
-        key = (id(edge_index), edge_index.data_ptr(), edge_index.shape[1], edge_index._version, n,
-               None if edge_weight is None else (id(edge_weight), edge_weight.data_ptr(), edge_weight._version))
+        # (tensors made under torch.inference_mode() track no version: ops.tensor_version gives -1 and the graph is rebuilt
+        # on every call, as ops.csr_cache does)
+        vi = ops.tensor_version(edge_index)
+        vw = 0 if edge_weight is None else ops.tensor_version(edge_weight)
+        if vi < 0 or vw < 0:
+            return build_graph(edge_index, edge_weight, n)
+        key = (id(edge_index), edge_index.data_ptr(), edge_index.shape[1], vi, n,
+               None if edge_weight is None else (id(edge_weight), edge_weight.data_ptr(), vw))
         hit = self.entries.get(key)
         if hit is not None and hit[0]() is edge_index and (edge_weight is None or hit[1]() is edge_weight):
             self.entries.move_to_end(key)
@@ -70,9 +76,16 @@ class _GraphCache:
 graphs = _GraphCache()
 stats = {"forward": 0, "backward": 0, "graph_builds": 0}          # calls that took this path (tests assert on them)
 
-# The index check of dif_tiny_graph_build (status[0] != 0: a node id outside [0, n)) is read WITHOUT a host synchronisation per
-# snapshot: every build writes its two status words into the next slot of a ring on its device; when the ring is full (and when a
-# caller asks, `_poll_status(wait=True)`) ONE read checks all its slots.
+# The index check of dif_tiny_graph_build (status[0] != 0: a node id outside [0, n); the entry is filed under node 0) is read
+# WITHOUT a host synchronisation per snapshot: every build writes its two status words into the next slot of a ring on its
+# device, and ONE read checks all slots
+#   * when the ring is full (128 builds),
+#   * at every model.train() / model.eval() switch (DIFFormer.train: once per epoch in the reference's loops,
+#     spatial-temporal/main.py:91, eval.py:9) and at interpreter exit,
+#   * right after the build when DIFFORMER_DEBUG=1 (one synchronisation per new graph: the error then comes from the offending
+#     call, as the reference's own index ops raise, difformer.py:66).
+# So a bad edge_index raises ValueError at the latest at the next mode switch -- DEFERRED, unlike the layer-by-layer path.
+DEBUG = os.environ.get("DIFFORMER_DEBUG", "0") == "1"
 _RING = 128
 _rings = {}            # device -> [int32 tensor [2 * _RING], next slot]
 
@@ -89,7 +102,8 @@ def _status_slot(dev):
 
 
 def _poll_status(wait=False):
-    """Raise for a bad edge_index seen by any build since the last check (wait=False: only when a ring is full -- never)."""
+    """Raise for a bad edge_index seen by any build since the last check (wait=False: nothing -- the ring reads itself when
+    full).  Synchronises with the device when any build is pending."""
     if not wait:
         return
     for ring in _rings.values():
@@ -134,7 +148,23 @@ def build_graph(edge_index, edge_weight, n):
     _lib.check(rc, "dif_tiny_graph_build")
     stats["graph_builds"] += 1
     g.keep = (buf, ei, w)
+    if DEBUG:
+        _poll_status(wait=True)
     return g
+
+
+def _poll_at_exit():
+    try:
+        _poll_status(wait=True)
+    except ValueError as e:           # nothing to unwind to any more: say it
+        import sys
+        print(f"difformer_amd: {e} (seen by an earlier forward of this process)", file=sys.stderr)
+    except Exception:
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(_poll_at_exit)
 
 
 def _plan(model, x, edge_index, edge_weight):
@@ -164,6 +194,8 @@ def _plan(model, x, edge_index, edge_weight):
     if kernel == "sigmoid" and n > MAX_NODES_SIGMOID:
         return None                          # O(n^2) pairs on ONE compute unit: from ~500 nodes the flash-style kernels win
     md = model.__dict__
+    if md["training"] and not (0.0 <= float(md["dropout"]) < 1.0):
+        return None                          # dropout = 1 (all zeros in training): the layer path's F.dropout semantics
     use_bn = bool(md["use_bn"])
     params = [w0, b0]
     params += [bns[0]._parameters["weight"], bns[0]._parameters["bias"]] if use_bn else [None, None]
@@ -276,5 +308,6 @@ def forward(model, x, edge_index, edge_weight):
         graph = graphs.get(edge_index, edge_weight, fields["n"])
         fields["gcn_scale"] *= graph.scale
     live = [p for p in params if p is not None]
-    state = (fields, params, graph, float(model.__dict__["dropout"]), bool(model.training))
+    training = bool(model.training)
+    state = (fields, params, graph, float(model.__dict__["dropout"]) if training else 0.0, training)       # eval: dropout is the identity
     return _TinyModel.apply(state, x, *live)

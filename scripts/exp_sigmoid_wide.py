@@ -6,7 +6,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from difformer_amd import autograd_ops as ag, ops  # noqa: E402
 
 dev = torch.device("cuda:0")

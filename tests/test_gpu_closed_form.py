@@ -125,6 +125,7 @@ def test_closed_form_attention_matches_the_simple_kernel(n, c, d, use_weight, de
                           (6000, 8, 192, True, -1, False, True, True),
                           (5000, 5, 300, True, 0.4, True, True, True),
                           (4000, 6, 400, False, -1, False, True, False),
+                          (3000, 6, 512, True, -1, False, True, True),          # the widest closed-form layer (ops.CLOSED_FORM_WIDE_MAX; ADVICE r5: raised)
                           (9000, 60, 132, True, -1, False, True, True),         # wide rows on the sliced product
                           # hidden 65..128 (run.sh:42-44 trains Pokec at 128): the one-pass kernel of csrc/simple_layer_wide.hip
                           (9000, 60, 128, True, -1, False, True, True),         # ... behind the sliced product at 128 columns
@@ -712,7 +713,8 @@ def test_gram_record_at_the_script_widths(n, c, dev):
     assert torch.equal(rec[c * c: c * c + c], r2[c * c: c * c + c])            # deterministic
 
 
-@pytest.mark.parametrize("C,D,n", [(300, 300, 5000), (68, 68, 3000), (128, 128, 4000), (400, 400, 6000), (132, 96, 5000)])
+@pytest.mark.parametrize("C,D,n", [(300, 300, 5000), (68, 68, 3000), (128, 128, 4000), (400, 400, 6000), (132, 96, 5000),
+                                   (512, 512, 4000)])
 def test_wide_coefficients_kernels_vs_float64_definition(C, D, n, dev):
     """dif_wide_coeffs_f64 (round 5: both float64 products of the wide closed form on own kernels) against the same algebra
     in float64 tensor ops, entry by entry -- the model-level parity metric barely sees [Mn | u] (the attention of the `simple`

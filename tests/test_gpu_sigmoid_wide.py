@@ -187,8 +187,12 @@ def test_script_size_forward_backward(dev):
 
 @pytest.mark.parametrize("hidden,layers,n", [(300, 2, 3000), (400, 2, 1500), (128, 8, 700)])
 def test_model_training_step_vs_oracle(hidden, layers, n, dev):
-    """The script configuration at a size the float64 autograd oracle finishes in seconds; (128, 8): the deepest sigmoid script
-    (node classification/run.sh:10 runs 8 layers) at a wide head."""
+    """The script configuration at a size the float64 autograd oracle finishes in seconds; (128, 8): the depth of the deepest
+    sigmoid script (node classification/run.sh:10 runs 8 layers) at a wide head.  There one tensor is beyond float32: Wk.bias of
+    the seventh layer (a bias on every key moves all scores of a query alike and nearly cancels in P / sum P) has entries below
+    1e-6 of the step's largest gradient entry, and the ORACLE ITSELF run in float32 misses it by 2.4e-4 on this metric.  Such a
+    tensor (largest reference entry < 2e-6 gmax) is held to an absolute bar instead: 1e-7 of gmax, float32's own resolution of
+    the step's largest gradient (the split-bfloat16 planes land at ~1.5e-8)."""
     from difformer_amd import DIFFormer
     torch.manual_seed(hidden + layers)
     f_in, c = 48, 10
@@ -217,8 +221,14 @@ def test_model_training_step_vs_oracle(hidden, layers, n, dev):
     assert abs(float(loss.detach()) - float(lref.detach())) < TOL * abs(float(lref.detach()))
     assert rel_err(xd.grad.cpu().numpy(), x64.grad.numpy()) < TOL
     gmax = max(float(v.grad.abs().max()) for v in pl.values())
-    errs = {k: grad_err(p.grad.cpu().numpy(), pl[k].grad.numpy(), gmax) for k, p in model.named_parameters()}
-    assert max(errs.values()) < TOL, {k: f"{e:.2e}" for k, e in errs.items() if e > 2e-5}
+    errs = {}
+    for k, p in model.named_parameters():
+        ref = pl[k].grad.numpy()
+        if float(np.abs(ref).max()) < 2e-6 * gmax:
+            errs[k] = float(np.abs(p.grad.cpu().double().numpy() - ref).max()) / (1e-7 * gmax) * TOL      # absolute bar, scaled onto TOL
+        else:
+            errs[k] = grad_err(p.grad.cpu().numpy(), ref, gmax)
+    assert max(errs.values()) < TOL, [(f"{e:.2e}", k) for e, k in sorted(((e, k) for k, e in errs.items()), reverse=True)[:6]]
 
 
 def test_exact_fp32_keeps_the_fp32_chain(dev):

@@ -60,6 +60,55 @@ def test_graph_build_flags_bad_indices(dev):
     tiny._poll_status(wait=True)
 
 
+def test_bad_indices_surface_at_the_next_mode_switch_and_inference_tensors_work(dev):
+    """(a) a run of fewer than 128 snapshots used to return silently wrong numbers for a node id outside [0, n) --
+    model.eval() / model.train() now reads the pending checks; DIFFORMER_DEBUG=1 reads them at the call (child process);
+    (b) graphs made under torch.inference_mode() track no version counter: the graph cache rebuilds instead of raising;
+    (c) dropout = 1.0 in eval mode is the identity (the whole-model path used to reject p >= 1 in both modes)."""
+    import os, subprocess, sys
+    from difformer_amd import DIFFormer, tiny
+    torch.manual_seed(0)
+    model = DIFFormer(4, 4, 1, num_layers=2, kernel="simple", use_graph=True, use_weight=False).to(dev).train()
+    x = torch.randn(30, 4, device=dev)
+    ei = _graph(30, 100, seed=2)
+    ei[0, 5] = 31
+    tiny._poll_status(wait=True)
+    before = tiny.stats["forward"]
+    model(x, ei.to(dev))
+    assert tiny.stats["forward"] == before + 1                       # took the whole-model path, no error yet
+    with pytest.raises(ValueError):
+        model.eval()
+    model.eval()                                                      # reported once
+    good = _graph(30, 100, seed=3).to(dev)
+    with torch.inference_mode():
+        gi = good.clone()
+        y1 = model(x, gi)
+        y2 = model(x, gi)
+    assert torch.equal(y1, y2)
+    with torch.no_grad():
+        assert torch.allclose(model(x, good), y1, rtol=0, atol=0)
+        model.dropout = 1.0
+        before = tiny.stats["forward"]
+        assert torch.equal(model(x, good), y1) and tiny.stats["forward"] == before + 1      # eval: identity, still one launch
+    model.dropout = 0.0
+    code = """
+import torch
+from difformer_amd import DIFFormer
+dev = torch.device('cuda:0')
+model = DIFFormer(4, 4, 1, num_layers=2, kernel='simple', use_graph=True, use_weight=False).to(dev)
+ei = torch.randint(0, 30, (2, 100)); ei[1, 3] = 99
+try:
+    model(torch.randn(30, 4, device=dev), ei.to(dev))
+    print('NO ERROR')
+except ValueError as e:
+    print('RAISED AT THE CALL')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, DIFFORMER_DEBUG="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert "RAISED AT THE CALL" in r.stdout, r.stdout + r.stderr[-1500:]
+
+
 def _oracle(p, x, ei, w, cfg, masks=None):
     """og.difformer_forward with the dropout masks of :192 / :204 applied where the reference applies them."""
     if masks is None:

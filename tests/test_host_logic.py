@@ -607,6 +607,14 @@ def test_constant_edge_weights_build_the_unweighted_csr(fake_backend):
         p = {k: v.detach().numpy().astype(np.float64) for k, v in model.state_dict().items()}
         ref = orc.difformer_forward(p, xin.double().numpy(), ei.numpy(), w.double().numpy(), cfg)
         assert np.abs(out.numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    # learnable weights initialised to a constant -- an eval pass under no_grad caches the UNWEIGHTED CSR under the
+    # weight tensor's key; the grad-enabled call that follows must not take that entry (edge_weight would get no gradient)
+    wl = torch.ones(ei.shape[1], requires_grad=True)
+    with torch.no_grad():
+        assert not ops.csr_cache.get(ei, wl, n, 32).weighted
+    assert ops.csr_cache.get(ei, wl, n, 32).weighted
+    gcn_conv(x, ei, wl).sum().backward()
+    assert wl.grad is not None and float(wl.grad.abs().sum()) > 0
     request_finalizer()
     assert ops.csr_cache.get(ei, torch.full((ei.shape[1],), 2.0), n, 32).weighted    # 80 nodes: not worth the check by default
 
