@@ -2,7 +2,7 @@
 On the GPU box:
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/cov -- python -m pytest $GRAFT_REPO_ROOT/tests -m gpu -q
-    python scripts/kernel_coverage.py gpurun_out/cov > profiles/r06_kernel_coverage.txt
+    python scripts/kernel_coverage.py gpurun_out/cov [more directories] > profiles/r06_kernel_coverage.txt
 Every `*kernel_stats.csv` / `*kernel_trace.csv` under the directory is read (the suite's child processes write their own),
 kernel names are normalised like scripts/kernel_symbols.py does, and the list of the library's kernels is printed with the number
 of launches the suite made of each; the ones never launched come last under `UNLAUNCHED`.  Exit code 1 if any is unlaunched."""
@@ -32,9 +32,15 @@ def launched(directory):
 
 
 def main():
-    directory = sys.argv[1]
-    lib = sys.argv[2] if len(sys.argv) > 2 else ks.DEFAULT_LIB
-    counts, nfiles = launched(directory)
+    dirs = [a for a in sys.argv[1:] if os.path.isdir(a)]
+    libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+    lib = libs[0] if libs else ks.DEFAULT_LIB
+    counts, nfiles = {}, 0
+    for d in dirs:                       # several runs (the suite in pieces): launches add up
+        c, nf = launched(d)
+        nfiles += nf
+        for k, v in c.items():
+            counts[k] = counts.get(k, 0) + v
     mine = ks.kernels(lib)
     missing = [k for k in mine if counts.get(k, 0) == 0]
     print(f"# kernel-instantiation coverage of `pytest tests -m gpu` ({nfiles} rocprofv3 kernel-stats files, one per process)")

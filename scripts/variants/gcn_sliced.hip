@@ -1,3 +1,6 @@
+// MEASUREMENT FORK of difformer_amd/csrc/gcn_sliced.hip as of round 5 (probes, traces, alternative layouts behind -D flags; results of most are
+// WRONG by design).  Not part of the product: built only by scripts/build_sliced_variants.sh (OBJ=gcn_sliced) into scripts/bin/.  The product
+// file carries none of these branches and compiles to the same device code as this fork without flags (round 6, checked).
 // a3 (hot half, dense graphs): feature-sliced normalised-adjacency product with the SOURCE rows staged in LDS
 //   out[r,:] = gcn_scale * dinv[r] * sum_{e in CSR row r} (dinv[src_e] * x[src_e,:])   (+ attn_scale * attn[r,:])
 // node classification/difformer.py:63-79 for edge_weight = None: value_e = dinv[col] * dinv[row] factors into a
@@ -44,11 +47,19 @@ using dif::f32x4;
 #ifndef DIF_SLICED_WG_PER_CU
 #define DIF_SLICED_WG_PER_CU 1
 #endif
-// (The timing probes, the 32-bit entry format, the scalar adds, the 8-read sweep and the wall-clock trace that
-// profiles/r04_experiments.md measured live in scripts/variants/gcn_sliced.hip, a fork of this file built by
-// scripts/build_sliced_variants.sh: measurement code does not ship.)  Entries: 16-bit tile-local row numbers in blocks of
-// eight steps x 64 lanes.
+// Timing probes (results are WRONG; profiles/r04_experiments.md): 1 = entry registers never reloaded inside a tile, 2 = LDS
+// reads without the adds, 3 = adds without the LDS reads, 4 = tiles loaded once (barriers kept), 5 = no tile loads, no barriers
+#ifndef DIF_SLICED_PROBE
+#define DIF_SLICED_PROBE 0
+#endif
+// Entry format of measurement builds (profiles/r04_experiments.md): -DDIF_SLICED_ENTRY32 stores every entry as the 32-bit
+// LDS byte address of its row (no address shift in the sweep) in blocks of FOUR steps x 64 lanes -- the same 1-KiB block,
+// twice the entry stream.  The default is the 16-bit tile-local row number in blocks of eight steps.
+#ifdef DIF_SLICED_ENTRY32
+constexpr int kSteps = 4;
+#else
 constexpr int kSteps = 8;
+#endif
 constexpr int kTileRowsMax = DIF_SLICED_TILE_ROWS;   // + 16 zero rows = 10,224 rows x 16 B = 163,584 B of LDS
 constexpr int kLdsRows = kTileRowsMax + 16;
 constexpr int kWgPerCU = DIF_SLICED_WG_PER_CU;
@@ -412,7 +423,11 @@ __device__ __forceinline__ void fill_blocks(const uint16_t* __restrict__ mine, c
         }
         // every lane has read its records (the loads above belong to instructions that completed for the whole wave
         // before the first dependent use); now the block takes its final content
+#ifdef DIF_SLICED_ENTRY32
+        blk[lane] = uint4{ent[0] << 4, ent[1] << 4, ent[2] << 4, ent[3] << 4};
+#else
         blk[lane] = uint4{ent[0] | (ent[1] << 16), ent[2] | (ent[3] << 16), ent[4] | (ent[5] << 16), ent[6] | (ent[7] << 16)};
+#endif
     }
 }
 
@@ -590,17 +605,39 @@ struct Epilogue {
     float* out;
     int64_t ldo;
     f32x4* partial;        // S > 1: [S][slices][G * 64] raw sums of the splits, finished by sliced_combine_kernel
+#ifdef DIF_SLICED_TRACE
+    long long* trace;      // measurement build only (scripts/exp_sliced_trace.py): per-tile wall-clock stamps of the first and last wave
+#endif
 };
 
 // one block of a round: eight entries (four packed dwords), 16-bit row number -> LDS byte address with one SDWA shift
 // each; the entry register is reloaded (its next block) as soon as the addresses are out, BEFORE the LDS reads, so the
 // load has the whole block in flight even in the phases where few rounds are active
-// float4 sum (two v_pk_add_f32)
+// float4 sum; measurement builds: -DDIF_SLICED_SCALAR_ADD forces four v_add_f32 instead of two v_pk_add_f32
 __device__ __forceinline__ f32x4 add4(f32x4 x, f32x4 y) {
+#ifdef DIF_SLICED_SCALAR_ADD
+    f32x4 r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.x) : "v"(x.x), "v"(y.x));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.y) : "v"(x.y), "v"(y.y));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.z) : "v"(x.z), "v"(y.z));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.w) : "v"(x.w), "v"(y.w));
+    return r;
+#else
     return x + y;
+#endif
 }
 
 __device__ __forceinline__ void block8(const f32x4* tile, uint4& e, const uint4* reload, f32x4& a) {
+#ifdef DIF_SLICED_ENTRY32
+    // four steps: the entries ARE the LDS byte addresses
+    const uint32_t ad[4] = {e.x, e.y, e.z, e.w};
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[q]);
+    e = *reload;
+    a = add4(a, add4(add4(v[0], v[1]), add4(v[2], v[3])));
+    asm volatile("" : "+v"(a));          // the sum is due HERE (the machine sinker otherwise parks every round's adds behind the last round's reads)
+#else
     const uint32_t four = 4;
     const uint32_t wds[4] = {e.x, e.y, e.z, e.w};
     uint32_t ad[8];
@@ -611,7 +648,41 @@ __device__ __forceinline__ void block8(const f32x4* tile, uint4& e, const uint4*
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
             : "=v"(ad[2 * q + 1]) : "v"(four), "v"(wds[q]));
     }
+#if DIF_SLICED_PROBE != 1
     e = *reload;
+#endif
+#if DIF_SLICED_PROBE == 2          // reads only: results kept alive, no adds
+    {
+        f32x4 v[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[4 * h + q]);
+            asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        }
+        return;
+    }
+#elif DIF_SLICED_PROBE == 3        // adds only: the addresses stand in for the rows
+    {
+        f32x4 v[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float f = __uint_as_float(ad[4 * h + q]); v[q] = f32x4{f, f, f, f}; }
+            a = add4(a, add4(add4(v[0], v[1]), add4(v[2], v[3])));
+            asm volatile("" : "+v"(a));
+        }
+        return;
+    }
+#endif
+#ifdef DIF_SLICED_READS8
+    // all eight reads in flight before the first add (32 result registers instead of 16)
+    f32x4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[q]);
+    a = add4(a, add4(add4(add4(v[0], v[1]), add4(v[2], v[3])), add4(add4(v[4], v[5]), add4(v[6], v[7]))));
+    asm volatile("" : "+v"(a));
+#else
     f32x4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[q]);
@@ -619,6 +690,8 @@ __device__ __forceinline__ void block8(const f32x4* tile, uint4& e, const uint4*
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tile) + ad[4 + q]);
     a = add4(a, add4(add4(v[0], v[1]), add4(v[2], v[3])));
+#endif
+#endif
 }
 
 // Phase M: the block rows in which exactly the rounds 0 .. M-1 are active (nb[M] <= k < nb[M-1]).
@@ -700,6 +773,13 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
         int t = tt + t0;                                                      // XCDs start on different tiles (t0)
         if (t >= ntl) t -= ntl;
         t += z * ntl;
+#ifdef DIF_SLICED_TRACE
+        const int tw = (threadIdx.x >> 6) == 0 ? 0 : ((static_cast<int>(threadIdx.x >> 6) == pl.W - 1) ? 1 : -1);
+        long long* tr4 = (tw >= 0 && lane == 0) ? ep.trace + ((static_cast<int64_t>(blockIdx.x) * 2 + tw) * pl.NT + tt) * 4 : nullptr;
+#define DIF_STAMP(i) do { if (tr4) tr4[i] = wall_clock64(); } while (0)
+#else
+#define DIF_STAMP(i) do { } while (0)
+#endif
         uint4 e[NA];
         int nb[NA];
         const uint4* cur = ell;
@@ -712,6 +792,9 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
                 e[j] = *((nb[j] > 0) ? cur + j * 64 : ell);                  // in flight across the tile load
             }
         }
+#if DIF_SLICED_PROBE == 5
+        if (tt == 0)
+#endif
         {
             // The tile's first loads are issued BEFORE the barrier (they land in registers, not in LDS), so their latency
             // runs under the wait for the slowest wave of the previous tile; the registers written first take the tail
@@ -726,7 +809,12 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
                 const f32x4* su = src + u * nth;
                 r[u] = (u * nth + static_cast<int>(tid) < T) ? su[tid] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            DIF_STAMP(0);
             __syncthreads();                                                  // everyone is done with the previous tile
+            DIF_STAMP(1);
+#if DIF_SLICED_PROBE == 4
+            if (tt == 0)
+#endif
 #pragma unroll
             for (int b = 0; b < 11; b += U) {                                 // batches of U rows per thread, 11 in all
 #pragma unroll
@@ -747,12 +835,18 @@ __device__ __forceinline__ void sweep(f32x4* tile, const uint4* __restrict__ ell
         // pending" into every phase loop and wait for ALL loads at the top of each block row.  They are complete here
         // (the LDS stores consumed them, and the entry loads were issued before them): say so.
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+#if DIF_SLICED_PROBE == 5
+        if (tt == 0)
+#endif
         __syncthreads();
+        DIF_STAMP(2);
         if (NR > 0) {
             int k = 0;
             Phases<NR, NA>::run(tile, k, cur, e, acc, nb);
         }
+        DIF_STAMP(3);
     }
+#undef DIF_STAMP
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int64_t pos = slot_of(j, pw, pl.PW) * 64 + lane;
@@ -946,8 +1040,15 @@ extern "C" int dif_sliced_spmm_f32(const uint16_t* entries, const int32_t* table
     DIF_REQUIRE(dif::aligned16(entries) && dif::aligned16(ys), DIF_E_BADARG, "dif_sliced_spmm: entries / ys must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t npad = static_cast<int64_t>(pl.T) * pl.NT;
+#ifdef DIF_SLICED_TRACE
+    const char* tp = getenv("DIF_SLICED_TRACE");
+    DIF_REQUIRE(tp != nullptr, DIF_E_BADARG, "trace build: DIF_SLICED_TRACE = device address of int64[blocks * 2 * tiles * 4]");
+    const Epilogue ep = {rowptr, dinv, row_order, parts, row_begin, n_pos, attn, lda, attn_scale, gcn_scale, out, ldo,
+                         static_cast<f32x4*>(ws), reinterpret_cast<long long*>(strtoull(tp, nullptr, 0))};
+#else
     const Epilogue ep = {rowptr, dinv, row_order, parts, row_begin, n_pos, attn, lda, attn_scale, gcn_scale, out, ldo,
                          static_cast<f32x4*>(ws)};
+#endif
     const uint4* e4 = reinterpret_cast<const uint4*>(entries);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(ys);
     switch (pl.R) {

@@ -1,3 +1,6 @@
+// MEASUREMENT FORK of difformer_amd/csrc/simple_layer.hip as of round 5 (probes, traces, alternative layouts behind -D flags; results of most are
+// WRONG by design).  Not part of the product: built only by scripts/build_sliced_variants.sh (OBJ=simple_layer) into scripts/bin/.  The product
+// file carries none of these branches and compiles to the same device code as this fork without flags (round 6, checked).
 // a1 + a4 + a5 tail in closed form for the `simple` kernel with query_input == source_input == x
 // (node classification/difformer.py:18-39, :115-140, :200-203), H == 1, C_in <= 64, D <= 64, eval mode.
 //
@@ -797,9 +800,17 @@ __device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
 // l15 exactly once -> no bank conflicts.  (The row-major layout with a 68-float stride, conflict-free for groups of 16
 // CONSECUTIVE lanes, put lanes (0, 12) and (1, 11) of the first hardware group on one quad: SQ_LDS_BANK_CONFLICT was 34 %
 // of the kernel's LDS cycles, profiles/r02_pmc_traffic_c4.json.)
+#ifdef DIF_LAYER_OLD_LAYOUT
+constexpr int kWBlock = 64 * 68;
+#else
 constexpr int kWBlock = 64 * 64;           // (the NEXT variant folds 2 x 40 x 64 floats through the two blocks: 8,192 there)
+#endif
 __device__ __forceinline__ int widx(int f, int c) {
+#ifdef DIF_LAYER_OLD_LAYOUT          // measurement build: the row-major layout with a 68-float stride (needs 64 * 68 floats)
+    return f * 68 + c;
+#else
     return ((((f >> 4) * 4 + (c >> 4)) * 4 + ((c >> 2) & 3)) << 6) + ((f & 15) << 2) + (c & 3);
+#endif
 }
 
 // y[ft] (+)= W_tile x^T for the four feature tiles; W in LDS in the widx layout
@@ -845,8 +856,11 @@ __device__ __forceinline__ void project_split(f32x4 (&y)[4], const f32x4 (&xa)[4
         }
 }
 
+#ifndef DIF_LAYER_PROBE
+#define DIF_LAYER_PROBE 0         // measurement builds (scripts/exp_layer_probes.py): 1 no products, 2 no weight staging,
+#endif                            // 3 no slice-major copy, 4 no row-major store, 5 the graph rows are not read
 #ifndef DIF_GATHER_WG
-#define DIF_GATHER_WG 4           // workgroups per CU the GATHER variants are compiled for (probes / old layouts: scripts/variants/simple_layer.hip)
+#define DIF_GATHER_WG 4           // measurement builds: workgroups per CU the GATHER variants are compiled for
 #endif
 template <bool EXACT, bool GRAPH_W, bool NEXT, typename T = float, bool HEAD = false, bool GATHER = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * (HEAD ? kHeadWaves : kWaves),
@@ -869,7 +883,8 @@ void simple_layer_kernel(LayerArgsT<T> a) {
     const int64_t n_tiles = (a.n_rows + 15) / 16;
     const int64_t n_fast = EXACT ? a.n_rows / 16 : 0;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * NW + wave, stride = static_cast<int64_t>(gridDim.x) * NW;
-    if (EXACT && (reinterpret_cast<uintptr_t>(a.coef) & 15u) == 0 && (!GRAPH_W || (reinterpret_cast<uintptr_t>(a.Wv) & 15u) == 0)) {
+    if (DIF_LAYER_PROBE == 2) {        // measurement build: no weight staging (the LDS holds whatever it holds)
+    } else if (EXACT && (reinterpret_cast<uintptr_t>(a.coef) & 15u) == 0 && (!GRAPH_W || (reinterpret_cast<uintptr_t>(a.Wv) & 15u) == 0)) {
         // dense 64 x 64 blocks: all eight 16-byte loads of a thread are in flight before the first LDS store (an
         // element-wise loop runs 32 load -> store round trips back to back: ~30 us of prologue per workgroup)
         // Thread -> fragment map of the staging: a wave instruction reads eight ROWS x 128 contiguous bytes (whole cache
@@ -974,8 +989,13 @@ void simple_layer_kernel(LayerArgsT<T> a) {
         f32x4 y[4];
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) y[ft] = *reinterpret_cast<const f32x4*>(&sm_cn[16 * ft + 4 * lg]);
+#if DIF_LAYER_PROBE == 1           // measurement build: no products (the rows stand in for them)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) y[ft] += xa[ft];
+#else
         if constexpr (SPLIT) project_split(y, xa, reinterpret_cast<const bf16x8*>(&sm_w[0][0]), reinterpret_cast<const bf16x8*>(&sm_w[0][0]) + 512, lane);
         else project_t(y, xa, sm_w[0], l15, lg);
+#endif
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) y[ft] *= rden;
         if (GATHER || a.ax) {
@@ -986,14 +1006,24 @@ void simple_layer_kernel(LayerArgsT<T> a) {
 #pragma unroll
                 for (int cq = 0; cq < 4; ++cq) ga[cq] *= a.gcn_scale;          // ax = g_s A_hat x; the bias term scales below
             } else {
+#if DIF_LAYER_PROBE == 5
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) ga[cq] = xa[cq];
+#else
                 load_rows<G>(ga, a.ax, a.ldax, row, a.n_rows, lg, C);
+#endif
                 rsv = (a.rs && row_ok) ? a.rs[row] : 0.f;
             }
             if (GRAPH_W) {        // the second product accumulates on top of the attention term
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft) y[ft] += *reinterpret_cast<const f32x4*>(&sm_bv[16 * ft + 4 * lg]) * rsv;
+#if DIF_LAYER_PROBE == 1
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) y[ft] += ga[ft];
+#else
                 if constexpr (SPLIT) project_split(y, ga, reinterpret_cast<const bf16x8*>(&sm_w[0][0]) + 1024, reinterpret_cast<const bf16x8*>(&sm_w[0][0]) + 1536, lane);
                 else project_t(y, ga, sm_w[1], l15, lg);
+#endif
             } else {          // use_weight = False: the aggregated rows are the graph term (C == D), same layout
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft) y[ft] += ga[ft];
@@ -1098,12 +1128,12 @@ void simple_layer_kernel(LayerArgsT<T> a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (a.out && row_ok && (EXACT || f < D)) {
+            if (a.out && row_ok && (EXACT || f < D) && DIF_LAYER_PROBE != 4) {
                 if (EXACT || ((a.ldo & 3) == 0 && f + 3 < D)) Elem<T>::st4(a.out + row * a.ldo + f, v);
                 else
                     for (int r = 0; r < 4; ++r) if (f + r < D) Elem<T>::st(a.out + row * a.ldo + f + r, v[r]);
             }
-            if (!NEXT && a.ys_next) {
+            if (!NEXT && a.ys_next && DIF_LAYER_PROBE != 3) {
                 // slice-major pre-scaled copy for the next layer's SpMM straight from the registers: this lane holds
                 // slice 4ft + lg of its row, the 16 lanes of a group 16 consecutive rows -> 256 contiguous bytes
                 if (row_ok && (EXACT || f < D)) a.ys_next[static_cast<int64_t>(4 * ft + lg) * a.npad + row] = v * dscale;
@@ -1594,7 +1624,7 @@ int layer_entry(const T* x, int64_t ldx, int64_t n_rows, int C, int D, const flo
     const bool exact = C == 64 && D == 64 && ldo % 4 == 0 && (!x0 || ldx0 % 4 == 0);
     const bool gw = (ax != nullptr || gather) && Wv != nullptr;
     // dense 64 x 64 float32 layers (the headline shape): both products on split-bfloat16 operands unless DIFFORMER_EXACT_FP32=1
-    const bool split = exact && f32 && !next && !gather && !dif::exact_fp32() &&
+    const bool split = exact && f32 && !next && !gather && !dif::exact_fp32() && DIF_LAYER_PROBE == 0 &&
                        (reinterpret_cast<uintptr_t>(coef) & 15u) == 0 && (!gw || (reinterpret_cast<uintptr_t>(Wv) & 15u) == 0);
     if (split) {
         if constexpr (std::is_same<T, float>::value) {

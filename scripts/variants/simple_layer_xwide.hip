@@ -1,3 +1,6 @@
+// MEASUREMENT FORK of difformer_amd/csrc/simple_layer_xwide.hip as of round 5 (probes, traces, alternative layouts behind -D flags; results of most are
+// WRONG by design).  Not part of the product: built only by scripts/build_sliced_variants.sh (OBJ=simple_layer_xwide) into scripts/bin/.  The product
+// file carries none of these branches and compiles to the same device code as this fork without flags (round 6, checked).
 // a1 + a4 + a5 tail at the widths the reference's image / text scripts train with (image and text/run.sh:27: hidden 300;
 // two lines at 400): the closed-form `simple` layer for 128 < max(C, D) <= 416 in ONE pass over the rows.
 //
@@ -34,7 +37,10 @@ __device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
 }
 
 constexpr int kXWaves = 8;             // 128 rows per workgroup and weight chunk
-// (timing probes: scripts/variants/simple_layer_xwide.hip, built by scripts/build_sliced_variants.sh)
+// timing probes of measurement builds (results WRONG): 1 = no weight staging, 2 = no products at all, 3 = no LDS fragment reads
+#ifndef DIF_XWIDE_PROBE
+#define DIF_XWIDE_PROBE 0
+#endif
 
 struct XArgs {
     const float* x; int64_t ldx;
@@ -114,21 +120,33 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void simple_layer_xwide_kernel(XAr
             __builtin_amdgcn_global_load_lds(src + piece * 64 + lane, dst + piece * 64, 16, 0, 0);
     };
     auto product = [&](f32x4 (&y)[FCMAX * 2], const bf16x8 (&xh)[KBMAX], const bf16x8 (&xl)[KBMAX], const bf16x8* __restrict__ packed) {
+#if DIF_XWIDE_PROBE == 2
+        return;
+#endif
         __syncthreads();                                                    // everyone is done with both buffers
+#if DIF_XWIDE_PROBE != 1
         stage(packed, 0);
+#endif
 #pragma unroll
         for (int fc = 0; fc < FCMAX; ++fc) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): this wave's pieces of chunk fc have landed
             __syncthreads();                                                // ... everybody's have, and chunk fc - 1 is done with
+#if DIF_XWIDE_PROBE != 1
             if (fc + 1 < FCMAX) stage(packed, fc + 1);                      // flies under this chunk's products
+#endif
             const bf16x8* w = sm_w + (fc & 1) * chunk;
 #pragma unroll
             for (int kb = 0; kb < KBMAX; ++kb) {
                 bf16x8 wh[2], wl[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
+#if DIF_XWIDE_PROBE == 3
+                    wh[u] = xh[(kb + u) % KBMAX];
+                    wl[u] = xl[(kb + u) % KBMAX];
+#else
                     wh[u] = w[kb * 128 + u * 64 + lane];
                     wl[u] = w[KB * 128 + kb * 128 + u * 64 + lane];
+#endif
                 }
                 // small terms first; the two feature tiles alternate so that no MFMA waits on the one just issued
                 y[2 * fc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[0], xl[kb], y[2 * fc], 0, 0, 0);
