@@ -512,3 +512,101 @@ def test_layer_tail_backward_every_width(hidden, dev):
     refs = [leaves[0].grad, leaves[1].grad, leaves[2].grad, leaves[3].grad, leaves[4].grad]
     for a, b, nm in zip(got, refs, ("d_conv", "d_x0", "d_prev", "d_ln_weight", "d_ln_bias")):
         assert rel_err(a.cpu().numpy(), b.numpy()) < TOL, nm
+
+
+# ================================================================== both sides of the host's dispatch thresholds
+# The host picks kernel families by thresholds fitted on synthetic graphs (ops.SLICED_MIN_DEGREE = 48 entries per row,
+# ops.SLICED_MIN_ROWS = 8,192 nodes, ops.MIX_THRESHOLD = 2.5, 16 entries per row for a wave per row): a graph just below and
+# one just above each must give the oracle's numbers, and must take the families the threshold is meant to separate.
+def _regular_graph(n, per_row, seed):
+    """exactly `per_row` entries in every row: per_row - 1 random sources + the self loop (main.py:75-76)."""
+    g = torch.Generator().manual_seed(seed)
+    dst = torch.arange(n).repeat_interleave(per_row - 1)
+    src = torch.randint(0, n, (n * (per_row - 1),), generator=g)
+    return torch.stack([torch.cat([src, torch.arange(n)]), torch.cat([dst, torch.arange(n)])])
+
+
+def _conv_both_ways(dev, n, ei, width=64):
+    from difformer_amd import gcn_conv
+    x = torch.randn(n, 1, width, generator=torch.Generator().manual_seed(n))
+    out, names = _launched(lambda: gcn_conv(x.to(dev), ei.to(dev), None))
+    ref = orc.gcn_conv(x.double().numpy(), ei.numpy(), None)
+    return rel_err(out.cpu().numpy(), ref), names
+
+
+@pytest.mark.parametrize("per_row,sliced", [(47, False), (48, True), (49, True)])
+def test_threshold_entries_per_row_of_the_sliced_product(per_row, sliced, dev):
+    err, names = _conv_both_ways(dev, 9000, _regular_graph(9000, per_row, per_row))
+    assert err < TOL and ("dif_sliced_spmm_f32" in names) == sliced and ("dif_gcn_spmm_f32" in names) != sliced, names
+
+
+@pytest.mark.parametrize("n,sliced", [(8191, False), (8192, True), (8193, True)])
+def test_threshold_node_count_of_the_sliced_product(n, sliced, dev):
+    err, names = _conv_both_ways(dev, n, _regular_graph(n, 60, n))
+    assert err < TOL and ("dif_sliced_spmm_f32" in names) == sliced, names
+
+
+@pytest.mark.parametrize("per_row", [15, 16, 17])
+def test_threshold_wave_per_row_or_lane_group_per_row(per_row, dev):
+    """dif_gcn_spmm: from 16 entries per row a whole wave walks a row, below a lane group does (csrc/gcn_spmm.hip)."""
+    err, names = _conv_both_ways(dev, 5000, _regular_graph(5000, per_row, per_row))
+    assert err < TOL and "dif_gcn_spmm_f32" in names
+
+
+@pytest.mark.parametrize("inside,mixed", [(0.70, False), (0.80, True)])
+def test_threshold_mixed_node_order_for_community_graphs(inside, mixed, dev):
+    """ops.MIX_THRESHOLD: the mean over rows of (largest per-tile share of the row's entries) x tiles.  Three source tiles, a
+    fraction `inside` of every row's entries from the row's own tile, the rest uniform: score = 1 + 2 inside = 2.4 / 2.6 -- the
+    model runs the second graph in a mixed node order (ops.MixedGraph) and both give the oracle's logits."""
+    from difformer_amd import DIFFormer, ops
+    n, per_row = 30000, 56
+    be = ops.get_backend()
+    plan = be.sliced_plan(n, n, 64)
+    tiles, tile_rows = int(plan[7]), int(plan[6])
+    assert tiles == 3
+    g = torch.Generator().manual_seed(int(inside * 100))
+    dst = torch.arange(n).repeat_interleave(per_row - 1)
+    own = (dst // tile_rows) * tile_rows
+    width = torch.minimum(torch.full_like(own, tile_rows), n - own)
+    local = own + (torch.rand(dst.shape, generator=g) * width).long()
+    anywhere = torch.randint(0, n, dst.shape, generator=g)
+    src = torch.where(torch.rand(dst.shape, generator=g) < inside, local, anywhere)
+    ei = torch.stack([torch.cat([src, torch.arange(n)]), torch.cat([dst, torch.arange(n)])])
+    eid = ei.to(dev)
+    mix = ops.mix_cache.get(eid, n, 64)
+    assert (mix is not None) == mixed
+    torch.manual_seed(1)
+    model = DIFFormer(16, 64, 5, num_layers=2, kernel="simple", use_graph=True).to(dev).eval()
+    x = torch.randn(n, 16, generator=g)
+    with torch.no_grad():
+        out = model(x.to(dev), eid)
+    cfg = dict(hidden_channels=64, num_layers=2, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=True, use_graph=True, graph_weight=-1, use_source=False)
+    p = {k: v.detach().cpu().double().numpy() for k, v in model.state_dict().items()}
+    ref = orc.difformer_forward(p, x.double().numpy(), ei.numpy(), None, cfg)
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("hidden", [64, 68, 128, 132])
+def test_threshold_widths_of_the_closed_form_families(hidden, dev):
+    """ops.CLOSED_FORM_WIDE_MIN (64): up to 64 columns the record kernels of csrc/simple_layer.hip, 65..128 the one-pass kernel of
+    csrc/simple_layer_wide.hip, beyond it csrc/simple_layer_xwide.hip -- each side of both borders against the oracle."""
+    assert _model_forward(dev, 9000, 24, hidden, 7, 2, "simple", _graph(9000, 6, hidden), True, torch.float32) < TOL
+
+
+@pytest.mark.parametrize("width", [64, 65, 512, 513])
+def test_threshold_widths_of_the_sigmoid_families(width, dev):
+    """a2: <= 64 columns per head the register-fragment kernels (csrc/sigmoid_attn.hip), 65..512 the plane kernels
+    (csrc/sigmoid_wide.hip), beyond 512 the generic fp32 kernel -- forward and gradient on each side of both borders."""
+    from difformer_amd import autograd_ops as ag
+    g = torch.Generator().manual_seed(width)
+    q, k, v, go = (torch.randn(n, 1, width, generator=g) * s for n, s in ((300, 3.0 / width ** 0.5), (260, 0.5), (260, 1.0), (300, 1.0)))
+    leaves = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    out = ag.sigmoid_attention(*leaves)
+    out.backward(go.to(dev))
+    q64, k64, v64, g64 = (t.double().numpy() for t in (q, k, v, go))
+    assert rel_err(out.detach().cpu().numpy(), orc.sigmoid_attention(q64, k64, v64)) < TOL
+    refs = orc.sigmoid_attention_grad_blocked(q64, k64, v64, g64)
+    gmax = max(np.abs(r).max() for r in refs)
+    for got, want in zip(leaves, refs):
+        assert float(np.abs(got.grad.cpu().double().numpy() - want).max()) / gmax < TOL
