@@ -16,7 +16,11 @@
  *   - return 0 on success, a negative DIF_E_* code for a rejected argument, or a positive
  *     hipError_t for a runtime failure; `dif_last_error()` returns a thread-local message.
  *     No C++ exception crosses this boundary;
- *   - functions are stateless and re-entrant; one process per GPU for multi-GPU.
+ *   - functions keep no state between calls and are re-entrant, with ONE exception: dif_set_exact_fp32() flips a
+ *     process-global switch (seeded from DIFFORMER_EXACT_FP32) that every launcher reads when it picks the matrix core of
+ *     its products.  Set it before the first call or between launches; flipping it from one host thread while another is
+ *     inside a dif_* call gives that call either setting (workspace sizes are computed for both).  One process per GPU
+ *     for multi-GPU.
  */
 #ifndef DIFFORMER_HIP_H
 #define DIFFORMER_HIP_H
@@ -92,8 +96,17 @@ int dif_project_reduce_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in
  * tensor is never materialised.
  * Products: float32 heads of at most 64 channels with 16-byte aligned rows contract on split-bfloat16 operands
  * (hi + lo, bf16 matrix core; ~7e-6 of the float64 result) in dif_sigmoid_attn_f32; dif_set_exact_fp32(1) keeps the
- * fp32 matrix core.  dif_sigmoid_attn_fwd_f32 / dif_sigmoid_attn_bwd_f32 (training) always run the fp32 chain
- * (DIFFORMER_SIGMOID_BWD_SPLIT=1 opts the backward in): gradients made of cancelling rows amplify the operands' error.
+ * fp32 matrix core.  dif_sigmoid_attn_fwd_f32 / dif_sigmoid_attn_bwd_f32 (training) run heads up to 64 channels on the fp32
+ * chain (DIFFORMER_SIGMOID_BWD_SPLIT=1 opts the backward in): gradients made of cancelling rows amplify the operands' error.
+ * float32 heads of 65 .. 512 channels (image and text/run.sh:17,35,54: hidden 300 / 400, N ~ 15,000) -- all three entry
+ * points: csrc/sigmoid_wide.hip.  Every operand goes in as two bfloat16 PLANES (x = hi + lo) packed in MFMA fragment order by
+ * a pre-pass into the workspace, the streamed side moves global -> LDS by LDS-DMA, each wave keeps 16 query (or key) rows'
+ * fragments and ALL output columns' accumulators in registers, scores are formed once per (query, key) pair; values enter
+ * centred (v - column mean: out_n is a convex combination of the value rows, so the centre passes through exactly and the
+ * products carry only the rows' spread).  Forward ~1e-6 .. 1e-5 of the float64 result, gradients ~3e-5 of each tensor's largest
+ * entry.  Under dif_set_exact_fp32(1) these widths run the generic fp32 forward kernel and dif_sigmoid_attn_bwd_f32 returns
+ * DIF_E_SHAPE (the host then differentiates with tensor operations).  Workspaces: packed planes (8 bytes per element and
+ * orientation) + per-split partial sums, dif_sigmoid_workspace_bytes / dif_sigmoid_bwd_workspace_bytes; 256-byte aligned use.
  * ------------------------------------------------------------------------------------- */
 size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M, int D);
 int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
@@ -102,7 +115,7 @@ int dif_sigmoid_attn_f32(const float* q, int64_t ldq, const float* k, int64_t ld
                          dif_stream_t stream);
 /* f3 (training, main.py:117-131): dif_sigmoid_attn_fwd_f32 = dif_sigmoid_attn_f32 that also leaves the row sums
  * den float[N,H] = sum_l sigmoid(q_n . k_l); dif_sigmoid_attn_bwd_f32 turns g = dL/dout [N,H,D] into dq [N,H,M],
- * dk [L,H,M], dv [L,H,D] (M, D <= 64; DIF_E_SHAPE otherwise) by recomputing sigma tile by tile -- the [N,L,H] tensors are
+ * dk [L,H,M], dv [L,H,D] (M, D <= 512; DIF_E_SHAPE otherwise) by recomputing sigma tile by tile -- the [N,L,H] tensors are
  * never materialised:  delta_n = g_n . out_n,  dV_l = sum_n (P_nl / den_n) g_n,
  * dS_nl = (g_n . v_l - delta_n) P_nl (1 - P_nl) / den_n,  dQ = dS K,  dK = dS^T Q.  Deterministic.
  * workspace: dif_sigmoid_bwd_workspace_bytes(N, L, H, M, D), 16-byte aligned. */
