@@ -254,8 +254,9 @@ __device__ __forceinline__ void store_acc(const f32x4 (&o)[2 * KS], float den_to
 
 // S^T[streamed row 4 lg + r of row tile rt][stationary row l15 of tile qt] = Y X^T over the KS column steps.  PF = how many
 // steps ahead the fragments are read (a ring of PF + 1 register sets).
-template <int KS, int NP, int QT, int PF>
-__device__ __forceinline__ void score_stage(const bf16x8* tile, const bf16x8 (&xs)[QT][NP][KS], f32x4 (&res)[QT][2]) {
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int KS, int NP, int QT, int PF, typename Hook = NoHook>
+__device__ __forceinline__ void score_stage(const bf16x8* tile, const bf16x8 (&xs)[QT][NP][KS], f32x4 (&res)[QT][2], Hook hook = Hook()) {
     constexpr int FR = 2 * KS;
     constexpr int RING = PF + 1;
     using TT = Terms<NP>;
@@ -290,6 +291,7 @@ __device__ __forceinline__ void score_stage(const bf16x8* tile, const bf16x8 (&x
                 for (int qt = 0; qt < QT; ++qt)
                     sa[TT::acc(i)][qt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[ks % RING][TT::a(i)][rt], xs[qt][TT::b(i)][ks],
                                                                                    sa[TT::acc(i)][qt][rt], 0, 0, 0);
+        hook(ks);
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
@@ -298,8 +300,8 @@ __device__ __forceinline__ void score_stage(const bf16x8* tile, const bf16x8 (&x
 }
 
 // O^T[col 16 ct + 4 lg + r][stationary row l15 of tile qt] += Z^T B over the 32 streamed rows (B = the planes of sigma(S^T) or dS^T)
-template <int KS, int NP, int QT, int PF>
-__device__ __forceinline__ void accumulate_stage(const bf16x8* tile, const bf16x8 (&pb)[QT][NP], f32x4 (&o)[QT][2 * KS]) {
+template <int KS, int NP, int QT, int PF, typename Hook = NoHook>
+__device__ __forceinline__ void accumulate_stage(const bf16x8* tile, const bf16x8 (&pb)[QT][NP], f32x4 (&o)[QT][2 * KS], Hook hook = Hook()) {
     constexpr int FR = 2 * KS;
     constexpr int RING = PF + 1;
     using TT = Terms<NP>;
@@ -329,6 +331,7 @@ __device__ __forceinline__ void accumulate_stage(const bf16x8* tile, const bf16x
                 for (int qt = 0; qt < QT; ++qt)
                     o[qt][2 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[g % RING][TT::a(tm)][i], pb[qt][TT::b(tm)], o[qt][2 * g + i],
                                                                               0, 0, 0);
+        hook(g);
     }
 }
 
@@ -344,6 +347,27 @@ __device__ __forceinline__ void dma_1k(const bf16x8* gsrc, const bf16x8* lds_dst
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+#ifndef SIGW_ALTLOAD
+#define SIGW_ALTLOAD 0
+#endif
+#ifndef SIGW_SPREAD
+#define SIGW_SPREAD 0        // DMA pieces issued one at a time between the product steps, sibling waves on alternating steps
+#endif
+// -DSIGW_ALTLOAD=1: only HALF of the waves issue a tile's DMA (the older half the value tiles, the younger half the key tiles), twice
+// the pieces each: while one wave of a SIMD spends its ~100 cycles per DMA instruction, its sibling is already multiplying
+template <int KS, int NP, int W>
+__device__ __forceinline__ void issue_half(const bf16x8* tile, bf16x8* dst, int wave, int lane, int which) {
+    constexpr int PIECES = NP * 2 * KS;
+    constexpr int HW = W / 2;
+    if ((wave / HW) != which) { __builtin_amdgcn_sched_barrier(0); return; }
+    const int w2 = wave % HW;
+#pragma unroll
+    for (int i = 0; i < (PIECES + HW - 1) / HW; ++i) {
+        const int piece = w2 + i * HW;
+        if (PIECES % HW == 0 || piece < PIECES) dma_1k(tile + piece * 64 + lane, dst + piece * 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 template <int KS, int NP, int W>
 __device__ __forceinline__ void issue_tile(const bf16x8* tile, bf16x8* dst, int wave, int lane) {
@@ -451,12 +475,37 @@ __global__ __launch_bounds__(64 * W) void sigw_fwd_kernel(FwdArgs a) {
         } else {
 #if SIGW_REGSTAGE
             stg.load(zbase + static_cast<int64_t>(t) * TILE, wave, lane);
+#elif SIGW_SPREAD
+            // (issued piece by piece between the score steps below)
+#elif SIGW_ALTLOAD
+            issue_half<KS, NP, W>(zbase + static_cast<int64_t>(t) * TILE, zbuf, wave, lane, 0);
 #else
             issue_tile<KS, NP, W>(zbase + static_cast<int64_t>(t) * TILE, zbuf, wave, lane);
 #endif
         }
         f32x4 s[QT][2];
+#if SIGW_SPREAD
+        {   // one DMA piece after every other step, the two waves of a SIMD (w, w + W / 2) on alternating steps
+            const bf16x8* zt = zbase + static_cast<int64_t>(t) * TILE;
+            constexpr int PIECES = NP * FR, PPW = (PIECES + W - 1) / W;
+            const int phase = (wave >= W / 2) ? 1 : 0;
+            auto hook = [&](int ks) {
+                const int i = (ks - phase) >> 1;
+                if (!QUAD && ((ks - phase) & 1) == 0 && ks >= phase && i < PPW) {
+                    const int piece = wave + i * W;
+                    if (PIECES % W == 0 || piece < PIECES) dma_1k(zt + piece * 64 + lane, zbuf + piece * 64);
+                }
+            };
+            score_stage<KS, NP, QT, (W == 8 ? 1 : pf4(KS))>(ybuf + lane, xf, s, hook);
+            // pieces that did not fit the steps
+            for (int i = (KS - phase + 1) / 2; !QUAD && i < PPW; ++i) {
+                const int piece = wave + i * W;
+                if (PIECES % W == 0 || piece < PIECES) dma_1k(zt + piece * 64 + lane, zbuf + piece * 64);
+            }
+        }
+#else
         score_stage<KS, NP, QT, (W == 8 ? 1 : pf4(KS))>(ybuf + lane, xf, s);
+#endif
         bf16x8 pb[QT][NP];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -476,13 +525,41 @@ __global__ __launch_bounds__(64 * W) void sigw_fwd_kernel(FwdArgs a) {
             stg.store(zbuf, wave, lane);
             __syncthreads();
             if (t + 1 < t1) stg.load(ybase + static_cast<int64_t>(t + 1) * TILE, wave, lane);
+#elif SIGW_SPREAD
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+#elif SIGW_ALTLOAD
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            if (t + 1 < t1) issue_half<KS, NP, W>(ybase + static_cast<int64_t>(t + 1) * TILE, ybuf, wave, lane, 1);
 #else
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
             if (t + 1 < t1) issue_tile<KS, NP, W>(ybase + static_cast<int64_t>(t + 1) * TILE, ybuf, wave, lane);
 #endif
         }
+#if SIGW_SPREAD
+        {
+            const bf16x8* yt = ybase + static_cast<int64_t>(t + 1) * TILE;
+            constexpr int PIECES = NP * FR, PPW = (PIECES + W - 1) / W;
+            const int phase = (wave >= W / 2) ? 1 : 0;
+            const bool more = !QUAD && t + 1 < t1;
+            auto hook = [&](int g) {
+                const int i = (g - phase) >> 1;
+                if (more && ((g - phase) & 1) == 0 && g >= phase && i < PPW) {
+                    const int piece = wave + i * W;
+                    if (PIECES % W == 0 || piece < PIECES) dma_1k(yt + piece * 64 + lane, ybuf + piece * 64);
+                }
+            };
+            accumulate_stage<KS, NP, QT, (W == 8 ? 1 : pf4(KS))>(zbuf + lane, pb, o, hook);
+            for (int i = (KS - phase + 1) / 2; more && i < PPW; ++i) {
+                const int piece = wave + i * W;
+                if (PIECES % W == 0 || piece < PIECES) dma_1k(yt + piece * 64 + lane, ybuf + piece * 64);
+            }
+        }
+#else
         accumulate_stage<KS, NP, QT, (W == 8 ? 1 : pf4(KS))>(zbuf + lane, pb, o);
+#endif
 #if SIGW_REGSTAGE
         if (!QUAD && t + 1 < t1) stg.store(ybuf, wave, lane);
 #endif

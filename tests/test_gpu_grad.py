@@ -439,3 +439,45 @@ def test_whole_training_step_as_one_graph(dev):
     assert max(abs(a - b) / abs(b) for a, b in zip(losses_g, losses_e[-3:])) < 1e-4, (losses_g, losses_e)
     for (k, a), (_, b) in zip(eager.named_parameters(), twin.named_parameters()):
         assert rel_err(b.detach().cpu().numpy(), a.detach().cpu().numpy()) < 1e-3, k
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_deepest_sigmoid_script_eight_layers(exact, dev):
+    """`node classification/run.sh:10`: Cora, DIFFormer-a, --num_layers 8 --hidden_channels 64 --kernel sigmoid --use_graph --use_bn
+    --use_residual (the deepest script had no parity case).  Inference forward (default build: split-bfloat16 operands in
+    the attention; exact: every product on the fp32 matrix core) and one training step, against the float64 oracle."""
+    from difformer_amd import DIFFormer, ops
+    torch.manual_seed(8)
+    n, f_in, c = 2708, 1433, 7
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(n, f_in, generator=g)
+    x = x / x.sum(dim=1, keepdim=True)
+    pairs = torch.randint(0, n, (2, 5278), generator=g)
+    ei = torch.cat([pairs, pairs.flip(0), torch.arange(n).repeat(2, 1)], dim=1)
+    cfg = dict(hidden_channels=64, num_layers=8, num_heads=1, kernel="sigmoid", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=False, use_graph=True, graph_weight=-1, use_source=False)
+    model = DIFFormer(f_in, 64, c, num_layers=8, alpha=0.5, dropout=0.0, num_heads=1, kernel="sigmoid", use_bn=True, use_residual=True,
+                      use_graph=True, use_weight=False).to(dev)
+    y, idx = torch.randint(0, c, (n,), generator=g), torch.randperm(n, generator=g)[:140]
+    was = ops.set_exact_fp32(exact)
+    try:
+        model.invalidate_caches()
+        model.eval()
+        with torch.no_grad():
+            out_eval = model(x.to(dev), ei.to(dev))
+        model.train()
+        out = model(x.to(dev), ei.to(dev))
+        loss = F.nll_loss(torch.log_softmax(out, dim=1)[idx.to(dev)], y.to(dev)[idx.to(dev)])
+        loss.backward()
+    finally:
+        ops.set_exact_fp32(was)
+        model.invalidate_caches()
+    pl = og.leaves({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    oref = og.difformer_forward(pl, x.double(), ei, None, cfg)
+    lref = og.training_loss(oref, y, idx)
+    lref.backward()
+    assert rel_err(out_eval.cpu().numpy(), oref.detach().numpy()) < TOL and rel_err(out.detach().cpu().numpy(), oref.detach().numpy()) < TOL
+    assert abs(float(loss.detach()) - float(lref.detach())) < TOL * abs(float(lref.detach()))
+    gmax = max(float(v.grad.abs().max()) for v in pl.values())
+    errs = {k: grad_err(p.grad.cpu().numpy(), pl[k].grad.numpy(), gmax) for k, p in model.named_parameters()}
+    assert max(errs.values()) < TOL, [(f"{e:.2e}", k) for e, k in sorted(((e, k) for k, e in errs.items()), reverse=True)[:5]]
