@@ -372,6 +372,101 @@ class _ClosedFormLayer(torch.autograd.Function):
         return dx, d_Wq, d_bq, d_Wk, d_bk, d_Wv, d_bv, d_x0, d_lnw, d_lnb, None, None, None, None, None, None
 
 
+class _ClosedFormLayerWide(torch.autograd.Function):
+    """_ClosedFormLayer at 128 columns (node classification/run.sh:42-44 trains Pokec at hidden 128; round 6, OPT-IN through
+    DIFFORMER_CLOSED_FORM_TRAINING_WIDE=1: correct, and 1.7x SLOWER than the operator path -- see difformer.py): the same
+    record formulation on the kernels the INFERENCE path of that width already runs -- q, k, v are never formed in either pass.
+        forward   Gram record (dif_gram_sym_f32) -> [Mn | u], [cn | cd] (dif_wide_coeffs_f64) -> aggregation of x ->
+                  the one-pass layer kernel (csrc/simple_layer_wide.hip)
+        backward  tail                dif_layer_tail_bwd on the pre-tail rows (the layer kernel once more, without its tail)
+                  graph term          as _ClosedFormLayer
+                  attention           Z = x [Mn | u] + [cn | cd] (row GEMM) -> d num = a d / den, d den = -<d num, num> / den;
+                                      d x += [d num | d den] [Mn | u]^T (row GEMM);  d [Mn | u] = x^T [d num | d den] and
+                                      d [cn | cd] = their column sums (ONE streaming reduce)
+                  coefficients        ops.closed_form_coeffs_backward ((C + 1)-square float64 matrices) -> d G~, d W~
+                  record              d x += x (dG + dG^T) + 1 d sx^T (row GEMM)"""
+
+    @staticmethod
+    def forward(ctx, x, Wq, bq, Wk, bk, Wv, bv, x0, ln_w, ln_b, csr, attn_scale, gcn_scale, residual, alpha, eps):
+        be = ops.get_backend()
+        n, C = x.shape
+        co = ops.WideCoefficients(Wq, bq, Wk, bk, Wv, bv)
+        D = co.D
+        rec = be.gram_sym(x)
+        B, bias = be.wide_coeffs(rec, C, n, co.S, co.V, co.P)
+        ax = rs = None
+        if csr is not None:
+            ax = ops.gcn_aggregate(csr, x.reshape(n, 1, C), None, 1.0, 1.0).reshape(n, C)
+            rs = csr.row_sums() if Wv is not None else None
+        gWv, gbv = (Wv, bv) if csr is not None else (None, None)
+        out = be.simple_layer_wide(x, B, bias, D, attn_scale, ax, gWv, gbv, rs, gcn_scale, x0, residual, alpha, ln_w, ln_b, eps)
+        ctx.save_for_backward(x, Wq, bq, Wk, bk, Wv, bv, x0, ln_w, ln_b, rec, B, bias, ax, rs)
+        ctx.csr, ctx.scales, ctx.tail, ctx.D = csr, (float(attn_scale), float(gcn_scale)), (bool(residual), float(alpha), float(eps)), D
+        ctx.edges = csr.hold_edges() if (csr is not None and csr._adjoint is None) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Wq, bq, Wk, bk, Wv, bv, x0, ln_w, ln_b, rec, B, bias, ax, rs = ctx.saved_tensors
+        (a_s, g_s), (residual, alpha, eps), csr, D = ctx.scales, ctx.tail, ctx.csr, ctx.D
+        be = ops.get_backend()
+        n, C = x.shape
+        g = g.contiguous()
+        gWv, gbv = (Wv, bv) if csr is not None else (None, None)
+        conv = be.simple_layer_wide(x, B, bias, D, a_s, ax, gWv, gbv, rs, g_s, None, False, alpha, None, None, eps).view(n, 1, D)
+        prev = x if residual else None
+        want = (True, x0 is not None and ctx.needs_input_grad[7], residual)
+        got = be.layer_tail_bwd(conv, x0, prev, alpha, ln_w, ln_b, eps, False, g, want)
+        if got is None:
+            got = _grad_by_recompute(_tail_expr(alpha, eps, ln_w is not None), (conv, x0, prev, ln_w, ln_b), g)
+        d, d_x0, dx, d_lnw, d_lnb = got
+        d = d.reshape(n, D)
+        del conv
+        d_Wv = d_bv = None
+        if csr is not None:
+            if Wv is not None:
+                d_ax = _row_gemm(be, d, Wv)
+                d3 = d.view(n, 1, D)
+                red = be.simple_reduce(d3, d3, ax.view(n, 1, C))                    # K^T V with K = d, V = ax
+                d_Wv = red[: D * C].view(D, C).clone()
+                d_bv = g_s * _weighted_column_sum(be, d, rs)
+            else:
+                d_ax = d
+            dx = ops.gcn_aggregate(csr.adjoint(), d_ax.reshape(n, 1, C), None if dx is None else dx.reshape(n, 1, C), 1.0, g_s,
+                                   None).reshape(n, C)
+            del d_ax
+        # attention term: numerator | denominator in one row GEMM, their gradients side by side in the same layout
+        dvw = B.shape[1]
+        Z = _row_gemm(be, x, B, bias)
+        inv = torch.reciprocal(Z[:, D])
+        DN = torch.zeros_like(Z)
+        torch.mul(d, (a_s * inv)[:, None], out=DN[:, :D])
+        DN[:, D] = (DN[:, :D] * Z[:, :D]).sum(dim=1).mul_(inv).neg_()
+        del Z, inv
+        dx = _row_gemm(be, DN, B.t().contiguous(), None, dx)
+        dn3 = DN.view(n, 1, dvw)
+        red = be.simple_reduce(dn3, dn3, x.view(n, 1, C))                           # K^T V = DN^T x [dvw, C], sum K = column sums of DN
+        dBt, dbias = red[: dvw * C].view(dvw, C), red[dvw * C: dvw * C + dvw]
+        del DN
+        # the record with its lower blocks mirrored (dif_gram_sym_f32 leaves the 64-blocks on and above the diagonal)
+        G = rec[: C * C].view(C, C)
+        blk = torch.arange(C, device=x.device) // 64
+        G = torch.where(blk[:, None] <= blk[None, :], G, G.t())
+        record = torch.cat([G.reshape(-1), rec[C * C: C * C + C]])
+        S, t, d_Wq, d_bq, d_Wk, d_bk, d_Wv_a, d_bv_a = ops.closed_form_coeffs_backward(
+            record, n, C, D, Wq, bq, Wk, bk, Wv, bv, 1.0, dBt[:D], dbias[:D], dBt[D], dbias[D])
+        dx = _row_gemm(be, x, S, t, dx)                                             # dx + x S + 1 t^T in one pass
+        if Wv is not None:
+            d_Wv = d_Wv_a if d_Wv is None else d_Wv.add_(d_Wv_a)
+            d_bv = d_bv_a if d_bv is None else d_bv.add_(d_bv_a)
+        return dx, d_Wq, d_bq, d_Wk, d_bk, d_Wv, d_bv, d_x0, d_lnw, d_lnb, None, None, None, None, None, None
+
+
+def closed_form_layer_wide(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps):
+    return _ClosedFormLayerWide.apply(x, Wq, bq, Wk, bk, Wv, bv, x0, ln_weight, ln_bias, csr, attn_scale, gcn_scale, residual,
+                                      alpha, eps)
+
+
 def closed_form_layer(x, Wq, bq, Wk, bk, Wv, bv, csr, attn_scale, gcn_scale, x0, residual, alpha, ln_weight, ln_bias, eps):
     return _ClosedFormLayer.apply(x, Wq, bq, Wk, bk, Wv, bv, x0, ln_weight, ln_bias, csr, attn_scale, gcn_scale, residual,
                                   alpha, eps)

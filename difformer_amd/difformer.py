@@ -30,6 +30,10 @@ __all__ = ["full_attention_conv", "gcn_conv", "DIFFormerConv", "DIFFormer"]
 _CHAIN_GRAM = os.environ.get("DIFFORMER_CHAIN_GRAM", "0") == "1"
 _AUTO_GRAPH = os.environ.get("DIFFORMER_AUTO_GRAPH", "1") != "0"
 _CLOSED_FORM_TRAINING = os.environ.get("DIFFORMER_CLOSED_FORM_TRAINING", "1") != "0"
+# 65 .. 128 columns (round 6, ag._ClosedFormLayerWide): OPT-IN.  Correct (tests/test_gpu_grad.py), and slower than the operator path:
+# a hidden-128 Pokec-batch step 5.86 ms against 3.41 -- the float64 coefficient algebra ((C + 1)-square products, ~55 library
+# launches per layer and step) costs more than the three projections it removes (profiles/r06_experiments.md section 5)
+_CLOSED_FORM_TRAINING_WIDE = os.environ.get("DIFFORMER_CLOSED_FORM_TRAINING_WIDE", "0") == "1"
 # A forward is captured and replayed as one hipGraph only while it is LAUNCH-bound: the capture keeps a private pool with one
 # forward's intermediates for the model's lifetime (~0.5 GB at the ogbn-proteins size, ~3 GB on the full Pokec graph) and
 # replay buys <= 2 % there (profiles/r04_e_bench_small_configs.json), against 2x at Cora size.  The gate is the forward's
@@ -218,9 +222,14 @@ class DIFFormerConv(nn.Module):
             params += [self.Wv.weight, self.Wv.bias]
         if not ag._needs_grad(x, *params, *tail_operands):
             return True
-        # training: the narrow float32 single-GPU closed form has a backward through the record (ag._ClosedFormLayer)
-        return (_CLOSED_FORM_TRAINING and not wide and x.dtype == torch.float32 and
-                (self.row_shard is None or self.row_shard.world <= 1) and hasattr(ops.get_backend(), "simple_reduce"))
+        # training: the float32 single-GPU closed form has a backward through the record -- up to 64 columns
+        # ag._ClosedFormLayer, 65 .. 128 (run.sh:42-44: hidden 128) ag._ClosedFormLayerWide on the one-pass wide layer kernel
+        be = ops.get_backend()
+        if wide and not (_CLOSED_FORM_TRAINING_WIDE and x.shape[1] == 128 and self.out_channels == 128 and not ops.EXACT_FP32 and
+                         hasattr(be, "simple_layer_wide") and hasattr(be, "wide_coeffs")):
+            return False
+        return (_CLOSED_FORM_TRAINING and x.dtype == torch.float32 and
+                (self.row_shard is None or self.row_shard.world <= 1) and hasattr(be, "simple_reduce"))
 
     def _layer(self, query_input, source_input, edge_index, edge_weight, x0=None, prev=None, alpha=0.5,
                ln_weight=None, ln_bias=None, eps=1e-5, want_qk=False, carry=None):
@@ -249,6 +258,10 @@ class DIFFormerConv(nn.Module):
                 g_s *= csr.weight_scale                         # a constant edge_weight (ops._CSRCache.get)
             Wv, bv = (self.Wv.weight, self.Wv.bias) if self.use_weight else (None, None)
             if x.shape[1] > 64 or self.out_channels > 64:          # the scripts' widths (hidden 128 / 300 / 400)
+                if ag._needs_grad(x, x0, ln_weight, ln_bias, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv):
+                    out = ag.closed_form_layer_wide(x, self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias, Wv, bv, csr, a_s,
+                                                    g_s, x0, prev is not None, alpha, ln_weight, ln_bias, eps)
+                    return out, None, None
                 params = [self.Wq.weight, self.Wq.bias, self.Wk.weight, self.Wk.bias] + ([Wv, bv] if self.use_weight else [])
                 key = ops.param_key(params)
                 if key is None or self._wide is None or self._wide[0] != key:      # weight-only factors: rebuilt when a parameter changes

@@ -481,3 +481,53 @@ def test_deepest_sigmoid_script_eight_layers(exact, dev):
     gmax = max(float(v.grad.abs().max()) for v in pl.values())
     errs = {k: grad_err(p.grad.cpu().numpy(), pl[k].grad.numpy(), gmax) for k, p in model.named_parameters()}
     assert max(errs.values()) < TOL, [(f"{e:.2e}", k) for e, k in sorted(((e, k) for k, e in errs.items()), reverse=True)[:5]]
+
+
+@pytest.mark.parametrize("hidden,use_graph,use_weight,use_source,n", [(128, True, True, False, 6000), (128, False, True, False, 4000),
+                                                                     (128, True, False, True, 3000), (128, True, True, True, 2500)])
+def test_training_through_the_record_at_128_columns(hidden, use_graph, use_weight, use_source, n, dev):
+    """node classification/run.sh:42-44 trains Pokec batches at hidden 128 (main-batch.py:135-142): one training step through the
+    Gram record at that width (ag._ClosedFormLayerWide, OPT-IN: neither pass forms q, k, v) -- loss, dx and every parameter gradient
+    against float64 autograd of the oracle, and the same step on the operator path (DIFFORMER_CLOSED_FORM_TRAINING_WIDE off)."""
+    from difformer_amd import DIFFormer, autograd_ops as ag, difformer as dmod, ops
+    torch.manual_seed(hidden + n)
+    f_in, c, layers = 20, 5, 2
+    g = torch.Generator().manual_seed(hidden)
+    cfg = dict(hidden_channels=hidden, num_layers=layers, num_heads=1, kernel="simple", alpha=0.5, use_bn=True, use_residual=True,
+               use_weight=use_weight, use_graph=use_graph, graph_weight=0.3 if use_source else -1, use_source=use_source)
+    model = DIFFormer(f_in, hidden, c, num_layers=layers, kernel="simple", dropout=0.0, use_graph=use_graph, use_weight=use_weight,
+                      graph_weight=cfg["graph_weight"], use_source=use_source).to(dev).train()
+    x = torch.randn(n, f_in, generator=g)
+    ei = torch.cat([torch.randint(0, n, (2, 6 * n), generator=g), torch.arange(n).repeat(2, 1)], dim=1) if use_graph else None
+    y, idx = torch.randint(0, c, (n,), generator=g), torch.randperm(n, generator=g)[: n // 2]
+
+    def step():
+        model.zero_grad()
+        xd = x.to(dev).requires_grad_(True)
+        out = model(xd, None if ei is None else ei.to(dev))
+        loss = F.nll_loss(torch.log_softmax(out, dim=1)[idx.to(dev)], y.to(dev)[idx.to(dev)])
+        loss.backward()
+        return loss, xd.grad, {k: p.grad.clone() for k, p in model.named_parameters()}
+    be = ops.get_backend()
+    was, dmod._CLOSED_FORM_TRAINING_WIDE = dmod._CLOSED_FORM_TRAINING_WIDE, True                 # opt-in path (slower than the operator path)
+    be.kernel_events = {}
+    try:
+        loss, dx, grads = step()
+    finally:
+        names, be.kernel_events = set(be.kernel_events), None
+        dmod._CLOSED_FORM_TRAINING_WIDE = was
+    assert "dif_simple_layer_f32" in names and "dif_simple_apply_f32" not in names             # the record path, not q / k / v
+    pl = og.leaves({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    lref = og.training_loss(og.difformer_forward(pl, x64, ei, None, cfg), y, idx)
+    lref.backward()
+    assert abs(float(loss.detach()) - float(lref.detach())) < TOL * abs(float(lref.detach()))
+    assert rel_err(dx.cpu().numpy(), x64.grad.numpy()) < TOL
+    gmax = max(float(v.grad.abs().max()) for v in pl.values())
+    errs = {k: grad_err(v.cpu().numpy(), pl[k].grad.numpy(), gmax) for k, v in grads.items()}
+    assert max(errs.values()) < TOL, [(f"{e:.2e}", k) for e, k in sorted(((e, k) for k, e in errs.items()), reverse=True)[:5]]
+    # the operator path (the default at these widths) gives the same step
+    assert not dmod._CLOSED_FORM_TRAINING_WIDE
+    loss2, dx2, grads2 = step()
+    assert abs(float(loss2.detach()) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
+    assert max(grad_err(grads[k].cpu().numpy(), grads2[k].cpu().numpy(), gmax) for k in grads) < TOL
