@@ -250,3 +250,34 @@ def test_exact_fp32_keeps_the_fp32_chain(dev):
     gmax = max(np.abs(dq).max(), np.abs(dk).max(), np.abs(dv).max())
     for got, want in ((qd, dq), (kd, dk), (vd, dv)):
         assert grad_err(got.grad.cpu().numpy(), want, gmax) < 1e-5
+
+
+def test_random_shapes_heads_strides_against_the_oracle(dev):
+    """Seeded fuzz over what the launcher branches on: widths that are / are not 4-element multiples (vector or scalar epilogue),
+    M != D, several heads, N != L down to single rows, operands that are column slices of wider buffers, gradients included."""
+    from difformer_amd import full_attention_conv
+    rng = np.random.default_rng(2026)
+    for trial in range(24):
+        h = int(rng.integers(1, 4))
+        m = int(rng.integers(65, 260)) if trial % 3 else int(rng.choice([68, 128, 300, 512]))
+        d = m if trial % 2 else int(rng.integers(65, 260))
+        n, l = int(rng.integers(1, 400)), int(rng.integers(1, 500))
+        g_ = torch.Generator().manual_seed(trial)
+        pad = int(rng.integers(0, 3)) * 4
+        qb = torch.randn(n, h * m + pad, generator=g_) * (3.0 / m ** 0.5)
+        kb = torch.randn(l, h * m + pad, generator=g_) * 0.5
+        vb = torch.randn(l, h * d + pad, generator=g_)
+        go = torch.randn(n, h, d, generator=g_)
+        qd, kd, vd = (b.to(dev).requires_grad_(True) for b in (qb, kb, vb))
+        q, k, v = qd[:, : h * m].reshape(n, h, m), kd[:, : h * m].reshape(l, h, m), vd[:, : h * d].reshape(l, h, d)
+        out = full_attention_conv(q, k, v, "sigmoid")
+        out.backward(go.to(dev))
+        q64, k64, v64 = (b[:, : h * w].reshape(r, h, w).double().numpy() for b, w, r in ((qb, m, n), (kb, m, l), (vb, d, l)))
+        assert rel_err(out.detach().cpu().numpy(), orc.sigmoid_attention(q64, k64, v64)) < TOL, (trial, n, l, h, m, d)
+        dq, dk, dv = orc.sigmoid_attention_grad_blocked(q64, k64, v64, go.double().numpy())
+        gmax = max(np.abs(dq).max(), np.abs(dk).max(), np.abs(dv).max())
+        floor = 1.0 if l == 1 else 2e-6
+        for got, want, w, nm in ((qd, dq, m, "dq"), (kd, dk, m, "dk"), (vd, dv, d, "dv")):
+            gg = got.grad[:, : h * w].reshape(want.shape).cpu().numpy()
+            assert grad_err(gg, want, gmax, floor=floor) < TOL, (trial, nm, n, l, h, m, d)
+            assert float(got.grad[:, h * w:].abs().sum()) == 0.0               # the padding columns of the buffers get no gradient
