@@ -159,13 +159,14 @@ class TinyCfg(ctypes.Structure):
     """dif_tiny_cfg of include/difformer_hip.h."""
     _fields_ = [(k, ctypes.c_int32) for k in ("n", "in_channels", "hidden", "out_channels", "num_layers", "kernel", "use_bn",
                                                "use_residual", "use_weight", "use_graph", "use_source", "training")] + \
-               [(k, ctypes.c_float) for k in ("alpha", "attn_scale", "gcn_scale", "dropout", "eps")] + [("nnz", ctypes.c_int64)]
+               [(k, ctypes.c_float) for k in ("alpha", "attn_scale", "gcn_scale", "dropout", "eps")] + \
+               [("launch_plan", ctypes.c_int32), ("nnz", ctypes.c_int64)]
 
 
 SIGNATURES["dif_wide_coeffs_f64"] = (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp])
 SIGNATURES["dif_gram_sym_workspace_bytes"] = (c_sz, [c_i64, c_int])
 SIGNATURES["dif_tiny_tape_floats"] = (c_sz, [c_int, c_int, c_int])
-SIGNATURES["dif_tiny_scratch_floats"] = (c_sz, [c_int, c_int])
+SIGNATURES["dif_tiny_scratch_floats"] = (c_sz, [c_int, c_int, c_int])
 SIGNATURES["dif_tiny_graph_workspace_bytes"] = (c_sz, [c_i64, c_i64])
 SIGNATURES["dif_tiny_graph_build"] = (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp])
 SIGNATURES["dif_tiny_forward_f32"] = (c_int, [ctypes.POINTER(TinyCfg), c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp])

@@ -14,196 +14,11 @@
 // `outer_sum`: outputs x node-chunks spread over the threads, chunk partials in LDS, added in chunk order in float64 --
 // bitwise reproducible.  The sigmoid kernel's O(N^2) pair loop keeps the stationary node in registers and streams the
 // others through LDS tiles (uniform addresses: broadcast reads).
-#include "dif_common.h"
+#include "tiny_common.h"
+
+using namespace tiny;
 
 namespace {
-
-constexpr int kMaxLayers = 8;
-constexpr int kMaxIn = 64;
-constexpr int kMaxOut = 8;
-constexpr int kMaxNodes = 4096;
-constexpr int kMaxEdges = 65535;
-
-struct LayerPtrs {
-    const float *wk, *bk, *wq, *bq, *wv, *bv, *lnw, *lnb;
-};
-struct LayerGrads {
-    float *wk, *bk, *wq, *bq, *wv, *bv, *lnw, *lnb;
-};
-
-struct TinyArgs {
-    int n, f_in, d, c, layers, sigmoid, use_bn, residual, use_weight, use_graph, use_source, training;
-    float alpha, a_s, g_s, p_drop, eps;
-    const float* x;
-    int64_t ldx;
-    const float *w0, *b0, *ln0w, *ln0b, *wo, *bo;
-    LayerPtrs lp[kMaxLayers];
-    const int* rowptr;      // forward: destination-major CSR; backward: its transpose (rows = sources, entries = destinations)
-    const int* nbr;
-    const float* val;
-    const float* rnd;       // [(layers + 1), n, d] uniform [0, 1) (training with dropout) or null
-    float* tape;
-    float* y;               // forward: [n, c]
-    // backward only
-    const float* gy;        // [n, c]
-    float *gw0, *gb0, *gln0w, *gln0b, *gwo, *gbo;
-    LayerGrads lg[kMaxLayers];
-    float* dx;              // [n, f_in] or null
-    float* scratch;
-};
-
-// ---- tape layout (floats); DP = padded hidden width (4 or 8) ---------------------------------------------------------
-//   H   [(L+1)][n][DP]   layer inputs (post LayerNorm / ReLU / dropout)
-//   Z   [(L+1)][n][DP]   pre-LayerNorm values (Z[0]: input Linear; Z[l+1]: layer l after the residual)
-//   ATT [L][n][DP]       attention output per layer (sigmoid backward needs it)
-//   DEN [L][n]           sigmoid row sums
-//   SUM [L][96]          simple kernel: K^T V [DP*DP], ksum [DP], vsum [DP], sum q^2, sum k^2
-//   QKV [3][n][DP]       forward scratch
-__host__ __device__ inline size_t tape_floats(int n, int DP, int L) {
-    return static_cast<size_t>(n) * DP * (2 * (L + 1) + L + 3) + static_cast<size_t>(L) * n + static_cast<size_t>(L) * 96;
-}
-constexpr int kBwdSlots = 14;
-__host__ __device__ inline size_t scratch_floats(int n, int DP) { return static_cast<size_t>(n) * DP * kBwdSlots + 3 * static_cast<size_t>(n); }
-
-template <int DP>
-struct Tape {
-    float *H, *Z, *ATT, *DEN, *SUM, *Q, *K, *V;
-    __device__ Tape(float* base, int n, int L) {
-        const size_t nd = static_cast<size_t>(n) * DP;
-        H = base;
-        Z = H + nd * (L + 1);
-        ATT = Z + nd * (L + 1);
-        DEN = ATT + nd * L;
-        SUM = DEN + static_cast<size_t>(L) * n;
-        Q = SUM + static_cast<size_t>(L) * 96;
-        K = Q + nd;
-        V = K + nd;
-    }
-};
-
-// out[m * C + c] = scale * sum_i A[i * lda + m] * (B ? B[i * ldb + c] : 1)    for m < M, c < C
-// O = M * C outputs; blockDim / O node-chunks per output (at most 64), partials in sPart (LDS, blockDim floats... doubles),
-// added in chunk order.  Ends with a __syncthreads(); `out` may be LDS or global.  Every thread of the block must call.
-__device__ void outer_sum(const float* __restrict__ A, int64_t lda, int M, const float* __restrict__ B, int64_t ldb, int C,
-                          int n, float scale, float* out, double* sPart) {
-    const int T = blockDim.x, t = threadIdx.x;
-    const int O = M * C;
-    for (int base = 0; base < O; base += T) {
-        const int Ob = min(O - base, T);
-        int chunks = T / Ob;
-        if (chunks > 64) chunks = 64;
-        const int len = (n + chunks - 1) / chunks;
-        const int o = t % Ob, ch = t / Ob;
-        if (ch < chunks) {
-            const int m = (base + o) / C, c = (base + o) % C;
-            const int i0 = ch * len, i1 = min(n, i0 + len);
-            double acc = 0.0;
-            if (B) {
-                for (int i = i0; i < i1; ++i) acc += static_cast<double>(A[i * lda + m]) * static_cast<double>(B[i * ldb + c]);
-            } else {
-                for (int i = i0; i < i1; ++i) acc += static_cast<double>(A[i * lda + m]);
-            }
-            sPart[ch * Ob + o] = acc;
-        }
-        __syncthreads();
-        if (t < Ob) {
-            double s = 0.0;
-            for (int k = 0; k < chunks; ++k) s += sPart[k * Ob + t];
-            out[base + t] = static_cast<float>(s * static_cast<double>(scale));
-        }
-        __syncthreads();
-    }
-}
-
-// LayerNorm statistics of one row (torch.nn.LayerNorm: biased variance, eps inside the root) over its d valid columns
-template <int DP>
-__device__ __forceinline__ void ln_stats(const float (&z)[DP], int d, float eps, float& mean, float& rstd) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) s += (k < d) ? z[k] : 0.f;
-    mean = s / static_cast<float>(d);
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) {
-        const float c = (k < d) ? z[k] - mean : 0.f;
-        v += c * c;
-    }
-    rstd = 1.0f / sqrtf(v / static_cast<float>(d) + eps);
-}
-
-template <int DP>
-__device__ __forceinline__ void load_row(const float* p, float (&r)[DP]) {
-    const float4* q = reinterpret_cast<const float4*>(p);
-#pragma unroll
-    for (int k = 0; k < DP / 4; ++k) {
-        const float4 v = q[k];
-        r[4 * k] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w;
-    }
-}
-template <int DP>
-__device__ __forceinline__ void store_row(float* p, const float (&r)[DP]) {
-    float4* q = reinterpret_cast<float4*>(p);
-#pragma unroll
-    for (int k = 0; k < DP / 4; ++k) q[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
-}
-
-// weights of one layer in LDS, zero-padded to DP x DP (row m = output feature m)
-template <int DP>
-struct LayerW {
-    float wq[DP * DP], wk[DP * DP], wv[DP * DP], bq[DP], bk[DP], bv[DP], lnw[DP], lnb[DP];
-};
-
-template <int DP>
-__device__ void load_layer(LayerW<DP>& s, const LayerPtrs& p, int d, bool use_weight, bool use_bn) {
-    for (int k = threadIdx.x; k < DP * DP; k += blockDim.x) {
-        const int m = k / DP, c = k % DP;
-        const bool in = m < d && c < d;
-        s.wq[k] = in ? p.wq[m * d + c] : 0.f;
-        s.wk[k] = in ? p.wk[m * d + c] : 0.f;
-        s.wv[k] = (in && use_weight) ? p.wv[m * d + c] : 0.f;
-    }
-    for (int k = threadIdx.x; k < DP; k += blockDim.x) {
-        const bool in = k < d;
-        s.bq[k] = in ? p.bq[k] : 0.f;
-        s.bk[k] = in ? p.bk[k] : 0.f;
-        s.bv[k] = (in && use_weight) ? p.bv[k] : 0.f;
-        s.lnw[k] = (in && use_bn) ? p.lnw[k] : 0.f;
-        s.lnb[k] = (in && use_bn) ? p.lnb[k] : 0.f;
-    }
-}
-
-template <int DP>
-__device__ __forceinline__ void matvec(const float* W, const float* b, const float (&h)[DP], float (&o)[DP]) {
-#pragma unroll
-    for (int m = 0; m < DP; ++m) {
-        float acc = b ? b[m] : 0.f;
-#pragma unroll
-        for (int c = 0; c < DP; ++c) acc += W[m * DP + c] * h[c];
-        o[m] = acc;
-    }
-}
-// o[c] += sum_m W[m][c] g[m]
-template <int DP>
-__device__ __forceinline__ void matvec_t_add(const float* W, const float (&g)[DP], float (&o)[DP]) {
-#pragma unroll
-    for (int c = 0; c < DP; ++c) {
-        float acc = 0.f;
-#pragma unroll
-        for (int m = 0; m < DP; ++m) acc += W[m * DP + c] * g[m];
-        o[c] += acc;
-    }
-}
-
-__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
-
-// dropout of one row with the caller's uniforms: keep iff r >= p, scaled by 1 / (1 - p) (torch.nn.functional.dropout)
-template <int DP>
-__device__ __forceinline__ void dropout_row(float (&h)[DP], const float* rnd, int64_t at, int d, float p) {
-    const float keep = 1.0f / (1.0f - p);
-#pragma unroll
-    for (int k = 0; k < DP; ++k)
-        if (k < d) h[k] = (rnd[at + k] >= p) ? h[k] * keep : 0.f;
-}
 
 // ======================================================================================================================
 // forward
@@ -1035,7 +850,19 @@ int check_cfg(const dif_tiny_cfg* cfg) {
                 cfg->num_layers);
     DIF_REQUIRE(cfg->kernel == 0 || cfg->kernel == 1, DIF_E_BADARG, "dif_tiny: kernel 0 (simple) or 1 (sigmoid)");
     DIF_REQUIRE(cfg->dropout >= 0.f && cfg->dropout < 1.f, DIF_E_BADARG, "dif_tiny: dropout in [0, 1)");
+    DIF_REQUIRE(cfg->launch_plan >= 0 && cfg->launch_plan <= 2, DIF_E_BADARG, "dif_tiny: launch_plan 0 (by size), 1 (one workgroup) or 2 (grid)");
+    DIF_REQUIRE(cfg->launch_plan != 2 || cfg->kernel == 1, DIF_E_BADARG, "dif_tiny: launch_plan 2 (grid) exists for kernel 1 (sigmoid) only");
     return 0;
+}
+
+// `sigmoid`: the n^2 pairs of a layer on one compute unit, or one launch per layer over the chip (tiny_sigmoid_grid.hip).
+// Measured on MI355X (profiles/r06_tiny_sigmoid_grid.txt): device time crosses at ~64 nodes (49 us against 48 per training
+// snapshot; 72 against 225 at 129 nodes, 90 against 3,350 at 1,068); in the launch-bound training loop of spatial-temporal/
+// main.py the 20-node dataset is 7 % faster on one workgroup (2 launches, not 7), the 129-node one 13 % faster on the grid.
+constexpr int kGridFromNodes = 64;
+bool grid_plan(const dif_tiny_cfg* cfg) {
+    if (cfg->kernel != 1 || cfg->launch_plan == 1) return false;
+    return cfg->launch_plan == 2 || cfg->n > kGridFromNodes;
 }
 
 // params / grads: 6 + 8 * layers pointers in the order
@@ -1074,7 +901,7 @@ extern "C" size_t dif_tiny_tape_floats(int n, int hidden, int num_layers) {
     return tape_floats(n, hidden <= 4 ? 4 : 8, num_layers);
 }
 
-extern "C" size_t dif_tiny_scratch_floats(int n, int hidden) { return scratch_floats(n, hidden <= 4 ? 4 : 8); }
+extern "C" size_t dif_tiny_scratch_floats(int n, int hidden, int num_layers) { return scratch_floats(n, hidden <= 4 ? 4 : 8, num_layers); }
 
 extern "C" size_t dif_tiny_graph_workspace_bytes(int64_t E, int64_t N) {
     (void)N;
@@ -1110,6 +937,7 @@ extern "C" int dif_tiny_forward_f32(const dif_tiny_cfg* cfg, const float* x, int
                 "dif_tiny_forward_f32: use_graph without a CSR");
     a.rowptr = rowptr; a.nbr = src; a.val = val; a.rnd = rnd; a.tape = tape; a.y = y;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (grid_plan(cfg)) return grid_sigmoid_forward(a, st);
     const int T = block_threads(cfg->n);
     if (cfg->hidden <= 4) hipLaunchKernelGGL(tiny_forward_kernel<4>, dim3(1), dim3(T), 0, st, a);
     else hipLaunchKernelGGL(tiny_forward_kernel<8>, dim3(1), dim3(T), 0, st, a);
@@ -1139,6 +967,7 @@ extern "C" int dif_tiny_backward_f32(const dif_tiny_cfg* cfg, const float* x, in
                     DIF_E_BADARG, "dif_tiny_backward_f32: null gradient buffer of layer %d", l);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (grid_plan(cfg)) return grid_sigmoid_backward(a, st);
     const int T = block_threads(cfg->n);
     if (cfg->hidden <= 4) hipLaunchKernelGGL(tiny_backward_kernel<4>, dim3(1), dim3(T), 0, st, a);
     else hipLaunchKernelGGL(tiny_backward_kernel<8>, dim3(1), dim3(T), 0, st, a);

@@ -7,7 +7,8 @@ launches and ~1.1 ms of host time per training snapshot for 0.33 ms of kernels (
 is ONE launch (+ one for a graph not seen before, + one `torch.rand` when dropout is on), its backward one more, under one
 autograd node that hands every parameter its gradient.
 
-Taken for: one head, float32, n <= 4,096 (`sigmoid`: <= 512 -- its O(n^2) pair loop runs on one compute unit), hidden <= 8,
+Taken for: one head, float32, n <= 4,096 (`sigmoid` above 64 nodes: L + 1 launches forward and L + 2 backward, a layer's
+O(n^2) pair loop spread over the chip -- csrc/tiny_sigmoid_grid.hip -- behind the same two C calls), hidden <= 8,
 <= 64 input features, <= 8 outputs, <= 8 layers, every flag of the constructor, graphs of <= 65,535 entries (prepared by
 `dif_tiny_graph_build`, one workgroup per direction).  Everything else -- `--special_treat dense` at n = 1,068 (1.14 M
 entries), `edge_weight` tensors that want a gradient -- takes the layer-by-layer path.  DIFFORMER_TINY=0 switches it off.
@@ -26,7 +27,8 @@ from .backend_hip import _stream
 
 ENABLED = os.environ.get("DIFFORMER_TINY", "1") != "0"
 MAX_NODES, MAX_HIDDEN, MAX_IN, MAX_OUT, MAX_LAYERS, MAX_EDGES = 4096, 8, 64, 8, 8, 65535
-MAX_NODES_SIGMOID = int(os.environ.get("DIFFORMER_TINY_SIGMOID_NODES", "512"))
+MAX_NODES_SIGMOID = int(os.environ.get("DIFFORMER_TINY_SIGMOID_NODES", "4096"))
+PLAN = int(os.environ.get("DIFFORMER_TINY_PLAN", "0"))     # dif_tiny_cfg.launch_plan for `sigmoid`: 0 by size, 1 one workgroup, 2 grid
 
 
 class TinyGraph:
@@ -192,7 +194,7 @@ def _plan(model, x, edge_index, edge_weight):
     if kernel not in ("simple", "sigmoid") or c0["num_heads"] != 1 or c0["out_channels"] != d:
         return None
     if kernel == "sigmoid" and n > MAX_NODES_SIGMOID:
-        return None                          # O(n^2) pairs on ONE compute unit: from ~500 nodes the flash-style kernels win
+        return None
     md = model.__dict__
     if md["training"] and not (0.0 <= float(md["dropout"]) < 1.0):
         return None                          # dropout = 1 (all zeros in training): the layer path's F.dropout semantics
@@ -242,7 +244,8 @@ class _TinyModel(torch.autograd.Function):
         xc = x if (x.stride(1) == 1 and (n == 1 or x.stride(0) >= x.shape[1])) else x.contiguous()
         ldx = xc.stride(0) if n > 1 else xc.shape[1]
         rnd = torch.rand((L + 1, n, d), device=dev) if (training and p_drop > 0.0) else None
-        cfg = _lib.TinyCfg(training=int(training), dropout=float(p_drop), nnz=0 if graph is None else graph.nnz, **fields)
+        cfg = _lib.TinyCfg(training=int(training), dropout=float(p_drop), nnz=0 if graph is None else graph.nnz,
+                           launch_plan=PLAN if fields["kernel"] == 1 else 0, **fields)
         tape = torch.empty(int(lib.dif_tiny_tape_floats(n, d, L)), dtype=torch.float32, device=dev)
         y = torch.empty((n, c), dtype=torch.float32, device=dev)
         pa = _ptr_array(params)
@@ -282,7 +285,7 @@ class _TinyModel(torch.autograd.Function):
             views.append(v)
             o += s + pd
         dx = flat[o: o + n * cfg.in_channels].view(n, cfg.in_channels) if want_dx else None
-        scratch = torch.empty(int(lib.dif_tiny_scratch_floats(n, d)), dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.dif_tiny_scratch_floats(n, d, cfg.num_layers)), dtype=torch.float32, device=dev)
         gyc = gy if gy.is_contiguous() else gy.contiguous()
         rc = lib.dif_tiny_backward_f32(ctypes.byref(cfg), xc.data_ptr(), ctx.ldx, _ptr_array(params),
                                        None if graph is None else graph.rowptr_t, None if graph is None else graph.dst_t,

@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--cpu-port", action="store_true")
     ap.add_argument("--reference", action="store_true")
     ap.add_argument("--no-gpu", action="store_true")
+    ap.add_argument("--only", default="", help="run the datasets whose name contains this")
     args = ap.parse_args()
     shapes = [("chickenpox", 20, 4, 4, 104, False, False, True), ("covid", 129, 8, 12, 50, True, False, True),
               ("wikimath", 1068, 14, 10, 146, False, False, False), ("chickenpox-dense", 20, 4, 4, 104, False, True, True),
@@ -128,6 +129,8 @@ def main():
         impls.append((f"reference-file({torch.get_num_threads()} threads)", load_st().DIFFormer, torch.device("cpu")))
     print(f"{'dataset':18s} {'kernel':8s} {'graph':6s} {'T':>4s}  " + "  ".join(f"{n:>28s}" for n, _, _ in impls))
     for name, n, d, deg, T, dynamic, dense, cumulative in shapes:
+        if args.only not in name:
+            continue
         host = data(n, d, deg, T, dynamic, dense)
         for kernel in ("simple", "sigmoid"):
             for use_graph in ((True,) if dense else (True, False)):

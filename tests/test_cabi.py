@@ -146,9 +146,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 def test_tiny_model_entry_points_check_their_arguments(lib):
     """dif_tiny_*: size helpers are host arithmetic; the configuration is validated before any HIP call."""
     from difformer_amd import _lib
-    assert lib.dif_tiny_tape_floats(20, 4, 2) == 20 * 4 * (2 * 3 + 2 + 3) + 2 * 20 + 2 * 96
-    assert lib.dif_tiny_tape_floats(20, 5, 2) == 20 * 8 * (2 * 3 + 2 + 3) + 2 * 20 + 2 * 96       # hidden 5..8: padded to 8
-    assert lib.dif_tiny_scratch_floats(1068, 4) == 1068 * 4 * 14 + 3 * 1068
+    def splits(n):                                  # csrc/tiny_common.h key_splits
+        G = (n + 63) // 64
+        return 1 if n <= 512 else max(1, min((256 + G - 1) // G, n // 64, 16))
+
+    def tape(n, dp, L):                             # H, Z [L+1]; ATT, ATTLO [L]; two q/k/v sets; DEN; SUM; the splits' sums
+        f = n * dp * (2 * (L + 1) + 2 * L + 6) + L * n + L * 96
+        return f + (-f) % 4 + 2 * splits(n) * n * (dp + 1)
+
+    def scratch(n, dp, L):
+        one = n * dp * 14 + 3 * n
+        g = n * dp * (5 * L + 15) + 4 * n
+        return max(one, g + (-g) % 4 + 2 * splits(n) * n * 3 * dp)
+
+    assert lib.dif_tiny_tape_floats(20, 4, 2) == tape(20, 4, 2)
+    assert lib.dif_tiny_tape_floats(20, 5, 2) == tape(20, 8, 2)                                    # hidden 5..8: padded to 8
+    assert lib.dif_tiny_tape_floats(1068, 4, 2) == tape(1068, 4, 2) and splits(1068) == 16 and splits(4096) == 4
+    assert lib.dif_tiny_scratch_floats(1068, 4, 2) == scratch(1068, 4, 2)
+    assert lib.dif_tiny_scratch_floats(20, 8, 1) == scratch(20, 8, 1)
     assert lib.dif_tiny_graph_workspace_bytes(100, 20) >= 4 * 100 * 4
     cfg = _lib.TinyCfg(n=5000, in_channels=4, hidden=4, out_channels=1, num_layers=2, kernel=0, use_bn=1, use_residual=1,
                        use_weight=0, use_graph=0, use_source=0, training=0, alpha=0.5, attn_scale=1.0, gcn_scale=1.0, dropout=0.0,
@@ -159,5 +174,9 @@ def test_tiny_model_entry_points_check_their_arguments(lib):
     assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -2
     cfg.hidden = 4
     assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -1
+    cfg.launch_plan = 2                             # the grid plan exists for `sigmoid` (kernel 1) only
+    assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -1
+    assert b"launch_plan" in lib.dif_last_error()
+    cfg.launch_plan = 0
     assert lib.dif_tiny_graph_build(None, None, 70000, 20, None, None, None, None, None, None, None, None, 0, None) == -2
     assert lib.dif_tiny_graph_build(None, None, 10, 20, None, None, None, None, None, None, None, None, 0, None) == -1

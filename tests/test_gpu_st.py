@@ -47,16 +47,14 @@ def _model(c, dev):
 @pytest.fixture(autouse=True)
 def _which_path(request):
     """Every model of this file is the scripts' configuration (hidden 4, one head, <= 1,068 nodes): its forwards run as the
-    whole-model kernels of csrc/tiny_model.hip (difformer_amd/tiny.py) -- except the two shapes that path hands back to the
-    layer-by-layer kernels: `sigmoid` beyond 512 nodes (wikimath) and graphs beyond 65,535 entries (`dense` at n = 1,068)."""
+    whole-model kernels of csrc/tiny_model.hip / csrc/tiny_sigmoid_grid.hip (difformer_amd/tiny.py; wikimath with `sigmoid`:
+    the grid plan) -- except the one shape that path hands back to the layer-by-layer kernels: graphs beyond 65,535 entries
+    (`dense` at n = 1,068)."""
     from difformer_amd import tiny
     before = dict(tiny.stats)
     yield
     name = request.node.name
-    layer_path = ("wikimath" in name and ("sigmoid" in name or "dense" in name)) or "sigmoid-True-False" in name or \
-        "sigmoid-True-True" in name or "simple-True-True" in name            # test_wikimath_branch[kernel-use_graph-dense]
-    if "test_wikimath_branch" in name and "sigmoid" not in name and not name.endswith("True]"):
-        layer_path = False
+    layer_path = ("wikimath" in name and "dense" in name) or ("test_wikimath_branch" in name and name.endswith("True]"))
     took = tiny.stats["forward"] > before["forward"]
     assert took != layer_path, (name, took)
     tiny._poll_status(wait=True)

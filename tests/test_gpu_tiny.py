@@ -138,8 +138,6 @@ def _cases():
     for k in range(36):
         n = int(sizes[k % len(sizes)])
         kernel = "sigmoid" if k % 2 else "simple"
-        if kernel == "sigmoid" and n > 512:
-            n = 500 if n > 700 else 385
         out.append(dict(n=n, f_in=int(rng.choice([1, 4, 8, 14, 33, 64])), hidden=int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8])),
                         c=int(rng.choice([1, 1, 2, 8])), layers=int(rng.choice([1, 2, 2, 3, 4])), kernel=kernel,
                         use_bn=bool(rng.rand() < 0.7), use_residual=bool(rng.rand() < 0.7), use_weight=bool(rng.rand() < 0.5),
@@ -152,8 +150,29 @@ def _cases():
     return out
 
 
-@pytest.mark.parametrize("c", _cases(), ids=lambda c: f"{c['kernel']}-n{c['n']}-d{c['hidden']}-L{c['layers']}-s{c['seed']}")
+_ID = lambda c: f"{c['kernel']}-n{c['n']}-d{c['hidden']}-L{c['layers']}-s{c['seed']}"
+
+
+@pytest.mark.parametrize("c", _cases(), ids=_ID)
 def test_forward_and_backward_every_flag(c, dev):
+    """Every case on the plan the library picks by size (`sigmoid` above 64 nodes: one launch per layer over the chip,
+    csrc/tiny_sigmoid_grid.hip; everything else: one workgroup, csrc/tiny_model.hip)."""
+    _run_case(c, dev)
+
+
+@pytest.mark.parametrize("plan", [1, 2], ids=["one-workgroup", "grid"])
+@pytest.mark.parametrize("c", [c for c in _cases() if c["kernel"] == "sigmoid"], ids=_ID)
+def test_sigmoid_on_both_launch_plans(c, plan, dev, monkeypatch):
+    """The `sigmoid` cases with the plan forced: both sides of the size threshold run both kernels (the one-workgroup plan
+    capped at 700 nodes here: 9 M pairs per layer on one compute unit is what the grid plan exists to avoid)."""
+    from difformer_amd import tiny
+    if plan == 1 and c["n"] > 700:
+        c = dict(c, n=700)
+    monkeypatch.setattr(tiny, "PLAN", plan)
+    _run_case(c, dev)
+
+
+def _run_case(c, dev):
     from difformer_amd import DIFFormer, tiny
     n, d, L = c["n"], c["hidden"], c["layers"]
     torch.manual_seed(100 + c["seed"])
