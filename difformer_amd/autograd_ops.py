@@ -428,7 +428,7 @@ class _ClosedFormLayerWide(torch.autograd.Function):
                 d_ax = _row_gemm(be, d, Wv)
                 d3 = d.view(n, 1, D)
                 red = be.simple_reduce(d3, d3, ax.view(n, 1, C))                    # K^T V with K = d, V = ax
-                d_Wv = red[: D * C].view(D, C).clone()
+                d_Wv = red[: D * C].view(D, C) * g_s                                 # (ax is A x unscaled here; g_s rides in the kernel)
                 d_bv = g_s * _weighted_column_sum(be, d, rs)
             else:
                 d_ax = d
