@@ -147,23 +147,46 @@ __global__ __launch_bounds__(256) void sigw_pack_kernel(const float* __restrict_
 // the difference is far smaller than either term and the split error came back amplified (last layer of an 8-layer model:
 // 1.5e-4 of a Wk.bias gradient).  With c = the column mean both terms shrink to the rows' spread; the forward sums
 // P (v - c) and adds c back for the same reason.
+constexpr int kColsumRows = 64;
+__host__ __device__ inline int64_t colsum_blocks(int64_t L) { return (L + kColsumRows - 1) / kColsumRows; }
+// partial [blocks][HD]: a thread owns a column of the block's 64 rows, eight loads in flight (the column walk is latency-bound:
+// one accumulator per thread made this 52 us at 15,000 x 300, two small kernels were 8 % of that forward)
 __global__ __launch_bounds__(256) void sigw_colsum_kernel(const float* __restrict__ v, int64_t ldv, int64_t L, int HD,
                                                           float* __restrict__ partial) {
-    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 128;
-    const int64_t r1 = r0 + 128 < L ? r0 + 128 : L;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kColsumRows;
+    const int rows = static_cast<int>(r0 + kColsumRows < L ? kColsumRows : L - r0);
     for (int c = threadIdx.x; c < HD; c += 256) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += v[r * ldv + c];
-        partial[static_cast<int64_t>(blockIdx.x) * HD + c] = s;
+        const float* p = v + r0 * ldv + c;
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.f;
+        int r = 0;
+        for (; r + 8 <= rows; r += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += p[static_cast<int64_t>(r + u) * ldv];
+        }
+        for (; r < rows; ++r) a[0] += p[static_cast<int64_t>(r) * ldv];
+        partial[static_cast<int64_t>(blockIdx.x) * HD + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
 }
+// cmean [HD]: a workgroup owns 64 columns, its four waves every fourth block of partials (fixed order: reproducible)
 __global__ __launch_bounds__(256) void sigw_colmean_kernel(const float* __restrict__ partial, int blocks, int64_t L, int HD,
                                                            float* __restrict__ cmean) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= HD) return;
-    float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += partial[static_cast<int64_t>(b) * HD + c];
-    cmean[c] = s / static_cast<float>(L);
+    __shared__ float sS[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < HD) {
+        int b = w;
+        for (; b + 12 < blocks; b += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += partial[static_cast<int64_t>(b + 4 * u) * HD + c];
+        }
+        for (; b < blocks; b += 4) a[0] += partial[static_cast<int64_t>(b) * HD + c];
+    }
+    sS[w][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (w == 0 && c < HD) cmean[c] = ((sS[0][lane] + sS[1][lane]) + (sS[2][lane] + sS[3][lane])) / static_cast<float>(L);
 }
 
 // delta~[h][n] = g_n . (out_n - c) / den_n for n < N, 0 up to NPAD (one wave per (n, h)); c [H][D] = the value rows' centre
@@ -616,13 +639,13 @@ int launch_combine(const SweepPlan& p, const SweepOut& w, int64_t NX, int H, int
 
 // cmean [H][D] = column means of v; partial: ceil(L / 128) x H D floats
 inline size_t colmean_bytes(int64_t L, int H, int D) {
-    return align256(static_cast<size_t>((L + 127) / 128) * H * D * sizeof(float)) + align256(static_cast<size_t>(H) * D * sizeof(float));
+    return align256(static_cast<size_t>(colsum_blocks(L)) * H * D * sizeof(float)) + align256(static_cast<size_t>(H) * D * sizeof(float));
 }
 int launch_colmean(const float* v, int64_t ldv, int64_t L, int H, int D, float* partial, float* cmean, hipStream_t st) {
-    const int blocks = static_cast<int>((L + 127) / 128);
+    const int blocks = static_cast<int>(colsum_blocks(L));
     hipLaunchKernelGGL(sigw_colsum_kernel, dim3(blocks), dim3(256), 0, st, v, ldv, L, H * D, partial);
     if (int rc = dif::launch_status("sigw_colsum_kernel")) return rc;
-    hipLaunchKernelGGL(sigw_colmean_kernel, dim3((H * D + 255) / 256), dim3(256), 0, st, partial, blocks, L, H * D, cmean);
+    hipLaunchKernelGGL(sigw_colmean_kernel, dim3((H * D + 63) / 64), dim3(256), 0, st, partial, blocks, L, H * D, cmean);
     return dif::launch_status("sigw_colmean_kernel");
 }
 
@@ -668,7 +691,7 @@ int sigw_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const flo
     bf16x8* qr = static_cast<bf16x8*>(cv.take(packed_bytes(N, H, KS, kNP)));
     bf16x8* kr = static_cast<bf16x8*>(cv.take(packed_bytes(L, H, KS, kNP)));
     bf16x8* vc = static_cast<bf16x8*>(cv.take(packed_bytes(L, H, KS, kNP)));
-    float* cpart = static_cast<float*>(cv.take(static_cast<size_t>((L + 127) / 128) * H * D * sizeof(float)));
+    float* cpart = static_cast<float*>(cv.take(static_cast<size_t>(colsum_blocks(L)) * H * D * sizeof(float)));
     float* cmean = static_cast<float*>(cv.take(static_cast<size_t>(H) * D * sizeof(float)));
     if (int rc = launch_colmean(v, ldv, L, H, D, cpart, cmean, st)) return rc;
     if (int rc = launch_pack(q, ldq, N, M, H, KS, nullptr, nullptr, qr, nullptr, st)) return rc;
@@ -720,7 +743,7 @@ int sigw_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const flo
     bf16x8* vr = static_cast<bf16x8*>(cv.take(pl));
     const int64_t ndpad = (N + 63) / 64 * 64 + 64;
     float* delta = static_cast<float*>(cv.take(static_cast<size_t>(H) * ndpad * sizeof(float)));
-    float* cpart = static_cast<float*>(cv.take(static_cast<size_t>((L + 127) / 128) * H * D * sizeof(float)));
+    float* cpart = static_cast<float*>(cv.take(static_cast<size_t>(colsum_blocks(L)) * H * D * sizeof(float)));
     float* cmean = static_cast<float*>(cv.take(static_cast<size_t>(H) * D * sizeof(float)));
     float* part = reinterpret_cast<float*>(cv.p);
     if (int rc = launch_colmean(v, ldv, L, H, D, cpart, cmean, st)) return rc;
