@@ -467,12 +467,15 @@ def main():
     # correction + WRITE_SIZE, calibrated; scripts/pmc_traffic.sh) stored under profiles/ -- a counter run cannot
     # share a process with this timed run.  Only valid for the single-GPU workload it was collected on.
     traffic = tsrc = None
-    for tfile in ("r06_pmc_traffic_c4.json", "r05_pmc_traffic_c4.json", "r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
+    for tfile in ("r06_pmc_traffic_c4.json", "r06_pmc_traffic_pokec_full.json", "r05_pmc_traffic_c4.json", "r04_pmc_traffic_c4.json",
+                  "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json", "r01_pmc_traffic_c4.json"):
         tpath = os.path.join(ROOT, "profiles", tfile)
         if world == 1 and use_graph and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and dom_key in tj.get("kernels", {}):
-                traffic = tj["kernels"][dom_key].get("hbm_bytes_per_launch")
+            # the key is a kernel name or the common prefix of a kernel family (`spmm_`: the heaviest member counts)
+            hits = [v for k, v in tj.get("kernels", {}).items() if dom_key and k.startswith(dom_key)]
+            if tj.get("workload") == args.workload and hits:
+                traffic = max(h.get("hbm_bytes_per_launch", 0.0) for h in hits)
                 tsrc = f"profiles/{tfile} (rocprofv3 PMC, separate passes)"
                 break
     src = "HIP events on the launching stream, only this entry point bracketed (bench.py::dominant_alone)"
@@ -507,6 +510,13 @@ def main():
     else:
         roofline.update({"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None, "algorithmic_bytes_per_launch": alg_bytes})
+    if traffic and dom_ms and bound != "mfma":
+        # what the memory system actually moved per launch over the same time: a gather of neighbour rows that no cache holds
+        # (full Pokec: 417 MB of rows against 32 MB of L2) sits at the HBM roofline on ITS traffic while `frac` -- algorithmic bytes,
+        # every row once -- stays small; a low traffic_frac would mean latency- or issue-bound instead
+        roofline["traffic_gbs"] = traffic / (dom_ms * 1e-3) / 1e9
+        roofline["traffic_frac"] = roofline["traffic_gbs"] / HBM_PEAK_GBS
+        roofline["traffic_over_algorithmic"] = traffic / alg_bytes if alg_bytes else None
     if bound == "lds" and dom_ms:
         # every entry is one 16-byte LDS read per 16-byte feature slice -- nnz x F x 4 bytes per launch whatever the padding
         lds_bytes = 1.0 * nnz * (n_local / n) * hidden * 4
