@@ -283,3 +283,16 @@ def test_larger_models_keep_the_layer_path(dev):
     model = DIFFormer(8, 4, 2).to(dev).train()
     model(x, ei, w).sum().backward()                        # edge_weight wants a gradient: the operator path returns it
     assert w.grad is not None and tiny.stats["forward"] == before
+
+
+@pytest.mark.parametrize("n,hidden,layers,edges", [(4096, 8, 8, 65535), (4095, 7, 3, 30000), (1068, 4, 2, 27000), (577, 5, 5, 0)])
+def test_sigmoid_grid_plan_at_its_limits(n, hidden, layers, edges, dev):
+    """The grid plan at the limits of the C entry points (4,096 nodes, hidden 8, 8 layers, 65,535 entries), at a node count that
+    leaves a ragged last block and ragged key splits, at wikimath's shape and without a graph: output, dx and every parameter
+    gradient against the float64 oracle."""
+    c = dict(n=n, f_in=14, hidden=hidden, c=3, layers=layers, kernel="sigmoid", use_bn=True, use_residual=True, use_weight=hidden != 4,
+             use_graph=edges > 0, use_source=hidden == 5, graph_weight=0.3 if hidden == 7 else -1.0, alpha=0.5, weighted=hidden != 4,
+             deg=1, iso=0, dropout=0.0, seed=n + hidden)
+    if edges:
+        c["deg"] = max(1, (edges - n) // n)
+    _run_case(c, dev)
