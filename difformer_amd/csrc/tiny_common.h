@@ -43,6 +43,8 @@ struct TinyArgs {
 // launch is ~2,000 waves, a wave keeping >= 8 keys
 constexpr int kNodes = 64;
 constexpr int kMaxBlocks = kMaxNodes / kNodes;
+// `simple` on the grid: a node block leaves its share of a layer's sums over nodes (<= 96 values, double) per set
+__host__ __device__ inline size_t block_sums_floats(int n) { return 2 * 2 * static_cast<size_t>((n + kNodes - 1) / kNodes) * 96; }
 __host__ __device__ inline int key_splits(int n) {
     if (n <= 512) return 1;                    // one launch per layer: 8 waves x <= 64 keys
     const int G = (n + kNodes - 1) / kNodes;
@@ -64,7 +66,9 @@ __host__ __device__ inline int key_splits(int n) {
 __host__ __device__ inline size_t tape_floats(int n, int DP, int L) {
     size_t f = static_cast<size_t>(n) * DP * (2 * (L + 1) + 2 * L + 6) + static_cast<size_t>(L) * n + static_cast<size_t>(L) * 96;
     f += (-f) & 3;
-    return f + 2 * static_cast<size_t>(key_splits(n)) * n * (DP + 1);      // the key splits' partial sums (double)
+    // `sigmoid`: the key splits' partial sums [K][n][DP + 1];  `simple`: the node blocks' partial sums [2 sets][G][96]  (double)
+    const size_t pairs = 2 * static_cast<size_t>(key_splits(n)) * n * (DP + 1), blocks = block_sums_floats(n);
+    return f + (pairs > blocks ? pairs : blocks);
 }
 constexpr int kBwdSlots = 14;
 // one workgroup: 14 [n][DP] slots + 3 [n] arrays; the grid kernels (tiny_sigmoid_grid.hip): 5 slots per layer kept for the
@@ -74,7 +78,8 @@ __host__ __device__ inline size_t scratch_floats(int n, int DP, int L) {
     const size_t one = nd * kBwdSlots + 3 * static_cast<size_t>(n);
     size_t grid = nd * (5 * static_cast<size_t>(L) + 15) + 4 * static_cast<size_t>(n);
     grid += (-grid) & 3;
-    grid += 2 * static_cast<size_t>(key_splits(n)) * n * 3 * DP;
+    const size_t pairs = 2 * static_cast<size_t>(key_splits(n)) * n * 3 * DP, blocks = block_sums_floats(n);
+    grid += pairs > blocks ? pairs : blocks;
     return one > grid ? one : grid;
 }
 
@@ -226,8 +231,10 @@ __device__ __forceinline__ void dropout_row(float (&h)[DP], const float* rnd, in
         if (k < d) h[k] = (rnd[at + k] >= p) ? h[k] * keep : 0.f;
 }
 
-// tiny_sigmoid_grid.hip: `a` filled as for the one-workgroup kernels; forward: L + 1 launches, backward: L + 2
+// tiny_sigmoid_grid.hip / tiny_simple_grid.hip: `a` filled as for the one-workgroup kernels; forward: L + 1 launches, backward: L + 2
 int grid_sigmoid_forward(const TinyArgs& a, hipStream_t st);
 int grid_sigmoid_backward(const TinyArgs& a, hipStream_t st);
+int grid_simple_forward(const TinyArgs& a, hipStream_t st);
+int grid_simple_backward(const TinyArgs& a, hipStream_t st);
 
 }  // namespace tiny

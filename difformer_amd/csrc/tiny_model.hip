@@ -851,18 +851,22 @@ int check_cfg(const dif_tiny_cfg* cfg) {
     DIF_REQUIRE(cfg->kernel == 0 || cfg->kernel == 1, DIF_E_BADARG, "dif_tiny: kernel 0 (simple) or 1 (sigmoid)");
     DIF_REQUIRE(cfg->dropout >= 0.f && cfg->dropout < 1.f, DIF_E_BADARG, "dif_tiny: dropout in [0, 1)");
     DIF_REQUIRE(cfg->launch_plan >= 0 && cfg->launch_plan <= 2, DIF_E_BADARG, "dif_tiny: launch_plan 0 (by size), 1 (one workgroup) or 2 (grid)");
-    DIF_REQUIRE(cfg->launch_plan != 2 || cfg->kernel == 1, DIF_E_BADARG, "dif_tiny: launch_plan 2 (grid) exists for kernel 1 (sigmoid) only");
     return 0;
 }
 
-// `sigmoid`: the n^2 pairs of a layer on one compute unit, or one launch per layer over the chip (tiny_sigmoid_grid.hip).
-// Measured on MI355X (profiles/r06_tiny_sigmoid_grid.txt): device time crosses at ~64 nodes (49 us against 48 per training
-// snapshot; 72 against 225 at 129 nodes, 90 against 3,350 at 1,068); in the launch-bound training loop of spatial-temporal/
-// main.py the 20-node dataset is 7 % faster on one workgroup (2 launches, not 7), the 129-node one 13 % faster on the grid.
+// One workgroup for the whole model, or one launch per layer stage over the chip (tiny_sigmoid_grid.hip / tiny_simple_grid.hip).
+// `sigmoid` (the n^2 pairs of a layer), measured on MI355X (profiles/r06_tiny_sigmoid_grid.txt): device time crosses at ~64 nodes
+// (49 us against 48 per training snapshot; 72 against 225 at 129 nodes, 90 against 3,350 at 1,068); in the launch-bound training
+// loop of spatial-temporal/main.py the 20-node dataset is 7 % faster on one workgroup (2 launches, not 7), the 129-node one 13 %
+// faster on the grid.  `simple` has no pair loop: per training snapshot one workgroup takes 100 us at 129 nodes, 116 at 256, 300 at 1,068
+// against 72 / 75 / 88 on the grid (7 launches instead of 2); the launch-bound loop at 129 nodes is 8 % FASTER on one workgroup,
+// wikimath's (1,068 nodes, graph term) 24 % faster on the grid (profiles/r06_tiny_sigmoid_grid.txt section 4).
 constexpr int kGridFromNodes = 64;
+constexpr int kGridFromNodesSimple = 256;
 bool grid_plan(const dif_tiny_cfg* cfg) {
-    if (cfg->kernel != 1 || cfg->launch_plan == 1) return false;
-    return cfg->launch_plan == 2 || cfg->n > kGridFromNodes;
+    if (cfg->launch_plan == 1) return false;
+    if (cfg->launch_plan == 2) return true;
+    return cfg->n > (cfg->kernel == 1 ? kGridFromNodes : kGridFromNodesSimple);
 }
 
 // params / grads: 6 + 8 * layers pointers in the order
@@ -937,7 +941,7 @@ extern "C" int dif_tiny_forward_f32(const dif_tiny_cfg* cfg, const float* x, int
                 "dif_tiny_forward_f32: use_graph without a CSR");
     a.rowptr = rowptr; a.nbr = src; a.val = val; a.rnd = rnd; a.tape = tape; a.y = y;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (grid_plan(cfg)) return grid_sigmoid_forward(a, st);
+    if (grid_plan(cfg)) return cfg->kernel == 1 ? grid_sigmoid_forward(a, st) : grid_simple_forward(a, st);
     const int T = block_threads(cfg->n);
     if (cfg->hidden <= 4) hipLaunchKernelGGL(tiny_forward_kernel<4>, dim3(1), dim3(T), 0, st, a);
     else hipLaunchKernelGGL(tiny_forward_kernel<8>, dim3(1), dim3(T), 0, st, a);
@@ -967,7 +971,7 @@ extern "C" int dif_tiny_backward_f32(const dif_tiny_cfg* cfg, const float* x, in
                     DIF_E_BADARG, "dif_tiny_backward_f32: null gradient buffer of layer %d", l);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (grid_plan(cfg)) return grid_sigmoid_backward(a, st);
+    if (grid_plan(cfg)) return cfg->kernel == 1 ? grid_sigmoid_backward(a, st) : grid_simple_backward(a, st);
     const int T = block_threads(cfg->n);
     if (cfg->hidden <= 4) hipLaunchKernelGGL(tiny_backward_kernel<4>, dim3(1), dim3(T), 0, st, a);
     else hipLaunchKernelGGL(tiny_backward_kernel<8>, dim3(1), dim3(T), 0, st, a);

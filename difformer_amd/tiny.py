@@ -8,7 +8,8 @@ is ONE launch (+ one for a graph not seen before, + one `torch.rand` when dropou
 autograd node that hands every parameter its gradient.
 
 Taken for: one head, float32, n <= 4,096 (`sigmoid` above 64 nodes: L + 1 launches forward and L + 2 backward, a layer's
-O(n^2) pair loop spread over the chip -- csrc/tiny_sigmoid_grid.hip -- behind the same two C calls), hidden <= 8,
+O(n^2) pair loop spread over the chip -- csrc/tiny_sigmoid_grid.hip --, `simple` above 256 nodes likewise --
+csrc/tiny_simple_grid.hip --, behind the same two C calls), hidden <= 8,
 <= 64 input features, <= 8 outputs, <= 8 layers, every flag of the constructor, graphs of <= 65,535 entries (prepared by
 `dif_tiny_graph_build`, one workgroup per direction).  Everything else -- `--special_treat dense` at n = 1,068 (1.14 M
 entries), `edge_weight` tensors that want a gradient -- takes the layer-by-layer path.  DIFFORMER_TINY=0 switches it off.
@@ -28,7 +29,7 @@ from .backend_hip import _stream
 ENABLED = os.environ.get("DIFFORMER_TINY", "1") != "0"
 MAX_NODES, MAX_HIDDEN, MAX_IN, MAX_OUT, MAX_LAYERS, MAX_EDGES = 4096, 8, 64, 8, 8, 65535
 MAX_NODES_SIGMOID = int(os.environ.get("DIFFORMER_TINY_SIGMOID_NODES", "4096"))
-PLAN = int(os.environ.get("DIFFORMER_TINY_PLAN", "0"))     # dif_tiny_cfg.launch_plan for `sigmoid`: 0 by size, 1 one workgroup, 2 grid
+PLAN = int(os.environ.get("DIFFORMER_TINY_PLAN", "0"))     # dif_tiny_cfg.launch_plan: 0 by size, 1 one workgroup, 2 one launch per layer stage over the chip
 
 
 class TinyGraph:
@@ -245,7 +246,7 @@ class _TinyModel(torch.autograd.Function):
         ldx = xc.stride(0) if n > 1 else xc.shape[1]
         rnd = torch.rand((L + 1, n, d), device=dev) if (training and p_drop > 0.0) else None
         cfg = _lib.TinyCfg(training=int(training), dropout=float(p_drop), nnz=0 if graph is None else graph.nnz,
-                           launch_plan=PLAN if fields["kernel"] == 1 else 0, **fields)
+                           launch_plan=PLAN, **fields)
         tape = torch.empty(int(lib.dif_tiny_tape_floats(n, d, L)), dtype=torch.float32, device=dev)
         y = torch.empty((n, c), dtype=torch.float32, device=dev)
         pa = _ptr_array(params)

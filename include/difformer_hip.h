@@ -708,7 +708,8 @@ int dif_layer_tail_bf16(const void* conv, int64_t ldc, int64_t n_rows, int H, in
  * layer-by-layer path: the graph preparation, the forward, the backward.  One head, float32, n <= 4,096 nodes,
  * hidden <= 8, <= 64 input features, <= 8 outputs, <= 8 layers.  kernel = 1 ('sigmoid') above 64 nodes (run.sh:39-43:
  * wikimath, 1,068 nodes): the same two calls issue one launch per layer (two beyond 512 nodes) plus one, the layer's
- * O(n^2) pair loop spread over the chip (csrc/tiny_sigmoid_grid.hip); launch_plan forces either form.
+ * O(n^2) pair loop spread over the chip (csrc/tiny_sigmoid_grid.hip); kernel = 0 ('simple') above 256 nodes likewise
+ * (csrc/tiny_simple_grid.hip: the sums over nodes met across launches); launch_plan forces either form.
  *
  * dif_tiny_graph_build   replaces gcn_conv's graph side (node classification/difformer.py:64-75 =
  *   spatial-temporal/difformer.py:64-75: degree(col), d_norm_in / d_norm_out, value = w * d_in * d_out, nan_to_num,
@@ -736,7 +737,7 @@ typedef struct {
     int32_t kernel;                 /* 0 = 'simple', 1 = 'sigmoid' */
     int32_t use_bn, use_residual, use_weight, use_graph, use_source, training;
     float alpha, attn_scale, gcn_scale, dropout, eps;
-    int32_t launch_plan;            /* 0 = by size; 1 = one workgroup; 2 = one launch per layer over the chip (kernel 1 only) */
+    int32_t launch_plan;            /* 0 = by size; 1 = one workgroup; 2 = one launch per layer stage over the chip */
     int64_t nnz;
 } dif_tiny_cfg;
 size_t dif_tiny_tape_floats(int n, int hidden, int num_layers);

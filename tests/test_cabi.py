@@ -152,12 +152,12 @@ def test_tiny_model_entry_points_check_their_arguments(lib):
 
     def tape(n, dp, L):                             # H, Z [L+1]; ATT, ATTLO [L]; two q/k/v sets; DEN; SUM; the splits' sums
         f = n * dp * (2 * (L + 1) + 2 * L + 6) + L * n + L * 96
-        return f + (-f) % 4 + 2 * splits(n) * n * (dp + 1)
+        return f + (-f) % 4 + max(2 * splits(n) * n * (dp + 1), 4 * ((n + 63) // 64) * 96)
 
     def scratch(n, dp, L):
         one = n * dp * 14 + 3 * n
         g = n * dp * (5 * L + 15) + 4 * n
-        return max(one, g + (-g) % 4 + 2 * splits(n) * n * 3 * dp)
+        return max(one, g + (-g) % 4 + max(2 * splits(n) * n * 3 * dp, 4 * ((n + 63) // 64) * 96))
 
     assert lib.dif_tiny_tape_floats(20, 4, 2) == tape(20, 4, 2)
     assert lib.dif_tiny_tape_floats(20, 5, 2) == tape(20, 8, 2)                                    # hidden 5..8: padded to 8
@@ -174,7 +174,7 @@ def test_tiny_model_entry_points_check_their_arguments(lib):
     assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -2
     cfg.hidden = 4
     assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -1
-    cfg.launch_plan = 2                             # the grid plan exists for `sigmoid` (kernel 1) only
+    cfg.launch_plan = 3                             # 0 by size, 1 one workgroup, 2 grid
     assert lib.dif_tiny_forward_f32(ctypes.byref(cfg), None, 4, None, None, None, None, None, None, None, None) == -1
     assert b"launch_plan" in lib.dif_last_error()
     cfg.launch_plan = 0

@@ -161,12 +161,12 @@ def test_forward_and_backward_every_flag(c, dev):
 
 
 @pytest.mark.parametrize("plan", [1, 2], ids=["one-workgroup", "grid"])
-@pytest.mark.parametrize("c", [c for c in _cases() if c["kernel"] == "sigmoid"], ids=_ID)
-def test_sigmoid_on_both_launch_plans(c, plan, dev, monkeypatch):
-    """The `sigmoid` cases with the plan forced: both sides of the size threshold run both kernels (the one-workgroup plan
+@pytest.mark.parametrize("c", _cases(), ids=_ID)
+def test_both_launch_plans(c, plan, dev, monkeypatch):
+    """Every case with the plan forced: both sides of the size thresholds run both sets of kernels (`sigmoid` on one workgroup
     capped at 700 nodes here: 9 M pairs per layer on one compute unit is what the grid plan exists to avoid)."""
     from difformer_amd import tiny
-    if plan == 1 and c["n"] > 700:
+    if plan == 1 and c["kernel"] == "sigmoid" and c["n"] > 700:
         c = dict(c, n=700)
     monkeypatch.setattr(tiny, "PLAN", plan)
     _run_case(c, dev)
@@ -286,11 +286,14 @@ def test_larger_models_keep_the_layer_path(dev):
 
 
 @pytest.mark.parametrize("n,hidden,layers,edges", [(4096, 8, 8, 65535), (4095, 7, 3, 30000), (1068, 4, 2, 27000), (577, 5, 5, 0)])
-def test_sigmoid_grid_plan_at_its_limits(n, hidden, layers, edges, dev):
+@pytest.mark.parametrize("kernel", ["sigmoid", "simple"])
+def test_grid_plan_at_its_limits(n, hidden, layers, edges, kernel, dev, monkeypatch):
     """The grid plan at the limits of the C entry points (4,096 nodes, hidden 8, 8 layers, 65,535 entries), at a node count that
     leaves a ragged last block and ragged key splits, at wikimath's shape and without a graph: output, dx and every parameter
     gradient against the float64 oracle."""
-    c = dict(n=n, f_in=14, hidden=hidden, c=3, layers=layers, kernel="sigmoid", use_bn=True, use_residual=True, use_weight=hidden != 4,
+    from difformer_amd import tiny
+    monkeypatch.setattr(tiny, "PLAN", 2)
+    c = dict(n=n, f_in=14, hidden=hidden, c=3, layers=layers, kernel=kernel, use_bn=True, use_residual=True, use_weight=hidden != 4,
              use_graph=edges > 0, use_source=hidden == 5, graph_weight=0.3 if hidden == 7 else -1.0, alpha=0.5, weighted=hidden != 4,
              deg=1, iso=0, dropout=0.0, seed=n + hidden)
     if edges:
