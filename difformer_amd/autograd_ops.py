@@ -198,7 +198,7 @@ class _GcnAggregate(torch.autograd.Function):
 
 class _LayerTail(torch.autograd.Function):
     """Forward and backward are one HIP pass each (csrc/layer_tail.hip, csrc/layer_tail_bwd.hip); shapes the backward
-    kernel does not cover (D % 4 != 0, D > 256, bf16 storage) re-derive the gradient with tensor ops."""
+    kernel does not cover (D % 4 != 0, D > 512, bf16 storage) re-derive the gradient with tensor ops."""
 
     @staticmethod
     def forward(ctx, conv, x0, prev, alpha, w, b, eps, relu):

@@ -1116,10 +1116,10 @@ class HipBackend:
     def layer_tail_bwd(self, conv, x0, prev, alpha, ln_weight, ln_bias, eps, relu, grad_out, want):
         """Backward of layer_tail in one pass (csrc/layer_tail_bwd.hip).  want = (conv, x0, prev) booleans.
         -> (d_conv [n,H,D] | None, d_x0 | None, d_prev | None, d_ln_weight | None, d_ln_bias | None); None when the
-        shape is not covered (D % 4 != 0, D > 256, bf16 storage): the caller re-derives the gradient with tensor ops."""
+        shape is not covered (D % 4 != 0, D > 512, bf16 storage): the caller re-derives the gradient with tensor ops."""
         dev = _require_device(conv, x0, prev, ln_weight, ln_bias, grad_out)
         n, H, D = conv.shape
-        if D % 4 or D > 256 or any(t is not None and t.dtype != torch.float32 for t in (conv, x0, prev, ln_weight, grad_out)):
+        if D % 4 or D > 512 or any(t is not None and t.dtype != torch.float32 for t in (conv, x0, prev, ln_weight, grad_out)):
             return None
         conv, ldc = _row_major(conv, H * D)
         g, ldg = _row_major(grad_out, D)

@@ -17,8 +17,9 @@ using dif::f32x4;
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-// G lanes x 4 elements hold one row (D <= 4G, D % 4 == 0); 256 / G rows per workgroup pass.
-template <int G>
+// G lanes x V vectors of 4 elements hold one row (D <= 4 G V, D % 4 == 0; V = 2 with G = 64 for 257 .. 512 columns: hidden 300 / 400,
+// image and text/run.sh); 256 / G rows per workgroup pass.
+template <int G, int V = 1>
 __global__ __launch_bounds__(256) void layer_tail_bwd_kernel(const float* __restrict__ conv, int64_t ldc, int64_t n_rows, int H,
                                                              int D, const float* __restrict__ x0, int64_t ldx0,
                                                              const float* __restrict__ prev, int64_t ldp, float alpha,
@@ -29,90 +30,128 @@ __global__ __launch_bounds__(256) void layer_tail_bwd_kernel(const float* __rest
                                                              float* __restrict__ dprev, int64_t lddp,
                                                              float* __restrict__ ws, int64_t ws_stride) {
     constexpr int RPB = 256 / G;
-    __shared__ f32x4 sm[2][256];
+    __shared__ f32x4 sm[2][V][256];
     const int li = threadIdx.x % G, rl = threadIdx.x / G;
-    const int col = 4 * li;
-    const bool active = col < D;
+    int col[V];
+    bool active[V];
     const float inv_h = 1.0f / static_cast<float>(H);
     const float inv_d = 1.0f / static_cast<float>(D);
-    f32x4 w4 = {1.f, 1.f, 1.f, 1.f}, b4 = zero4();
-    if (ln_w && active) {
-        w4 = *reinterpret_cast<const f32x4*>(ln_w + col);
-        b4 = *reinterpret_cast<const f32x4*>(ln_b + col);
+    f32x4 w4[V], b4[V], dw[V], db[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+        col[u] = 4 * (li + u * G);
+        active[u] = col[u] < D;
+        w4[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+        b4[u] = zero4();
+        if (ln_w && active[u]) {
+            w4[u] = *reinterpret_cast<const f32x4*>(ln_w + col[u]);
+            b4[u] = *reinterpret_cast<const f32x4*>(ln_b + col[u]);
+        }
+        dw[u] = zero4();
+        db[u] = zero4();
     }
-    f32x4 dw = zero4(), db = zero4();
     const int64_t nrb = (n_rows + RPB - 1) / RPB;
     for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         const int64_t row = rb * RPB + rl;
-        const bool ok = active && row < n_rows;
-        f32x4 z = zero4(), gy = zero4();
-        if (ok) {
-            const float* c = conv + row * ldc + col;
-            for (int h = 0; h < H; ++h) z += *reinterpret_cast<const f32x4*>(c + static_cast<int64_t>(h) * D);
-            if (H > 1) z *= inv_h;
-            if (x0) z += *reinterpret_cast<const f32x4*>(x0 + row * ldx0 + col);
-            if (prev) z = alpha * z + (1.0f - alpha) * *reinterpret_cast<const f32x4*>(prev + row * ldp + col);
-            gy = *reinterpret_cast<const f32x4*>(g + row * ldg + col);
+        bool ok[V];
+        f32x4 z[V], gy[V], dz2[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            ok[u] = active[u] && row < n_rows;
+            z[u] = zero4();
+            gy[u] = zero4();
+            if (ok[u]) {
+                const float* c = conv + row * ldc + col[u];
+                for (int h = 0; h < H; ++h) z[u] += *reinterpret_cast<const f32x4*>(c + static_cast<int64_t>(h) * D);
+                if (H > 1) z[u] *= inv_h;
+                if (x0) z[u] += *reinterpret_cast<const f32x4*>(x0 + row * ldx0 + col[u]);
+                if (prev) z[u] = alpha * z[u] + (1.0f - alpha) * *reinterpret_cast<const f32x4*>(prev + row * ldp + col[u]);
+                gy[u] = *reinterpret_cast<const f32x4*>(g + row * ldg + col[u]);
+            }
+            dz2[u] = gy[u];
         }
-        f32x4 dz2 = gy;
         if (ln_w) {
-            float s = z[0] + z[1] + z[2] + z[3];
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < V; ++u) s += z[u][0] + z[u][1] + z[u][2] + z[u][3];
 #pragma unroll
             for (int m = 1; m < G; m <<= 1) s += __shfl_xor(s, m, 64);
             const float mu = s * inv_d;
-            const f32x4 dz = ok ? (z - mu) : zero4();
-            float v = dz[0] * dz[0] + dz[1] * dz[1] + dz[2] * dz[2] + dz[3] * dz[3];
+            f32x4 dz[V], xh[V], gw[V];
+            float v = 0.f;
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                dz[u] = ok[u] ? (z[u] - mu) : zero4();
+                v += dz[u][0] * dz[u][0] + dz[u][1] * dz[u][1] + dz[u][2] * dz[u][2] + dz[u][3] * dz[u][3];
+            }
 #pragma unroll
             for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
             const float rstd = 1.0f / sqrtf(v * inv_d + eps);
-            const f32x4 xh = dz * rstd;
-            if (relu) {
-                const f32x4 y = xh * w4 + b4;
+            float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gy[i] = y[i] > 0.f ? gy[i] : 0.f;
+            for (int u = 0; u < V; ++u) {
+                xh[u] = dz[u] * rstd;
+                if (relu) {
+                    const f32x4 y = xh[u] * w4[u] + b4[u];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gy[u][i] = y[i] > 0.f ? gy[u][i] : 0.f;
+                }
+                dw[u] += gy[u] * xh[u];
+                db[u] += gy[u];
+                gw[u] = gy[u] * w4[u];
+                m1 += gw[u][0] + gw[u][1] + gw[u][2] + gw[u][3];
+                m2 += gw[u][0] * xh[u][0] + gw[u][1] * xh[u][1] + gw[u][2] * xh[u][2] + gw[u][3] * xh[u][3];
             }
-            dw += gy * xh;
-            db += gy;
-            const f32x4 gw = gy * w4;
-            float m1 = gw[0] + gw[1] + gw[2] + gw[3];
-            float m2 = gw[0] * xh[0] + gw[1] * xh[1] + gw[2] * xh[2] + gw[3] * xh[3];
 #pragma unroll
             for (int m = 1; m < G; m <<= 1) {
                 m1 += __shfl_xor(m1, m, 64);
                 m2 += __shfl_xor(m2, m, 64);
             }
-            dz2 = rstd * (gw - m1 * inv_d - xh * (m2 * inv_d));
+#pragma unroll
+            for (int u = 0; u < V; ++u) dz2[u] = rstd * (gw[u] - m1 * inv_d - xh[u] * (m2 * inv_d));
         } else if (relu) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dz2[i] = z[i] > 0.f ? gy[i] : 0.f;
-        }
-        if (ok) {
-            f32x4 dzz = dz2;
-            if (prev) {
-                if (dprev) *reinterpret_cast<f32x4*>(dprev + row * lddp + col) = (1.0f - alpha) * dz2;
-                dzz = alpha * dz2;
+            for (int u = 0; u < V; ++u) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dz2[u][i] = z[u][i] > 0.f ? gy[u][i] : 0.f;
             }
-            if (dx0) *reinterpret_cast<f32x4*>(dx0 + row * lddx0 + col) = dzz;
+        }
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            if (!ok[u]) continue;
+            f32x4 dzz = dz2[u];
+            if (prev) {
+                if (dprev) *reinterpret_cast<f32x4*>(dprev + row * lddp + col[u]) = (1.0f - alpha) * dz2[u];
+                dzz = alpha * dz2[u];
+            }
+            if (dx0) *reinterpret_cast<f32x4*>(dx0 + row * lddx0 + col[u]) = dzz;
             if (dconv) {
                 const f32x4 dc = H > 1 ? dzz * inv_h : dzz;
-                for (int h = 0; h < H; ++h) *reinterpret_cast<f32x4*>(dconv + row * lddc + static_cast<int64_t>(h) * D + col) = dc;
+                for (int h = 0; h < H; ++h) *reinterpret_cast<f32x4*>(dconv + row * lddc + static_cast<int64_t>(h) * D + col[u]) = dc;
             }
         }
     }
     if (!ws) return;
     // fold the RPB row slots of the workgroup (same column group li) in a fixed order
-    sm[0][threadIdx.x] = dw;
-    sm[1][threadIdx.x] = db;
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+        sm[0][u][threadIdx.x] = dw[u];
+        sm[1][u][threadIdx.x] = db[u];
+    }
     __syncthreads();
-    if (rl == 0 && active) {
-        f32x4 a = zero4(), b = zero4();
-        for (int r = 0; r < RPB; ++r) {
-            a += sm[0][r * G + li];
-            b += sm[1][r * G + li];
+    if (rl == 0) {
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            if (!active[u]) continue;
+            f32x4 a = zero4(), b = zero4();
+            for (int r = 0; r < RPB; ++r) {
+                a += sm[0][u][r * G + li];
+                b += sm[1][u][r * G + li];
+            }
+            float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
+            *reinterpret_cast<f32x4*>(rec + col[u]) = a;
+            *reinterpret_cast<f32x4*>(rec + D + col[u]) = b;
         }
-        float* rec = ws + static_cast<int64_t>(blockIdx.x) * ws_stride;
-        *reinterpret_cast<f32x4*>(rec + col) = a;
-        *reinterpret_cast<f32x4*>(rec + D + col) = b;
     }
 }
 
@@ -132,7 +171,7 @@ int tail_group(int D) {
 }  // namespace
 
 extern "C" size_t dif_layer_tail_bwd_workspace_bytes(int64_t n_rows, int D) {
-    if (n_rows <= 0 || D <= 0 || D % 4 != 0 || D > 256) return 0;
+    if (n_rows <= 0 || D <= 0 || D % 4 != 0 || D > 512) return 0;
     return static_cast<size_t>(tail_bwd_blocks(n_rows, tail_group(D))) * 2 * D * sizeof(float);
 }
 
@@ -142,7 +181,7 @@ extern "C" int dif_layer_tail_bwd_f32(const float* conv, int64_t ldc, int64_t n_
                                       float* d_conv, int64_t lddc, float* d_x0, int64_t lddx0, float* d_prev, int64_t lddp,
                                       float* d_ln, void* workspace, size_t workspace_bytes, dif_stream_t stream) {
     DIF_REQUIRE(n_rows > 0 && H > 0 && D > 0, DIF_E_BADARG, "dif_layer_tail_bwd: n_rows, H, D must be positive");
-    DIF_REQUIRE(D % 4 == 0 && D <= 256, DIF_E_SHAPE, "dif_layer_tail_bwd: needs D %% 4 == 0 and D <= 256 (got %d)", D);
+    DIF_REQUIRE(D % 4 == 0 && D <= 512, DIF_E_SHAPE, "dif_layer_tail_bwd: needs D %% 4 == 0 and D <= 512 (got %d)", D);
     DIF_REQUIRE(conv && grad_out, DIF_E_BADARG, "dif_layer_tail_bwd: null pointer");
     DIF_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr) && (ln_weight == nullptr) == (d_ln == nullptr), DIF_E_BADARG,
                 "dif_layer_tail_bwd: ln_weight, ln_bias and d_ln must be given together");
@@ -162,8 +201,8 @@ extern "C" int dif_layer_tail_bwd_f32(const float* conv, int64_t ldc, int64_t n_
         ws = static_cast<float*>(workspace);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DIF_TAILB(GG)                                                                                                     \
-    hipLaunchKernelGGL((layer_tail_bwd_kernel<GG>), dim3(blocks), dim3(256), 0, st, conv, ldc, n_rows, H, D, x0, ldx0, prev, \
+#define DIF_TAILB(...)                                                                                                    \
+    hipLaunchKernelGGL((layer_tail_bwd_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, conv, ldc, n_rows, H, D, x0, ldx0, prev, \
                        ldp, alpha, ln_weight, ln_bias, ln_eps, relu, grad_out, ldg, d_conv, lddc, d_x0, lddx0, d_prev, lddp, \
                        ws, static_cast<int64_t>(2 * D))
     switch (G) {
@@ -173,7 +212,10 @@ extern "C" int dif_layer_tail_bwd_f32(const float* conv, int64_t ldc, int64_t n_
         case 8: DIF_TAILB(8); break;
         case 16: DIF_TAILB(16); break;
         case 32: DIF_TAILB(32); break;
-        default: DIF_TAILB(64); break;
+        default:
+            if (D <= 256) DIF_TAILB(64);
+            else DIF_TAILB(64, 2);
+            break;
     }
 #undef DIF_TAILB
     if (int rc = dif::launch_status("layer_tail_bwd_kernel")) return rc;

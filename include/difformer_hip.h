@@ -552,7 +552,7 @@ int dif_gcn_spmm_tail_f32(const int32_t* rowptr, const int32_t* blkptr, int n_bl
 
 /* ---------------------------------------------------------------------------------------
  * f3  backward of dif_layer_tail_f32 (what loss.backward(), main.py:130, asks of difformer.py:137-140, :200-203 and of
- *     the input layer's LayerNorm -> ReLU, :189-191; the reference leaves it to autograd).  fp32, D % 4 == 0, D <= 256,
+ *     the input layer's LayerNorm -> ReLU, :189-191; the reference leaves it to autograd).  fp32, D % 4 == 0, D <= 512,
  *     16-byte aligned rows (DIF_E_SHAPE / DIF_E_BADARG otherwise).  The row is re-derived from the forward's inputs
  *     (conv, x0, prev) and every gradient leaves in one pass:
  *       d_conv [n,H,D] (each head gets dz / H), d_x0 [n,D], d_prev [n,D]  (each may be NULL: not wanted),

@@ -493,9 +493,10 @@ def test_batched_simple_attention_every_shape(B, mx, M, D, dev):
 
 
 # ================================================================== f3: layer-tail backward at every lane-group width
-@pytest.mark.parametrize("hidden", [4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("hidden", [4, 8, 16, 32, 64, 128, 256, 260, 300, 400, 512])
 def test_layer_tail_backward_every_width(hidden, dev):
-    """layer_tail_bwd_kernel<G>: D / 4 = 1 .. 64 lanes per row (hidden 8: G = 2) -- against float64 autograd of
+    """layer_tail_bwd_kernel<G, V>: D / 4 = 1 .. 64 lanes per row (hidden 8: G = 2), two vectors per lane from 257 columns (hidden 300 /
+    400: image and text/run.sh) -- against float64 autograd of
     the tail expression (difformer.py:137-140, 200-203)."""
     from difformer_amd import ops
     be = ops.get_backend()

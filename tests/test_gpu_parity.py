@@ -1645,7 +1645,8 @@ def test_split_product_own_blocks_then_the_rest(world, zipf, dt, dev):
 @pytest.mark.parametrize("n,H,D,use_x0,use_prev,use_ln,relu", [
     (5000, 1, 64, True, True, True, False), (3001, 2, 64, False, True, True, False), (4097, 1, 128, True, False, True, True),
     (2500, 1, 32, False, False, True, True), (2000, 3, 16, True, True, False, False), (1000, 1, 64, False, False, False, True),
-    (70000, 1, 64, True, True, True, False), (300, 1, 256, False, True, True, False)])
+    (70000, 1, 64, True, True, True, False), (300, 1, 256, False, True, True, False), (15000, 1, 300, False, True, True, False),
+    (1300, 2, 400, True, True, True, True), (777, 1, 512, True, False, False, True)])
 def test_layer_tail_backward_kernel_matches_float64_autograd(n, H, D, use_x0, use_prev, use_ln, relu):
     """dif_layer_tail_bwd_f32 against torch autograd of difformer.py:137-140, :200-203 in float64."""
     from difformer_amd import autograd_ops as ag
