@@ -452,7 +452,11 @@ extern "C" int dif_rowgemm_f32(const float* A, int64_t lda, const float* Mat, in
         if (allowed[vec] != hipSuccess)
             return dif::fail(static_cast<int>(allowed[vec]), "dif_rowgemm_f32: LDS attribute: %s", hipGetErrorString(allowed[vec]));
         int64_t gw = (n_steps + 2 * kRgWaves - 1) / (2 * kRgWaves);          // >= 2 steps per wave: the staging is amortised
-        const int64_t cap = (lds <= 80 * 1024 ? 2 : 1) * dif::kCUs;
+        // ONE round of workgroups over the chip, column blocks and heads included: 15,000 x 300 -> 300 (hidden 300 training,
+        // image and text/run.sh) was 59 x 5 = 295 workgroups of 82 KB LDS on 256 compute units -- a second round for 39 of them
+        // doubled the 40 us; a workgroup walks more row steps instead (its slab is staged once either way)
+        int64_t cap = (lds <= 80 * 1024 ? 2 : 1) * dif::kCUs / (static_cast<int64_t>(CT) * H);
+        if (cap < 1) cap = 1;
         if (gw > cap) gw = cap;
         const dim3 grid(static_cast<unsigned>(gw), CT, H), block(64 * kRgWaves);
         if (vec)
