@@ -66,7 +66,6 @@ __global__ __launch_bounds__(kThreads) void grid_simple_forward_kernel(const Tin
 #pragma unroll
     for (int m = 0; m < DP; ++m) { h[m] = 0.f; q[m] = 0.f; k[m] = 0.f; v[m] = 0.f; }
     int next_set = 0;
-    bool project_next = true;
 
     if (stage == 0) {
         for (int kk = t; kk < DP * kMaxIn; kk += T) {
@@ -118,7 +117,6 @@ __global__ __launch_bounds__(kThreads) void grid_simple_forward_kernel(const Tin
         const float* set = tp.qkv(l & 1);
         const float* Vl = set + 2 * nd;
         next_set = (l + 1) & 1;
-        project_next = !last;
         if (live) {
             load_row<DP>(set + static_cast<size_t>(i) * DP, q);
             // :20-38  closed form of the attention from the layer's sums
@@ -190,7 +188,6 @@ __global__ __launch_bounds__(kThreads) void grid_simple_forward_kernel(const Tin
         if (last) return;
     }
     // ---- projections of the next layer (:115-120) and this block's share of its sums ----
-    (void)project_next;
     if (live) {
         project<DP>(sNext, a.use_weight, h, q, k, v);
         float* nxt = tp.qkv(next_set);
@@ -237,7 +234,6 @@ __device__ __forceinline__ void tail_backward(const TinyArgs& a, const Tape<DP>&
                                               float (&row)[2 * DP + 2]) {
     const int n = a.n;
     const size_t at_i = static_cast<size_t>(i) * DP;
-    const int set = l & 1;
     float datt[DP], q[DP], k[DP], v[DP];
     tail_backward_common<DP>(a, tp, gs, w, l, i, dy, drop, keep, datt, q, k, v);
     const float q2 = sSum[DP * DP + 2 * DP], k2 = sSum[DP * DP + 2 * DP + 1];
@@ -275,7 +271,6 @@ __device__ __forceinline__ void tail_backward(const TinyArgs& a, const Tape<DP>&
     for (int m = 0; m < DP; ++m) { row[m] = q[m]; row[DP + m] = dnum[m]; }
     row[2 * DP] = dden;
     row[2 * DP + 1] = ts;
-    (void)set;
 }
 
 template <int DP>
