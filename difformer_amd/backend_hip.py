@@ -490,6 +490,11 @@ class HipBackend:
         sub = subset.contiguous()
         E, B = int(ei.shape[1]), int(sub.numel())
         ew = None if edge_weight is None else _f32(edge_weight, "edge_weight").contiguous()
+        if E == 0:                                             # nothing to filter (an empty tensor has no address to hand over)
+            if B and bool(((sub < 0) | (sub >= num_nodes)).any()):
+                raise IndexError(f"difformer_amd: subset / edge_index hold node ids outside [0, {num_nodes})")
+            return (torch.empty((2, 0), dtype=torch.int64, device=dev),
+                    None if ew is None else torch.empty(0, dtype=torch.float32, device=dev))
         out_ei = torch.empty((2, max(E, 1)), dtype=torch.int64, device=dev)
         out_w = None if ew is None else torch.empty(max(E, 1), dtype=torch.float32, device=dev)
         count = torch.empty(1, dtype=torch.int64, device=dev)

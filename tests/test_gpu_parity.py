@@ -1143,6 +1143,23 @@ def test_subgraph_relabel_matches_numpy(dev):
     assert u.tolist() == [[0, 1, 1, 2], [1, 0, 2, 1]]
 
 
+@pytest.mark.parametrize("n,e,bsz", [(100, 1, 100), (100, 63, 50), (100, 64, 100), (100, 65, 7), (500, 4095, 500), (500, 4096, 250),
+                                     (500, 4097, 499), (3000, 300001, 3000), (3000, 300001, 1), (20000, 2000003, 6000), (50, 0, 10)])
+def test_subgraph_edge_counts_around_the_mask_words_and_chunks(n, e, bsz, dev):
+    """dif_subgraph keeps one BIT per edge (a wave's ballot = a 64-edge mask word) and scans per-chunk counts (4,096 edges): edge
+    counts on both sides of a word / chunk boundary, every edge kept (the subset is all nodes), a single node, no edges -- bit-exact
+    against the numpy restatement of main-batch.py:131."""
+    from difformer_amd import graph_utils as gu
+    g = torch.Generator().manual_seed(n + e)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = torch.rand(e, generator=g)
+    subset = torch.randperm(n, generator=g)[:bsz]
+    ref, ref_w = orc.subgraph(subset.numpy(), ei.numpy(), w.numpy(), relabel_nodes=True, num_nodes=n)
+    out, ow = gu.subgraph(subset.to(dev), ei.to(dev), w.to(dev), relabel_nodes=True, num_nodes=n)
+    assert out.shape == ref.shape and np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(ow.cpu().numpy(), ref_w)
+
+
 @pytest.mark.parametrize("n,e,m,bsz,weighted", [(50000, 1200000, 50000, 10000, True), (50000, 1200000, 31234, 7000, False),
                                                  (3000, 40000, 3000, 10, False), (1000, 5000, 1000, 1000, True)])
 def test_subgraph_batches_equal_the_per_batch_calls(n, e, m, bsz, weighted, dev):
