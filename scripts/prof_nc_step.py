@@ -29,4 +29,14 @@ steps(); steps()
 import time
 t0 = time.perf_counter(); steps(); print("per step ms", (time.perf_counter() - t0) / 13 * 1e3)
 pr = cProfile.Profile(); pr.enable(); steps(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:3000])
+# the forward alone (the autograd engine runs the backward on its own thread: not seen by cProfile)
+def fwd():
+    model.train()
+    for i, ei in enumerate(subs):
+        out = model(x[perm[i * BATCH:(i + 1) * BATCH]], ei)
+    torch.cuda.synchronize()
+fwd()
+t0 = time.perf_counter(); fwd(); print("forward per batch ms", (time.perf_counter() - t0) / 13 * 1e3)
+pr = cProfile.Profile(); pr.enable(); fwd(); pr.disable()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats("difformer_amd|built-in", 45); print(s.getvalue()[:9000])
