@@ -17,6 +17,7 @@ entries), `edge_weight` tensors that want a gradient -- takes the layer-by-layer
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 import weakref
 from collections import OrderedDict
@@ -29,6 +30,7 @@ from .backend_hip import _stream
 ENABLED = os.environ.get("DIFFORMER_TINY", "1") != "0"
 MAX_NODES, MAX_HIDDEN, MAX_IN, MAX_OUT, MAX_LAYERS, MAX_EDGES = 4096, 8, 64, 8, 8, 65535
 MAX_NODES_SIGMOID = int(os.environ.get("DIFFORMER_TINY_SIGMOID_NODES", "4096"))
+PACK = os.environ.get("DIFFORMER_TINY_PACK", "1") != "0"     # the parameters as one flat autograd input when forwards repeat (_Pack)
 PLAN = int(os.environ.get("DIFFORMER_TINY_PLAN", "0"))     # dif_tiny_cfg.launch_plan: 0 by size, 1 one workgroup, 2 one launch per layer stage over the chip
 
 
@@ -233,12 +235,62 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
+def _layout(live):
+    """Offsets (floats, 16-byte aligned) of the parameters in ONE flat buffer -> (offsets, total)."""
+    offs, o = [], 0
+    for p in live:
+        offs.append(o)
+        o += p.numel() + (-p.numel()) % 4
+    return offs, o
+
+
+class _Pack(torch.autograd.Function):
+    """The model's parameters as ONE flat tensor.  The spatial-temporal loop sums the costs of a hundred snapshots before ONE
+    backward (main.py:105-121); with the parameters as separate inputs of every snapshot's node the autograd engine adds a
+    hundred gradients per PARAMETER -- 16 small launches per snapshot, 80 of the 173 us a snapshot's backward took.  Through
+    this node every snapshot hands back one flat gradient and the split into parameters runs once per backward."""
+
+    @staticmethod
+    def forward(ctx, slot, *live):
+        ctx.slot = slot
+        offs, total = _layout(live)
+        flat = torch.zeros(total, dtype=torch.float32, device=live[0].device)
+        torch._foreach_copy_([flat[o: o + p.numel()].view(p.shape) for o, p in zip(offs, live)], list(live))
+        ctx.meta = (offs, [p.shape for p in live])
+        return flat
+
+    @staticmethod
+    def backward(ctx, g):
+        offs, shapes = ctx.meta
+        ctx.slot[1] = None                                # a graph that has been walked may have been freed: the next forward packs anew
+        return (None,) + tuple(g[o: o + math.prod(sh)].view(sh) if need else None
+                               for o, sh, need in zip(offs, shapes, ctx.needs_input_grad[1:]))
+
+
+_packs = weakref.WeakKeyDictionary()        # model -> [key of the parameter versions, flat copy or None]  (not ON the model: deepcopy)
+
+
+def _packed(model, live):
+    """The flat copy of the parameters for this forward, or None.  Built on the SECOND training forward that sees the same
+    parameter versions (a loop that steps the optimiser after every snapshot, wikimath, never pays for it), reused until a
+    parameter changes or a backward has run through it."""
+    key = tuple((id(p), p._version, p.requires_grad) for p in live)
+    slot = _packs.get(model)
+    if slot is not None and slot[0] == key:
+        if slot[1] is None:
+            slot[1] = _Pack.apply(slot, *live)
+        return slot[1]
+    _packs[model] = [key, None]
+    return None
+
+
 class _TinyModel(torch.autograd.Function):
-    """DIFFormer.forward as one launch; backward = one launch handing x and every parameter its gradient."""
+    """DIFFormer.forward as one launch; backward = one launch handing x and every parameter its gradient.  The parameters come
+    as separate tensors (`flat_layout` None) or as ONE flat tensor (_Pack) with its layout."""
 
     @staticmethod
     def forward(ctx, state, x, *live_params):
-        fields, params, graph, p_drop, training = state
+        fields, params, graph, p_drop, training, flat_layout = state
         lib = _lib.load()
         dev = x.device
         n, d, L, c = fields["n"], fields["hidden"], fields["num_layers"], fields["out_channels"]
@@ -249,7 +301,11 @@ class _TinyModel(torch.autograd.Function):
                            launch_plan=PLAN, **fields)
         tape = torch.empty(int(lib.dif_tiny_tape_floats(n, d, L)), dtype=torch.float32, device=dev)
         y = torch.empty((n, c), dtype=torch.float32, device=dev)
-        pa = _ptr_array(params)
+        if flat_layout is None:
+            pa = _ptr_array(params)
+        else:                                             # addresses inside the flat copy, in the C ABI's slot order
+            base, it = live_params[0].data_ptr(), iter(flat_layout)
+            pa = (ctypes.c_void_p * len(params))(*[None if p is None else base + 4 * next(it) for p in params])
         rc = lib.dif_tiny_forward_f32(ctypes.byref(cfg), xc.data_ptr(), ldx, pa,
                                       None if graph is None else graph.rowptr, None if graph is None else graph.src,
                                       None if graph is None else graph.val,
@@ -258,6 +314,9 @@ class _TinyModel(torch.autograd.Function):
         stats["forward"] += 1
         ctx.cfg, ctx.graph, ctx.rnd, ctx.tape, ctx.ldx = cfg, graph, rnd, tape, ldx
         ctx.slots = [p is not None for p in params]
+        ctx.flat_layout, ctx.pa = flat_layout, pa
+        ctx.sizes = [p.numel() for p in params if p is not None]
+        ctx.shapes = [p.shape for p in params if p is not None]
         ctx.save_for_backward(xc, *live_params)
         return y
 
@@ -268,34 +327,35 @@ class _TinyModel(torch.autograd.Function):
         dev = xc.device
         cfg, graph = ctx.cfg, ctx.graph
         n, d = cfg.n, cfg.hidden
-        it = iter(live)
-        params = [next(it) if has else None for has in ctx.slots]
-        sizes = [p.numel() for p in live]
+        sizes, shapes = ctx.sizes, ctx.shapes
         want_dx = ctx.needs_input_grad[1]
-        pad = [(-s) % 4 for s in sizes]
-        flat = torch.empty(sum(sizes) + sum(pad) + (n * cfg.in_channels if want_dx else 0), dtype=torch.float32, device=dev)
-        grads, views, o = [], [], 0
-        it = iter(zip(live, sizes, pad))
-        for has in ctx.slots:
-            if not has:
-                grads.append(None)
-                continue
-            p, s, pd = next(it)
-            v = flat[o: o + s].view(p.shape)
-            grads.append(v)
-            views.append(v)
-            o += s + pd
+        offs, o = [], 0
+        for sz in sizes:
+            offs.append(o)
+            o += sz + (-sz) % 4
+        # (packed: the padding between parameters is part of the gradient handed back -- zeros, not stale memory)
+        flat = (torch.zeros if ctx.flat_layout is not None else torch.empty)(o + (n * cfg.in_channels if want_dx else 0),
+                                                                             dtype=torch.float32, device=dev)
+        base, it = flat.data_ptr(), iter(offs)
+        grads = (ctypes.c_void_p * len(ctx.slots))(*[base + 4 * next(it) if has else None for has in ctx.slots])
         dx = flat[o: o + n * cfg.in_channels].view(n, cfg.in_channels) if want_dx else None
         scratch = torch.empty(int(lib.dif_tiny_scratch_floats(n, d, cfg.num_layers)), dtype=torch.float32, device=dev)
         gyc = gy if gy.is_contiguous() else gy.contiguous()
-        rc = lib.dif_tiny_backward_f32(ctypes.byref(cfg), xc.data_ptr(), ctx.ldx, _ptr_array(params),
+        if ctx.flat_layout is not None:
+            pa = ctx.pa
+        else:
+            li = iter(live)
+            pa = _ptr_array([next(li) if has else None for has in ctx.slots])
+        rc = lib.dif_tiny_backward_f32(ctypes.byref(cfg), xc.data_ptr(), ctx.ldx, pa,
                                        None if graph is None else graph.rowptr_t, None if graph is None else graph.dst_t,
                                        None if graph is None else graph.val_t,
                                        None if ctx.rnd is None else ctx.rnd.data_ptr(), ctx.tape.data_ptr(), gyc.data_ptr(),
-                                       _ptr_array(grads), None if dx is None else dx.data_ptr(), scratch.data_ptr(), _stream(dev))
+                                       grads, None if dx is None else dx.data_ptr(), scratch.data_ptr(), _stream(dev))
         _lib.check(rc, "dif_tiny_backward_f32")
         stats["backward"] += 1
-        return (None, dx) + tuple(views)
+        if ctx.flat_layout is not None:
+            return (None, dx, flat[:o])
+        return (None, dx) + tuple(flat[a: a + sz].view(sh) for a, sz, sh in zip(offs, sizes, shapes))
 
 
 def forward(model, x, edge_index, edge_weight):
@@ -313,5 +373,10 @@ def forward(model, x, edge_index, edge_weight):
         fields["gcn_scale"] *= graph.scale
     live = [p for p in params if p is not None]
     training = bool(model.training)
-    state = (fields, params, graph, float(model.__dict__["dropout"]) if training else 0.0, training)       # eval: dropout is the identity
-    return _TinyModel.apply(state, x, *live)
+    p_drop = float(model.__dict__["dropout"]) if training else 0.0           # eval: dropout is the identity
+    flat = None
+    if PACK and torch.is_grad_enabled() and any(p.requires_grad for p in live):
+        flat = _packed(model, live)
+    if flat is not None:
+        return _TinyModel.apply((fields, params, graph, p_drop, training, _layout(live)[0]), x, flat)
+    return _TinyModel.apply((fields, params, graph, p_drop, training, None), x, *live)
