@@ -299,3 +299,50 @@ def test_grid_plan_at_its_limits(n, hidden, layers, edges, kernel, dev, monkeypa
     if edges:
         c["deg"] = max(1, (edges - n) // n)
     _run_case(c, dev)
+
+
+def test_summed_costs_with_packed_parameters_match_the_separate_path(dev, monkeypatch):
+    """spatial-temporal/main.py:105-121 sums the snapshots' costs before ONE backward(retain_graph=True): from the second forward on
+    unchanged parameters they enter as one flat tensor (tiny._Pack).  Same gradients as with separate inputs, a second backward
+    over the retained graph doubles them, a frozen parameter gets none, an optimiser step retires the flat copy, and the model
+    can still be deep-copied."""
+    import copy
+    from difformer_amd import DIFFormer, tiny
+    n, T = 20, 6
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(n, 4, generator=g).to(dev) for _ in range(T)]
+    ys = [torch.randn(n, generator=g).to(dev) for _ in range(T)]
+    ei = torch.cat([torch.randint(0, n, (2, 70), generator=g), torch.arange(n).repeat(2, 1)], 1).to(dev)
+
+    def run(pack):
+        monkeypatch.setattr(tiny, "PACK", pack)
+        torch.manual_seed(11)
+        model = DIFFormer(4, 4, 1, num_layers=2, num_heads=1, kernel="simple", use_bn=True, use_residual=True, use_graph=True,
+                          use_weight=False, dropout=0.0).to(dev).train()
+        model.fcs[0].bias.requires_grad_(False)
+        cost = 0
+        for x, y in zip(xs, ys):
+            cost = cost + torch.mean((model(x, ei)[:, 0] - y) ** 2)
+        cost = cost / T
+        cost.backward(retain_graph=True)
+        once = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        cost.backward()
+        twice = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        return model, float(cost.detach()), once, twice
+    m0, c0, once0, twice0 = run(False)
+    before = tiny.stats["forward"]
+    m1, c1, once1, twice1 = run(True)
+    assert tiny.stats["forward"] == before + T
+    assert tiny._packs.get(m1) is not None and m1.fcs[0].bias.grad is None and "fcs.0.bias" not in once1
+    assert abs(c0 - c1) <= 1e-6 * abs(c0) and once0.keys() == once1.keys()
+    gmax = max(float(v.abs().max()) for v in once0.values())
+    for k in once0:
+        assert float((once0[k] - once1[k]).abs().max()) <= 2e-6 * gmax, k
+        assert float((twice1[k] - 2 * once1[k]).abs().max()) <= 2e-6 * gmax, k
+    # the flat copy belongs to one set of parameter versions
+    opt = torch.optim.SGD([p for p in m1.parameters() if p.requires_grad], lr=0.1)
+    opt.step()
+    out = m1(xs[0], ei)
+    assert tiny._packs[m1][1] is None                       # first forward after the step: separate inputs again
+    out.sum().backward()
+    assert torch.isfinite(copy.deepcopy(m1)(xs[0], ei)).all()
