@@ -370,6 +370,120 @@ __global__ __launch_bounds__(64 * kRgWaves) void rowgemm_wide_kernel(const float
     }
 }
 
+// ---- the same contraction on split-bfloat16 operands (round 6: `simple` training at hidden 300 / 400, image and text/run.sh) ----
+// rowgemm_wide_kernel is bound by the fp32 matrix core (64 v_mfma_f32_16x16x4_f32 of 32 cycles per 16 rows and 64 channels:
+// 87 us for 15,000 x 300 -> 300, 20 % of that pipe's peak with the staging and the column blocks' re-reads of A).  Same shape of
+// work -- a workgroup owns 64 output columns of one head and keeps their [K x 64] slab of Mat in LDS, its eight waves walk
+// 16-row steps with the next 64 channels of A arriving under the products -- but the slab sits there as ready-split A fragments
+// ([hi | lo][feature tile < 4][k-block][lane] x 16 bytes, as in rowgemm_split.h) and the rows are split as they arrive: three
+// v_mfma_f32_16x16x32_bf16 per (feature tile, 32 channels) = 24 instructions of 16 cycles per 64 channels.  The dropped lo.lo
+// term is 2^-16 of a product (~4e-6 of the result; the gradients are held to 1e-4); DIFFORMER_EXACT_FP32=1 keeps the fp32 kernel.
+// K <= 512 and K, C multiples of 4 with 16-byte aligned rows (the launcher checks); LDS: 16 KiB per 64 channels.
+typedef __bf16 rw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 rw_bf16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64 * kRgWaves) void rowgemm_wide_split_kernel(const float* __restrict__ A, int64_t lda, int a_head_stride,
+                                                                           const float* __restrict__ Mat, int ldm, int mat_head_stride,
+                                                                           int mat_t, float mat_scale, const float* __restrict__ bias,
+                                                                           const float* __restrict__ r, int H,
+                                                                           const float* __restrict__ u, float u_scale,
+                                                                           const float* __restrict__ Cin, int64_t ldc,
+                                                                           const float* __restrict__ beta_dev, int64_t n_rows, int K,
+                                                                           int C, float* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) rw_bf16x8 sm_wfrag[];      // [hi | lo][ft < 4][kb < KB][lane]
+    const int h = blockIdx.z, ct = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int KT = (K + 63) >> 6, KB = 2 * KT;
+    const float* mat = Mat + static_cast<int64_t>(h) * mat_head_stride;
+    const int n_frag = 4 * KB * 64;
+    for (int e = threadIdx.x; e < n_frag; e += 64 * kRgWaves) {
+        const int ln = e & 63, kb = (e >> 6) % KB, ft = (e >> 6) / KB;
+        const int c = ct * 64 + 16 * ft + (ln & 15), k0 = 32 * kb + 4 * (ln >> 4);
+        const int cc = c < C ? c : C - 1;
+        f32x4 w0, w1;                       // raw loads from clamped indices, masked afterwards (a guarded load waits where it is issued)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ka = (k0 + t < K) ? k0 + t : K - 1, kc = (k0 + 16 + t < K) ? k0 + 16 + t : K - 1;
+            w0[t] = mat_t ? mat[static_cast<int64_t>(cc) * ldm + ka] : mat[static_cast<int64_t>(ka) * ldm + cc];
+            w1[t] = mat_t ? mat[static_cast<int64_t>(cc) * ldm + kc] : mat[static_cast<int64_t>(kc) * ldm + cc];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            w0[t] = (c < C && k0 + t < K) ? mat_scale * w0[t] : 0.f;
+            w1[t] = (c < C && k0 + 16 + t < K) ? mat_scale * w1[t] : 0.f;
+        }
+        const rw_bf16x4 h0 = __builtin_convertvector(w0, rw_bf16x4), h1 = __builtin_convertvector(w1, rw_bf16x4);
+        const rw_bf16x4 l0 = __builtin_convertvector(w0 - __builtin_convertvector(h0, f32x4), rw_bf16x4);
+        const rw_bf16x4 l1 = __builtin_convertvector(w1 - __builtin_convertvector(h1, f32x4), rw_bf16x4);
+        sm_wfrag[e] = rw_bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        sm_wfrag[n_frag + e] = rw_bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+    __syncthreads();
+
+    const float beta = (Cin && beta_dev) ? *beta_dev : 1.0f;
+    const int64_t n_steps = (n_rows + 15) / 16;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kRgWaves + wave;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kRgWaves;
+    // a tile of A: channels 64 kt + 16 c + 4 lg .. + 3 of row 16 st + l15 (raw loads from clamped addresses, masked when used)
+    auto load_a = [&](f32x4 (&av)[4], int64_t st, int kt) {
+        const int64_t row = st * 16 + l15;
+        const float* base = A + (row < n_rows ? row : n_rows - 1) * lda + h * a_head_stride;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k0 = kt * 64 + 16 * c + 4 * lg;
+            av[c] = *reinterpret_cast<const f32x4*>(base + (k0 < K ? k0 : 0));
+        }
+    };
+    f32x4 an[4];
+    load_a(an, first < n_steps ? first : n_steps - 1, 0);
+    for (int64_t st = first; st < n_steps; st += stride) {
+        const int64_t row = st * 16 + l15;
+        const bool row_ok = row < n_rows;
+        f32x4 acc[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt) {
+            rw_bf16x8 xh[2], xl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 a0 = an[2 * j], a1 = an[2 * j + 1];
+                if (!(row_ok && kt * 64 + 32 * j + 4 * lg < K)) a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(row_ok && kt * 64 + 32 * j + 16 + 4 * lg < K)) a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const rw_bf16x4 h0 = __builtin_convertvector(a0, rw_bf16x4), h1 = __builtin_convertvector(a1, rw_bf16x4);
+                const rw_bf16x4 l0 = __builtin_convertvector(a0 - __builtin_convertvector(h0, f32x4), rw_bf16x4);
+                const rw_bf16x4 l1 = __builtin_convertvector(a1 - __builtin_convertvector(h1, f32x4), rw_bf16x4);
+                xh[j] = rw_bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                xl[j] = rw_bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            }
+            if (kt + 1 < KT) load_a(an, st, kt + 1);                           // the next channels / rows arrive under these products
+            else load_a(an, st + stride < n_steps ? st + stride : st, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int at = (t4 * KB + 2 * kt + j) * 64 + lane;
+                    const rw_bf16x8 wh = sm_wfrag[at], wl = sm_wfrag[n_frag + at];
+                    acc[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[j], acc[t4], 0, 0, 0);      // small terms first
+                    acc[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[j], acc[t4], 0, 0, 0);
+                    acc[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[j], acc[t4], 0, 0, 0);
+                }
+        }
+        if (!row_ok) continue;
+        const float rv = r ? r[row * H + h] * u_scale : 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int c0 = ct * 64 + 16 * t4 + 4 * lg;              // the lane holds out^T[c0 .. c0 + 3][row]
+            if (c0 >= C) continue;
+            f32x4 o = acc[t4];
+            if (bias) o += *reinterpret_cast<const f32x4*>(bias + h * C + c0);
+            if (r) o += rv * *reinterpret_cast<const f32x4*>(u + h * C + c0);
+            if (Cin) o += beta * *reinterpret_cast<const f32x4*>(Cin + row * ldc + h * C + c0);
+            *reinterpret_cast<f32x4*>(out + row * ldo + h * C + c0) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t dif_simple_bwd_workspace_bytes(int64_t n_rows, int H, int M, int D) {
@@ -439,6 +553,22 @@ extern "C" int dif_rowgemm_f32(const float* A, int64_t lda, const float* Mat, in
     if ((K > 64 || C > 64) && K <= 128 && C <= 128 && H == 1 && vec && n_rows >= 4096 && !dif::exact_fp32()) {
         return rowgemm_split_launch("dif_rowgemm_f32", st, A, lda, Mat, ldm, mat_t, mat_scale, bias, r, u, u_scale, Cin, ldc, beta_dev, n_rows, K, C,
                                     out, ldo, nullptr, nullptr, 0.f);
+    }
+    if ((K > 64 || C > 64) && vec && n_rows >= 1024 && !dif::exact_fp32()) {
+        const int KT = (K + 63) / 64, CT = (C + 63) / 64;
+        const size_t lds = static_cast<size_t>(2) * 4 * (2 * KT) * 64 * 16;                  // 16 KiB per 64 channels
+        constexpr int kLdsMaxSplit = 2 * 4 * 16 * 64 * 16;
+        static const hipError_t allowed_split = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_wide_split_kernel),
+                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxSplit);
+        if (allowed_split != hipSuccess)
+            return dif::fail(static_cast<int>(allowed_split), "dif_rowgemm_f32: LDS attribute: %s", hipGetErrorString(allowed_split));
+        int64_t gw = (n_steps + 2 * kRgWaves - 1) / (2 * kRgWaves);
+        int64_t cap = (lds <= 80 * 1024 ? 2 : 1) * dif::kCUs / (static_cast<int64_t>(CT) * H);      // one round of workgroups
+        if (cap < 1) cap = 1;
+        if (gw > cap) gw = cap;
+        hipLaunchKernelGGL(rowgemm_wide_split_kernel, dim3(static_cast<unsigned>(gw), CT, H), dim3(64 * kRgWaves), lds, st, A, lda, K, Mat,
+                           ldm, mat_head_stride, mat_t, mat_scale, bias, r, H, u, u_scale, Cin, ldc, beta_dev, n_rows, K, C, out, ldo);
+        return dif::launch_status("rowgemm_wide_split_kernel");
     }
     if (K > 64 || C > 64) {
         const int KT = (K + 63) / 64, CT = (C + 63) / 64;

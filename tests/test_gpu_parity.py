@@ -1942,6 +1942,29 @@ def test_reduce_slab_kernel_with_wide_k(n, m, d, dev):
     assert abs(r[m * d + m + d + 1] - (k64 ** 2).sum()) < 1e-5 * (k64 ** 2).sum()
 
 
+@pytest.mark.parametrize("n,K,C", [(15000, 300, 300), (13000, 400, 400), (2000, 512, 64), (5000, 68, 300), (1024, 132, 196),
+                                   (18846, 300, 304), (3000, 64, 192)])
+def test_rowgemm_wide_split_kernel_vs_float64(n, K, C, dev):
+    """dif_rowgemm_f32 beyond 128 columns from 1,024 rows (hidden 300 / 400 of image and text/run.sh in training): a workgroup per 64
+    output columns with its slab of the matrix as split-bfloat16 fragments in LDS (round 6; the fp32 kernel below that size and under
+    DIFFORMER_EXACT_FP32=1) -- A Mat + bias + accumulate against float64, a column slice as A, bitwise repeatable."""
+    from difformer_amd import ops
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(n + K + C)
+    wide = torch.randn(n, K + 8, generator=g).to(dev)
+    A = wide[:, 4:4 + K]
+    mat = (torch.randn(K, C, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    acc = torch.randn(n, C, generator=g).to(dev)
+    be.kernel_events = {}
+    out = be.row_gemm(A, mat, bias, acc)
+    launched, be.kernel_events = set(be.kernel_events), None
+    assert "dif_rowgemm_f32" in launched
+    ref = A.double() @ mat.double() + bias.double() + acc.double()
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+    assert torch.equal(be.row_gemm(A, mat, bias, acc), out)
+
+
 @pytest.mark.parametrize("n,K,C", [(100000, 128, 128), (5000, 100, 128), (4096, 128, 72), (6000, 68, 96)])
 def test_rowgemm_split_kernel_vs_float64(n, K, C, dev):
     """dif_rowgemm_f32 at one head of 65..128 x 65..128 from 4,096 rows: all output columns per workgroup, split-bfloat16 operands
