@@ -497,15 +497,16 @@ class HipBackend:
                     None if ew is None else torch.empty(0, dtype=torch.float32, device=dev))
         out_ei = torch.empty((2, max(E, 1)), dtype=torch.int64, device=dev)
         out_w = None if ew is None else torch.empty(max(E, 1), dtype=torch.float32, device=dev)
-        count = torch.empty(1, dtype=torch.int64, device=dev)
-        status = torch.empty(1, dtype=torch.int32, device=dev)
+        res = torch.zeros(2, dtype=torch.int64, device=dev)    # [kept count | status word]: ONE read-back
+        count, status = res[:1], res[1:].view(torch.int32)
         ws_bytes = self.lib.dif_subgraph_workspace_bytes(E, num_nodes)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _timed(self, "dif_subgraph", dev):
             rc = self.lib.dif_subgraph(_ptr(ei), E, num_nodes, _ptr(sub), B, _ptr(ew), _ptr(out_ei), _ptr(out_w),
                                        _ptr(count), _ptr(status), _ptr(ws), ws_bytes, _stream(dev))
         _lib.check(rc, "dif_subgraph")
-        kept, bad = int(count.item()), int(status.item())       # one sync: the result size is data dependent
+        kept, bad = res.tolist()                                # one sync: the result size is data dependent
+        bad &= 0xFFFFFFFF
         if bad:
             raise IndexError(f"difformer_amd: subset / edge_index hold node ids outside [0, {num_nodes})")
         out = torch.stack([out_ei[0, :kept], out_ei[1, :kept]])
@@ -520,8 +521,8 @@ class HipBackend:
         E = int(ei.shape[1])
         cap = (2 * E if undirected else E) + (num_nodes if add_loops else 0)
         out = torch.empty((2, max(cap, 1)), dtype=torch.int64, device=dev)
-        count = torch.empty(1, dtype=torch.int64, device=dev)
-        status = torch.empty(1, dtype=torch.int32, device=dev)
+        res = torch.zeros(2, dtype=torch.int64, device=dev)    # [kept count | status word]: ONE read-back
+        count, status = res[:1], res[1:].view(torch.int32)
         ws_bytes = self.lib.dif_graph_prepare_workspace_bytes(E, num_nodes, int(bool(undirected)))
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
         with _timed(self, "dif_graph_prepare", dev):
@@ -529,7 +530,8 @@ class HipBackend:
                                             int(bool(add_loops)), max(cap, 1), _ptr(out), _ptr(count), _ptr(status), _ptr(ws),
                                             ws_bytes, _stream(dev))
         _lib.check(rc, "dif_graph_prepare")
-        kept, bad = int(count.item()), int(status.item())       # one sync: the result size is data dependent
+        kept, bad = res.tolist()                                # one sync: the result size is data dependent
+        bad &= 0xFFFFFFFF
         if bad:
             raise IndexError(f"difformer_amd: edge_index holds node ids outside [0, {num_nodes})")
         return torch.stack([out[0, :kept], out[1, :kept]])
