@@ -417,6 +417,20 @@ int gram_chunks(int64_t n_rows) {
     if (p < 1) p = 1;
     return static_cast<int>(p);
 }
+// the input-layer kernel: ONE workgroup per CU, as the Gram kernel below.  Measured at the ogbn-proteins rows (8,283 tiles = 4.04 per
+// wave, profiles/r06_experiments.md section 8): 36.3 us with one workgroup per CU, 40.6 with two, 50.4 with three -- every workgroup
+// pays its weight staging, the fold of eight waves' Gram accumulators and a 16.6-KB partial record, which costs more than the
+// second round of waves hides.  DIF_INPUT_GRAM_PER_CU=2 / 3 reproduces the comparison.
+int input_gram_chunks(int64_t n_rows) {
+    static const int per_cu = [] { const char* e = getenv("DIF_INPUT_GRAM_PER_CU"); return e ? atoi(e) : 1; }();
+    if (per_cu <= 1) return gram_chunks(n_rows);
+    const int64_t tiles = (n_rows + 15) / 16;
+    int64_t p = (tiles + 2 * kGramWaves - 1) / (2 * kGramWaves);
+    const int64_t cap = static_cast<int64_t>(per_cu > kRecordChunksPerCU ? kRecordChunksPerCU : per_cu) * dif::kCUs;
+    if (p > cap) p = cap;
+    if (p < 1) p = 1;
+    return static_cast<int>(p);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // Coefficients: one workgroup of 1024 threads, four 64^3 products through LDS.
@@ -1276,7 +1290,7 @@ extern "C" int dif_input_gram_f32(const float* x, int64_t ldx, int64_t n_rows, i
         DIF_REQUIRE(plan[0] == D / 4 && npad >= n_rows, DIF_E_BADARG, "dif_input_gram: plan does not match D / n_rows");
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int P = gram_chunks(n_rows);
+    const int P = input_gram_chunks(n_rows);
     const int64_t rec = (static_cast<int64_t>(D) * D + D + 3) & ~int64_t(3);
     float* ws = static_cast<float*>(workspace);
     const int xvec = (C_in % 4 == 0) && (ldx % 4 == 0) && dif::aligned16(x);
