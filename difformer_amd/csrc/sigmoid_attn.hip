@@ -427,9 +427,13 @@ extern "C" size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M
         const int S2 = key_splits(N, L, H, D, true);
         if (S2 > S) S = S2;
     }
-    if (S == 1) return 0;
     const size_t DT = (D + kDTile - 1) / kDTile;
-    return static_cast<size_t>(S) * N * H * (static_cast<size_t>(D) + DT) * sizeof(float);
+    size_t need = S == 1 ? 0 : static_cast<size_t>(S) * N * H * (static_cast<size_t>(D) + DT) * sizeof(float);
+    if (dif::sigw_narrow_pays(M, D, N, L, false)) {                  // 33 .. 64 columns with enough pairs: the plane kernels may run
+        const size_t planes = dif::sigw_fwd_workspace_bytes(N, L, H, M, D);
+        if (planes > need) need = planes;
+    }
+    return need;
 }
 
 namespace {
@@ -452,7 +456,9 @@ int sigmoid_attn(const char* who, const T* q, int64_t ldq, const T* k, int64_t l
     if constexpr (std::is_same<T, float>::value) {
         // heads of 65 .. 512 columns (image and text/run.sh:17,35,54: hidden 300 / 400): every operand as split-bfloat16 planes, packed
         // in MFMA fragment order, scores formed once per (query, key) pair for all D columns (csrc/sigmoid_wide.hip)
-        if (dif::sigw_covers(M, D) && !dif::exact_fp32())
+        // ... and heads of 33 .. 64 columns in inference from the sizes where those kernels win (sigw_narrow_pays: never with row
+        // sums asked for -- training keeps this file's fp32 chain)
+        if ((dif::sigw_covers(M, D) || dif::sigw_narrow_pays(M, D, N, L, den != nullptr)) && !dif::exact_fp32())
             return dif::sigw_fwd(q, ldq, k, ldk, v, ldv, N, L, H, M, D, out, ldo, den, workspace, workspace_bytes,
                                  static_cast<hipStream_t>(stream));
     }

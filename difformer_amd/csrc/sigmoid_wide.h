@@ -8,6 +8,7 @@
 namespace dif {
 
 bool sigw_covers(int M, int D);                         // 64 < max(M, D) <= 512
+bool sigw_narrow_pays(int M, int D, int64_t N, int64_t L, bool training);   // 32 < max(M, D) <= 64 and enough pairs for the plane kernels
 size_t sigw_fwd_workspace_bytes(int64_t N, int64_t L, int H, int M, int D);
 int sigw_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int64_t N, int64_t L, int H,
              int M, int D, float* out, int64_t ldo, float* den_or_null, void* workspace, size_t workspace_bytes, hipStream_t st);

@@ -611,7 +611,7 @@ int launch_bwd_t(const BwdArgs& a, const SweepPlan& p, hipStream_t st) {
 int launch_fwd(int KS, const FwdArgs& a, const SweepPlan& p, hipStream_t st) {
     switch (KS) {
 #define DIF_CASE(K) case K: return launch_fwd_t<K>(a, p, st);
-        DIF_CASE(3) DIF_CASE(4) DIF_CASE(5) DIF_CASE(6) DIF_CASE(7) DIF_CASE(8) DIF_CASE(9) DIF_CASE(10)
+        DIF_CASE(2) DIF_CASE(3) DIF_CASE(4) DIF_CASE(5) DIF_CASE(6) DIF_CASE(7) DIF_CASE(8) DIF_CASE(9) DIF_CASE(10)
         DIF_CASE(11) DIF_CASE(12) DIF_CASE(13) DIF_CASE(14) DIF_CASE(15) DIF_CASE(16)
 #undef DIF_CASE
     }
@@ -667,6 +667,17 @@ namespace dif {
 bool sigw_covers(int M, int D) {
     const int c = M > D ? M : D;
     return c > 64 && c <= 32 * kMaxKS;
+}
+
+// 33 .. 64 columns per head (KS = 2): the same plane kernels against csrc/sigmoid_attn.hip.  Measured (scripts/exp_sigw_narrow.py,
+// M = D = 64): inference forward 0.714 -> 0.406 ms at 20,000 rows, 0.119 -> 0.103 at 8,192, 0.028 -> 0.041 at 2,708 (slower: the
+// packs and the partial sums are a fixed cost) -- taken for INFERENCE from 2^25 pairs.  Training forward + backward would go
+// 4.86 -> 1.95 ms at 20,000 rows, but the deepest script (node classification/run.sh:10: 8 layers, hidden 64) then has two last-layer
+// gradients at 1.9e-4 of themselves (tests/test_gpu_grad.py::test_deepest_sigmoid_script_eight_layers; the fp32 chain: < 1e-4):
+// training at <= 64 columns keeps the fp32-chain kernels, as round 5 decided for the split operands of the narrow kernel.
+bool sigw_narrow_pays(int M, int D, int64_t N, int64_t L, bool training) {
+    const int c = M > D ? M : D;
+    return !training && c > 32 && c <= 64 && N * L >= (int64_t(1) << 25);
 }
 
 size_t sigw_fwd_workspace_bytes(int64_t N, int64_t L, int H, int M, int D) {

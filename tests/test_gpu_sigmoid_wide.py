@@ -281,3 +281,25 @@ def test_random_shapes_heads_strides_against_the_oracle(dev):
             gg = got.grad[:, : h * w].reshape(want.shape).cpu().numpy()
             assert grad_err(gg, want, gmax, floor=floor) < TOL, (trial, nm, n, l, h, m, d)
             assert float(got.grad[:, h * w:].abs().sum()) == 0.0               # the padding columns of the buffers get no gradient
+
+
+@pytest.mark.parametrize("n,l,h,m,d", [(6000, 6000, 1, 64, 64), (5800, 5900, 2, 48, 64), (9000, 4000, 1, 36, 40)])
+def test_inference_at_33_to_64_columns_takes_the_plane_kernels_from_2_25_pairs(n, l, h, m, d, dev):
+    """Heads of 33 .. 64 columns: the inference forward runs on the packed split-bfloat16 planes from 2^25 (query, key) pairs (0.71 ->
+    0.41 ms at 20,000 x 20,000 x 64); below that size, with row sums asked for (training) and under exact fp32 it stays on
+    csrc/sigmoid_attn.hip.  Against the blocked float64 oracle; the training call of the same shape against it too."""
+    from difformer_amd import autograd_ops as ag, ops
+    g = torch.Generator().manual_seed(n + m)
+    q = torch.randn(n, h, m, generator=g) * (2.0 / m ** 0.5)
+    k = torch.randn(l, h, m, generator=g) * 0.5
+    v = torch.randn(l, h, d, generator=g)
+    be = ops.get_backend()
+    with torch.no_grad():
+        out = be.sigmoid_attention(q.to(dev), k.to(dev), v.to(dev))
+    ref = orc.sigmoid_attention_blocked(q.double().numpy(), k.double().numpy(), v.double().numpy(), 2048)
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+    qd = q.to(dev).requires_grad_(True)
+    out_t = ag.sigmoid_attention(qd, k.to(dev), v.to(dev))
+    assert rel_err(out_t.detach().cpu().numpy(), ref) < TOL
+    out_t.sum().backward()
+    assert torch.isfinite(qd.grad).all()
