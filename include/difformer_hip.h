@@ -105,7 +105,8 @@ int dif_project_reduce_f32(const float* x, int64_t ldx, int64_t n_rows, int C_in
  * centred (v - column mean: out_n is a convex combination of the value rows, so the centre passes through exactly and the
  * products carry only the rows' spread).  Forward ~1e-6 .. 1e-5 of the float64 result, gradients ~3e-5 of each tensor's largest
  * entry.  Under dif_set_exact_fp32(1) these widths run the generic fp32 forward kernel and dif_sigmoid_attn_bwd_f32 returns
- * DIF_E_SHAPE (the host then differentiates with tensor operations).  Workspaces: packed planes (8 bytes per element and
+ * DIF_E_SHAPE (the host then differentiates with tensor operations).  Heads of 33 .. 64 channels take the same plane kernels in
+ * dif_sigmoid_attn_f32 (inference) from 2^25 (query, key) pairs; the training entry points never do.  Workspaces: packed planes (8 bytes per element and
  * orientation) + per-split partial sums, dif_sigmoid_workspace_bytes / dif_sigmoid_bwd_workspace_bytes; 256-byte aligned use.
  * ------------------------------------------------------------------------------------- */
 size_t dif_sigmoid_workspace_bytes(int64_t N, int64_t L, int H, int M, int D);
