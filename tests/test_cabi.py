@@ -56,7 +56,9 @@ def test_version_and_size_helpers(lib):
     assert lib.dif_simple_workspace_bytes(0, 1, 64, 64) == 0
     small, big = lib.dif_csr_workspace_bytes(1000, 100, 1), lib.dif_csr_workspace_bytes(79255038, 132534, 13)
     assert 0 < small < big and big > 4 * 4 * 79255038
-    assert lib.dif_sigmoid_workspace_bytes(16384, 16384, 1, 64, 64) == 0         # 512 query groups = one full round: no key split
+    assert lib.dif_sigmoid_workspace_bytes(16384, 16384, 1, 32, 32) == 0         # 512 query groups = one full round: no key split
+    assert lib.dif_sigmoid_workspace_bytes(16384, 16384, 1, 64, 64) > 0          # 33 .. 64 columns from 2^25 pairs: the packed planes of csrc/sigmoid_wide.hip
+    assert lib.dif_sigmoid_workspace_bytes(5000, 5000, 1, 64, 64) < lib.dif_sigmoid_workspace_bytes(6000, 6000, 1, 64, 64)
     assert lib.dif_sigmoid_workspace_bytes(20000, 20000, 1, 64, 64) > 0          # 625 groups: split to trim the last round
     assert lib.dif_sigmoid_workspace_bytes(2708, 2708, 1, 64, 64) > 0            # Cora: keys split over workgroups
 
